@@ -1,0 +1,76 @@
+"""CPU: the oracle reproduces every golden vector produced by the reference itself
+(tests/golden/make_golden.py).  This is what pins the oracle (the reference has no tests)."""
+import pytest
+import torch
+
+from cases import CASES, oracle_cfg
+from helpers import case_tensors, flatten_outputs, load_golden, rel_l2, surrogate
+from oracle import afft_oracle as O
+
+TOL = 2e-5  # fp32 reference vs fp32 restatement; measured worst 1.4e-6
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_matches_reference_golden(name):
+    z, _ = load_golden(name)
+    c, state, data, tgt, sub = case_tensors(name)
+    P = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    cfg = oracle_cfg(c)
+    if c.get("soft"):
+        f3 = {m: torch.flatten(d.mean([-1, -2]).permute(0, 1, 3, 2), 1, 2) for m, d in data.items()}
+        f3, t_s, s_s, ign = O.mixup(f3, tgt, sub, c["num_classes"], c["label_smoothing"], c["lam"])
+        out = O.cmfp_early(P, f3, cfg)
+        total, losses = O.loss(out, t_s, s_s, soft=True, ignore=ign)
+    elif c.get("fp_output_len", 1) > 1:
+        out = O.base_model_forward(P, data, cfg)
+        total, losses = surrogate(out), {}
+    else:
+        out = O.base_model_forward(P, data, cfg)
+        total, losses = O.loss(out, tgt, sub)
+    flat = flatten_outputs(out)
+    n_checked = 0
+    for k in z.files:
+        if k.startswith("out:"):
+            key = k[4:]
+            if key == "attentions/modality_attns" and c["fuser"] == "ca":
+                continue
+            ref = torch.from_numpy(z[k])
+            assert flat[key].shape == ref.shape, (key, flat[key].shape, ref.shape)
+            assert rel_l2(flat[key], ref) < TOL, key
+            n_checked += 1
+    assert n_checked >= 6
+    assert abs(float(total) - float(z["loss:total"])) < TOL * max(1.0, abs(float(z["loss:total"])))
+    for k, v in losses.items():
+        assert abs(float(v) - float(z["loss:" + k])) < TOL * max(1.0, abs(float(z["loss:" + k]))), k
+    total.backward()
+    ng = 0
+    for k in z.files:
+        if k.startswith("grad:"):
+            g = P[k[5:]].grad
+            assert g is not None, k
+            assert rel_l2(g, torch.from_numpy(z[k])) < 5e-5, k
+            ng += 1
+    assert ng >= 5
+    # norms of ALL parameter gradients
+    names = [str(s) for s in z["gradnames"]]
+    for nm, gn in zip(names, z["gradnorm"]):
+        assert abs(float(P[nm].grad.norm()) - gn) < 1e-4 * max(gn, 1e-3), nm
+
+
+def test_kat_activations_and_softmax():
+    """Known-answer checks for the constants that differ between the two transformers."""
+    x = torch.tensor([-3.0, -1.0, 0.0, 0.5, 2.0])
+    assert torch.allclose(O.gelu_erf(x), torch.nn.functional.gelu(x), atol=1e-6)
+    assert torch.allclose(O.gelu_tanh(x), torch.nn.functional.gelu(x, approximate="tanh"), atol=1e-6)
+    assert abs(float(O.gelu_erf(torch.tensor(1.0))) - 0.8413447) < 1e-6
+    assert abs(float(O.gelu_tanh(torch.tensor(1.0))) - 0.8411920) < 1e-6
+    m = O.make_mask("causal", 3)
+    p = torch.softmax(torch.zeros(3, 3) + m, -1)
+    assert torch.equal(p[0], torch.tensor([1.0, 0.0, 0.0]))  # masked probabilities are exactly 0
+    d = O.make_mask("diag", 3)
+    assert torch.softmax(torch.zeros(3, 3) + d, -1)[1, 1] == 0
+    y5 = O.layer_norm(torch.tensor([[1.0, 2.0, 4.0]]), None, None, 1e-5)
+    y6 = O.layer_norm(torch.tensor([[1.0, 2.0, 4.0]]), None, None, 1e-6)
+    assert not torch.equal(y5, y6) and torch.allclose(y5, y6, atol=1e-5)
+    oh = O.one_hot(torch.tensor([2]), 4, 0.4)
+    assert torch.allclose(oh, torch.tensor([[0.1, 0.1, 0.7, 0.1]]))
