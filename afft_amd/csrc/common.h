@@ -1,0 +1,185 @@
+// Shared device/host helpers for the gfx950 kernels (wave64, MFMA, LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/afft_hip.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits in memory
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define AFFT_LDS __attribute__((address_space(3)))
+#define AFFT_GLOBAL __attribute__((address_space(1)))
+
+void afft_set_error(const char* fmt, ...);
+
+#define AFFT_CHECK(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      afft_set_error(__VA_ARGS__);       \
+      return 1;                          \
+    }                                    \
+  } while (0)
+
+#define AFFT_LAUNCH_CHECK()                                                     \
+  do {                                                                          \
+    hipError_t e_ = hipGetLastError();                                          \
+    if (e_ != hipSuccess) {                                                     \
+      afft_set_error("%s:%d HIP launch error: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      return 2;                                                                 \
+    }                                                                           \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
+  return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+__device__ __forceinline__ float ld_any(const void* p, int64_t idx, int dtype) {
+  return dtype == AFFT_F32 ? ((const float*)p)[idx] : bf2f(((const bf16_t*)p)[idx]);
+}
+__device__ __forceinline__ void st_any(void* p, int64_t idx, int dtype, float v) {
+  if (dtype == AFFT_F32) ((float*)p)[idx] = v; else ((bf16_t*)p)[idx] = f2bf(v);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- activations (nn.GELU exact erf: models/transformerblock.py:119 ; HF gelu_new: GPT2MLP)
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_erf_f(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  float u = 0.79788456080286536f * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float dgelu_tanh_f(float x) {
+  float x2 = x * x;
+  float u = 0.79788456080286536f * (x + 0.044715f * x * x2);
+  float t = tanhf(u);
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.79788456080286536f * (1.0f + 3.0f * 0.044715f * x2);
+}
+
+// ---- GEMM epilogue shared by the bf16 fast path and the fp32 path ------------------------------
+struct EpiParams {
+  int M, N;
+  float alpha;
+  const float* bias;
+  int act;
+  const void* aux; int64_t ldaux; int aux_dtype;
+  void* pre; int64_t ldpre; int pre_dtype;
+  const float* rowscale;
+  const float* residual; int64_t ldres;
+  int accumulate;
+  void* out; int64_t ldo; int out_dtype;
+  void* out2; int64_t ldo2; int out2_dtype;
+  int vec4;  // host-verified: every ld % 4 == 0 and bases 16-byte aligned -> 4-wide accesses legal
+};
+
+__device__ __forceinline__ void store4(void* base, int64_t idx, int dtype, const float (&v)[4]) {
+  if (dtype == AFFT_F32) {
+    *(float4*)((float*)base + idx) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    uint2 u;
+    u.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+    u.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    *(uint2*)((bf16_t*)base + idx) = u;
+  }
+}
+__device__ __forceinline__ void load4(const void* base, int64_t idx, int dtype, float (&v)[4]) {
+  if (dtype == AFFT_F32) {
+    float4 t = *(const float4*)((const float*)base + idx);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+    uint2 u = *(const uint2*)((const bf16_t*)base + idx);
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+  }
+}
+
+__device__ __forceinline__ float apply_act(int act, float v, float aux) {
+  switch (act) {
+    case AFFT_ACT_GELU_ERF: return gelu_erf_f(v);
+    case AFFT_ACT_GELU_TANH: return gelu_tanh_f(v);
+    case AFFT_ACT_DGELU_ERF: return v * dgelu_erf_f(aux);
+    case AFFT_ACT_DGELU_TANH: return v * dgelu_tanh_f(aux);
+    default: return v;
+  }
+}
+
+// v[0..3] = accumulators for C[m, n..n+3]
+__device__ __forceinline__ void epilogue4(const EpiParams& e, int m, int n, float (&v)[4]) {
+  if (m >= e.M || n >= e.N) return;
+  const bool full = e.vec4 && (n + 3 < e.N);
+  const float rs = e.rowscale ? e.rowscale[m] : 1.0f;
+  if (full) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] *= e.alpha;
+    if (e.bias) {
+      float4 b = *(const float4*)(e.bias + n);
+      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (e.pre) store4(e.pre, (int64_t)m * e.ldpre + n, e.pre_dtype, v);
+    if (e.act != AFFT_ACT_NONE) {
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      if (e.act >= AFFT_ACT_DGELU_ERF) load4(e.aux, (int64_t)m * e.ldaux + n, e.aux_dtype, a);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = apply_act(e.act, v[r], a[r]);
+    }
+    if (e.rowscale) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= rs;
+    }
+    if (e.residual) {
+      float4 t = *(const float4*)(e.residual + (int64_t)m * e.ldres + n);
+      v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    }
+    if (e.accumulate) {
+      float4 t = *(const float4*)((const float*)e.out + (int64_t)m * e.ldo + n);
+      v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    }
+    store4(e.out, (int64_t)m * e.ldo + n, e.out_dtype, v);
+    if (e.out2) store4(e.out2, (int64_t)m * e.ldo2 + n, e.out2_dtype, v);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int nn = n + r;
+      if (nn >= e.N) break;
+      float x = v[r] * e.alpha;
+      if (e.bias) x += e.bias[nn];
+      if (e.pre) st_any(e.pre, (int64_t)m * e.ldpre + nn, e.pre_dtype, x);
+      float a = 0.f;
+      if (e.act >= AFFT_ACT_DGELU_ERF) a = ld_any(e.aux, (int64_t)m * e.ldaux + nn, e.aux_dtype);
+      x = apply_act(e.act, x, a);
+      x *= rs;
+      if (e.residual) x += e.residual[(int64_t)m * e.ldres + nn];
+      if (e.accumulate) x += ((const float*)e.out)[(int64_t)m * e.ldo + nn];
+      st_any(e.out, (int64_t)m * e.ldo + nn, e.out_dtype, x);
+      if (e.out2) st_any(e.out2, (int64_t)m * e.ldo2 + nn, e.out2_dtype, x);
+    }
+  }
+}

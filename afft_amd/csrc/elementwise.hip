@@ -1,0 +1,211 @@
+// HBM-bound data movement: dtype casts (+ transposed copy through an LDS tile), SA-Fuser token
+// assembly, bias-gradient column sums, periodic (position / token) row tables, Nesterov SGD.
+#include <stdarg.h>
+
+#include "common.h"
+
+// ---- error plumbing shared by every translation unit
+static thread_local char g_err[512] = "";
+void afft_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* afft_last_error(void) { return g_err; }
+extern "C" int afft_version(void) { return 1; }
+
+namespace {
+
+// 64x64 tile per workgroup; coalesced read along cols, coalesced writes along cols (dst) and rows (dst_t)
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, int64_t lds_, int rows, int cols,
+                                                   void* __restrict__ dst, int64_t ldd, int dst_dtype,
+                                                   void* __restrict__ dst_t, int64_t ldt, int pad_cols) {
+  __shared__ float tile[64][65];
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int rr = ty; rr < 64; rr += 4) {
+    const int r = r0 + rr, c = c0 + tx;
+    float v = 0.f;
+    if (r < rows && c < cols) v = src[(int64_t)r * lds_ + c];
+    tile[rr][tx] = v;
+    if (dst && r < rows && c < pad_cols) st_any(dst, (int64_t)r * ldd + c, dst_dtype, v);
+  }
+  if (dst_t) {
+    __syncthreads();
+    for (int cc = ty; cc < 64; cc += 4) {
+      const int c = c0 + cc, r = r0 + tx;
+      if (c < cols && r < rows) st_any(dst_t, (int64_t)c * ldt + r, dst_dtype, tile[tx][cc]);
+    }
+  }
+}
+
+struct Modal8 { const float* p[8]; int64_t ld[8]; };
+
+__global__ __launch_bounds__(256) void assemble_kernel(Modal8 mods, int S, const float* __restrict__ token,
+                                                       int64_t tok_stride_t, const float* __restrict__ mod_embed,
+                                                       int T, int d, float* __restrict__ X) {
+  const int row = blockIdx.x;  // row = bt*S + s
+  const int bt = row / S, s = row - bt * S;
+  const float* src = s == 0 ? token + (int64_t)(bt % T) * tok_stride_t : mods.p[s - 1] + (int64_t)bt * mods.ld[s - 1];
+  const float* emb = mod_embed ? mod_embed + (int64_t)s * d : nullptr;
+  float* dst = X + (int64_t)row * d;
+  for (int c = threadIdx.x * 4; c < d; c += 1024) {
+    float4 v = *(const float4*)(src + c);
+    if (emb) {
+      const float4 e = *(const float4*)(emb + c);
+      v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+    }
+    *(float4*)(dst + c) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ src, int64_t lds_, int dtype, int rows,
+                                                     int cols, int rows_per_block, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += ld_any(src, (int64_t)r * lds_ + c, dtype);
+  atomicAdd(out + c, s);
+}
+
+__global__ __launch_bounds__(256) void add_rows_periodic_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                const float* __restrict__ table, int64_t ldt,
+                                                                int period, int d, float* __restrict__ y, int64_t ldy) {
+  const int row = blockIdx.x;
+  const float* xr = x + (int64_t)row * ldx;
+  const float* tr = table + (int64_t)(row % period) * ldt;
+  float* yr = y + (int64_t)row * ldy;
+  for (int c = threadIdx.x * 4; c < d; c += 1024) {
+    const float4 a = *(const float4*)(xr + c);
+    const float4 b = *(const float4*)(tr + c);
+    *(float4*)(yr + c) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_rows_periodic_kernel(const float* __restrict__ src, int64_t lds_, int rows,
+                                                                   int period, int d, float* __restrict__ out,
+                                                                   int64_t ldo) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int p = blockIdx.y;
+  if (c >= d) return;
+  float s = 0.f;
+  for (int r = p; r < rows; r += period) s += src[(int64_t)r * lds_ + c];
+  out[(int64_t)p * ldo + c] += s;
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ buf, int64_t n, float lr, float mom, float wd,
+                                                  float gscale, int first) {
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      float4 pv = *(float4*)(p + i);
+      const float4 gv = *(const float4*)(g + i);
+      float4 bv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *(float4*)(buf + i);
+      float gg[4] = {gv.x * gscale + wd * pv.x, gv.y * gscale + wd * pv.y, gv.z * gscale + wd * pv.z, gv.w * gscale + wd * pv.w};
+      float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+      float pp[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        bb[r] = first ? gg[r] : mom * bb[r] + gg[r];
+        pp[r] -= lr * (gg[r] + mom * bb[r]);
+      }
+      *(float4*)(buf + i) = make_float4(bb[0], bb[1], bb[2], bb[3]);
+      *(float4*)(p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    } else {
+      for (int64_t j = i; j < n; ++j) {
+        const float gg = g[j] * gscale + wd * p[j];
+        const float bb = first ? gg : mom * buf[j] + gg;
+        buf[j] = bb;
+        p[j] -= lr * (gg + mom * bb);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int afft_cast(const float* src, int64_t lds_, int32_t rows, int32_t cols, void* dst, int64_t ldd,
+                         int32_t dst_dtype, void* dst_t, int64_t ldt, int32_t zero_pad, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(src && (dst || dst_t), "cast: null pointer");
+  AFFT_CHECK(!dst || ldd >= cols, "cast: ldd < cols");
+  AFFT_CHECK(!dst_t || ldt >= rows, "cast: ldt < rows");
+  if (rows == 0 || cols == 0) return 0;
+  const int pad_cols = (dst && zero_pad) ? (int)ldd : cols;
+  dim3 grid((pad_cols + 63) / 64, (rows + 63) / 64);
+  hipLaunchKernelGGL(cast_kernel, grid, dim3(256), 0, stream, src, lds_, rows, cols, dst, ldd, dst_dtype, dst_t, ldt,
+                     pad_cols);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int afft_assemble_tokens(const float* const* feats, const int64_t* ldf, int32_t n_mod, const float* token,
+                                    int64_t tok_stride_t, const float* mod_embed, int32_t BT, int32_t T, int32_t d,
+                                    float* X, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(feats && ldf && token && X, "assemble_tokens: null pointer");
+  AFFT_CHECK(n_mod >= 1 && n_mod <= 8, "assemble_tokens: %d modalities (1..8 supported)", n_mod);
+  AFFT_CHECK(d % 4 == 0, "assemble_tokens: d %% 4 != 0");
+  Modal8 m;
+  for (int i = 0; i < 8; ++i) { m.p[i] = i < n_mod ? feats[i] : nullptr; m.ld[i] = i < n_mod ? ldf[i] : 0; }
+  for (int i = 0; i < n_mod; ++i) AFFT_CHECK(m.p[i] && m.ld[i] % 4 == 0, "assemble_tokens: modality %d pointer/stride", i);
+  if (BT == 0) return 0;
+  const int S = n_mod + 1;
+  hipLaunchKernelGGL(assemble_kernel, dim3(BT * S), dim3(256), 0, stream, m, S, token, tok_stride_t, mod_embed, T, d, X);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int afft_colsum(const void* src, int64_t lds_, int32_t dtype, int32_t rows, int32_t cols, float* out,
+                           int32_t accumulate, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(src && out, "colsum: null pointer");
+  if (cols == 0) return 0;
+  if (!accumulate) {
+    if (hipMemsetAsync(out, 0, sizeof(float) * cols, stream) != hipSuccess) { afft_set_error("colsum: memset failed"); return 2; }
+  }
+  if (rows == 0) return 0;
+  const int rpb = 64;
+  dim3 grid((cols + 255) / 256, (rows + rpb - 1) / rpb);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, src, lds_, dtype, rows, cols, rpb, out);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int afft_add_rows_periodic(const float* x, int64_t ldx, const float* table, int64_t ldt, int32_t rows,
+                                      int32_t period, int32_t d, float* y, int64_t ldy, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(x && table && y && period > 0, "add_rows_periodic: bad argument");
+  AFFT_CHECK(d % 4 == 0 && ldx % 4 == 0 && ldt % 4 == 0 && ldy % 4 == 0, "add_rows_periodic: sizes must be multiples of 4");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(add_rows_periodic_kernel, dim3(rows), dim3(256), 0, stream, x, ldx, table, ldt, period, d, y, ldy);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int afft_reduce_rows_periodic(const float* src, int64_t lds_, int32_t rows, int32_t period, int32_t d,
+                                         float* out, int64_t ldo, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(src && out && period > 0, "reduce_rows_periodic: bad argument");
+  if (rows == 0 || d == 0) return 0;
+  dim3 grid((d + 255) / 256, period);
+  hipLaunchKernelGGL(reduce_rows_periodic_kernel, grid, dim3(256), 0, stream, src, lds_, rows, period, d, out, ldo);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int afft_sgd_nesterov(float* p, const float* g, float* buf, int64_t n, float lr, float mom, float wd,
+                                 float gscale, int32_t first_step, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(p && g && buf, "sgd: null pointer");
+  AFFT_CHECK(((uintptr_t)p & 15) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)buf & 15) == 0, "sgd: buffers must be 16-byte aligned");
+  if (n == 0) return 0;
+  int64_t blocks = (n + 1023) / 1024;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(sgd_kernel, dim3((int)blocks), dim3(256), 0, stream, p, g, buf, n, lr, mom, wd, gscale, first_step);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,123 @@
+// Fused softmax cross-entropy (forward + gradient in one pass over the logits) and MSE.
+// Semantics: common/runner.py:13-37 (MultiDimCrossEntropy, reduction='none', ignore_index=-1 or a
+// boolean row filter for soft targets), :164-166 (MSELoss, both arguments carry gradient).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = is_max ? wave_max(v) : wave_sum(v);
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  float r = sh[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = is_max ? fmaxf(r, sh[w]) : r + sh[w];
+  return r;
+}
+
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, int64_t ldl, int C,
+                                                         const int64_t* __restrict__ labels,
+                                                         const float* __restrict__ soft, int64_t lds,
+                                                         const uint8_t* __restrict__ keep, float gscale,
+                                                         float* __restrict__ loss_sum, void* __restrict__ dlogits,
+                                                         int64_t ldd, int d_dtype, float* __restrict__ row_loss) {
+  __shared__ float sh[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* x = logits + (int64_t)row * ldl;
+  bool kept = true;
+  int64_t lab = -1;
+  if (labels) { lab = labels[row]; kept = lab >= 0; }
+  if (keep) kept = kept && keep[row] != 0;
+  if (!kept) {  // uniform per block
+    if (dlogits) for (int c = tid; c < ldd; c += 256) st_any(dlogits, (int64_t)row * ldd + c, d_dtype, 0.f);
+    if (row_loss && tid == 0) row_loss[row] = 0.f;
+    return;
+  }
+  float m = -INFINITY;
+  for (int c = tid; c < C; c += 256) m = fmaxf(m, x[c]);
+  m = block_reduce(m, sh, true);
+  float se = 0.f, tsum = 0.f, tx = 0.f;
+  const float* t = soft ? soft + (int64_t)row * lds : nullptr;
+  for (int c = tid; c < C; c += 256) {
+    se += expf(x[c] - m);
+    if (t) { tsum += t[c]; tx += t[c] * x[c]; }
+  }
+  se = block_reduce(se, sh, false);
+  const float lse = m + logf(se);
+  float loss;
+  if (t) {
+    tsum = block_reduce(tsum, sh, false);
+    tx = block_reduce(tx, sh, false);
+    loss = lse * tsum - tx;
+  } else {
+    tsum = 1.f;
+    loss = lse - x[lab];
+  }
+  if (tid == 0) {
+    if (row_loss) row_loss[row] = loss;
+    if (loss_sum) atomicAdd(loss_sum, loss);
+  }
+  if (dlogits) {
+    const float inv = 1.0f / se;
+    for (int c = tid; c < ldd; c += 256) {
+      float g = 0.f;
+      if (c < C) {
+        const float p = expf(x[c] - m) * inv;
+        const float tc = t ? t[c] : (c == lab ? 1.f : 0.f);
+        g = gscale * (p * tsum - tc);
+      }
+      st_any(dlogits, (int64_t)row * ldd + c, d_dtype, g);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b,
+                                                  int64_t ldb, int rows, int d, float gscale,
+                                                  float* __restrict__ loss_sum, float* __restrict__ da, int64_t ldda,
+                                                  float* __restrict__ db, int64_t lddb) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  const int64_t total = (int64_t)rows * d;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / d), c = (int)(i - (int64_t)r * d);
+    const float diff = a[(int64_t)r * lda + c] - b[(int64_t)r * ldb + c];
+    acc += diff * diff;
+    const float g = 2.f * gscale * diff;
+    if (da) da[(int64_t)r * ldda + c] += g;
+    if (db) db[(int64_t)r * lddb + c] -= g;
+  }
+  acc = block_reduce(acc, sh, false);
+  if (threadIdx.x == 0 && loss_sum) atomicAdd(loss_sum, acc);
+}
+
+}  // namespace
+
+extern "C" int afft_softmax_ce(const float* logits, int64_t ldl, int32_t rows, int32_t C, const int64_t* labels,
+                               const float* soft, int64_t lds, const uint8_t* keep, float gscale, float* loss_sum,
+                               void* dlogits, int64_t ldd, int32_t d_dtype, float* row_loss, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(logits, "softmax_ce: null logits");
+  AFFT_CHECK((labels != nullptr) != (soft != nullptr), "softmax_ce: give exactly one of labels / soft targets");
+  AFFT_CHECK(C > 0 && ldl >= C && (!dlogits || ldd >= C), "softmax_ce: bad sizes");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(rows), dim3(256), 0, stream, logits, ldl, C, labels, soft, lds, keep,
+                     gscale, loss_sum, dlogits, ldd, d_dtype, row_loss);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int afft_mse(const float* a, int64_t lda, const float* b, int64_t ldb, int32_t rows, int32_t d,
+                        float gscale, float* loss_sum, float* da, int64_t ldda, float* db, int64_t lddb,
+                        void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(a && b, "mse: null pointer");
+  if (rows == 0 || d == 0) return 0;
+  const int64_t total = (int64_t)rows * d;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(mse_kernel, dim3(grid), dim3(256), 0, stream, a, lda, b, ldb, rows, d, gscale, loss_sum, da, ldda,
+                     db, lddb);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,200 @@
+// LayerNorm forward / backward (HBM-bound; one wave per row, 16-byte accesses, wave-level reductions).
+// nn.LayerNorm semantics (biased variance, eps inside the sqrt): models/fusion.py:281,362,
+// models/transformerblock.py:122,127,150-152 (eps 1e-6) and HF GPT-2 ln_1/ln_2/ln_f (eps 1e-5).
+#include "common.h"
+
+namespace {
+
+constexpr int LN_WAVES = 4;  // rows per workgroup step
+
+template <int NV>  // float4 chunks per lane: d <= 256*NV
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                     const float* __restrict__ w, const float* __restrict__ b,
+                                                     float eps, int rows, int d, void* __restrict__ y, int64_t ldy,
+                                                     int y_dtype, float* __restrict__ mean, float* __restrict__ rstd) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * LN_WAVES + wave;
+  if (row >= rows) return;
+  const float* xr = x + (int64_t)row * ldx;
+  const int nq = d >> 2;  // float4 count (d % 4 == 0 checked on the host)
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < NV; ++t) {
+    const int q = lane + 64 * t;
+    v[t] = q < nq ? *(const float4*)(xr + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[t].x + v[t].y) + (v[t].z + v[t].w);
+  }
+  const float mu = wave_sum(s) / (float)d;
+  float ss = 0.f;
+#pragma unroll
+  for (int t = 0; t < NV; ++t) {
+    const int q = lane + 64 * t;
+    if (q < nq) {
+      const float a = v[t].x - mu, bq = v[t].y - mu, c = v[t].z - mu, e = v[t].w - mu;
+      ss += (a * a + bq * bq) + (c * c + e * e);
+    }
+  }
+  const float rs = rsqrtf(wave_sum(ss) / (float)d + eps);
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+#pragma unroll
+  for (int t = 0; t < NV; ++t) {
+    const int q = lane + 64 * t;
+    if (q < nq) {
+      float o[4] = {(v[t].x - mu) * rs, (v[t].y - mu) * rs, (v[t].z - mu) * rs, (v[t].w - mu) * rs};
+      if (w) {
+        const float4 ww = *(const float4*)(w + 4 * q);
+        o[0] *= ww.x; o[1] *= ww.y; o[2] *= ww.z; o[3] *= ww.w;
+      }
+      if (b) {
+        const float4 bb = *(const float4*)(b + 4 * q);
+        o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w;
+      }
+      store4(y, (int64_t)row * ldy + 4 * q, y_dtype, o);
+    }
+  }
+}
+
+// backward: each wave walks rows r = part*4+wave, += 4*nparts; keeps dw/db partial sums for its columns
+// in registers, combined across the 4 waves through LDS, one [2][d] slab per workgroup.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, int64_t lddy, int dy_dtype,
+                                                     const float* __restrict__ x, int64_t ldx,
+                                                     const float* __restrict__ w, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, int rows, int d,
+                                                     const float* __restrict__ dx_in, float* __restrict__ dx_out,
+                                                     int64_t lddx, bf16_t* __restrict__ dx_bf16,
+                                                     float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = (float*)smem;  // [4 waves][2][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nq = d >> 2;
+  float4 pw[NV], pb[NV];
+#pragma unroll
+  for (int t = 0; t < NV; ++t) pw[t] = pb[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float inv_d = 1.0f / (float)d;
+  for (int row = blockIdx.x * LN_WAVES + wave; row < rows; row += gridDim.x * LN_WAVES) {
+    const float mu = mean[row], rs = rstd[row];
+    const float* xr = x + (int64_t)row * ldx;
+    float g[NV][4], xh[NV][4];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+      const int q = lane + 64 * t;
+      if (q < nq) {
+        float dyv[4];
+        load4(dy, (int64_t)row * lddy + 4 * q, dy_dtype, dyv);
+        const float4 xv = *(const float4*)(xr + 4 * q);
+        float4 ww = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (w) ww = *(const float4*)(w + 4 * q);
+        xh[t][0] = (xv.x - mu) * rs; xh[t][1] = (xv.y - mu) * rs; xh[t][2] = (xv.z - mu) * rs; xh[t][3] = (xv.w - mu) * rs;
+        g[t][0] = dyv[0] * ww.x; g[t][1] = dyv[1] * ww.y; g[t][2] = dyv[2] * ww.z; g[t][3] = dyv[3] * ww.w;
+        pw[t].x += dyv[0] * xh[t][0]; pw[t].y += dyv[1] * xh[t][1]; pw[t].z += dyv[2] * xh[t][2]; pw[t].w += dyv[3] * xh[t][3];
+        pb[t].x += dyv[0]; pb[t].y += dyv[1]; pb[t].z += dyv[2]; pb[t].w += dyv[3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { c1 += g[t][r]; c2 += g[t][r] * xh[t][r]; }
+      }
+    }
+    c1 = wave_sum(c1) * inv_d;
+    c2 = wave_sum(c2) * inv_d;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+      const int q = lane + 64 * t;
+      if (q < nq) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = rs * (g[t][r] - c1 - xh[t][r] * c2);
+        const int64_t idx = (int64_t)row * lddx + 4 * q;
+        if (dx_in) {
+          const float4 a = *(const float4*)(dx_in + idx);
+          o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w;
+        }
+        *(float4*)(dx_out + idx) = make_float4(o[0], o[1], o[2], o[3]);
+        if (dx_bf16) store4(dx_bf16, idx, AFFT_BF16, o);
+      }
+    }
+  }
+  // combine the 4 waves' column partials
+#pragma unroll
+  for (int t = 0; t < NV; ++t) {
+    const int q = lane + 64 * t;
+    if (q < nq) {
+      *(float4*)(red + (wave * 2 + 0) * d + 4 * q) = pw[t];
+      *(float4*)(red + (wave * 2 + 1) * d + 4 * q) = pb[t];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * d; c += 256) {
+    const int which = c / d, col = c - which * d;
+    float s = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < LN_WAVES; ++wv) s += red[(wv * 2 + which) * d + col];
+    partial[(int64_t)blockIdx.x * 2 * d + c] = s;
+  }
+}
+
+__global__ void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nparts, int d, float* __restrict__ dw,
+                                     float* __restrict__ db) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * d) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * 2 * d + c];
+  if (c < d) { if (dw) dw[c] += s; } else { if (db) db[c - d] += s; }
+}
+
+int pick_nv(int d) {
+  const int nq = d / 4;
+  for (int nv = 1; nv <= 16; nv *= 2)
+    if (nq <= 64 * nv) return nv;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int afft_layernorm_bwd_nparts(int32_t rows) {
+  int n = (rows + LN_WAVES - 1) / LN_WAVES;
+  return n < 1 ? 1 : (n > 512 ? 512 : n);
+}
+
+extern "C" int afft_layernorm_fwd(const float* x, int64_t ldx, const float* w, const float* b, float eps,
+                                  int32_t rows, int32_t d, void* y, int64_t ldy, int32_t y_dtype, float* mean,
+                                  float* rstd, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(x && y, "layernorm_fwd: null pointer");
+  AFFT_CHECK(d > 0 && d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "layernorm_fwd: d/ld must be multiples of 4 (d=%d)", d);
+  const int nv = pick_nv(d);
+  AFFT_CHECK(nv != 0, "layernorm_fwd: d=%d exceeds 4096", d);
+  if (rows == 0) return 0;
+  const int grid = (rows + LN_WAVES - 1) / LN_WAVES;
+#define LN_FWD(NV) hipLaunchKernelGGL(ln_fwd_kernel<NV>, dim3(grid), dim3(256), 0, stream, x, ldx, w, b, eps, rows, d, y, ldy, y_dtype, mean, rstd)
+  switch (nv) { case 1: LN_FWD(1); break; case 2: LN_FWD(2); break; case 4: LN_FWD(4); break; case 8: LN_FWD(8); break; default: LN_FWD(16); }
+#undef LN_FWD
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int afft_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx,
+                                  const float* w, const float* mean, const float* rstd, int32_t rows, int32_t d,
+                                  const float* dx_in, float* dx_out, int64_t lddx, void* dx_bf16, float* dw,
+                                  float* db, float* partial, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(dy && x && mean && rstd && dx_out && partial, "layernorm_bwd: null pointer");
+  AFFT_CHECK(d > 0 && d % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "layernorm_bwd: d/ld must be multiples of 4");
+  const int nv = pick_nv(d);
+  AFFT_CHECK(nv != 0 && d <= 4096, "layernorm_bwd: d=%d exceeds 4096", d);
+  if (rows == 0) return 0;
+  const int grid = afft_layernorm_bwd_nparts(rows);
+  const size_t lds = (size_t)LN_WAVES * 2 * d * sizeof(float);
+#define LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(grid), dim3(256), lds, stream, dy, lddy, dy_dtype, x, ldx, w, mean, rstd, rows, d, dx_in, dx_out, lddx, (bf16_t*)dx_bf16, partial)
+  switch (nv) { case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; case 4: LN_BWD(4); break; case 8: LN_BWD(8); break; default: LN_BWD(16); }
+#undef LN_BWD
+  AFFT_LAUNCH_CHECK();
+  if (dw || db) {
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, stream, partial, grid, d, dw, db);
+    AFFT_LAUNCH_CHECK();
+  }
+  return 0;
+}

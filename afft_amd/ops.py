@@ -1,0 +1,205 @@
+"""Tensor-level wrappers over the C-ABI (include/afft_hip.h).  PyTorch is used for device memory and
+streams only; every computation below runs in the hand-written HIP kernels of libafft_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from ._lib import (ACT_DGELU_ERF, ACT_DGELU_TANH, ACT_GELU_ERF, ACT_GELU_TANH, ACT_NONE, BF16, F32, MASK_CAUSAL,
+                   MASK_DIAG, MASK_NONE)
+
+Tensor = torch.Tensor
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _dt(t: Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"afft_amd: unsupported dtype {t.dtype}")
+
+
+def _p(t: Optional[Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("afft_amd: tensors must live on the GPU (there is no CPU path)")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rowmajor(t: Tensor, what: str):
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError(f"afft_amd: {what} must be a 2-D tensor with unit column stride, got {tuple(t.shape)} {t.stride()}")
+    return t.stride(0)
+
+
+def gemm(a: Tensor, b: Tensor, out: Tensor, *, a_t: bool = False, b_t: bool = False, bias: Optional[Tensor] = None,
+         act: int = ACT_NONE, aux: Optional[Tensor] = None, pre: Optional[Tensor] = None,
+         rowscale: Optional[Tensor] = None, residual: Optional[Tensor] = None, accumulate: bool = False,
+         out2: Optional[Tensor] = None, alpha: float = 1.0) -> Tensor:
+    """out = epilogue(alpha * A @ B).  A = a (or a.T if a_t), B = b (or b.T if b_t); a, b 2-D views."""
+    M, K = (a.shape[1], a.shape[0]) if a_t else (a.shape[0], a.shape[1])
+    Kb, N = (b.shape[1], b.shape[0]) if b_t else (b.shape[0], b.shape[1])
+    if K != Kb:
+        raise ValueError(f"afft_amd.gemm: inner sizes differ ({K} vs {Kb})")
+    if a.dtype != b.dtype:
+        raise TypeError("afft_amd.gemm: operand dtypes differ")
+    if out.shape[0] != M or out.shape[1] != N:
+        raise ValueError(f"afft_amd.gemm: out is {tuple(out.shape)}, expected ({M},{N})")
+    d = L.GemmDesc()
+    d.M, d.N, d.K, d.dtype = M, N, K, _dt(a)
+    d.A = _p(a)
+    d.a_rs, d.a_cs = (a.stride(1), a.stride(0)) if a_t else (a.stride(0), a.stride(1))
+    d.B = _p(b)
+    d.b_rs, d.b_cs = (b.stride(1), b.stride(0)) if b_t else (b.stride(0), b.stride(1))
+    d.alpha = alpha
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
+    d.bias = _p(bias)
+    d.act = act
+    if aux is not None:
+        d.aux, d.ldaux, d.aux_dtype = _p(aux), _rowmajor(aux, "aux"), _dt(aux)
+    if pre is not None:
+        d.pre, d.ldpre, d.pre_dtype = _p(pre), _rowmajor(pre, "pre"), _dt(pre)
+    if rowscale is not None:
+        assert rowscale.dtype == torch.float32 and rowscale.numel() == M
+    d.rowscale = _p(rowscale)
+    if residual is not None:
+        assert residual.dtype == torch.float32
+        d.residual, d.ldres = _p(residual), _rowmajor(residual, "residual")
+    d.accumulate = 1 if accumulate else 0
+    d.out, d.ldo, d.out_dtype = _p(out), _rowmajor(out, "out"), _dt(out)
+    if out2 is not None:
+        d.out2, d.ldo2, d.out2_dtype = _p(out2), _rowmajor(out2, "out2"), _dt(out2)
+    L.check(L.lib().afft_gemm(C.byref(d), _stream()), "gemm")
+    return out
+
+
+def layernorm_fwd(x: Tensor, w: Optional[Tensor], b: Optional[Tensor], eps: float, y: Tensor,
+                  mean: Optional[Tensor] = None, rstd: Optional[Tensor] = None) -> Tensor:
+    """x fp32 [rows,d] view (row stride free), y [rows,d] fp32/bf16."""
+    assert x.dtype == torch.float32
+    rows, d = x.shape
+    L.check(L.lib().afft_layernorm_fwd(_p(x), _rowmajor(x, "x"), _p(w), _p(b), eps, rows, d, _p(y),
+                                       _rowmajor(y, "y"), _dt(y), _p(mean), _p(rstd), _stream()), "layernorm_fwd")
+    return y
+
+
+def layernorm_bwd(dy: Tensor, x: Tensor, w: Optional[Tensor], mean: Tensor, rstd: Tensor, dx_out: Tensor,
+                  dx_in: Optional[Tensor] = None, dx_bf16: Optional[Tensor] = None, dw: Optional[Tensor] = None,
+                  db: Optional[Tensor] = None) -> Tensor:
+    rows, d = x.shape
+    nparts = L.lib().afft_layernorm_bwd_nparts(rows)
+    partial = torch.empty(nparts * 2 * d, dtype=torch.float32, device=x.device)
+    lddx = _rowmajor(dx_out, "dx_out")
+    if dx_in is not None:
+        assert _rowmajor(dx_in, "dx_in") == lddx
+    if dx_bf16 is not None:
+        assert dx_bf16.dtype == torch.bfloat16 and _rowmajor(dx_bf16, "dx_bf16") == lddx
+    L.check(L.lib().afft_layernorm_bwd(_p(dy), _rowmajor(dy, "dy"), _dt(dy), _p(x), _rowmajor(x, "x"), _p(w),
+                                       _p(mean), _p(rstd), rows, d, _p(dx_in), _p(dx_out), lddx, _p(dx_bf16),
+                                       _p(dw), _p(db), _p(partial), _stream()), "layernorm_bwd")
+    return dx_out
+
+
+def attention_fwd(q: Tensor, k: Tensor, v: Tensor, nseq: int, L_: int, H: int, hd: int, scale: float, mask: int,
+                  out: Tensor, probs: Optional[Tensor]) -> Tensor:
+    assert q.dtype == k.dtype == v.dtype == out.dtype
+    L.check(L.lib().afft_attention_fwd(_p(q), _rowmajor(q, "q"), _p(k), _rowmajor(k, "k"), _p(v), _rowmajor(v, "v"),
+                                       _dt(q), nseq, L_, H, hd, scale, mask, _p(out), _rowmajor(out, "out"),
+                                       _p(probs), _stream()), "attention_fwd")
+    return out
+
+
+def attention_bwd(dout: Tensor, q: Tensor, k: Tensor, v: Tensor, probs: Tensor, nseq: int, L_: int, H: int, hd: int,
+                  scale: float, dq: Tensor, dk: Tensor, dv: Tensor):
+    assert dout.dtype == q.dtype == k.dtype == v.dtype == dq.dtype == dk.dtype == dv.dtype
+    L.check(L.lib().afft_attention_bwd(_p(dout), _rowmajor(dout, "dout"), _p(q), _rowmajor(q, "q"), _p(k),
+                                       _rowmajor(k, "k"), _p(v), _rowmajor(v, "v"), _dt(q), _p(probs), nseq, L_, H,
+                                       hd, scale, _p(dq), _rowmajor(dq, "dq"), _p(dk), _rowmajor(dk, "dk"), _p(dv),
+                                       _rowmajor(dv, "dv"), _stream()), "attention_bwd")
+
+
+def softmax_ce(logits: Tensor, C_: int, *, labels: Optional[Tensor] = None, soft: Optional[Tensor] = None,
+               keep: Optional[Tensor] = None, gscale: float = 1.0, loss_sum: Optional[Tensor] = None,
+               dlogits: Optional[Tensor] = None, row_loss: Optional[Tensor] = None):
+    """logits fp32 [rows, >=C] view. labels int64 [rows] (-1 ignored) or soft fp32 [rows, C]; keep uint8 [rows]."""
+    rows = logits.shape[0]
+    assert logits.dtype == torch.float32
+    if labels is not None:
+        assert labels.dtype == torch.int64 and labels.numel() == rows and labels.is_contiguous()
+    if soft is not None:
+        assert soft.dtype == torch.float32 and soft.shape[0] == rows
+    if keep is not None:
+        assert keep.dtype == torch.uint8 and keep.numel() == rows
+    L.check(L.lib().afft_softmax_ce(_p(logits), _rowmajor(logits, "logits"), rows, C_, _p(labels), _p(soft),
+                                    _rowmajor(soft, "soft") if soft is not None else 0, _p(keep), gscale,
+                                    _p(loss_sum), _p(dlogits),
+                                    _rowmajor(dlogits, "dlogits") if dlogits is not None else 0,
+                                    _dt(dlogits) if dlogits is not None else 0, _p(row_loss), _stream()), "softmax_ce")
+
+
+def mse(a: Tensor, b: Tensor, gscale: float, loss_sum: Optional[Tensor], da: Optional[Tensor], db: Optional[Tensor]):
+    rows, d = a.shape
+    assert a.dtype == b.dtype == torch.float32 and b.shape == a.shape
+    L.check(L.lib().afft_mse(_p(a), _rowmajor(a, "a"), _p(b), _rowmajor(b, "b"), rows, d, gscale, _p(loss_sum),
+                             _p(da), _rowmajor(da, "da") if da is not None else 0, _p(db),
+                             _rowmajor(db, "db") if db is not None else 0, _stream()), "mse")
+
+
+def cast(src: Tensor, dst: Optional[Tensor], dst_t: Optional[Tensor] = None, zero_pad: bool = False):
+    """fp32 [rows, cols] -> dst [rows, >=cols] and/or dst_t [cols, >=rows] (dtype of dst)."""
+    rows, cols = src.shape
+    assert src.dtype == torch.float32
+    ref = dst if dst is not None else dst_t
+    L.check(L.lib().afft_cast(_p(src), _rowmajor(src, "src"), rows, cols, _p(dst),
+                              dst.stride(0) if dst is not None else 0, _dt(ref), _p(dst_t),
+                              dst_t.stride(0) if dst_t is not None else 0, 1 if zero_pad else 0, _stream()), "cast")
+
+
+def assemble_tokens(feats: Sequence[Tensor], token: Tensor, tok_stride_t: int, mod_embed: Optional[Tensor], BT: int,
+                    T: int, d: int, X: Tensor):
+    n = len(feats)
+    ptrs = (C.c_void_p * n)(*[_p(f) for f in feats])
+    lds = (C.c_int64 * n)(*[_rowmajor(f, "feat") for f in feats])
+    for f in feats:
+        assert f.dtype == torch.float32 and f.shape == (BT, d)
+    assert X.is_contiguous() and X.dtype == torch.float32
+    L.check(L.lib().afft_assemble_tokens(ptrs, lds, n, _p(token), tok_stride_t, _p(mod_embed), BT, T, d, _p(X),
+                                         _stream()), "assemble_tokens")
+    return X
+
+
+def colsum(src: Tensor, out: Tensor, accumulate: bool = False):
+    rows, cols = src.shape
+    assert out.dtype == torch.float32 and out.numel() >= cols
+    L.check(L.lib().afft_colsum(_p(src), _rowmajor(src, "src"), _dt(src), rows, cols, _p(out),
+                                1 if accumulate else 0, _stream()), "colsum")
+    return out
+
+
+def add_rows_periodic(x: Tensor, table: Tensor, period: int, y: Tensor):
+    rows, d = x.shape
+    L.check(L.lib().afft_add_rows_periodic(_p(x), _rowmajor(x, "x"), _p(table), _rowmajor(table, "table"), rows,
+                                           period, d, _p(y), _rowmajor(y, "y"), _stream()), "add_rows_periodic")
+    return y
+
+
+def reduce_rows_periodic(src: Tensor, period: int, out: Tensor):
+    rows, d = src.shape
+    L.check(L.lib().afft_reduce_rows_periodic(_p(src), _rowmajor(src, "src"), rows, period, d, _p(out),
+                                              _rowmajor(out, "out"), _stream()), "reduce_rows_periodic")
+    return out
+
+
+def sgd_nesterov(p: Tensor, g: Tensor, buf: Tensor, lr: float, mom: float, wd: float, gscale: float, first: bool):
+    assert p.is_contiguous() and g.is_contiguous() and buf.is_contiguous()
+    L.check(L.lib().afft_sgd_nesterov(_p(p), _p(g), _p(buf), p.numel(), lr, mom, wd, gscale, 1 if first else 0,
+                                      _stream()), "sgd_nesterov")

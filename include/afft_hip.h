@@ -1,0 +1,137 @@
+/* afft_hip.h -- C-ABI of the MI355X (gfx950) kernels behind the AFFT hot path.
+ *
+ * The reference (zeyun-zhong/AFFT) is pure Python/PyTorch and has NO FFI of its own
+ * ("Native components: none"), so this ABI is what a maintainer would bind
+ * from the reference's Python modules with ctypes.  Every entry point
+ * names the reference code whose arithmetic it replaces (paths relative to the reference).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocator); the library
+ *     never allocates, frees or retains them; `stream` is a hipStream_t passed as void*;
+ *   - no entry point synchronises the host; all work is enqueued on `stream`;
+ *   - return value 0 = success; non-zero = error, text via afft_last_error() (thread-local);
+ *   - matrices are row-major with explicit element strides; dtype codes below.
+ */
+#ifndef AFFT_HIP_H
+#define AFFT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { AFFT_F32 = 0, AFFT_BF16 = 1 };
+enum { AFFT_ACT_NONE = 0, AFFT_ACT_GELU_ERF = 1, AFFT_ACT_GELU_TANH = 2,
+       AFFT_ACT_DGELU_ERF = 3,   /* v *= d/du gelu_erf(aux[m,n])  (backward of nn.GELU)  */
+       AFFT_ACT_DGELU_TANH = 4 };/* v *= d/du gelu_new(aux[m,n])  (backward of HF gelu_new) */
+enum { AFFT_MASK_NONE = 0, AFFT_MASK_DIAG = 1, AFFT_MASK_CAUSAL = 2 };
+
+const char* afft_last_error(void);
+int afft_version(void);
+
+/* ------------------------------------------------------------------ GEMM + fused epilogue
+ * C[m,n] = epilogue( alpha * sum_k A(m,k) * B(k,n) ),  A(m,k) = A[m*a_rs + k*a_cs],
+ * B(k,n) = B[k*b_rs + n*b_cs].   Replaces every nn.Linear / HF Conv1D on the path:
+ *   models/transformerblock.py:14,16,21,34,48-50,84-89 ; models/feature_mapping.py:59-61 ;
+ *   models/future_prediction.py:108-121,246-255 ; HF modeling_gpt2.py Conv1D (c_attn, c_proj, c_fc)
+ * and their backward (dgrad: dX = dY*W ; wgrad: dW = dY^T*X).
+ * epilogue order: v = alpha*acc ; v += bias[n] ; pre[m,n] = v ; v = act(v | aux[m,n]) ;
+ *                 v *= rowscale[m] ; v += residual[m,n] ; v += out[m,n] if accumulate ; store out, out2.
+ * dtype = operand dtype of A and B (both the same).  With AFFT_BF16 operands, k-contiguous
+ * ("NT": a_cs==1,b_rs==1) and k-strided ("TN": a_rs==1,b_cs==1) layouts with K%64==0 and 16-byte
+ * aligned rows take the MFMA bf16 fast path (fp32 accumulate); anything else, and every AFFT_F32 call,
+ * runs the exact-fp32 MFMA path (v_mfma_f32_32x32x2_f32).                                            */
+typedef struct {
+  int32_t M, N, K;
+  int32_t dtype;
+  const void* A; int64_t a_rs, a_cs;
+  const void* B; int64_t b_rs, b_cs;
+  float alpha;
+  const float* bias;                 /* [N] or NULL */
+  int32_t act;
+  const void* aux; int64_t ldaux; int32_t aux_dtype;   /* read by DGELU_* */
+  void* pre; int64_t ldpre; int32_t pre_dtype;         /* optional store of the pre-activation */
+  const float* rowscale;             /* [M] or NULL (DropPath / per-row loss weights) */
+  const float* residual; int64_t ldres;                /* fp32 or NULL */
+  int32_t accumulate;                /* out (fp32 only) += */
+  void* out; int64_t ldo; int32_t out_dtype;
+  void* out2; int64_t ldo2; int32_t out2_dtype;        /* optional second copy */
+} afft_gemm_t;
+int afft_gemm(const afft_gemm_t* g, void* stream);
+
+/* ------------------------------------------------------------------ LayerNorm
+ * nn.LayerNorm(eps) fwd/bwd: models/fusion.py:281,362 ; transformerblock.py:122,127,150-152 ;
+ * HF GPT2 ln_1/ln_2/ln_f (eps 1e-5).   x is fp32 [rows, d] (row stride ldx); y dtype selectable.
+ * A row stride ldx = S*d selects token 0 of every frame (fuser tail, models/fusion.py:362-364: only
+ * token 0 of the final LayerNorm is used).  w / b may be NULL (elementwise_affine=False). */
+int afft_layernorm_fwd(const float* x, int64_t ldx, const float* w, const float* b,
+                       float eps, int32_t rows, int32_t d, void* y, int64_t ldy, int32_t y_dtype,
+                       float* mean, float* rstd, void* stream);
+/* dx_out[r] = (dx_in ? dx_in[r] : 0) + LN'(dy)[r]; dw/db are ACCUMULATED into (+=).  dy dtype selectable.
+ * dx_bf16 (optional) receives a bf16 copy of dx_out (feeds the next dgrad/wgrad GEMMs).
+ * partial: fp32 workspace of at least 2*d*afft_layernorm_bwd_nparts(rows) floats. */
+int afft_layernorm_bwd_nparts(int32_t rows);
+int afft_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx,
+                       const float* w, const float* mean, const float* rstd,
+                       int32_t rows, int32_t d, const float* dx_in, float* dx_out, int64_t lddx,
+                       void* dx_bf16, float* dw, float* db, float* partial, void* stream);
+
+/* ------------------------------------------------------------------ small-sequence attention
+ * softmax(q k^T * scale + mask) v per (sequence, head); L <= 32 tokens per sequence.
+ *   SA-Fuser: L = M+1 modality tokens of one frame  (models/transformerblock.py:24-33, fusion.py:338-349)
+ *   GPT-2:    L = T frames, causal                   (HF modeling_gpt2.py eager_attention_forward)
+ *   CA-Fuser: causal self and cross attention        (models/transformerblock.py:56-76)
+ * q/k/v: [nseq*L, *] with row strides ldq/ldk/ldv, head h at columns h*hd..; out [nseq*L, H*hd].
+ * probs: fp32 [nseq, H, L, L] (the attention weights the reference returns; also saved for backward). */
+int afft_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                       int32_t dtype, int32_t nseq, int32_t L, int32_t H, int32_t hd, float scale, int32_t mask,
+                       void* out, int64_t ldo, float* probs, void* stream);
+int afft_attention_bwd(const void* dout, int64_t lddo, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                       const void* v, int64_t ldv, int32_t dtype, const float* probs, int32_t nseq, int32_t L,
+                       int32_t H, int32_t hd, float scale, void* dq, int64_t lddq, void* dk, int64_t lddk,
+                       void* dv, int64_t lddv, void* stream);
+
+/* ------------------------------------------------------------------ losses (common/runner.py:13-37,112-168)
+ * Softmax cross-entropy over C classes, fwd + bwd in one pass.
+ *   hard: labels int64[rows], label -1 = ignored row (loss 0, grad 0);   soft: targets fp32 [rows, C] and
+ *   optional keep uint8[rows] (0 = row removed).  loss_sum += sum of row losses (fp32 atomic);
+ *   dlogits[r,:] = gscale * (softmax - target) for kept rows, 0 otherwise; columns C..ldd-1 are zeroed. */
+int afft_softmax_ce(const float* logits, int64_t ldl, int32_t rows, int32_t C, const int64_t* labels,
+                    const float* soft, int64_t lds, const uint8_t* keep, float gscale, float* loss_sum,
+                    void* dlogits, int64_t ldd, int32_t d_dtype, float* row_loss, void* stream);
+/* MSE between a[rows,d] and b[rows,d] (fp32): loss_sum += sum (a-b)^2 ; da = gscale*2*(a-b) ; db = -da
+ * (common/runner.py:164-166: both sides carry gradient). da/db may be NULL; they are ACCUMULATED (+=). */
+int afft_mse(const float* a, int64_t lda, const float* b, int64_t ldb, int32_t rows, int32_t d, float gscale,
+             float* loss_sum, float* da, int64_t ldda, float* db, int64_t lddb, void* stream);
+
+/* ------------------------------------------------------------------ data movement / elementwise
+ * fp32 [rows, cols] -> dst dtype copy; if dst_t != NULL also writes the transpose [cols, rows] (ld = ldt).
+ * Used for the cached bf16 weights (W and W^T) and activation casts. Columns cols..ldd-1 of dst are zero-filled
+ * when zero_pad != 0 (K padding for the fast GEMM path). */
+int afft_cast(const float* src, int64_t lds, int32_t rows, int32_t cols, void* dst, int64_t ldd, int32_t dst_dtype,
+              void* dst_t, int64_t ldt, int32_t zero_pad, void* stream);
+/* ModalTokenCMFuser token assembly (models/fusion.py:338-352): X[(b*T+t), s, :] for s=0 the modal token
+ * (token + (t)*tok_stride_t; stride 0 = one universal token), s>=1 modality s-1 at feats[s-1] + (b*T+t)*ldf[s-1];
+ * + modality_embedding[s,:] if given.  feats / ldf are HOST arrays of n_mod (<= 8) device pointers / strides. */
+int afft_assemble_tokens(const float* const* feats, const int64_t* ldf, int32_t n_mod, const float* token,
+                         int64_t tok_stride_t, const float* mod_embed, int32_t BT, int32_t T, int32_t d,
+                         float* X, void* stream);
+/* column sums: out[n] (+)= sum_m src[m, n]   (bias gradients; src dtype selectable) */
+int afft_colsum(const void* src, int64_t lds, int32_t dtype, int32_t rows, int32_t cols, float* out,
+                int32_t accumulate, void* stream);
+/* y[r, :] = x[r, :] + table[(r % period), :]   (GPT-2 wpe / CA-Fuser position embedding; fp32) */
+int afft_add_rows_periodic(const float* x, int64_t ldx, const float* table, int64_t ldt, int32_t rows,
+                           int32_t period, int32_t d, float* y, int64_t ldy, void* stream);
+/* out[(r % period), :] += sum over r of src[r, :]  (gradient of the above table) */
+int afft_reduce_rows_periodic(const float* src, int64_t lds, int32_t rows, int32_t period, int32_t d,
+                              float* out, int64_t ldo, void* stream);
+/* Nesterov-momentum SGD over one flat fp32 parameter buffer (conf/opt/optimizer/sgd.yaml, train.py:262):
+ *   g += wd*p ; buf = mom*buf + g ; p -= lr*(g + mom*buf) ; grad is scaled by gscale first (1/world). */
+int afft_sgd_nesterov(float* p, const float* g, float* buf, int64_t n, float lr, float mom, float wd,
+                      float gscale, int32_t first_step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFFT_HIP_H */

@@ -1,0 +1,324 @@
+"""GPU: every C-ABI kernel against plain fp32/fp64 torch math on the same seeded inputs.
+
+Tolerances: fp32 kernels 2e-5 relative-L2 (exact-fp32 MFMA, different summation order only);
+bf16-operand kernels 1e-2 (bf16 rounding of the inputs is applied to the reference too, so what is
+left is accumulation order + output rounding)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import rel_l2  # noqa: E402
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def bfr(t):  # round to bf16 and back (reference sees the same operand values)
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _act(kind, v, aux):
+    from oracle import afft_oracle as O
+    if kind == 0:
+        return v
+    if kind == 1:
+        return O.gelu_erf(v)
+    if kind == 2:
+        return O.gelu_tanh(v)
+    x = aux.clone().requires_grad_(True)
+    (O.gelu_erf(x) if kind == 3 else O.gelu_tanh(x)).sum().backward()
+    return v * x.grad
+
+
+GEMM_CASES = [
+    # name, M, N, K, dtype, layout, epilogue
+    ("nt_bf16_full", 256, 384, 256, "bf16", "nt", dict()),
+    ("nt_bf16_tails", 200, 3806, 128, "bf16", "nt", dict(bias=True, out_f32=True, ldo_pad=3840)),
+    ("nt_bf16_gelu", 130, 512, 192, "bf16", "nt", dict(bias=True, act=1, pre=True)),
+    ("nt_bf16_tanh_res", 128, 256, 64, "bf16", "nt", dict(bias=True, act=2)),
+    ("nt_bf16_residual", 320, 256, 512, "bf16", "nt", dict(bias=True, residual=True, out_f32=True, rowscale=True)),
+    ("nt_bf16_dgelu", 128, 256, 128, "bf16", "nt", dict(act=3)),
+    ("nt_bf16_dgelu_tanh", 64, 128, 64, "bf16", "nt", dict(act=4, out2=True)),
+    ("tn_bf16_full", 256, 384, 256, "bf16", "tn", dict(out_f32=True)),
+    ("tn_bf16_tails_acc", 3806, 200, 192, "bf16", "tn", dict(out_f32=True, accumulate=True, lda_pad=3840, ldb_pad=256)),
+    ("tn_bf16_small", 24, 64, 64, "bf16", "tn", dict(out_f32=True)),
+    ("nt_bf16_fallback_k", 70, 50, 24, "bf16", "nt", dict(bias=True, out_f32=True)),   # K % 64 != 0 -> fp32-MFMA path
+    ("nt_f32", 150, 130, 100, "f32", "nt", dict(bias=True, act=1, pre=True)),
+    ("nn_f32", 96, 200, 77, "f32", "nn", dict(bias=True, residual=True, out_f32=True)),
+    ("tn_f32", 66, 70, 130, "f32", "tn", dict(accumulate=True, out_f32=True)),
+    ("tt_f32", 33, 65, 17, "f32", "tt", dict(out_f32=True, alpha=0.5)),
+    ("nt_f32_dgelu", 64, 64, 64, "f32", "nt", dict(act=4)),
+]
+
+
+@pytest.mark.parametrize("case", GEMM_CASES, ids=[c[0] for c in GEMM_CASES])
+def test_gemm(case):
+    from afft_amd import ops
+    name, M, N, K, dt, layout, ep = case
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float32
+    a_t, b_t = layout[0] == "t", layout[1] == "t"
+    lda_pad, ldb_pad = ep.get("lda_pad"), ep.get("ldb_pad")
+    A = rnd(M, K, seed=1)            # logical A
+    Bm = rnd(K, N, seed=2)           # logical B
+    if dt == "bf16":
+        A, Bm = bfr(A), bfr(Bm)
+
+    def store(logical, transposed, pad):
+        t = logical.t().contiguous() if transposed else logical.contiguous()
+        if pad:
+            buf = torch.zeros(t.shape[0], pad)
+            buf[:, :t.shape[1]] = t
+            return buf.to(tdt).to(dev())[:, :t.shape[1]]
+        return t.to(tdt).to(dev())
+
+    a_store = store(A, a_t, lda_pad)
+    # B storage: 'n' second letter => stored [K,N]; 't' => stored [N,K]
+    b_store = store(Bm, b_t, ldb_pad)
+    bias = rnd(N, seed=3) if ep.get("bias") else None
+    act = ep.get("act", 0)
+    aux = rnd(M, N, seed=4) if act >= 3 else None
+    if aux is not None and dt == "bf16":
+        aux = bfr(aux)
+    res = rnd(M, N, seed=5) if ep.get("residual") else None
+    rowscale = (rnd(M, seed=6).abs() + 0.5) if ep.get("rowscale") else None
+    out_dt = torch.float32 if (ep.get("out_f32") or dt == "f32") else torch.bfloat16
+    ldo = ep.get("ldo_pad", N)
+    out_buf = torch.zeros(M, ldo, dtype=out_dt, device=dev())
+    out = out_buf[:, :N]
+    init = None
+    if ep.get("accumulate"):
+        init = rnd(M, N, seed=7)
+        out.copy_(init.to(dev()))
+    pre = torch.zeros(M, N, dtype=tdt, device=dev()) if ep.get("pre") else None
+    out2 = torch.zeros(M, N, dtype=torch.float32 if out_dt == torch.bfloat16 else torch.bfloat16, device=dev()) if ep.get("out2") else None
+    alpha = ep.get("alpha", 1.0)
+    ops.gemm(a_store, b_store, out, a_t=a_t, b_t=b_t, bias=None if bias is None else bias.to(dev()), act=act,
+             aux=None if aux is None else aux.to(tdt).to(dev()), pre=pre,
+             rowscale=None if rowscale is None else rowscale.to(dev()),
+             residual=None if res is None else res.to(dev()), accumulate=bool(ep.get("accumulate")), out2=out2,
+             alpha=alpha)
+    torch.cuda.synchronize()
+    ref = alpha * (A.double() @ Bm.double()).float()
+    if bias is not None:
+        ref = ref + bias
+    pre_ref = ref.clone()
+    ref = _act(act, ref, aux)
+    if rowscale is not None:
+        ref = ref * rowscale[:, None]
+    if res is not None:
+        ref = ref + res
+    if init is not None:
+        ref = ref + init
+    tol = 2e-5 if (dt == "f32") else (1e-2 if out_dt == torch.bfloat16 else 2e-3)
+    if name == "nt_bf16_fallback_k":
+        tol = 2e-5
+    assert rel_l2(out.float().cpu(), ref) < tol, name
+    if pre is not None:
+        assert rel_l2(pre.float().cpu(), pre_ref) < (2e-5 if dt == "f32" else 1e-2)
+    if out2 is not None:
+        assert rel_l2(out2.float().cpu(), ref) < 1e-2
+    if ldo != N:  # padding columns untouched
+        assert float(out_buf[:, N:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("rows,d,dt", [(37, 64, "f32"), (300, 1024, "bf16"), (130, 2048, "f32"), (5, 128, "bf16")])
+def test_layernorm_fwd_bwd(rows, d, dt):
+    from afft_amd import ops
+    ydt = torch.float32 if dt == "f32" else torch.bfloat16
+    x = rnd(rows, d, seed=1, scale=2.0) + 0.3
+    w = rnd(d, seed=2) * 0.2 + 1.0
+    b = rnd(d, seed=3) * 0.1
+    eps = 1e-6
+    xg = x.to(dev())
+    y = torch.empty(rows, d, dtype=ydt, device=dev())
+    mean = torch.empty(rows, device=dev())
+    rstd = torch.empty(rows, device=dev())
+    ops.layernorm_fwd(xg, w.to(dev()), b.to(dev()), eps, y, mean, rstd)
+    xr = x.clone().double().requires_grad_(True)
+    wr = w.clone().double().requires_grad_(True)
+    br = b.clone().double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (d,), wr, br, eps)
+    assert rel_l2(y.float().cpu(), yr.float()) < (2e-5 if dt == "f32" else 5e-3)
+    dy = rnd(rows, d, seed=4)
+    if dt == "bf16":
+        dy = bfr(dy)
+    dx_in = rnd(rows, d, seed=5)
+    yr.backward(dy.double())
+    dx = torch.empty(rows, d, device=dev())
+    dxb = torch.empty(rows, d, dtype=torch.bfloat16, device=dev())
+    dw = torch.full((d,), 0.5, device=dev())
+    db = torch.full((d,), -0.25, device=dev())
+    ops.layernorm_bwd(dy.to(ydt).to(dev()), xg, w.to(dev()), mean, rstd, dx, dx_in=dx_in.to(dev()), dx_bf16=dxb, dw=dw, db=db)
+    torch.cuda.synchronize()
+    assert rel_l2(dx.cpu(), xr.grad.float() + dx_in) < 3e-5
+    assert rel_l2(dxb.float().cpu(), xr.grad.float() + dx_in) < 5e-3
+    assert rel_l2(dw.cpu() - 0.5, wr.grad.float()) < 3e-5
+    assert rel_l2(db.cpu() + 0.25, br.grad.float()) < 3e-5
+
+
+def test_layernorm_strided_token0_and_no_affine():
+    from afft_amd import ops
+    BT, S, d = 12, 5, 64
+    X = rnd(BT * S, d, seed=9).to(dev())
+    y = torch.empty(BT, d, device=dev())
+    ops.layernorm_fwd(X.view(BT, S * d)[:, :d], None, None, 1e-6, y)
+    ref = torch.nn.functional.layer_norm(X.cpu().view(BT, S, d)[:, 0], (d,), None, None, 1e-6)
+    assert rel_l2(y.cpu(), ref) < 2e-5
+
+
+ATTN_CASES = [(7, 5, 4, 16, 0, "f32"), (6, 5, 4, 64, 1, "f32"), (3, 16, 2, 64, 2, "f32"), (2, 32, 2, 32, 2, "f32"),
+              (9, 5, 4, 256, 0, "bf16"), (4, 16, 4, 512, 2, "bf16"), (3, 6, 4, 128, 1, "bf16"), (5, 1, 2, 32, 0, "f32")]
+
+
+@pytest.mark.parametrize("nseq,L,H,hd,mask,dt", ATTN_CASES)
+def test_attention_fwd_bwd(nseq, L, H, hd, mask, dt):
+    from afft_amd import ops
+    from oracle import afft_oracle as O
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    d = H * hd
+    qkv = rnd(nseq * L, 3 * d, seed=1)
+    dout = rnd(nseq * L, d, seed=2)
+    if dt == "bf16":
+        qkv, dout = bfr(qkv), bfr(dout)
+    g = qkv.to(tdt).to(dev())
+    q, k, v = g[:, :d], g[:, d:2 * d], g[:, 2 * d:]
+    out = torch.empty(nseq * L, d, dtype=tdt, device=dev())
+    probs = torch.empty(nseq, H, L, L, device=dev())
+    scale = hd ** -0.5
+    ops.attention_fwd(q, k, v, nseq, L, H, hd, scale, mask, out, probs)
+    qr = qkv.clone().double().requires_grad_(True)
+    t = qr.view(nseq, L, 3, H, hd).permute(2, 0, 3, 1, 4)
+    m = O.make_mask(["none", "diag", "causal"][mask], L, torch.float64)
+    o_ref, p_ref = O._softmax_attend(t[0], t[1], t[2], scale, m)
+    tol = 2e-5 if dt == "f32" else 1e-2
+    assert rel_l2(out.float().cpu(), o_ref.reshape(nseq * L, d).float()) < tol
+    assert rel_l2(probs.cpu(), p_ref.float()) < (2e-5 if dt == "f32" else 2e-3)
+    if mask:  # masked probabilities are exactly zero
+        pm = probs.cpu()
+        idx = torch.isinf(m)
+        assert float(pm[..., idx].abs().max()) == 0.0
+    o_ref.reshape(nseq * L, d).backward(dout.double())
+    dg = torch.zeros(nseq * L, 3 * d, dtype=tdt, device=dev())
+    ops.attention_bwd(dout.to(tdt).to(dev()), q, k, v, probs, nseq, L, H, hd, scale, dg[:, :d], dg[:, d:2 * d], dg[:, 2 * d:])
+    torch.cuda.synchronize()
+    assert rel_l2(dg.float().cpu(), qr.grad.float()) < (3e-5 if dt == "f32" else 2e-2)
+
+
+@pytest.mark.parametrize("rows,C,soft", [(37, 3806, False), (20, 11, False), (33, 3806, True), (16, 7, True)])
+def test_softmax_ce(rows, C, soft):
+    from afft_amd import ops
+    ld = ((C + 63) // 64) * 64
+    logits = rnd(rows, C, seed=1, scale=3.0)
+    buf = torch.zeros(rows, ld, device=dev())
+    buf[:, :C] = logits.to(dev())
+    lg = buf[:, :C]
+    loss_sum = torch.zeros(1, device=dev())
+    row_loss = torch.empty(rows, device=dev())
+    dl = torch.full((rows, ld), 7.0, dtype=torch.bfloat16, device=dev())
+    lr = logits.clone().double().requires_grad_(True)
+    gscale = 1.0 / rows
+    if not soft:
+        g = torch.Generator().manual_seed(3)
+        labels = torch.randint(0, C, (rows,), generator=g)
+        labels[::5] = -1
+        ops.softmax_ce(lg, C, labels=labels.to(dev()), gscale=gscale, loss_sum=loss_sum, dlogits=dl, row_loss=row_loss)
+        ref = torch.nn.functional.cross_entropy(lr, labels, ignore_index=-1, reduction="none")
+        (ref.sum() * gscale).backward()
+    else:
+        t = torch.softmax(rnd(rows, C, seed=4), -1) * 0.6
+        t[:, 1] += 0.4
+        keep = torch.ones(rows, dtype=torch.uint8)
+        keep[::4] = 0
+        ops.softmax_ce(lg, C, soft=t.to(dev()), keep=keep.to(dev()), gscale=gscale, loss_sum=loss_sum, dlogits=dl, row_loss=row_loss)
+        ref = torch.nn.functional.cross_entropy(lr, t.double(), reduction="none") * keep.double()
+        (ref.sum() * gscale).backward()
+    torch.cuda.synchronize()
+    assert rel_l2(row_loss.cpu(), ref.float()) < 1e-5
+    assert abs(float(loss_sum) - float(ref.sum())) < 1e-4 * max(1.0, float(ref.sum()))
+    assert rel_l2(dl[:, :C].float().cpu(), lr.grad.float()) < 5e-3
+    assert float(dl[:, C:].float().abs().max()) == 0.0
+
+
+def test_mse_and_elementwise():
+    from afft_amd import ops
+    rows, d = 45, 64
+    a, b = rnd(rows, d, seed=1), rnd(rows, d, seed=2)
+    ls = torch.zeros(1, device=dev())
+    da = torch.ones(rows, d, device=dev())
+    db = torch.zeros(rows, d, device=dev())
+    gs = 1.0 / (rows * d)
+    ops.mse(a.to(dev()), b.to(dev()), gs, ls, da, db)
+    torch.cuda.synchronize()
+    assert abs(float(ls) - float(((a - b) ** 2).sum())) < 1e-3
+    assert rel_l2(da.cpu() - 1.0, 2 * gs * (a - b)) < 1e-5
+    assert rel_l2(db.cpu(), -2 * gs * (a - b)) < 1e-5
+
+    # cast + transpose with padding
+    W = rnd(70, 24, seed=3)
+    w16 = torch.zeros(70, 64, dtype=torch.bfloat16, device=dev())
+    wt16 = torch.zeros(24, 128, dtype=torch.bfloat16, device=dev())
+    ops.cast(W.to(dev()), w16, wt16, zero_pad=True)
+    torch.cuda.synchronize()
+    assert torch.equal(w16[:, :24].cpu(), W.to(torch.bfloat16)) and float(w16[:, 24:].float().abs().max()) == 0
+    assert torch.equal(wt16[:, :70].cpu(), W.t().to(torch.bfloat16)) and float(wt16[:, 70:].float().abs().max()) == 0
+
+    # token assembly (SA-Fuser, models/fusion.py:338-352)
+    B, T, dd, Mn = 3, 4, 64, 4
+    feats = [rnd(B * T, dd, seed=10 + i) for i in range(Mn)]
+    tok = rnd(T, dd, seed=20)
+    emb = rnd(Mn + 1, dd, seed=21)
+    X = torch.empty(B * T, Mn + 1, dd, device=dev())
+    ops.assemble_tokens([f.to(dev()) for f in feats], tok.to(dev()), dd, emb.to(dev()), B * T, T, dd, X)
+    ref = torch.stack([tok.repeat(B, 1)] + feats, dim=1) + emb
+    assert torch.equal(X.cpu(), ref)
+    X2 = torch.empty(B * T, Mn + 1, dd, device=dev())
+    ops.assemble_tokens([f.to(dev()) for f in feats], tok[:1].contiguous().to(dev()), 0, None, B * T, T, dd, X2)
+    assert torch.equal(X2.cpu(), torch.stack([tok[:1].expand(B * T, dd)] + feats, dim=1))
+
+    # column sums (bias gradients)
+    src = rnd(333, 130, seed=30)
+    out = torch.full((130,), 2.0, device=dev())
+    ops.colsum(src.to(torch.bfloat16).to(dev()), out, accumulate=True)
+    assert rel_l2(out.cpu() - 2.0, bfr(src).sum(0)) < 1e-4
+    ops.colsum(src.to(dev()), out, accumulate=False)
+    assert rel_l2(out.cpu(), src.sum(0)) < 1e-5
+
+    # periodic tables
+    x = rnd(B * T, dd, seed=31)
+    tab = rnd(T, dd, seed=32)
+    y = torch.empty(B * T, dd, device=dev())
+    ops.add_rows_periodic(x.to(dev()), tab.to(dev()), T, y)
+    assert torch.equal(y.cpu(), x + tab.repeat(B, 1))
+    acc = torch.ones(T, dd, device=dev())
+    ops.reduce_rows_periodic(x.to(dev()), T, acc)
+    assert rel_l2(acc.cpu() - 1.0, x.view(B, T, dd).sum(0)) < 1e-5
+
+    # Nesterov SGD vs torch.optim.SGD
+    n = 1000 + 3
+    p0, g0, g1 = rnd(n, seed=40), rnd(n, seed=41), rnd(n, seed=42)
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([pr], lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-3)
+    pg, buf = p0.clone().to(dev()), torch.empty(n, device=dev())
+    for step, g in enumerate((g0, g1)):
+        pr.grad = g.clone()
+        opt.step()
+        ops.sgd_nesterov(pg, g.to(dev()), buf, 0.1, 0.9, 1e-3, 1.0, step == 0)
+    assert rel_l2(pg.cpu(), pr.detach()) < 1e-6
+
+
+def test_errors_are_reported():
+    from afft_amd import ops
+    a = torch.zeros(4, 4, device=dev())
+    with pytest.raises(RuntimeError, match="sequence length"):
+        ops.attention_fwd(a, a, a, 1, 64, 1, 4, 1.0, 0, a, None)
+    with pytest.raises(ValueError):
+        ops.gemm(a, torch.zeros(5, 4, device=dev()), a)
