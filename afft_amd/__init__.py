@@ -1,0 +1,27 @@
+"""afft_amd: MI355X-native (gfx950) implementation of AFFT's data-parallel hot path -- the SA-/CA-Fuser
+modality-fusion transformer, the GPT-2 style causal future predictor, the classifier heads and the
+three-term anticipation loss, forward and backward -- behind the reference's own module interface.
+
+    afft_amd.models.*          mirrors of the reference's models/{base_model,fusion,transformerblock,
+                               future_prediction,feature_mapping}.py
+    afft_amd.common.runner     mirror of common/runner.py (loss + step wrapper)
+    afft_amd.parallel          data-parallel gradient reduction over RCCL/xGMI + fused SGD
+    afft_amd.ops / _lib        the C-ABI (include/afft_hip.h) via ctypes
+"""
+import sys as _sys
+
+from .runtime import precision, set_grad_mode, set_precision  # noqa: F401
+
+
+def install_as_models():
+    """Make ``import models.fusion`` / Hydra ``_target_: models.fusion.ModalTokenCMFuser`` resolve to this
+    package, so the reference's train.py / conf/ work unchanged."""
+    import importlib
+    pkg = importlib.import_module("afft_amd.models")
+    _sys.modules["models"] = pkg
+    for name in ("base_model", "fusion", "transformerblock", "future_prediction", "feature_mapping"):
+        _sys.modules[f"models.{name}"] = importlib.import_module(f"afft_amd.models.{name}")
+    crun = importlib.import_module("afft_amd.common.runner")
+    if "common" in _sys.modules:
+        _sys.modules["common.runner"] = crun
+        setattr(_sys.modules["common"], "runner", crun)

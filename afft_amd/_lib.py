@@ -18,6 +18,10 @@ MASK_NONE, MASK_DIAG, MASK_CAUSAL = 0, 1, 2
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
 
+class Dropout(C.Structure):
+    _fields_ = [("p", f32), ("key", C.c_uint32), ("path_p", f32), ("path_key", C.c_uint32), ("path_group", i32)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [
         ("M", i32), ("N", i32), ("K", i32), ("dtype", i32),
@@ -33,6 +37,7 @@ class GemmDesc(C.Structure):
         ("accumulate", i32),
         ("out", vp), ("ldo", i64), ("out_dtype", i32),
         ("out2", vp), ("ldo2", i64), ("out2_dtype", i32),
+        ("drop", Dropout),
     ]
 
 
@@ -42,12 +47,13 @@ _SIGS = {
     "afft_layernorm_fwd": ([vp, i64, vp, vp, f32, i32, i32, vp, i64, i32, vp, vp, vp], C.c_int),
     "afft_layernorm_bwd_nparts": ([i32], C.c_int),
     "afft_layernorm_bwd": ([vp, i64, i32, vp, i64, vp, vp, vp, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp], C.c_int),
-    "afft_attention_fwd": ([vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, i32, vp, i64, vp, vp], C.c_int),
-    "afft_attention_bwd": ([vp, i64, vp, i64, vp, i64, vp, i64, i32, vp, i32, i32, i32, i32, f32,
+    "afft_attention_fwd": ([vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, i32, f32, C.c_uint32,
+                            vp, i64, vp, vp], C.c_int),
+    "afft_attention_bwd": ([vp, i64, vp, i64, vp, i64, vp, i64, i32, vp, i32, i32, i32, i32, f32, f32, C.c_uint32,
                             vp, i64, vp, i64, vp, i64, vp], C.c_int),
-    "afft_softmax_ce": ([vp, i64, i32, i32, vp, vp, i64, vp, f32, vp, vp, i64, i32, vp, vp], C.c_int),
-    "afft_mse": ([vp, i64, vp, i64, i32, i32, f32, vp, vp, i64, vp, i64, vp], C.c_int),
-    "afft_cast": ([vp, i64, i32, i32, vp, i64, i32, vp, i64, i32, vp], C.c_int),
+    "afft_softmax_ce": ([vp, i64, i32, i32, vp, vp, i64, vp, f32, vp, vp, vp, i64, i32, vp, vp], C.c_int),
+    "afft_mse": ([vp, i64, vp, i64, i32, i32, f32, vp, f32, vp, vp, i64, vp, i64, vp], C.c_int),
+    "afft_cast": ([vp, i64, i32, i32, vp, i64, i32, vp, i64, i32, C.POINTER(Dropout), vp], C.c_int),
     "afft_assemble_tokens": ([C.POINTER(vp), C.POINTER(i64), i32, vp, i64, vp, i32, i32, i32, vp, vp], C.c_int),
     "afft_colsum": ([vp, i64, i32, i32, i32, vp, i32, vp], C.c_int),
     "afft_add_rows_periodic": ([vp, i64, vp, i64, i32, i32, i32, vp, i64, vp], C.c_int),

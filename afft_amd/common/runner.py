@@ -1,0 +1,194 @@
+"""MI355X mirror of the reference's ``common/runner.py``: the loss (future CE + past CE + past-feature MSE)
+and the per-batch step wrapper.
+
+  MultiDimCrossEntropy  <- common/runner.py:13-37   fused softmax-CE kernel (hard labels with ignore_index=-1,
+                                                     or soft/one-hot targets with a boolean row filter)
+  BasicLossAccuracy     <- common/runner.py:40-168
+  Runner                <- common/runner.py:178-270
+
+Differences that do not change any reduced value: with soft targets the reference drops ignored rows and
+returns a shorter vector; here the vector keeps its length, ignored rows are 0 and the kept rows are scaled
+by rows/kept, so ``torch.mean`` (Runner._reduce_loss) gives the same number without a device->host sync.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from .. import functional as F_
+
+CLS_MAP_PREFIX = 'cls_map_'
+PAST_LOGITS_PREFIX = 'past_'
+
+
+def accuracy(output, target, topk=(1,)):
+    """top-k accuracy over flattened leading dims (common/utils.py:59-86)."""
+    if torch.all(target < 0):
+        return [torch.zeros([], device=output.device) for _ in range(len(topk))]
+    with torch.no_grad():
+        output = output.flatten(0, -2)
+        target = target.flatten()
+        maxk = max(topk)
+        batch_size = target.size(0)
+        _, pred = output.topk(maxk, 1, True, True)
+        pred = pred.t()
+        correct = pred.eq(target[None])
+        return [correct[:k].flatten().sum(dtype=torch.float32) * (100.0 / batch_size) for k in topk]
+
+
+class MultiDimCrossEntropy(nn.Module):
+    """Flattens the leading dimensions, then per-row cross entropy (reduction='none', ignore_index=-1)."""
+
+    def __init__(self, ignore_index: int = -1, reduction: str = 'none'):
+        super().__init__()
+        assert ignore_index == -1 and reduction == 'none', "the AFFT path uses ignore_index=-1, reduction='none'"
+
+    def forward(self, inp, tgt, one_hot: bool = False, ignore_index: Union[torch.Tensor, None] = None):
+        C = inp.size(-1)
+        inp2 = inp.reshape(-1, C)
+        rows = inp2.shape[0]
+        if not one_hot:
+            labels = tgt.reshape(-1).to(torch.int64).contiguous()
+            return F_.SoftmaxCE.apply(inp2, labels, None, None)
+        soft = tgt.reshape(-1, C).to(torch.float32).contiguous()
+        keep = None
+        if ignore_index is not None:
+            keep = (~ignore_index.reshape(-1)).to(torch.uint8).contiguous()
+        row_loss = F_.SoftmaxCE.apply(inp2, None, soft, keep)
+        if keep is not None:
+            row_loss = row_loss * (float(rows) / keep.sum().clamp(min=1).to(torch.float32))
+        return row_loss
+
+
+class BasicLossAccuracy(nn.Module):
+    """acc1 / acc5 / mt5r inputs and the three loss terms."""
+
+    def __init__(self, compute_metrics: bool = True):
+        super().__init__()
+        self.cls_criterion = MultiDimCrossEntropy(ignore_index=-1, reduction='none')
+        self.compute_metrics = compute_metrics
+
+    @staticmethod
+    def reg_criterion(a, b):
+        B, T, C = a.shape
+        return F_.MSE.apply(a.reshape(B * T, C).contiguous(), b.reshape(B * T, C).contiguous())
+
+    def forward_future_action(self, logits, tgt_val, mixup_enable, losses, metrics, acc1_key, acc5_key, mt5r_key,
+                              loss_key, key_suffix=''):
+        losses[loss_key + key_suffix] = self.cls_criterion(logits, tgt_val, one_hot=mixup_enable)
+        if not self.compute_metrics:
+            return
+        sequence_index = 0
+        if mixup_enable:
+            _vals, inds = torch.topk(tgt_val, 2, dim=1, largest=True, sorted=True)
+            rows = torch.arange(tgt_val.shape[0], device=logits.device)
+            seq = torch.full_like(rows, sequence_index)
+            preds = logits.detach().clone()
+            preds[rows, seq, inds[:, 0]] += preds[rows, seq, inds[:, 1]]
+            preds[rows, seq, inds[:, 1]] = 0.0
+            labels = inds[:, 0]
+        else:
+            preds = logits.detach()
+            labels = tgt_val.clone()
+        if len(labels.shape) == 1:
+            labels = labels.unsqueeze(dim=-1)
+        metrics[mt5r_key + key_suffix] = {'logits': preds[:, sequence_index, :].cpu().numpy(),
+                                          'labels': labels[:, sequence_index].cpu().numpy()}
+        acc1, acc5 = accuracy(preds, labels, topk=(1, min(5, preds.size(-1))))
+        metrics[acc1_key + key_suffix] = acc1
+        metrics[acc5_key + key_suffix] = acc5
+
+    def forward_past_action(self, past_logits, past_target, mixup_enable, losses, loss_key,
+                            past_target_ignore_index=None, key_suffix=''):
+        if mixup_enable:
+            assert past_logits.shape == past_target.shape
+            assert past_target_ignore_index is not None
+            loss = self.cls_criterion(past_logits, past_target, one_hot=True, ignore_index=past_target_ignore_index)
+        else:
+            past_target = past_target.squeeze(-1)
+            assert past_logits.shape[:-1] == past_target.shape
+            loss = self.cls_criterion(past_logits, past_target)
+        losses[loss_key + key_suffix] = loss
+
+    def forward(self, outputs, target, target_subclips, mixup_enable: bool = False,
+                target_subclips_ignore_index: Union[Dict, None] = None):
+        losses, metrics = {}, {}
+        for tgt_type, tgt_val in target.items():
+            for modk in outputs[f'logits/{tgt_type}']:
+                logits = outputs[f'logits/{tgt_type}'][modk]
+                assert len(logits.shape) == 3
+                self.forward_future_action(logits, tgt_val, mixup_enable, losses, metrics,
+                                           f'acc1_{tgt_type}_{modk}', f'acc5_{tgt_type}_{modk}',
+                                           f'mt5r_{tgt_type}_{modk}', f'cls_{tgt_type}_{modk}')
+            past_key = f'{PAST_LOGITS_PREFIX}logits/{tgt_type}'
+            if past_key in outputs and target_subclips is not None:
+                for modk in outputs[past_key]:
+                    ign = None if target_subclips_ignore_index is None else target_subclips_ignore_index[tgt_type]
+                    self.forward_past_action(outputs[past_key][modk], target_subclips[tgt_type], mixup_enable,
+                                             losses, f'past_cls_{tgt_type}_{modk}', ign)
+            if 'orig_past' in outputs and 'past_futures' in outputs:
+                for modk, upd in outputs['past_futures'].items():
+                    if modk not in outputs['orig_past']:
+                        continue
+                    losses[f'past_reg_{modk}'] = self.reg_criterion(upd[:, 1:], outputs['orig_past'][modk][:, 1:])
+        return losses, metrics
+
+
+def get_loss_wts(loss_wts: Dict, key: str) -> float:
+    for k, v in loss_wts.items():
+        if key.startswith(k):
+            return v
+    raise ValueError(f'{key} not contained in predefined loss_wts: {loss_wts}')
+
+
+class Runner:
+    """wrapper class of BasicLossAccuracy, runs on each batch, returns all metrics"""
+
+    def __init__(self, model, device, loss_wts, compute_metrics: bool = True):
+        self.model = model
+        self.device = device
+        self.loss_acc_fn = BasicLossAccuracy(compute_metrics)
+        self.loss_wts = loss_wts
+
+    @staticmethod
+    def _reduce_loss(losses, loss_wts, sync: bool = True):
+        losses = {key: torch.mean(val) for key, val in losses.items()}
+        losses_wtd = []
+        for key, val in losses.items():
+            w = get_loss_wts(loss_wts, key)
+            if w > 0:
+                losses_wtd.append(w * val)
+        loss = torch.sum(torch.stack(losses_wtd))
+        if not sync:
+            return loss, {k: v.detach() for k, v in losses.items()}
+        if torch.isnan(loss):
+            raise ValueError('The loss is NaN!')
+        losses_metric = {k: v.item() for k, v in losses.items()}
+        losses_metric['total_loss'] = loss.item()
+        return loss, losses_metric
+
+    def __call__(self, data, mixup_fn: Optional[Callable] = None, mixup_backbone: Optional[bool] = True):
+        data, timings = data
+        feature_dict = {mod: t.to(self.device, non_blocking=True) for mod, t in data["data_dict"].items()}
+        target = {k: v.to(self.device, non_blocking=True) for k, v in data['target'].items()}
+        target_subclips = None
+        if 'target_subclips' in data:
+            target_subclips = {k: v.to(self.device, non_blocking=True) for k, v in data['target_subclips'].items()}
+        kwargs = dict(mixup_fn=None, target=target, target_subclips=target_subclips,
+                      target_subclips_ignore_index=None)
+        if mixup_fn is not None:
+            if not mixup_backbone:
+                feature_dict, target, target_subclips, ign = mixup_fn(feature_dict, target, target_subclips)
+                kwargs.update(target=target, target_subclips=target_subclips, target_subclips_ignore_index=ign)
+            else:
+                kwargs['mixup_fn'] = mixup_fn
+        outputs, out_t = self.model(feature_dict, **kwargs)
+        losses, metrics = self.loss_acc_fn(outputs, out_t['target'], out_t['target_subclips'],
+                                           mixup_enable=(mixup_fn is not None),
+                                           target_subclips_ignore_index=out_t['target_subclips_ignore_index'])
+        loss, losses_metric = self._reduce_loss(losses, self.loss_wts)
+        metrics.update(losses_metric)
+        metrics.update(timings)
+        return loss, metrics

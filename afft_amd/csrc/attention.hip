@@ -16,7 +16,8 @@ __device__ __forceinline__ bool masked(int mask, int i, int j) {
 template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, int64_t ldq, const T* __restrict__ k,
                                                        int64_t ldk, const T* __restrict__ v, int64_t ldv, int L, int H,
-                                                       int hd, float scale, int mask, T* __restrict__ out, int64_t ldo,
+                                                       int hd, float scale, int mask, unsigned dthresh, unsigned dkey,
+                                                       float dinv, T* __restrict__ out, int64_t ldo,
                                                        float* __restrict__ probs) {
   __shared__ float sc[LMAX][LMAX + 1];
   const int seq = blockIdx.x / H, h = blockIdx.x % H;
@@ -50,10 +51,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, 
     }
     const float inv = 1.0f / sum;
     float* pr = probs ? probs + (((int64_t)seq * H + h) * L + i) * L : nullptr;
+    const unsigned base = (unsigned)((((int64_t)seq * H + h) * L + i) * L);
     for (int j = 0; j < L; ++j) {
       const float p = sc[i][j] * inv;
-      sc[i][j] = p;
-      if (pr) pr[j] = p;
+      if (pr) pr[j] = p;  // pre-dropout probabilities (backward regenerates the mask)
+      sc[i][j] = (dthresh && !drop_keep(dkey, base + j, dthresh)) ? 0.f : p * dinv;
     }
   }
   __syncthreads();
@@ -75,9 +77,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ dou
                                                        int64_t ldq, const T* __restrict__ k, int64_t ldk,
                                                        const T* __restrict__ v, int64_t ldv,
                                                        const float* __restrict__ probs, int L, int H, int hd, float scale,
+                                                       unsigned dthresh, unsigned dkey, float dinv,
                                                        T* __restrict__ dq, int64_t lddq, T* __restrict__ dk, int64_t lddk,
                                                        T* __restrict__ dv, int64_t lddv) {
-  __shared__ float pp[LMAX][LMAX + 1];  // probabilities
+  __shared__ float pp[LMAX][LMAX + 1];  // probabilities (pre-dropout), later the dropped-out P' used by dV
   __shared__ float ds[LMAX][LMAX + 1];  // dP, then dS*scale
   const int seq = blockIdx.x / H, h = blockIdx.x % H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -99,9 +102,19 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ dou
   __syncthreads();
   if (tid < L) {
     const int i = tid;
+    const unsigned base = (unsigned)((((int64_t)seq * H + h) * L + i) * L);
     float dot = 0.f;
-    for (int j = 0; j < L; ++j) dot += pp[i][j] * ds[i][j];
-    for (int j = 0; j < L; ++j) ds[i][j] = pp[i][j] * (ds[i][j] - dot) * scale;
+    for (int j = 0; j < L; ++j) {
+      // ds holds dP' (gradient of the dropped-out probabilities); dP = dP' * m/(1-p)
+      const float m = (dthresh && !drop_keep(dkey, base + j, dthresh)) ? 0.f : dinv;
+      ds[i][j] *= m;
+      dot += pp[i][j] * ds[i][j];
+    }
+    for (int j = 0; j < L; ++j) {
+      const float m = (dthresh && !drop_keep(dkey, base + j, dthresh)) ? 0.f : dinv;
+      ds[i][j] = pp[i][j] * (ds[i][j] - dot) * scale;
+      pp[i][j] *= m;  // P' for dV
+    }
   }
   __syncthreads();
   for (int c = tid; c < hd; c += 256) {
@@ -140,20 +153,24 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ dou
 
 extern "C" int afft_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                                   int32_t dtype, int32_t nseq, int32_t L, int32_t H, int32_t hd, float scale,
-                                  int32_t mask, void* out, int64_t ldo, float* probs, void* stream_) {
+                                  int32_t mask, float drop_p, uint32_t drop_key, void* out, int64_t ldo, float* probs,
+                                  void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(q && k && v && out, "attention_fwd: null pointer");
   AFFT_CHECK(L >= 1 && L <= LMAX, "attention_fwd: sequence length %d outside 1..%d", L, LMAX);
   AFFT_CHECK(mask >= AFFT_MASK_NONE && mask <= AFFT_MASK_CAUSAL, "attention_fwd: bad mask %d", mask);
   AFFT_CHECK(!(mask == AFFT_MASK_DIAG && L == 1), "attention_fwd: diagonal mask with L=1 masks every key");
+  AFFT_CHECK(drop_p >= 0.f && drop_p < 1.f, "attention_fwd: dropout p outside [0,1)");
   if (nseq == 0) return 0;
+  afft_dropout_t dd = {drop_p, drop_key, 0.f, 0u, 1};
+  const DropParams dp = make_drop(&dd);
   const dim3 grid(nseq * H), block(256);
   if (dtype == AFFT_F32)
     hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, 0, stream, (const float*)q, ldq, (const float*)k, ldk,
-                       (const float*)v, ldv, L, H, hd, scale, mask, (float*)out, ldo, probs);
+                       (const float*)v, ldv, L, H, hd, scale, mask, dp.thresh, dp.key, dp.inv_keep, (float*)out, ldo, probs);
   else if (dtype == AFFT_BF16)
     hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
-                       (const bf16_t*)v, ldv, L, H, hd, scale, mask, (bf16_t*)out, ldo, probs);
+                       (const bf16_t*)v, ldv, L, H, hd, scale, mask, dp.thresh, dp.key, dp.inv_keep, (bf16_t*)out, ldo, probs);
   else AFFT_CHECK(false, "attention_fwd: bad dtype %d", dtype);
   AFFT_LAUNCH_CHECK();
   return 0;
@@ -161,21 +178,24 @@ extern "C" int afft_attention_fwd(const void* q, int64_t ldq, const void* k, int
 
 extern "C" int afft_attention_bwd(const void* dout, int64_t lddo, const void* q, int64_t ldq, const void* k, int64_t ldk,
                                   const void* v, int64_t ldv, int32_t dtype, const float* probs, int32_t nseq, int32_t L,
-                                  int32_t H, int32_t hd, float scale, void* dq, int64_t lddq, void* dk, int64_t lddk,
-                                  void* dv, int64_t lddv, void* stream_) {
+                                  int32_t H, int32_t hd, float scale, float drop_p, uint32_t drop_key, void* dq,
+                                  int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(dout && q && k && v && probs && dq && dk && dv, "attention_bwd: null pointer");
   AFFT_CHECK(L >= 1 && L <= LMAX, "attention_bwd: sequence length %d outside 1..%d", L, LMAX);
+  AFFT_CHECK(drop_p >= 0.f && drop_p < 1.f, "attention_bwd: dropout p outside [0,1)");
   if (nseq == 0) return 0;
+  afft_dropout_t dd = {drop_p, drop_key, 0.f, 0u, 1};
+  const DropParams dp = make_drop(&dd);
   const dim3 grid(nseq * H), block(256);
   if (dtype == AFFT_F32)
     hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, block, 0, stream, (const float*)dout, lddo, (const float*)q, ldq,
-                       (const float*)k, ldk, (const float*)v, ldv, probs, L, H, hd, scale, (float*)dq, lddq,
-                       (float*)dk, lddk, (float*)dv, lddv);
+                       (const float*)k, ldk, (const float*)v, ldv, probs, L, H, hd, scale, dp.thresh, dp.key, dp.inv_keep,
+                       (float*)dq, lddq, (float*)dk, lddk, (float*)dv, lddv);
   else if (dtype == AFFT_BF16)
     hipLaunchKernelGGL(attn_bwd_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)dout, lddo, (const bf16_t*)q, ldq,
-                       (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, probs, L, H, hd, scale, (bf16_t*)dq, lddq,
-                       (bf16_t*)dk, lddk, (bf16_t*)dv, lddv);
+                       (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, probs, L, H, hd, scale, dp.thresh, dp.key, dp.inv_keep,
+                       (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv);
   else AFFT_CHECK(false, "attention_bwd: bad dtype %d", dtype);
   AFFT_LAUNCH_CHECK();
   return 0;

@@ -68,6 +68,51 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- counter-based dropout RNG: keep(idx) is a pure function of (key, element index), so backward regenerates
+//      the forward mask instead of storing it. key is drawn per call site and step on the host.
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ bool drop_keep(unsigned key, unsigned idx, unsigned thresh) {
+  return mix32(mix32(idx) ^ key) >= thresh;   // P(keep) = 1 - thresh / 2^32
+}
+struct DropParams {
+  unsigned thresh;      // element dropout: p * 2^32 (0 = off)
+  unsigned key;
+  float inv_keep;       // 1 / (1 - p)
+  unsigned path_thresh; // DropPath per row group (0 = off)
+  unsigned path_key;
+  float path_inv_keep;
+  int path_group;       // rows per sample (frame / clip)
+};
+inline DropParams make_drop(const afft_dropout_t* d) {
+  DropParams o = {0u, 0u, 1.0f, 0u, 0u, 1.0f, 1};
+  if (!d) return o;
+  if (d->p > 0.f) {
+    double t = (double)d->p * 4294967296.0;
+    o.thresh = t >= 4294967295.0 ? 0xffffffffu : (unsigned)t;
+    o.key = d->key;
+    o.inv_keep = 1.0f / (1.0f - d->p);
+  }
+  if (d->path_p > 0.f) {
+    double t = (double)d->path_p * 4294967296.0;
+    o.path_thresh = t >= 4294967295.0 ? 0xffffffffu : (unsigned)t;
+    o.path_key = d->path_key;
+    o.path_inv_keep = 1.0f / (1.0f - d->path_p);
+    o.path_group = d->path_group > 0 ? d->path_group : 1;
+  }
+  return o;
+}
+__device__ __forceinline__ float drop_row_scale(const DropParams& d, int m) {
+  if (!d.path_thresh) return 1.0f;
+  return drop_keep(d.path_key, (unsigned)(m / d.path_group), d.path_thresh) ? d.path_inv_keep : 0.0f;
+}
+__device__ __forceinline__ float drop_elem_scale(const DropParams& d, unsigned idx) {
+  if (!d.thresh) return 1.0f;
+  return drop_keep(d.key, idx, d.thresh) ? d.inv_keep : 0.0f;
+}
+
 // ---- activations (nn.GELU exact erf: models/transformerblock.py:119 ; HF gelu_new: GPT2MLP)
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float dgelu_erf_f(float x) {
@@ -98,6 +143,7 @@ struct EpiParams {
   void* out; int64_t ldo; int out_dtype;
   void* out2; int64_t ldo2; int out2_dtype;
   int vec4;  // host-verified: every ld % 4 == 0 and bases 16-byte aligned -> 4-wide accesses legal
+  DropParams drop;  // dropout on the (activated) GEMM output + DropPath row scale, before the residual add
 };
 
 __device__ __forceinline__ void store4(void* base, int64_t idx, int dtype, const float (&v)[4]) {
@@ -135,7 +181,8 @@ __device__ __forceinline__ float apply_act(int act, float v, float aux) {
 __device__ __forceinline__ void epilogue4(const EpiParams& e, int m, int n, float (&v)[4]) {
   if (m >= e.M || n >= e.N) return;
   const bool full = e.vec4 && (n + 3 < e.N);
-  const float rs = e.rowscale ? e.rowscale[m] : 1.0f;
+  const float rs = (e.rowscale ? e.rowscale[m] : 1.0f) * drop_row_scale(e.drop, m);
+  const bool scaled = e.rowscale || e.drop.path_thresh;
   if (full) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] *= e.alpha;
@@ -150,7 +197,11 @@ __device__ __forceinline__ void epilogue4(const EpiParams& e, int m, int n, floa
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = apply_act(e.act, v[r], a[r]);
     }
-    if (e.rowscale) {
+    if (e.drop.thresh) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= drop_elem_scale(e.drop, (unsigned)m * (unsigned)e.N + (unsigned)(n + r));
+    }
+    if (scaled) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] *= rs;
     }
@@ -175,6 +226,7 @@ __device__ __forceinline__ void epilogue4(const EpiParams& e, int m, int n, floa
       float a = 0.f;
       if (e.act >= AFFT_ACT_DGELU_ERF) a = ld_any(e.aux, (int64_t)m * e.ldaux + nn, e.aux_dtype);
       x = apply_act(e.act, x, a);
+      x *= drop_elem_scale(e.drop, (unsigned)m * (unsigned)e.N + (unsigned)nn);
       x *= rs;
       if (e.residual) x += e.residual[(int64_t)m * e.ldres + nn];
       if (e.accumulate) x += ((const float*)e.out)[(int64_t)m * e.ldo + nn];

@@ -20,14 +20,18 @@ namespace {
 // 64x64 tile per workgroup; coalesced read along cols, coalesced writes along cols (dst) and rows (dst_t)
 __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, int64_t lds_, int rows, int cols,
                                                    void* __restrict__ dst, int64_t ldd, int dst_dtype,
-                                                   void* __restrict__ dst_t, int64_t ldt, int pad_cols) {
+                                                   void* __restrict__ dst_t, int64_t ldt, int pad_cols,
+                                                   const DropParams drop) {
   __shared__ float tile[64][65];
   const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int rr = ty; rr < 64; rr += 4) {
     const int r = r0 + rr, c = c0 + tx;
     float v = 0.f;
-    if (r < rows && c < cols) v = src[(int64_t)r * lds_ + c];
+    if (r < rows && c < cols) {
+      v = src[(int64_t)r * lds_ + c];
+      v *= drop_elem_scale(drop, (unsigned)r * (unsigned)cols + (unsigned)c) * drop_row_scale(drop, r);
+    }
     tile[rr][tx] = v;
     if (dst && r < rows && c < pad_cols) st_any(dst, (int64_t)r * ldd + c, dst_dtype, v);
   }
@@ -128,7 +132,8 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 }  // namespace
 
 extern "C" int afft_cast(const float* src, int64_t lds_, int32_t rows, int32_t cols, void* dst, int64_t ldd,
-                         int32_t dst_dtype, void* dst_t, int64_t ldt, int32_t zero_pad, void* stream_) {
+                         int32_t dst_dtype, void* dst_t, int64_t ldt, int32_t zero_pad, const afft_dropout_t* drop,
+                         void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(src && (dst || dst_t), "cast: null pointer");
   AFFT_CHECK(!dst || ldd >= cols, "cast: ldd < cols");
@@ -137,7 +142,7 @@ extern "C" int afft_cast(const float* src, int64_t lds_, int32_t rows, int32_t c
   const int pad_cols = (dst && zero_pad) ? (int)ldd : cols;
   dim3 grid((pad_cols + 63) / 64, (rows + 63) / 64);
   hipLaunchKernelGGL(cast_kernel, grid, dim3(256), 0, stream, src, lds_, rows, cols, dst, ldd, dst_dtype, dst_t, ldt,
-                     pad_cols);
+                     pad_cols, make_drop(drop));
   AFFT_LAUNCH_CHECK();
   return 0;
 }

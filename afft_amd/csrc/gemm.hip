@@ -252,6 +252,8 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
   e.accumulate = d->accumulate;
   e.out = d->out; e.ldo = d->ldo; e.out_dtype = d->out_dtype;
   e.out2 = d->out2; e.ldo2 = d->ldo2; e.out2_dtype = d->out2_dtype;
+  AFFT_CHECK(d->drop.p >= 0.f && d->drop.p < 1.f && d->drop.path_p >= 0.f && d->drop.path_p < 1.f, "afft_gemm: dropout p outside [0,1)");
+  e.drop = make_drop(&d->drop);
   auto ok4 = [](const void* p, int64_t ld, int dtype) {
     if (!p) return true;
     const uintptr_t align = dtype == AFFT_F32 ? 16 : 8;

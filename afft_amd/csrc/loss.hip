@@ -20,6 +20,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
                                                          const int64_t* __restrict__ labels,
                                                          const float* __restrict__ soft, int64_t lds,
                                                          const uint8_t* __restrict__ keep, float gscale,
+                                                         const float* __restrict__ row_g,
                                                          float* __restrict__ loss_sum, void* __restrict__ dlogits,
                                                          int64_t ldd, int d_dtype, float* __restrict__ row_loss) {
   __shared__ float sh[4];
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
   }
   if (dlogits) {
     const float inv = 1.0f / se;
+    if (row_g) gscale *= row_g[row];
     for (int c = tid; c < ldd; c += 256) {
       float g = 0.f;
       if (c < C) {
@@ -74,11 +76,13 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b,
                                                   int64_t ldb, int rows, int d, float gscale,
+                                                  const float* __restrict__ g_dev, float lscale,
                                                   float* __restrict__ loss_sum, float* __restrict__ da, int64_t ldda,
                                                   float* __restrict__ db, int64_t lddb) {
   __shared__ float sh[4];
   float acc = 0.f;
   const int64_t total = (int64_t)rows * d;
+  if (g_dev) gscale *= g_dev[0];
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int r = (int)(i / d), c = (int)(i - (int64_t)r * d);
     const float diff = a[(int64_t)r * lda + c] - b[(int64_t)r * ldb + c];
@@ -88,36 +92,37 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, i
     if (db) db[(int64_t)r * lddb + c] -= g;
   }
   acc = block_reduce(acc, sh, false);
-  if (threadIdx.x == 0 && loss_sum) atomicAdd(loss_sum, acc);
+  if (threadIdx.x == 0 && loss_sum) atomicAdd(loss_sum, acc * lscale);
 }
 
 }  // namespace
 
 extern "C" int afft_softmax_ce(const float* logits, int64_t ldl, int32_t rows, int32_t C, const int64_t* labels,
-                               const float* soft, int64_t lds, const uint8_t* keep, float gscale, float* loss_sum,
-                               void* dlogits, int64_t ldd, int32_t d_dtype, float* row_loss, void* stream_) {
+                               const float* soft, int64_t lds, const uint8_t* keep, float gscale, const float* row_g,
+                               float* loss_sum, void* dlogits, int64_t ldd, int32_t d_dtype, float* row_loss,
+                               void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(logits, "softmax_ce: null logits");
   AFFT_CHECK((labels != nullptr) != (soft != nullptr), "softmax_ce: give exactly one of labels / soft targets");
   AFFT_CHECK(C > 0 && ldl >= C && (!dlogits || ldd >= C), "softmax_ce: bad sizes");
   if (rows == 0) return 0;
   hipLaunchKernelGGL(softmax_ce_kernel, dim3(rows), dim3(256), 0, stream, logits, ldl, C, labels, soft, lds, keep,
-                     gscale, loss_sum, dlogits, ldd, d_dtype, row_loss);
+                     gscale, row_g, loss_sum, dlogits, ldd, d_dtype, row_loss);
   AFFT_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int afft_mse(const float* a, int64_t lda, const float* b, int64_t ldb, int32_t rows, int32_t d,
-                        float gscale, float* loss_sum, float* da, int64_t ldda, float* db, int64_t lddb,
-                        void* stream_) {
+                        float gscale, const float* g_dev, float lscale, float* loss_sum, float* da, int64_t ldda,
+                        float* db, int64_t lddb, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(a && b, "mse: null pointer");
   if (rows == 0 || d == 0) return 0;
   const int64_t total = (int64_t)rows * d;
   int grid = (int)((total + 255) / 256);
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(mse_kernel, dim3(grid), dim3(256), 0, stream, a, lda, b, ldb, rows, d, gscale, loss_sum, da, ldda,
-                     db, lddb);
+  hipLaunchKernelGGL(mse_kernel, dim3(grid), dim3(256), 0, stream, a, lda, b, ldb, rows, d, gscale, g_dev, lscale, loss_sum,
+                     da, ldda, db, lddb);
   AFFT_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,561 @@
+"""autograd.Function wiring of the HIP kernels: one Function per transformer sub-layer (pre-LN attention,
+pre-LN MLP, pre-LN cross-attention), plus linear / layer-norm / token-assembly / position-table / loss ops.
+
+Every forward and backward below is a fixed sequence of C-ABI kernel launches (afft_amd.ops); torch is
+only the allocator, the stream and the autograd tape.  Residual stream, LayerNorm statistics, softmax
+probabilities, losses, master weights and gradients are fp32; GEMM operands are bf16 (speed mode) or fp32
+(parity mode) according to afft_amd.runtime.precision().
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import ops, runtime as rt
+from ._lib import (ACT_DGELU_ERF, ACT_DGELU_TANH, ACT_GELU_ERF, ACT_GELU_TANH, ACT_NONE, MASK_CAUSAL, MASK_DIAG,
+                   MASK_NONE)
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------- activation buffers
+class Act:
+    """A GEMM operand/result buffer [rows, width] in the activation dtype. In bf16 mode it is allocated
+    [pad64(rows), pad64(width)] with zero tails so it can be the k-contiguous operand of the next GEMM
+    (K = pad64(width)) and the k-strided operand of a wgrad GEMM (K = pad64(rows))."""
+    __slots__ = ("buf", "rows", "width")
+
+    def __init__(self, rows: int, width: int, device, dtype=None, like: Optional[Tensor] = None):
+        dtype = dtype or rt.act_dtype()
+        self.rows, self.width = rows, width
+        if dtype == torch.bfloat16:
+            pr, pw = rt.pad64(rows), rt.pad64(width)
+            self.buf = (torch.empty if (pr == rows and pw == width) else torch.zeros)(pr, pw, dtype=dtype, device=device)
+        else:
+            self.buf = torch.empty(rows, width, dtype=dtype, device=device)
+
+    @property
+    def live(self) -> Tensor:            # [rows, width]
+        return self.buf[:self.rows, :self.width]
+
+    @property
+    def k(self) -> Tensor:               # [rows, pad(width)] : A operand, k-contiguous
+        return self.buf[:self.rows]
+
+    @property
+    def tn(self) -> Tensor:              # [pad(rows), width] : wgrad operand, k-strided
+        return self.buf[:, :self.width]
+
+    def cols(self, c0: int, c1: int) -> Tensor:
+        return self.buf[:self.rows, c0:c1]
+
+
+def to_act(x: Tensor, drop=None) -> Act:
+    """fp32 [rows, width] (any row stride) -> Act in the activation dtype (a cast kernel in bf16 mode;
+    in fp32 mode the tensor is used in place when dense).  drop: optional _lib.Dropout replayed/applied
+    element-wise during the copy (backward of an epilogue dropout, or forward dropout of a GEMM input)."""
+    rows, width = x.shape
+    if rt.precision() == "fp32" and drop is None:
+        a = Act.__new__(Act)
+        a.rows, a.width = rows, width
+        a.buf = x if x.stride(1) == 1 else x.contiguous()
+        return a
+    a = Act(rows, width, x.device)
+    ops.cast(x, a.live, drop=drop)
+    return a
+
+
+# --------------------------------------------------------------------------- linear algebra helpers
+def _lin_fwd(x: Act, W: Tensor, conv1d: bool, out: Tensor, **ep) -> Tensor:
+    """out[rows, n_out] = epilogue(x @ W^T) (nn.Linear, W [out,in]) or x @ W (HF Conv1D, W [in,out])."""
+    if rt.precision() == "bf16":
+        w16, wt16 = rt.weight_images(W)
+        b = wt16 if conv1d else w16          # [out, pad(in)]
+        return ops.gemm(x.k, b, out, b_t=True, **ep)
+    return ops.gemm(x.live, W, out, b_t=not conv1d, **ep)
+
+
+def _lin_dgrad(dy: Act, W: Tensor, conv1d: bool, out: Tensor, **ep) -> Tensor:
+    """out[rows, n_in] = epilogue(dy @ W) (nn.Linear) or dy @ W^T (Conv1D)."""
+    if rt.precision() == "bf16":
+        w16, wt16 = rt.weight_images(W)
+        b = w16 if conv1d else wt16          # [in, pad(out)]
+        return ops.gemm(dy.k, b, out, b_t=True, **ep)
+    return ops.gemm(dy.live, W, out, b_t=conv1d, **ep)
+
+
+def _wgrad(dy: Act, x: Act, W: Tensor, conv1d: bool) -> Optional[Tensor]:
+    """dW = dy^T x (nn.Linear) or x^T dy (Conv1D); accumulated into W.grad (sink mode) or returned."""
+    a, b = (x, dy) if conv1d else (dy, x)
+    if rt.grad_mode() == "sink":
+        g, acc = rt.SINK.grad_buffer(W)
+        ops.gemm(a.tn, b.tn, g, a_t=True, accumulate=acc)
+        _ready(W)
+        return None
+    g = torch.empty_like(W)
+    ops.gemm(a.tn, b.tn, g, a_t=True)
+    return g
+
+
+def _bgrad(dy: Tensor, bias: Optional[Tensor]) -> Optional[Tensor]:
+    if bias is None:
+        return None
+    if rt.grad_mode() == "sink":
+        g, acc = rt.SINK.grad_buffer(bias)
+        ops.colsum(dy, g, accumulate=acc)
+        _ready(bias)
+        return None
+    g = torch.empty_like(bias)
+    ops.colsum(dy, g, accumulate=False)
+    return g
+
+
+def _ready(p: Tensor):
+    cb = rt.SINK.on_grad_ready
+    if cb is not None:
+        cb(p)
+
+
+def _ln_bwd(dy: Tensor, x: Tensor, w: Optional[Tensor], b: Optional[Tensor], mean, rstd, dx_in: Optional[Tensor],
+            dx_out: Optional[Tensor] = None):
+    """returns (dx, dw, db) with dw/db None in sink mode (accumulated in place)."""
+    rows, d = x.shape
+    if dx_out is None:
+        dx_out = torch.empty(rows, d, dtype=torch.float32, device=x.device)
+    if rt.grad_mode() == "sink":
+        gw = gb = None
+        if w is not None:
+            gw, acc = rt.SINK.grad_buffer(w)
+            if not acc:
+                gw.zero_()
+        if b is not None:
+            gb, acc = rt.SINK.grad_buffer(b)
+            if not acc:
+                gb.zero_()
+        ops.layernorm_bwd(dy, x, w, mean, rstd, dx_out, dx_in=dx_in, dw=gw, db=gb)
+        if w is not None:
+            _ready(w)
+        if b is not None:
+            _ready(b)
+        return dx_out, None, None
+    gw = torch.zeros_like(w) if w is not None else None
+    gb = torch.zeros_like(b) if b is not None else None
+    ops.layernorm_bwd(dy, x, w, mean, rstd, dx_out, dx_in=dx_in, dw=gw, db=gb)
+    return dx_out, gw, gb
+
+
+def _stats(rows, device):
+    return torch.empty(rows, dtype=torch.float32, device=device), torch.empty(rows, dtype=torch.float32, device=device)
+
+
+def _attn_drop(drop):
+    return (drop.p_attn, drop.k_attn) if drop is not None else (0.0, 0)
+
+
+def _out_drop(drop):
+    return drop.out_desc() if drop is not None else None
+
+
+_GELU = {"erf": (ACT_GELU_ERF, ACT_DGELU_ERF), "tanh": (ACT_GELU_TANH, ACT_DGELU_TANH)}
+_MASK = {"none": MASK_NONE, "diag": MASK_DIAG, "causal": MASK_CAUSAL}
+
+
+# --------------------------------------------------------------------------- pre-LN self-attention sub-layer
+class AttnSublayer(torch.autograd.Function):
+    """y = x + proj(attn(split(qkv(LN(x)))))   -- Block / DecoderBlock self-attention half
+    (models/transformerblock.py:131-133,158-159) and GPT2Block's attention half (HF modeling_gpt2.py).
+    x: fp32 [nseq*L, d].  Returns (y fp32 [nseq*L, d], probs fp32 [nseq, H, L, L])."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, eps, conv1d, pre_ln=True, scale=None,
+                drop=None):
+        R, d = x.shape
+        nseq, hd = R // L, d // H
+        dev = x.device
+        mean, rstd = _stats(R if pre_ln else 0, dev)
+        if pre_ln:
+            xn = Act(R, d, dev)
+            ops.layernorm_fwd(x, ln_w, ln_b, eps, xn.live, mean, rstd)
+        else:  # bare Attention module (models/transformerblock.py:19-36): no norm, no residual
+            xn = to_act(x)
+        qkv = Act(R, 3 * d, dev)
+        _lin_fwd(xn, w_qkv, conv1d, qkv.live, bias=b_qkv)
+        ao = Act(R, d, dev)
+        probs = torch.empty(nseq, H, L, L, dtype=torch.float32, device=dev)
+        scale = float(scale) if scale else float(hd) ** -0.5
+        ops.attention_fwd(qkv.cols(0, d), qkv.cols(d, 2 * d), qkv.cols(2 * d, 3 * d), nseq, L, H, hd, scale,
+                          _MASK[mask], ao.live, probs, *(_attn_drop(drop)))
+        y = torch.empty(R, d, dtype=torch.float32, device=dev)
+        _lin_fwd(ao, w_proj, conv1d, y, bias=b_proj, residual=x if pre_ln else None, drop=_out_drop(drop))
+        ctx.save_for_backward(x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, mean, rstd, probs)
+        ctx.acts = (xn, qkv, ao)
+        ctx.cfg = (L, H, scale, conv1d, pre_ln, drop)
+        ctx.mark_non_differentiable(probs)
+        return y, probs
+
+    @staticmethod
+    def backward(ctx, dy, _dprobs):
+        x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, mean, rstd, probs = ctx.saved_tensors
+        xn, qkv, ao = ctx.acts
+        L, H, scale, conv1d, pre_ln, drop = ctx.cfg
+        R, d = x.shape
+        nseq, hd = R // L, d // H
+        dev = x.device
+        dy = dy.contiguous()
+        od = _out_drop(drop)
+        dya = to_act(dy, od)
+        g_wp = _wgrad(dya, ao, w_proj, conv1d)
+        g_bp = _bgrad(dy if od is None else dya.live, b_proj)
+        dao = Act(R, d, dev)
+        _lin_dgrad(dya, w_proj, conv1d, dao.live)
+        dqkv = Act(R, 3 * d, dev)
+        ops.attention_bwd(dao.live, qkv.cols(0, d), qkv.cols(d, 2 * d), qkv.cols(2 * d, 3 * d), probs, nseq, L, H, hd,
+                          scale, dqkv.cols(0, d), dqkv.cols(d, 2 * d), dqkv.cols(2 * d, 3 * d), *(_attn_drop(drop)))
+        g_wq = _wgrad(dqkv, xn, w_qkv, conv1d)
+        g_bq = _bgrad(dqkv.live, b_qkv)
+        if pre_ln:
+            dxn = Act(R, d, dev)
+            _lin_dgrad(dqkv, w_qkv, conv1d, dxn.live)
+            dx, g_lw, g_lb = _ln_bwd(dxn.live, x, ln_w, ln_b, mean, rstd, dx_in=dy)
+        else:
+            dx = torch.empty(R, d, dtype=torch.float32, device=dev)
+            _lin_dgrad(dqkv, w_qkv, conv1d, dx)
+            g_lw = g_lb = None
+        ctx.acts = None
+        return dx, g_lw, g_lb, g_wq, g_bq, g_wp, g_bp, None, None, None, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------- pre-LN MLP sub-layer
+class MLPSublayer(torch.autograd.Function):
+    """y = x + fc2(act(fc1(LN(x))))  -- models/transformerblock.py:84-89,134 (exact-erf GELU) and HF GPT2MLP (gelu_new)."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, eps, gelu, conv1d, pre_ln=True, drop=None):
+        R, d = x.shape
+        dev = x.device
+        hidden = w1.shape[1] if conv1d else w1.shape[0]
+        d_out = w2.shape[1] if conv1d else w2.shape[0]
+        mean, rstd = _stats(R if pre_ln else 0, dev)
+        if pre_ln:
+            xn = Act(R, d, dev)
+            ops.layernorm_fwd(x, ln_w, ln_b, eps, xn.live, mean, rstd)
+        else:  # bare MLP module (models/transformerblock.py:84-93)
+            xn = to_act(x)
+        u, h = Act(R, hidden, dev), Act(R, hidden, dev)
+        _lin_fwd(xn, w1, conv1d, h.live, bias=b1, act=_GELU[gelu][0], pre=u.live)
+        y = torch.empty(R, d_out, dtype=torch.float32, device=dev)
+        _lin_fwd(h, w2, conv1d, y, bias=b2, residual=x if pre_ln else None, drop=_out_drop(drop))
+        ctx.save_for_backward(x, ln_w, ln_b, w1, b1, w2, b2, mean, rstd)
+        ctx.acts = (xn, u, h)
+        ctx.cfg = (gelu, conv1d, hidden, pre_ln, drop)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, ln_w, ln_b, w1, b1, w2, b2, mean, rstd = ctx.saved_tensors
+        xn, u, h = ctx.acts
+        gelu, conv1d, hidden, pre_ln, drop = ctx.cfg
+        R, d = x.shape
+        dev = x.device
+        dy = dy.contiguous()
+        od = _out_drop(drop)
+        dya = to_act(dy, od)
+        g_w2 = _wgrad(dya, h, w2, conv1d)
+        g_b2 = _bgrad(dy if od is None else dya.live, b2)
+        du = Act(R, hidden, dev)
+        _lin_dgrad(dya, w2, conv1d, du.live, act=_GELU[gelu][1], aux=u.live)
+        g_w1 = _wgrad(du, xn, w1, conv1d)
+        g_b1 = _bgrad(du.live, b1)
+        if pre_ln:
+            dxn = Act(R, d, dev)
+            _lin_dgrad(du, w1, conv1d, dxn.live)
+            dx, g_lw, g_lb = _ln_bwd(dxn.live, x, ln_w, ln_b, mean, rstd, dx_in=dy)
+        else:
+            dx = torch.empty(R, d, dtype=torch.float32, device=dev)
+            _lin_dgrad(du, w1, conv1d, dx)
+            g_lw = g_lb = None
+        ctx.acts = None
+        return dx, g_lw, g_lb, g_w1, g_b1, g_w2, g_b2, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------- pre-LN cross-attention sub-layer
+class CrossAttnSublayer(torch.autograd.Function):
+    """y = x + proj(attn(q = w_q LN_q(x), k = w_k LN_kv(mem), v = w_v LN_kv(mem)))
+    -- DecoderBlock's cross-attention half, models/transformerblock.py:56-76,160."""
+
+    @staticmethod
+    def forward(ctx, x, mem, nq_w, nq_b, nkv_w, nkv_b, w_q, w_k, w_v, w_proj, b_proj, L, H, mask, eps, pre_ln=True,
+                scale=None, drop=None):
+        R, d = x.shape
+        nseq, hd = R // L, d // H
+        dev = x.device
+        mq, rq = _stats(R if pre_ln else 0, dev)
+        mk, rk = _stats(R if pre_ln else 0, dev)
+        if pre_ln:
+            xq, mkv = Act(R, d, dev), Act(R, d, dev)
+            ops.layernorm_fwd(x, nq_w, nq_b, eps, xq.live, mq, rq)
+            ops.layernorm_fwd(mem, nkv_w, nkv_b, eps, mkv.live, mk, rk)
+        else:  # bare CrossAttention module (models/transformerblock.py:56-76)
+            xq, mkv = to_act(x), to_act(mem)
+        q, k, v = Act(R, d, dev), Act(R, d, dev), Act(R, d, dev)
+        _lin_fwd(xq, w_q, False, q.live)
+        _lin_fwd(mkv, w_k, False, k.live)
+        _lin_fwd(mkv, w_v, False, v.live)
+        ao = Act(R, d, dev)
+        probs = torch.empty(nseq, H, L, L, dtype=torch.float32, device=dev)
+        scale = float(scale) if scale else float(hd) ** -0.5
+        ops.attention_fwd(q.live, k.live, v.live, nseq, L, H, hd, scale, _MASK[mask], ao.live, probs,
+                          *(_attn_drop(drop)))
+        y = torch.empty(R, d, dtype=torch.float32, device=dev)
+        _lin_fwd(ao, w_proj, False, y, bias=b_proj, residual=x if pre_ln else None, drop=_out_drop(drop))
+        ctx.save_for_backward(x, mem, nq_w, nq_b, nkv_w, nkv_b, w_q, w_k, w_v, w_proj, b_proj, mq, rq, mk, rk, probs)
+        ctx.acts = (xq, mkv, q, k, v, ao)
+        ctx.cfg = (L, H, scale, pre_ln, drop)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x, mem, nq_w, nq_b, nkv_w, nkv_b, w_q, w_k, w_v, w_proj, b_proj, mq, rq, mk, rk, probs) = ctx.saved_tensors
+        xq, mkv, q, k, v, ao = ctx.acts
+        L, H, scale, pre_ln, drop = ctx.cfg
+        R, d = x.shape
+        nseq, hd = R // L, d // H
+        dev = x.device
+        dy = dy.contiguous()
+        od = _out_drop(drop)
+        dya = to_act(dy, od)
+        g_wp = _wgrad(dya, ao, w_proj, False)
+        g_bp = _bgrad(dy if od is None else dya.live, b_proj)
+        dao = Act(R, d, dev)
+        _lin_dgrad(dya, w_proj, False, dao.live)
+        dq, dk, dv = Act(R, d, dev), Act(R, d, dev), Act(R, d, dev)
+        ops.attention_bwd(dao.live, q.live, k.live, v.live, probs, nseq, L, H, hd, scale, dq.live, dk.live, dv.live,
+                          *(_attn_drop(drop)))
+        g_q = _wgrad(dq, xq, w_q, False)
+        g_k = _wgrad(dk, mkv, w_k, False)
+        g_v = _wgrad(dv, mkv, w_v, False)
+        dmkv = torch.empty(R, d, dtype=torch.float32, device=dev)
+        _lin_dgrad(dk, w_k, False, dmkv)
+        _lin_dgrad(dv, w_v, False, dmkv, accumulate=True)
+        if pre_ln:
+            dxq = Act(R, d, dev)
+            _lin_dgrad(dq, w_q, False, dxq.live)
+            dx, g_qw, g_qb = _ln_bwd(dxq.live, x, nq_w, nq_b, mq, rq, dx_in=dy)
+            dmem, g_kw, g_kb = _ln_bwd(dmkv, mem, nkv_w, nkv_b, mk, rk, dx_in=None)
+        else:
+            dx = torch.empty(R, d, dtype=torch.float32, device=dev)
+            _lin_dgrad(dq, w_q, False, dx)
+            dmem, g_qw, g_qb, g_kw, g_kb = dmkv, None, None, None, None
+        ctx.acts = None
+        return dx, dmem, g_qw, g_qb, g_kw, g_kb, g_q, g_k, g_v, g_wp, g_bp, None, None, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------- plain linear (mapping, enc/dec, classifier)
+class Linear(torch.autograd.Function):
+    """y[rows, out] = x @ W^T (+ b), fp32 in / fp32 out: feature mapping (models/feature_mapping.py:59-61),
+    dim_encoder / dim_decoder (future_prediction.py:246-255) and the classifier (future_prediction.py:108-121)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, in_drop=None):
+        rows = x.shape[0]
+        n_out = W.shape[0]
+        xa = to_act(x, in_drop)   # Dropout(p) on the input: classifier (future_prediction.py:108)
+        ctx.in_drop = in_drop
+        ybuf = torch.empty(rows, rt.pad64(n_out) if n_out % 4 else n_out, dtype=torch.float32, device=x.device)
+        y = ybuf[:, :n_out]
+        _lin_fwd(xa, W, False, y, bias=b)
+        ctx.save_for_backward(W, b)
+        ctx.xa = xa
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        W, b = ctx.saved_tensors
+        xa = ctx.xa
+        dya = to_act(dy)
+        g_w = _wgrad(dya, xa, W, False)
+        g_b = _bgrad(dya.live if rt.precision() == "fp32" else dy if dy.stride(1) == 1 else dy.contiguous(), b)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(xa.rows, W.shape[1], dtype=torch.float32, device=dy.device)
+            _lin_dgrad(dya, W, False, dx)
+            if ctx.in_drop is not None:
+                ops.cast(dx, dx, drop=ctx.in_drop)   # replay the input mask on the gradient (in place)
+        ctx.xa = None
+        return dx, g_w, g_b, None
+
+
+# --------------------------------------------------------------------------- standalone LayerNorm (final norms)
+class LayerNormRows(torch.autograd.Function):
+    """y[r] = LN(X[r*stride_rows]) for r < rows: stride_rows = S picks token 0 of every frame
+    (models/fusion.py:362-364), stride_rows = 1 is a plain LayerNorm (GPT-2 ln_f, CA-Fuser norm)."""
+
+    @staticmethod
+    def forward(ctx, X, w, b, eps, stride_rows):
+        Rall, d = X.shape
+        rows = Rall // stride_rows
+        xv = X.view(rows, stride_rows * d)[:, :d]
+        mean, rstd = _stats(rows, X.device)
+        y = torch.empty(rows, d, dtype=torch.float32, device=X.device)
+        ops.layernorm_fwd(xv, w, b, eps, y, mean, rstd)
+        ctx.save_for_backward(X, w, b, mean, rstd)
+        ctx.stride_rows = stride_rows
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        X, w, b, mean, rstd = ctx.saved_tensors
+        s = ctx.stride_rows
+        Rall, d = X.shape
+        rows = Rall // s
+        dy = dy.contiguous()
+        if s == 1:
+            dX, gw, gb = _ln_bwd(dy, X, w, b, mean, rstd, dx_in=None)
+        else:
+            dX = torch.zeros_like(X)
+            _, gw, gb = _ln_bwd(dy, X.view(rows, s * d)[:, :d], w, b, mean, rstd, dx_in=None,
+                                dx_out=dX.view(rows, s * d)[:, :d])
+        return dX, gw, gb, None, None
+
+
+# --------------------------------------------------------------------------- SA-Fuser token assembly
+class AssembleTokens(torch.autograd.Function):
+    """X[(b,t), s, :] = [modal_token | feats...] (+ modality_embedding) -- models/fusion.py:338-352."""
+
+    @staticmethod
+    def forward(ctx, token, mod_embed, T, frame_level, *feats):
+        BT, d = feats[0].shape
+        S = len(feats) + 1
+        X = torch.empty(BT * S, d, dtype=torch.float32, device=feats[0].device)
+        tok2d = token.view(-1, d)
+        ops.assemble_tokens(list(feats), tok2d, d if frame_level else 0,
+                            None if mod_embed is None else mod_embed.view(S, d), BT, T, d, X.view(BT, S, d))
+        ctx.save_for_backward(token, mod_embed)
+        ctx.cfg = (T, frame_level, S, BT, d, [f.requires_grad for f in feats])
+        return X
+
+    @staticmethod
+    def backward(ctx, dX):
+        token, mod_embed = ctx.saved_tensors
+        T, frame_level, S, BT, d, needs = ctx.cfg
+        dX = dX.contiguous()
+        dX3 = dX.view(BT, S * d)
+        g_tok = g_emb = None
+        sink = rt.grad_mode() == "sink"
+        # modal token gradient: sum over frames of token-0 rows (per frame position if frame-level)
+        if sink:
+            gt, acc = rt.SINK.grad_buffer(token)
+            if not acc:
+                gt.zero_()
+        else:
+            gt = torch.zeros_like(token)
+            g_tok = gt
+        ops.reduce_rows_periodic(dX3[:, :d], T if frame_level else 1, gt.view(-1, d))
+        if sink:
+            _ready(token)
+        if mod_embed is not None:
+            if sink:
+                ge, acc = rt.SINK.grad_buffer(mod_embed)
+                if not acc:
+                    ge.zero_()
+            else:
+                ge = torch.zeros_like(mod_embed)
+                g_emb = ge
+            ops.reduce_rows_periodic(dX, S, ge.view(S, d))
+            if sink:
+                _ready(mod_embed)
+        gf = [dX3[:, (i + 1) * d:(i + 2) * d] if n else None for i, n in enumerate(needs)]
+        return (g_tok, g_emb, None, None, *gf)
+
+
+# --------------------------------------------------------------------------- periodic row table (wpe / position embeddings)
+class AddRowTable(torch.autograd.Function):
+    """y[r] = x[r] + table[offset + r % period]  -- GPT-2 wpe (HF modeling_gpt2.py:576-577) and the CA-Fuser
+    position embedding (models/fusion.py:255-262)."""
+
+    @staticmethod
+    def forward(ctx, x, table, period, offset):
+        y = torch.empty_like(x)
+        ops.add_rows_periodic(x, table[offset:offset + period], period, y)
+        ctx.save_for_backward(table)
+        ctx.cfg = (period, offset)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (table,) = ctx.saved_tensors
+        period, offset = ctx.cfg
+        dy = dy.contiguous()
+        if rt.grad_mode() == "sink":
+            g, acc = rt.SINK.grad_buffer(table)
+            if not acc:
+                g.zero_()
+            ops.reduce_rows_periodic(dy, period, g[offset:offset + period])
+            _ready(table)
+            return dy, None, None, None
+        g = torch.zeros_like(table)
+        ops.reduce_rows_periodic(dy, period, g[offset:offset + period])
+        return dy, g, None, None
+
+
+class ElementDropout(torch.autograd.Function):
+    """nn.Dropout(p) on an fp32 [rows, d] tensor (token / embedding dropout, models/fusion.py:355,
+    HF GPT2Model drop).  The mask is a pure function of (key, element index); backward replays it."""
+
+    @staticmethod
+    def forward(ctx, x, desc):
+        y = torch.empty_like(x)
+        ops.cast(x, y, drop=desc)
+        ctx.desc = desc
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        ops.cast(dy, dx, drop=ctx.desc)
+        return dx, None
+
+
+# --------------------------------------------------------------------------- losses
+class SoftmaxCE(torch.autograd.Function):
+    """Per-row softmax cross-entropy (reduction='none'); ignored rows give 0.  common/runner.py:13-37."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, soft, keep):
+        rows, C = logits.shape
+        row_loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
+        lg = logits if logits.stride(1) == 1 else logits.contiguous()
+        ops.softmax_ce(lg, C, labels=labels, soft=soft, keep=keep, row_loss=row_loss)
+        ctx.save_for_backward(lg, labels, soft, keep)
+        return row_loss
+
+    @staticmethod
+    def backward(ctx, g_rows):
+        lg, labels, soft, keep = ctx.saved_tensors
+        rows, C = lg.shape
+        d = torch.empty(rows, C, dtype=torch.float32, device=lg.device)
+        ops.softmax_ce(lg, C, labels=labels, soft=soft, keep=keep, dlogits=d, row_g=g_rows.contiguous())
+        return d, None, None, None
+
+
+class MSE(torch.autograd.Function):
+    """mean((a-b)^2), gradient to both sides (common/runner.py:164-166)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        rows, d = a.shape
+        out = torch.zeros((), dtype=torch.float32, device=a.device)
+        ops.mse(a, b, 1.0, out, None, None, lscale=1.0 / (rows * d))
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        rows, d = a.shape
+        da = torch.zeros(rows, d, dtype=torch.float32, device=a.device)
+        db = torch.zeros(rows, d, dtype=torch.float32, device=a.device)
+        ops.mse(a, b, 1.0 / (rows * d), None, da, db, g_dev=g.contiguous())
+        return da, db

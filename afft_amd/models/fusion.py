@@ -1,0 +1,147 @@
+"""MI355X mirror of the reference's ``models/fusion.py`` for the hot path:
+
+  ModalTokenCMFuser         (SA-Fuser with modality token)   <- models/fusion.py:273-365
+  TemporalCrossAttentFuser  (CA-Fuser)                       <- models/fusion.py:218-270
+
+Same constructor keywords (the Hydra surface of conf/model/fuser/{SA,CA}-Fuser.yaml), same parameter
+names (checkpoints load unchanged), same return values.  Token assembly, the transformer blocks and the
+final LayerNorm (on token 0 only: the reference normalises all S tokens and keeps one) run in HIP kernels.
+CMFuser / TemporalCMFuser / MATT are "next" rows of SURVEY.md 8(f) and are not provided here.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .. import dropout as D_
+from .. import functional as F_
+from .transformerblock import Block, DecoderBlock
+
+
+def trunc_normal_(t: Tensor, std: float = 0.02):
+    return nn.init.trunc_normal_(t, std=std)
+
+
+def _init_weights(m):
+    # timm VisionTransformer style init used by the reference (models/fusion.py:21-27)
+    if isinstance(m, nn.Linear):
+        trunc_normal_(m.weight, std=.02)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+
+
+def generate_square_subsequent_mask(sz: int):
+    return torch.triu(torch.full((sz, sz), float('-inf')), diagonal=1)
+
+
+def _check_same_shape(modal_feats: Dict[str, Tensor]):
+    shape = next(iter(modal_feats.values())).shape
+    assert all([v.shape == shape for v in modal_feats.values()]), \
+        'The shape of all inputs of the fusion module should be the same!'
+    return shape
+
+
+def _rows(f: Tensor, BT: int, C: int) -> Tensor:
+    f2 = f.reshape(BT, C)
+    return f2 if f2.dtype == torch.float32 else f2.float()
+
+
+class ModalTokenCMFuser(nn.Module):
+    """Corresponds to SA-Fuser with modality token in the paper"""
+
+    def __init__(self, dim, depth=1, num_heads=4, mlp_ratio=4., qkv_bias=False, qk_scale=None, embd_drop_rate=0.,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0., act_layer=nn.GELU,
+                 norm_elementwise=True, cross_attn=False, modalities=None, modal_encoding=False,
+                 frame_level_token=False, temporal_sequence_length=None):
+        super().__init__()
+        from functools import partial
+        norm_layer = partial(nn.LayerNorm, eps=1e-6, elementwise_affine=norm_elementwise)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]  # stochastic depth decay rule
+        self.blocks = nn.ModuleList([
+            Block(dim=dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                  drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[i], act_layer=act_layer,
+                  norm_layer=norm_layer) for i in range(depth)])
+        self.norm = norm_layer(dim)
+        self.num_mods = len(modalities) + 1  # + the modality-agnostic token
+        self.modality_embedding = nn.Parameter(torch.zeros(1, self.num_mods, dim)) if modal_encoding else None
+        self.embd_drop = nn.Dropout(embd_drop_rate)
+        self.cross_attn = cross_attn
+        self.frame_level_token = frame_level_token
+        self.temporal_sequence_length = temporal_sequence_length
+        if not frame_level_token:
+            self.modal_token = nn.Parameter(torch.zeros(1, 1, dim))
+        else:
+            assert temporal_sequence_length is not None, "Temporal sequence length must be provided!"
+            self.modal_token = nn.Parameter(torch.zeros(1, temporal_sequence_length, dim))
+        trunc_normal_(self.modal_token, std=.02)
+        if self.modality_embedding is not None:
+            trunc_normal_(self.modality_embedding, std=.02)
+        self.apply(_init_weights)
+
+    @staticmethod
+    def generate_cross_attention_mask(sz):
+        mask = torch.eye(sz)
+        return mask.masked_fill(mask == 1, float('-inf'))
+
+    def forward(self, modal_feats: Dict[str, Tensor], ordered_feature_list: Callable) -> Tuple[Tensor, Tensor]:
+        B, T, C = _check_same_shape(modal_feats)
+        feats = ordered_feature_list(modal_feats)
+        S = len(feats) + 1
+        if self.frame_level_token:
+            assert self.temporal_sequence_length == T, \
+                f"Temporal sequence length not valid {self.temporal_sequence_length} vs {T}"
+        BT = B * T
+        X = F_.AssembleTokens.apply(self.modal_token, self.modality_embedding, T, self.frame_level_token,
+                                    *[_rows(f, BT, C) for f in feats])          # [BT*S, C]
+        if self.training and self.embd_drop.p > 0:
+            X = F_.ElementDropout.apply(X, D_.elementwise(self.embd_drop.p))
+        mask = "diag" if self.cross_attn else "none"
+        attn_weights = []
+        for blk in self.blocks:
+            X, probs = blk.forward_rows(X, S, mask)                                # probs [BT, H, S, S]
+            attn_weights.append(probs.view(B, T, *probs.shape[1:]))
+        z = F_.LayerNormRows.apply(X, self.norm.weight, self.norm.bias, self.norm.eps, S)   # token 0 of each frame
+        return z.view(B, T, C), torch.stack(attn_weights).transpose(0, 1)
+
+
+class TemporalCrossAttentFuser(nn.Module):
+    """Corresponds to CA-Fuser in the paper: rgb is the query stream, every other modality a memory;
+    depth = number of modalities - 1."""
+
+    def __init__(self, dim, modalities=None, num_heads=4, mlp_ratio=4., qkv_bias=False, qk_scale=None,
+                 embd_drop_rate=0., drop_rate=0., attn_drop_rate=0., drop_path_rate=0., act_layer=nn.GELU,
+                 norm_layer=None, max_position_embeddings=128):
+        super().__init__()
+        from functools import partial
+        norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
+        depth = len(modalities) - 1
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+        self.blocks = nn.ModuleList([
+            DecoderBlock(dim=dim, mem_dim=None, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                         qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[i],
+                         act_layer=act_layer, norm_layer=norm_layer) for i in range(depth)])
+        self.norm = norm_layer(dim)
+        self.embd_drop = nn.Dropout(embd_drop_rate)
+        self.position_embeddings = nn.Embedding(max_position_embeddings, dim)
+        self.apply(_init_weights)
+
+    def forward(self, modal_feats: Dict[str, Tensor], ordered_feature_list: Callable) -> Tuple[Tensor, Tensor]:
+        B, T, C = _check_same_shape(modal_feats)
+        feats = ordered_feature_list(modal_feats)
+        BT = B * T
+        table = self.position_embeddings.weight
+        streams = []
+        for f in feats:
+            s = F_.AddRowTable.apply(_rows(f, BT, C).contiguous(), table, T, 0)
+            if self.training and self.embd_drop.p > 0:
+                s = F_.ElementDropout.apply(s, D_.elementwise(self.embd_drop.p))
+            streams.append(s)
+        x, mems = streams[0], streams[1:]
+        for i, blk in enumerate(self.blocks):
+            x = blk.forward_rows(x, mems[i], T, "causal")
+        x = F_.LayerNormRows.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, 1)
+        dummy_attention = torch.zeros(B, requires_grad=False)  # to satisfy the framework (models/fusion.py:269)
+        return x.view(B, T, C), dummy_attention

@@ -43,7 +43,7 @@ def _rowmajor(t: Tensor, what: str):
 def gemm(a: Tensor, b: Tensor, out: Tensor, *, a_t: bool = False, b_t: bool = False, bias: Optional[Tensor] = None,
          act: int = ACT_NONE, aux: Optional[Tensor] = None, pre: Optional[Tensor] = None,
          rowscale: Optional[Tensor] = None, residual: Optional[Tensor] = None, accumulate: bool = False,
-         out2: Optional[Tensor] = None, alpha: float = 1.0) -> Tensor:
+         out2: Optional[Tensor] = None, alpha: float = 1.0, drop: Optional["L.Dropout"] = None) -> Tensor:
     """out = epilogue(alpha * A @ B).  A = a (or a.T if a_t), B = b (or b.T if b_t); a, b 2-D views."""
     M, K = (a.shape[1], a.shape[0]) if a_t else (a.shape[0], a.shape[1])
     Kb, N = (b.shape[1], b.shape[0]) if b_t else (b.shape[0], b.shape[1])
@@ -78,6 +78,8 @@ def gemm(a: Tensor, b: Tensor, out: Tensor, *, a_t: bool = False, b_t: bool = Fa
     d.out, d.ldo, d.out_dtype = _p(out), _rowmajor(out, "out"), _dt(out)
     if out2 is not None:
         d.out2, d.ldo2, d.out2_dtype = _p(out2), _rowmajor(out2, "out2"), _dt(out2)
+    if drop is not None:
+        d.drop = drop
     L.check(L.lib().afft_gemm(C.byref(d), _stream()), "gemm")
     return out
 
@@ -110,26 +112,28 @@ def layernorm_bwd(dy: Tensor, x: Tensor, w: Optional[Tensor], mean: Tensor, rstd
 
 
 def attention_fwd(q: Tensor, k: Tensor, v: Tensor, nseq: int, L_: int, H: int, hd: int, scale: float, mask: int,
-                  out: Tensor, probs: Optional[Tensor]) -> Tensor:
+                  out: Tensor, probs: Optional[Tensor], drop_p: float = 0.0, drop_key: int = 0) -> Tensor:
     assert q.dtype == k.dtype == v.dtype == out.dtype
     L.check(L.lib().afft_attention_fwd(_p(q), _rowmajor(q, "q"), _p(k), _rowmajor(k, "k"), _p(v), _rowmajor(v, "v"),
-                                       _dt(q), nseq, L_, H, hd, scale, mask, _p(out), _rowmajor(out, "out"),
-                                       _p(probs), _stream()), "attention_fwd")
+                                       _dt(q), nseq, L_, H, hd, scale, mask, drop_p, drop_key, _p(out),
+                                       _rowmajor(out, "out"), _p(probs), _stream()), "attention_fwd")
     return out
 
 
 def attention_bwd(dout: Tensor, q: Tensor, k: Tensor, v: Tensor, probs: Tensor, nseq: int, L_: int, H: int, hd: int,
-                  scale: float, dq: Tensor, dk: Tensor, dv: Tensor):
+                  scale: float, dq: Tensor, dk: Tensor, dv: Tensor, drop_p: float = 0.0, drop_key: int = 0):
     assert dout.dtype == q.dtype == k.dtype == v.dtype == dq.dtype == dk.dtype == dv.dtype
     L.check(L.lib().afft_attention_bwd(_p(dout), _rowmajor(dout, "dout"), _p(q), _rowmajor(q, "q"), _p(k),
                                        _rowmajor(k, "k"), _p(v), _rowmajor(v, "v"), _dt(q), _p(probs), nseq, L_, H,
-                                       hd, scale, _p(dq), _rowmajor(dq, "dq"), _p(dk), _rowmajor(dk, "dk"), _p(dv),
+                                       hd, scale, drop_p, drop_key, _p(dq), _rowmajor(dq, "dq"), _p(dk),
+                                       _rowmajor(dk, "dk"), _p(dv),
                                        _rowmajor(dv, "dv"), _stream()), "attention_bwd")
 
 
 def softmax_ce(logits: Tensor, C_: int, *, labels: Optional[Tensor] = None, soft: Optional[Tensor] = None,
-               keep: Optional[Tensor] = None, gscale: float = 1.0, loss_sum: Optional[Tensor] = None,
-               dlogits: Optional[Tensor] = None, row_loss: Optional[Tensor] = None):
+               keep: Optional[Tensor] = None, gscale: float = 1.0, row_g: Optional[Tensor] = None,
+               loss_sum: Optional[Tensor] = None, dlogits: Optional[Tensor] = None,
+               row_loss: Optional[Tensor] = None):
     """logits fp32 [rows, >=C] view. labels int64 [rows] (-1 ignored) or soft fp32 [rows, C]; keep uint8 [rows]."""
     rows = logits.shape[0]
     assert logits.dtype == torch.float32
@@ -141,27 +145,31 @@ def softmax_ce(logits: Tensor, C_: int, *, labels: Optional[Tensor] = None, soft
         assert keep.dtype == torch.uint8 and keep.numel() == rows
     L.check(L.lib().afft_softmax_ce(_p(logits), _rowmajor(logits, "logits"), rows, C_, _p(labels), _p(soft),
                                     _rowmajor(soft, "soft") if soft is not None else 0, _p(keep), gscale,
-                                    _p(loss_sum), _p(dlogits),
+                                    _p(row_g), _p(loss_sum), _p(dlogits),
                                     _rowmajor(dlogits, "dlogits") if dlogits is not None else 0,
                                     _dt(dlogits) if dlogits is not None else 0, _p(row_loss), _stream()), "softmax_ce")
 
 
-def mse(a: Tensor, b: Tensor, gscale: float, loss_sum: Optional[Tensor], da: Optional[Tensor], db: Optional[Tensor]):
+def mse(a: Tensor, b: Tensor, gscale: float, loss_sum: Optional[Tensor], da: Optional[Tensor], db: Optional[Tensor],
+        g_dev: Optional[Tensor] = None, lscale: float = 1.0):
     rows, d = a.shape
     assert a.dtype == b.dtype == torch.float32 and b.shape == a.shape
-    L.check(L.lib().afft_mse(_p(a), _rowmajor(a, "a"), _p(b), _rowmajor(b, "b"), rows, d, gscale, _p(loss_sum),
+    L.check(L.lib().afft_mse(_p(a), _rowmajor(a, "a"), _p(b), _rowmajor(b, "b"), rows, d, gscale, _p(g_dev), lscale,
+                             _p(loss_sum),
                              _p(da), _rowmajor(da, "da") if da is not None else 0, _p(db),
                              _rowmajor(db, "db") if db is not None else 0, _stream()), "mse")
 
 
-def cast(src: Tensor, dst: Optional[Tensor], dst_t: Optional[Tensor] = None, zero_pad: bool = False):
+def cast(src: Tensor, dst: Optional[Tensor], dst_t: Optional[Tensor] = None, zero_pad: bool = False,
+         drop: Optional["L.Dropout"] = None):
     """fp32 [rows, cols] -> dst [rows, >=cols] and/or dst_t [cols, >=rows] (dtype of dst)."""
     rows, cols = src.shape
     assert src.dtype == torch.float32
     ref = dst if dst is not None else dst_t
     L.check(L.lib().afft_cast(_p(src), _rowmajor(src, "src"), rows, cols, _p(dst),
                               dst.stride(0) if dst is not None else 0, _dt(ref), _p(dst_t),
-                              dst_t.stride(0) if dst_t is not None else 0, 1 if zero_pad else 0, _stream()), "cast")
+                              dst_t.stride(0) if dst_t is not None else 0, 1 if zero_pad else 0,
+                              C.byref(drop) if drop is not None else None, _stream()), "cast")
 
 
 def assemble_tokens(feats: Sequence[Tensor], token: Tensor, tok_stride_t: int, mod_embed: Optional[Tensor], BT: int,

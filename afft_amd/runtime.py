@@ -1,0 +1,137 @@
+"""Host-side runtime shared by the mirrored reference modules: precision mode, cached bf16 weight
+images for the MFMA fast path, and the gradient sink that lets weight-gradient GEMMs accumulate
+straight into (flat, all-reduce-friendly) ``.grad`` storage.
+
+Precision modes
+  * ``bf16`` (default, the speed mode BASELINE.json's configs[1] names): bf16 operands on
+    v_mfma_f32_16x16x32_bf16, fp32 accumulation, fp32 residual stream / LayerNorm statistics /
+    softmax / losses / master weights / gradients.
+  * ``fp32`` (parity mode): every GEMM on the exact-fp32 MFMA path, all activations fp32; this is
+    the mode whose logits are checked to 1e-3 against the reference's fp32 CPU path.
+"""
+from __future__ import annotations
+
+import os
+import weakref
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+
+Tensor = torch.Tensor
+
+_PRECISION = os.environ.get("AFFT_PRECISION", "bf16")
+_GRAD_MODE = os.environ.get("AFFT_GRAD_MODE", "sink")  # 'sink' | 'autograd'
+
+
+def set_precision(p: str):
+    global _PRECISION
+    if p not in ("bf16", "fp32"):
+        raise ValueError("precision must be 'bf16' or 'fp32'")
+    _PRECISION = p
+
+
+def precision() -> str:
+    return _PRECISION
+
+
+def act_dtype() -> torch.dtype:
+    return torch.bfloat16 if _PRECISION == "bf16" else torch.float32
+
+
+def set_grad_mode(m: str):
+    """'sink': weight gradients are accumulated by the wgrad GEMM epilogue directly into param.grad
+    (no autograd accumulation, no per-parameter hooks; use afft_amd.parallel.GradReducer for DP).
+    'autograd': weight gradients are returned through autograd (works under torch DDP, slower)."""
+    global _GRAD_MODE
+    if m not in ("sink", "autograd"):
+        raise ValueError(m)
+    _GRAD_MODE = m
+
+
+def grad_mode() -> str:
+    return _GRAD_MODE
+
+
+def pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+# --------------------------------------------------------------------------- bf16 weight images
+class _WImage:
+    __slots__ = ("version", "ptr", "w", "wt")
+
+
+_wcache: "weakref.WeakKeyDictionary[Tensor, _WImage]" = weakref.WeakKeyDictionary()
+
+
+def weight_images(p: Tensor):
+    """(w16 [rows, pad64(cols)], wt16 [cols, pad64(rows)]) bf16 images of a 2-D fp32 parameter, zero padded,
+    refreshed when the parameter's version counter or storage changes (optimizer step, load_state_dict)."""
+    img = _wcache.get(p)
+    ver = p._version
+    if img is None or img.ptr != p.data_ptr() or img.w.device != p.device:
+        img = _WImage()
+        rows, cols = p.shape
+        img.w = torch.zeros(rows, pad64(cols), dtype=torch.bfloat16, device=p.device)
+        img.wt = torch.zeros(cols, pad64(rows), dtype=torch.bfloat16, device=p.device)
+        img.version = -1
+        img.ptr = p.data_ptr()
+        _wcache[p] = img
+    if img.version != ver:
+        with torch.no_grad():
+            ops.cast(p.detach(), img.w, img.wt)
+        img.version = ver
+    return img.w, img.wt
+
+
+def invalidate_weight_images():
+    for img in _wcache.values():
+        img.version = -1
+
+
+# --------------------------------------------------------------------------- gradient sink
+class GradSink:
+    """Tracks which parameter gradients have been written during the current backward pass so the first
+    wgrad of a step overwrites (no zero-fill pass over ~2.5 GB) and later ones accumulate."""
+
+    def __init__(self):
+        self.touched: Dict[int, bool] = {}
+        self.on_grad_ready = None  # callback(param) fired after a parameter's gradient has been produced
+
+    def begin_step(self):
+        self.touched.clear()
+
+    def grad_buffer(self, p: Tensor):
+        """(grad tensor, accumulate?)"""
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+            self.touched[id(p)] = True
+            return p.grad, True
+        first = not self.touched.get(id(p), False)
+        self.touched[id(p)] = True
+        return p.grad, not first
+
+    def finish_step(self, params):
+        """Zero the gradients of parameters that took no part in this step."""
+        for p in params:
+            if p.requires_grad and p.grad is not None and not self.touched.get(id(p), False):
+                p.grad.zero_()
+
+
+SINK = GradSink()
+
+
+def empty(*shape, dtype=torch.float32, device=None) -> Tensor:
+    return torch.empty(*shape, dtype=dtype, device=device)
+
+
+def padded_rows(rows: int, cols: int, dtype, device, zero_tail: bool = True) -> Tensor:
+    """[pad64(rows), cols] buffer whose tail rows are zero: lets a wgrad (TN) GEMM reduce over the row
+    dimension in whole 64-deep steps.  Returns the full padded buffer; use [:rows] for the live part."""
+    pr = pad64(rows)
+    t = torch.empty(pr, cols, dtype=dtype, device=device)
+    if zero_tail and pr != rows:
+        t[rows:].zero_()
+    return t

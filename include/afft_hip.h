@@ -27,6 +27,16 @@ enum { AFFT_ACT_NONE = 0, AFFT_ACT_GELU_ERF = 1, AFFT_ACT_GELU_TANH = 2,
        AFFT_ACT_DGELU_TANH = 4 };/* v *= d/du gelu_new(aux[m,n])  (backward of HF gelu_new) */
 enum { AFFT_MASK_NONE = 0, AFFT_MASK_DIAG = 1, AFFT_MASK_CAUSAL = 2 };
 
+/* Dropout description shared by the kernels that apply or replay a dropout mask.  keep(idx) is a pure
+ * function of (key, element index), so backward passes regenerate the forward mask instead of storing it.
+ * Element index of [m, n] in an [M, N] tensor is m*N + n.  p = 0 disables.  DropPath (stochastic depth,
+ * models/transformerblock.py:96-104): rows m with equal m / path_group form one sample. */
+typedef struct {
+  float p;            uint32_t key;        /* nn.Dropout(p) on elements */
+  float path_p;       uint32_t path_key;   /* DropPath(p) on row groups */
+  int32_t path_group;
+} afft_dropout_t;
+
 const char* afft_last_error(void);
 int afft_version(void);
 
@@ -36,8 +46,8 @@ int afft_version(void);
  *   models/transformerblock.py:14,16,21,34,48-50,84-89 ; models/feature_mapping.py:59-61 ;
  *   models/future_prediction.py:108-121,246-255 ; HF modeling_gpt2.py Conv1D (c_attn, c_proj, c_fc)
  * and their backward (dgrad: dX = dY*W ; wgrad: dW = dY^T*X).
- * epilogue order: v = alpha*acc ; v += bias[n] ; pre[m,n] = v ; v = act(v | aux[m,n]) ;
- *                 v *= rowscale[m] ; v += residual[m,n] ; v += out[m,n] if accumulate ; store out, out2.
+ * epilogue order: v = alpha*acc ; v += bias[n] ; pre[m,n] = v ; v = act(v | aux[m,n]) ; v = dropout(v) ;
+ *                 v *= rowscale[m]*droppath(m) ; v += residual[m,n] ; v += out[m,n] if accumulate ; store out, out2.
  * dtype = operand dtype of A and B (both the same).  With AFFT_BF16 operands, k-contiguous
  * ("NT": a_cs==1,b_rs==1) and k-strided ("TN": a_rs==1,b_cs==1) layouts with K%64==0 and 16-byte
  * aligned rows take the MFMA bf16 fast path (fp32 accumulate); anything else, and every AFFT_F32 call,
@@ -57,6 +67,7 @@ typedef struct {
   int32_t accumulate;                /* out (fp32 only) += */
   void* out; int64_t ldo; int32_t out_dtype;
   void* out2; int64_t ldo2; int32_t out2_dtype;        /* optional second copy */
+  afft_dropout_t drop;               /* dropout / DropPath on the output (train mode), p = 0 -> off */
 } afft_gemm_t;
 int afft_gemm(const afft_gemm_t* g, void* stream);
 
@@ -83,34 +94,41 @@ int afft_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const flo
  *   GPT-2:    L = T frames, causal                   (HF modeling_gpt2.py eager_attention_forward)
  *   CA-Fuser: causal self and cross attention        (models/transformerblock.py:56-76)
  * q/k/v: [nseq*L, *] with row strides ldq/ldk/ldv, head h at columns h*hd..; out [nseq*L, H*hd].
- * probs: fp32 [nseq, H, L, L] (the attention weights the reference returns; also saved for backward). */
+ * probs: fp32 [nseq, H, L, L] (the attention weights the reference returns; also saved for backward).
+ * drop_p/drop_key: attention-probability dropout (attn_drop / attn_pdrop); probs always holds the
+ * PRE-dropout probabilities (backward regenerates the mask). */
 int afft_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                        int32_t dtype, int32_t nseq, int32_t L, int32_t H, int32_t hd, float scale, int32_t mask,
-                       void* out, int64_t ldo, float* probs, void* stream);
+                       float drop_p, uint32_t drop_key, void* out, int64_t ldo, float* probs, void* stream);
 int afft_attention_bwd(const void* dout, int64_t lddo, const void* q, int64_t ldq, const void* k, int64_t ldk,
                        const void* v, int64_t ldv, int32_t dtype, const float* probs, int32_t nseq, int32_t L,
-                       int32_t H, int32_t hd, float scale, void* dq, int64_t lddq, void* dk, int64_t lddk,
-                       void* dv, int64_t lddv, void* stream);
+                       int32_t H, int32_t hd, float scale, float drop_p, uint32_t drop_key, void* dq, int64_t lddq,
+                       void* dk, int64_t lddk, void* dv, int64_t lddv, void* stream);
 
 /* ------------------------------------------------------------------ losses (common/runner.py:13-37,112-168)
  * Softmax cross-entropy over C classes, fwd + bwd in one pass.
  *   hard: labels int64[rows], label -1 = ignored row (loss 0, grad 0);   soft: targets fp32 [rows, C] and
  *   optional keep uint8[rows] (0 = row removed).  loss_sum += sum of row losses (fp32 atomic);
- *   dlogits[r,:] = gscale * (softmax - target) for kept rows, 0 otherwise; columns C..ldd-1 are zeroed. */
+ *   dlogits[r,:] = gscale * row_g[r] * (softmax*sum(target) - target) for kept rows, 0 otherwise (row_g NULL = 1:
+ *   the per-row upstream gradient of a reduction='none' loss); columns C..ldd-1 are zeroed. */
 int afft_softmax_ce(const float* logits, int64_t ldl, int32_t rows, int32_t C, const int64_t* labels,
-                    const float* soft, int64_t lds, const uint8_t* keep, float gscale, float* loss_sum,
-                    void* dlogits, int64_t ldd, int32_t d_dtype, float* row_loss, void* stream);
-/* MSE between a[rows,d] and b[rows,d] (fp32): loss_sum += sum (a-b)^2 ; da = gscale*2*(a-b) ; db = -da
- * (common/runner.py:164-166: both sides carry gradient). da/db may be NULL; they are ACCUMULATED (+=). */
+                    const float* soft, int64_t lds, const uint8_t* keep, float gscale, const float* row_g,
+                    float* loss_sum, void* dlogits, int64_t ldd, int32_t d_dtype, float* row_loss, void* stream);
+/* MSE between a[rows,d] and b[rows,d] (fp32): loss_sum += lscale * sum (a-b)^2 ;
+ * da += gscale*g_dev[0]*2*(a-b) ; db -= the same (common/runner.py:164-166: both sides carry gradient;
+ * g_dev = device scalar upstream gradient or NULL = 1).  da/db may be NULL. */
 int afft_mse(const float* a, int64_t lda, const float* b, int64_t ldb, int32_t rows, int32_t d, float gscale,
-             float* loss_sum, float* da, int64_t ldda, float* db, int64_t lddb, void* stream);
+             const float* g_dev, float lscale, float* loss_sum, float* da, int64_t ldda, float* db, int64_t lddb,
+             void* stream);
 
 /* ------------------------------------------------------------------ data movement / elementwise
  * fp32 [rows, cols] -> dst dtype copy; if dst_t != NULL also writes the transpose [cols, rows] (ld = ldt).
  * Used for the cached bf16 weights (W and W^T) and activation casts. Columns cols..ldd-1 of dst are zero-filled
- * when zero_pad != 0 (K padding for the fast GEMM path). */
+ * when zero_pad != 0 (K padding for the fast GEMM path).  drop (may be NULL) multiplies element [r,c] by the
+ * dropout / DropPath scale of index r*cols + c: the backward replay of a GEMM-epilogue dropout, or the forward
+ * dropout of a GEMM input (classifier Dropout(0.2), future_prediction.py:108). */
 int afft_cast(const float* src, int64_t lds, int32_t rows, int32_t cols, void* dst, int64_t ldd, int32_t dst_dtype,
-              void* dst_t, int64_t ldt, int32_t zero_pad, void* stream);
+              void* dst_t, int64_t ldt, int32_t zero_pad, const afft_dropout_t* drop, void* stream);
 /* ModalTokenCMFuser token assembly (models/fusion.py:338-352): X[(b*T+t), s, :] for s=0 the modal token
  * (token + (t)*tok_stride_t; stride 0 = one universal token), s>=1 modality s-1 at feats[s-1] + (b*T+t)*ldf[s-1];
  * + modality_embedding[s,:] if given.  feats / ldf are HOST arrays of n_mod (<= 8) device pointers / strides. */

@@ -253,13 +253,13 @@ def test_mse_and_elementwise():
     rows, d = 45, 64
     a, b = rnd(rows, d, seed=1), rnd(rows, d, seed=2)
     ls = torch.zeros(1, device=dev())
-    da = torch.ones(rows, d, device=dev())
+    da = torch.full((rows, d), 2.0 ** -10, device=dev())
     db = torch.zeros(rows, d, device=dev())
     gs = 1.0 / (rows * d)
     ops.mse(a.to(dev()), b.to(dev()), gs, ls, da, db)
     torch.cuda.synchronize()
     assert abs(float(ls) - float(((a - b) ** 2).sum())) < 1e-3
-    assert rel_l2(da.cpu() - 1.0, 2 * gs * (a - b)) < 1e-5
+    assert rel_l2(da.cpu() - 2.0 ** -10, 2 * gs * (a - b)) < 1e-4
     assert rel_l2(db.cpu(), -2 * gs * (a - b)) < 1e-5
 
     # cast + transpose with padding
