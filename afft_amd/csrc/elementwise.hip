@@ -100,13 +100,15 @@ __global__ __launch_bounds__(256) void reduce_rows_periodic_kernel(const float* 
   out[(int64_t)p * ldo + c] += s;
 }
 
-__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const void* __restrict__ g_, int g_dtype,
                                                   float* __restrict__ buf, int64_t n, float lr, float mom, float wd,
                                                   float gscale, int first) {
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
     if (i + 3 < n) {
       float4 pv = *(float4*)(p + i);
-      const float4 gv = *(const float4*)(g + i);
+      float g4[4];
+      load4(g_, i, g_dtype, g4);
+      const float4 gv = make_float4(g4[0], g4[1], g4[2], g4[3]);
       float4 bv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *(float4*)(buf + i);
       float gg[4] = {gv.x * gscale + wd * pv.x, gv.y * gscale + wd * pv.y, gv.z * gscale + wd * pv.z, gv.w * gscale + wd * pv.w};
       float bb[4] = {bv.x, bv.y, bv.z, bv.w};
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
       *(float4*)(p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
     } else {
       for (int64_t j = i; j < n; ++j) {
-        const float gg = g[j] * gscale + wd * p[j];
+        const float gg = ld_any(g_, j, g_dtype) * gscale + wd * p[j];
         const float bb = first ? gg : mom * buf[j] + gg;
         buf[j] = bb;
         p[j] -= lr * (gg + mom * bb);
@@ -202,15 +204,17 @@ extern "C" int afft_reduce_rows_periodic(const float* src, int64_t lds_, int32_t
   return 0;
 }
 
-extern "C" int afft_sgd_nesterov(float* p, const float* g, float* buf, int64_t n, float lr, float mom, float wd,
-                                 float gscale, int32_t first_step, void* stream_) {
+extern "C" int afft_sgd_nesterov(float* p, const void* g, int32_t g_dtype, float* buf, int64_t n, float lr, float mom,
+                                 float wd, float gscale, int32_t first_step, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(p && g && buf, "sgd: null pointer");
   AFFT_CHECK(((uintptr_t)p & 15) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)buf & 15) == 0, "sgd: buffers must be 16-byte aligned");
+  AFFT_CHECK(g_dtype == AFFT_F32 || g_dtype == AFFT_BF16, "sgd: bad gradient dtype");
   if (n == 0) return 0;
   int64_t blocks = (n + 1023) / 1024;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(sgd_kernel, dim3((int)blocks), dim3(256), 0, stream, p, g, buf, n, lr, mom, wd, gscale, first_step);
+  hipLaunchKernelGGL(sgd_kernel, dim3((int)blocks), dim3(256), 0, stream, p, g, g_dtype, buf, n, lr, mom, wd, gscale,
+                     first_step);
   AFFT_LAUNCH_CHECK();
   return 0;
 }

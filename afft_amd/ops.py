@@ -209,5 +209,5 @@ def reduce_rows_periodic(src: Tensor, period: int, out: Tensor):
 
 def sgd_nesterov(p: Tensor, g: Tensor, buf: Tensor, lr: float, mom: float, wd: float, gscale: float, first: bool):
     assert p.is_contiguous() and g.is_contiguous() and buf.is_contiguous()
-    L.check(L.lib().afft_sgd_nesterov(_p(p), _p(g), _p(buf), p.numel(), lr, mom, wd, gscale, 1 if first else 0,
+    L.check(L.lib().afft_sgd_nesterov(_p(p), _p(g), _dt(g), _p(buf), p.numel(), lr, mom, wd, gscale, 1 if first else 0,
                                       _stream()), "sgd_nesterov")

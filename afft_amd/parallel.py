@@ -1,0 +1,194 @@
+"""Data-parallel training runtime for the hot path: one process per GPU (torchrun), full weight replica per
+GPU, one exchange per step -- the gradient sum -- carried by RCCL over xGMI (torch.distributed backend
+"nccl" IS RCCL on ROCm), overlapped with the remaining backward.
+
+Replaces the reference's torch DDP wrapper + per-parameter SGD groups (train.py:189-225,352,364-368,251-265):
+
+  * parameters, gradients and momentum live in three flat fp32 buffers (views handed back to the modules), so
+    the optimizer is ONE fused Nesterov-SGD kernel launch and a bucket is a contiguous slice;
+  * weight-gradient GEMMs write straight into the flat gradient buffer (afft_amd.runtime.GradSink); when the last
+    gradient of a bucket has been produced the bucket's all-reduce is enqueued on a side stream.  xGMI is
+    point-to-point (7 links/GPU), so buckets are large (>= 64 MB) and few, and the payload can be sent as bf16
+    (``comm_dtype``) to halve the per-link bytes;
+  * nothing in the data path needs a collective besides that sum (clips are independent).
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ops, runtime as rt
+
+Tensor = torch.Tensor
+
+
+def _align(n: int, a: int = 64) -> int:
+    return (n + a - 1) // a * a
+
+
+class FlatParams:
+    """Re-homes every trainable parameter of `model` (and its .grad) in contiguous fp32 buffers."""
+
+    def __init__(self, model: torch.nn.Module):
+        self.params: List[Tensor] = [p for p in model.parameters() if p.requires_grad]
+        assert self.params, "no trainable parameters"
+        dev = self.params[0].device
+        self.offsets: List[int] = []
+        off = 0
+        for p in self.params:
+            assert p.dtype == torch.float32 and p.device == dev
+            self.offsets.append(off)
+            off += _align(p.numel())
+        self.total = off
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                n = p.numel()
+                self.flat_p[o:o + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat_p[o:o + n].view(p.shape)
+                p.grad = self.flat_g[o:o + n].view(p.shape)
+        rt.invalidate_weight_images()
+
+    def index_of(self) -> Dict[int, int]:
+        return {id(p): i for i, p in enumerate(self.params)}
+
+
+class GradReducer:
+    """Bucketed, backward-overlapped gradient all-reduce over the flat gradient buffer."""
+
+    def __init__(self, flat: FlatParams, group=None, bucket_elems: int = 32 * 1024 * 1024, comm_dtype: str = "fp32"):
+        self.flat = flat
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.comm_dtype = comm_dtype
+        self.buckets: List[tuple] = []        # (start, end) element ranges, in parameter order
+        self.bucket_of: List[int] = []        # param index -> bucket index
+        start, cur = 0, 0
+        for i, (p, o) in enumerate(zip(flat.params, flat.offsets)):
+            self.bucket_of.append(len(self.buckets))
+            cur = o + _align(p.numel())
+            if cur - start >= bucket_elems:
+                self.buckets.append((start, cur))
+                start = cur
+        if cur > start:
+            self.buckets.append((start, cur))
+        self.bucket_of = [min(b, len(self.buckets) - 1) for b in self.bucket_of]
+        self._pidx = flat.index_of()
+        self.expected: Optional[List[int]] = None     # ready-callbacks per bucket per step (learned on step 1)
+        self._count = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._handles: List = []
+        self._use_cuda = flat.flat_g.is_cuda
+        self.comm_stream = torch.cuda.Stream() if (self._use_cuda and self.world > 1) else None
+        self.flat_g16 = (torch.empty(flat.total, dtype=torch.bfloat16, device=flat.flat_g.device)
+                         if (comm_dtype == "bf16" and self.world > 1) else None)
+
+    # ---- step protocol
+    def begin_step(self):
+        self._count = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._handles = []
+        rt.SINK.begin_step()
+        rt.SINK.on_grad_ready = self._on_ready if self.world > 1 else None
+
+    def _on_ready(self, p: Tensor):
+        i = self._pidx.get(id(p))
+        if i is None:
+            return
+        b = self.bucket_of[i]
+        self._count[b] += 1
+        if self.expected is not None and not self._launched[b] and self._count[b] == self.expected[b]:
+            self._launch(b)
+
+    def _launch(self, b: int):
+        self._launched[b] = True
+        s, e = self.buckets[b]
+        if self._use_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                if self.flat_g16 is not None:
+                    n = e - s
+                    ops.cast(self.flat.flat_g[s:e].view(n // 64, 64), self.flat_g16[s:e].view(n // 64, 64))
+                    h = dist.all_reduce(self.flat_g16[s:e], group=self.group, async_op=True)
+                else:
+                    h = dist.all_reduce(self.flat.flat_g[s:e], group=self.group, async_op=True)
+        else:
+            h = dist.all_reduce(self.flat.flat_g[s:e], group=self.group, async_op=True)
+        self._handles.append(h)
+
+    def finish_step(self):
+        """Call after backward: zero untouched grads, launch whatever is still pending, wait for all buckets."""
+        rt.SINK.on_grad_ready = None
+        rt.SINK.finish_step(self.flat.params)
+        if self.world <= 1:
+            return
+        if self.expected is None:
+            self.expected = list(self._count)
+        # fixed order on every rank: buckets are launched last-to-first (the order backward completes them)
+        for b in reversed(range(len(self.buckets))):
+            if not self._launched[b]:
+                self._launch(b)
+        for h in self._handles:
+            h.wait()
+        if self._use_cuda:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def grad_for_optimizer(self):
+        """(flat gradient tensor, scale): summed over ranks; the optimizer applies 1/world."""
+        if self.flat_g16 is not None:
+            return self.flat_g16, 1.0 / self.world
+        return self.flat.flat_g, 1.0 / self.world
+
+
+class FusedSGD:
+    """Nesterov-momentum SGD over the flat buffers (conf/opt/optimizer/sgd.yaml + expts/01: lr 1e-3,
+    momentum 0.9, nesterov, wd 1e-6) -- one kernel launch for all 151 parameter tensors."""
+
+    def __init__(self, flat: FlatParams, lr: float = 1e-3, momentum: float = 0.9, weight_decay: float = 1e-6):
+        self.flat, self.lr, self.momentum, self.wd = flat, lr, momentum, weight_decay
+        self.buf = torch.zeros_like(flat.flat_p)
+        self.steps = 0
+
+    def step(self, grad: Optional[Tensor] = None, gscale: float = 1.0):
+        g = self.flat.flat_g if grad is None else grad
+        ops.sgd_nesterov(self.flat.flat_p, g, self.buf, self.lr, self.momentum, self.wd, gscale, self.steps == 0)
+        self.steps += 1
+        rt.invalidate_weight_images()   # bf16 weight images are re-cast on next use
+
+
+class Trainer:
+    """fwd + loss + bwd (+ overlapped gradient all-reduce) + fused SGD for a BaseModel."""
+
+    def __init__(self, model, loss_wts: Dict[str, float], lr=1e-3, momentum=0.9, weight_decay=1e-6,
+                 comm_dtype: str = "fp32", bucket_elems: int = 32 * 1024 * 1024, group=None):
+        from .common.runner import BasicLossAccuracy, Runner
+        self.model = model
+        self.flat = FlatParams(model)
+        self.reducer = GradReducer(self.flat, group=group, bucket_elems=bucket_elems, comm_dtype=comm_dtype)
+        self.opt = FusedSGD(self.flat, lr, momentum, weight_decay)
+        self.loss_fn = BasicLossAccuracy(compute_metrics=False)
+        self._reduce = Runner._reduce_loss
+        self.loss_wts = loss_wts
+
+    def forward_backward(self, feats: Dict[str, Tensor], target, target_subclips):
+        self.reducer.begin_step()
+        outputs, out_t = self.model(feats, mixup_fn=None, target=target, target_subclips=target_subclips,
+                                    target_subclips_ignore_index=None)
+        losses, _ = self.loss_fn(outputs, out_t['target'], out_t['target_subclips'])
+        loss, parts = self._reduce(losses, self.loss_wts, sync=False)
+        loss.backward()
+        self.reducer.finish_step()
+        return loss.detach(), parts
+
+    def step(self, feats, target, target_subclips, optimize: bool = True):
+        loss, parts = self.forward_backward(feats, target, target_subclips)
+        if optimize:
+            g, scale = self.reducer.grad_for_optimizer()
+            self.opt.step(g, scale)
+        return loss, parts

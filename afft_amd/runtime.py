@@ -63,13 +63,13 @@ class _WImage:
     __slots__ = ("version", "ptr", "w", "wt")
 
 
-_wcache: "weakref.WeakKeyDictionary[Tensor, _WImage]" = weakref.WeakKeyDictionary()
+_wlist: list = []   # weak references to parameters that own an image (for invalidate_weight_images)
 
 
 def weight_images(p: Tensor):
     """(w16 [rows, pad64(cols)], wt16 [cols, pad64(rows)]) bf16 images of a 2-D fp32 parameter, zero padded,
     refreshed when the parameter's version counter or storage changes (optimizer step, load_state_dict)."""
-    img = _wcache.get(p)
+    img = getattr(p, "_afft_img", None)
     ver = p._version
     if img is None or img.ptr != p.data_ptr() or img.w.device != p.device:
         img = _WImage()
@@ -78,7 +78,8 @@ def weight_images(p: Tensor):
         img.wt = torch.zeros(cols, pad64(rows), dtype=torch.bfloat16, device=p.device)
         img.version = -1
         img.ptr = p.data_ptr()
-        _wcache[p] = img
+        p._afft_img = img
+        _wlist.append(weakref.ref(p))
     if img.version != ver:
         with torch.no_grad():
             ops.cast(p.detach(), img.w, img.wt)
@@ -87,8 +88,13 @@ def weight_images(p: Tensor):
 
 
 def invalidate_weight_images():
-    for img in _wcache.values():
-        img.version = -1
+    alive = []
+    for r in _wlist:
+        p = r()
+        if p is not None and getattr(p, "_afft_img", None) is not None:
+            p._afft_img.version = -1
+            alive.append(r)
+    _wlist[:] = alive
 
 
 # --------------------------------------------------------------------------- gradient sink
@@ -114,7 +120,9 @@ class GradSink:
         return p.grad, not first
 
     def finish_step(self, params):
-        """Zero the gradients of parameters that took no part in this step."""
+        """Zero the gradients of parameters that took no part in this step (sink mode only)."""
+        if _GRAD_MODE != "sink":
+            return
         for p in params:
             if p.requires_grad and p.grad is not None and not self.touched.get(id(p), False):
                 p.grad.zero_()

@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py -- clips/sec (fwd+bwd) of the AFFT hot path on MI355X, BASELINE.json's metric.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1] / SURVEY.md 8d "cfg2"): SA-Fuser, 4 modalities (rgb, objects, audio, flow)
+x T=16 frames x d = D = 2048, depth 6 + 6 GPT-2 layers, 3806 classes, 64 clips per GPU, synthetic fp32 features
+resident in HBM, train mode with the reference's dropout rates (0.1, classifier 0.2, DropPath linspace(0,0.1)).
+One step = forward + 3-term loss + backward (+ bucketed gradient all-reduce for N > 1) + fused Nesterov-SGD update.
+Weak scaling: per-GPU batch fixed.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg2", help="cfg2 (default) | ek100 | cfg1 | cfg4 | cfg5")
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--comm-dtype", default="bf16", choices=["bf16", "fp32"], help="gradient all-reduce payload")
+    ap.add_argument("--no-optimizer", action="store_true", help="time fwd+loss+bwd(+all-reduce) only")
+    ap.add_argument("--eval-drop", action="store_true", help="disable dropout (eval-mode layers) in the timed steps")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    return ap.parse_args()
+
+
+def make_inputs(cfg, B, T, rank, device, ncls=3806):
+    g = torch.Generator().manual_seed(1234 + rank)
+    feats = {m: torch.randn(B, T, C, 1, 1, 1, generator=g).to(device) for m, C in cfg["modal_dims"].items()}
+    tgt = torch.randint(0, ncls, (B,), generator=g)
+    sub = torch.randint(0, ncls, (B, T, 1), generator=g)
+    drop = torch.rand(B, T, 1, generator=g) < 0.10
+    sub[drop] = -1
+    return feats, {"action": tgt.to(device)}, {"action": sub.to(device)}
+
+
+def build_model(name, device, drop=0.1):
+    from afft_amd.config import BASELINE_CONFIGS, make_model_cfg
+    from afft_amd.models.base_model import BaseModel
+    c = BASELINE_CONFIGS[name]
+    torch.manual_seed(42)   # conf/config.yaml:4
+    cfg = make_model_cfg(c["modal_dims"], c["common_dim"], c["fp_inter_dim"], fuser=c["fuser"], T=c["T"], drop=drop)
+    model = BaseModel(cfg, num_classes={"action": 3806}, class_mappings={})
+    return model.to(device), c
+
+
+# ----------------------------------------------------------------------------- roofline of the dominant kernel
+class GemmTimer:
+    """Wraps afft_amd.ops.gemm for ONE instrumented step: a HIP event pair on the launch stream around every
+    GEMM, so the average launch duration of the dominant kernel (gemm_bf16_kernel<NT>, forward + dgrad) and its
+    algorithmic FLOPs per launch are measured live, on the same workload as the timed region."""
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        from afft_amd import ops
+        self.ops = ops
+        self.orig = ops.gemm
+        timer = self
+
+        def timed(a, b, out, **kw):
+            a_t, b_t = kw.get("a_t", False), kw.get("b_t", False)
+            M, K = (a.shape[1], a.shape[0]) if a_t else (a.shape[0], a.shape[1])
+            N = b.shape[0] if b_t else b.shape[1]
+            fast = a.dtype == torch.bfloat16 and K % 64 == 0
+            kind = "tn" if (a_t and not b_t) else ("nt" if (not a_t and b_t) else "other")
+            if not fast:
+                kind = "f32path"
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = timer.orig(a, b, out, **kw)
+            e.record()
+            timer.records.append((kind, 2.0 * M * N * K, s, e))
+            return r
+
+        ops.gemm = timed
+        import afft_amd.functional as F_
+        F_.ops.gemm = timed
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.gemm = self.orig
+        import afft_amd.functional as F_
+        F_.ops.gemm = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, fl, s, e in self.records:
+            d = out.setdefault(kind, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["flops"] += fl
+            d["ms"] += s.elapsed_time(e)
+        return out
+
+
+def cpu_baseline(name, B, steps=2):
+    """The oracle (CPU restatement, proven equal to the reference: tests/test_oracle_golden.py) timed on this
+    host's cores on a bounded sample of the same workload: fwd + loss + bwd, eval-mode math."""
+    from oracle import afft_oracle as O
+    from afft_amd.config import BASELINE_CONFIGS
+    c = BASELINE_CONFIGS[name]
+    model, _ = build_model(name, "cpu", drop=0.0)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    del model
+    feats, tgt, sub = make_inputs(c, B, c["T"], 0, "cpu")
+    ocfg = dict(fuser=c["fuser"], depth=6, num_heads=4, fp_layers=6, fp_heads=4, fp_output_len=1,
+                num_classes={"action": 3806})
+    times = []
+    for i in range(steps + 1):
+        for p in P.values():
+            p.grad = None
+        t0 = time.perf_counter()
+        out = O.base_model_forward(P, feats, ocfg)
+        total, _ = O.loss(out, tgt["action"], sub["action"])
+        total.backward()
+        times.append(time.perf_counter() - t0)
+    times = sorted(times[1:])
+    t = times[len(times) // 2]
+    return {"value": round(B / t, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{name} B={B}: 1 warm-up + {steps} timed fwd+loss+bwd steps of oracle/afft_oracle.py (torch fp32 "
+                      f"CPU, {torch.get_num_threads()} threads of {os.cpu_count()} logical cores), median"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)   # "nccl" == RCCL on ROCm
+    assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import afft_amd
+    from afft_amd import dropout as D_
+    from afft_amd.config import gflop_per_clip
+    from afft_amd.parallel import Trainer
+    afft_amd.set_precision(args.precision)
+    afft_amd.set_grad_mode("sink")
+    D_.manual_seed(42 + rank)
+
+    model, c = build_model(args.config, device)
+    B, T = args.batch, c["T"]
+    feats, tgt, sub = make_inputs(c, B, T, rank, device)
+    wts = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
+    trainer = Trainer(model, wts, comm_dtype=args.comm_dtype)
+    model.train(not args.eval_drop)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(feats, tgt, sub, optimize=not args.no_optimizer)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = trainer.step(feats, tgt, sub, optimize=not args.no_optimizer)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss_val = float(loss)
+    ms_per_step = elapsed / args.steps * 1e3
+    clips_s = world * B * args.steps / elapsed
+    gf = gflop_per_clip(args.config, fwd_bwd=True)
+
+    result = {
+        "metric": "clips/sec (fwd+bwd) EK100 SA-Fuser 4-mod T=16", "value": round(clips_s, 2), "unit": "clips/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+        "data": "synthetic",
+        "config": {"workload": f"{args.config}: {c['fuser'].upper()}-Fuser {len(c['modal_dims'])}-modality T={T} "
+                               f"d={c['common_dim']} D={c['fp_inter_dim']} depth 6+6, 3806 classes, train mode "
+                               f"(dropout {'off' if args.eval_drop else 'on'}), step = fwd+loss+bwd"
+                               f"{'+allreduce' if world > 1 else ''}{'' if args.no_optimizer else '+nesterov-sgd'}",
+                   "per_gpu_batch": B, "global_batch": B * world, "seq_len": T,
+                   "parallelism": f"dp{world}", "grad_comm_dtype": args.comm_dtype if world > 1 else None},
+        "algorithmic_gflop_per_clip": round(gf, 2),
+        "model_tflops": round(clips_s * gf / 1e3, 1),
+        "mfma_frac_whole_step": round(clips_s * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+        "final_loss": round(loss_val, 4),
+    }
+
+    if rank == 0 and world == 1:
+        # forward latency, eval mode (BASELINE.json: "fwd p50 ms")
+        model.eval()
+        lat = []
+        with torch.no_grad():
+            for i in range(25):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                model(feats, mixup_fn=None, target=tgt, target_subclips=sub, target_subclips_ignore_index=None)
+                e.record()
+                torch.cuda.synchronize()
+                if i >= 5:
+                    lat.append(s.elapsed_time(e))
+        lat.sort()
+        result["fwd_p50_ms"] = round(lat[len(lat) // 2], 3)
+        model.train(not args.eval_drop)
+
+        if not args.no_roofline:
+            with GemmTimer() as gt:
+                trainer.step(feats, tgt, sub, optimize=False)
+            summ = gt.summary()
+            dom = "nt" if "nt" in summ else max(summ, key=lambda k: summ[k]["ms"])
+            d = summ[dom]
+            avg_ms = d["ms"] / d["launches"]
+            avg_fl = d["flops"] / d["launches"]
+            ach = avg_fl / (avg_ms * 1e-3) / 1e12
+            dtype_peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3
+            result["roofline"] = {
+                "kernel": "gemm_bf16_kernel<NT> (forward + dgrad GEMMs, v_mfma_f32_16x16x32_bf16)" if dom == "nt" else dom,
+                "bound": "mfma", "achieved": round(ach, 1), "peak": dtype_peak, "unit": "TFLOP/s",
+                "frac": round(ach / dtype_peak, 4), "traffic": None,
+                "launches_per_step": d["launches"], "avg_launch_ms": round(avg_ms, 4),
+                "avg_algorithmic_gflop_per_launch": round(avg_fl / 1e9, 2),
+                "by_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else None}
+                              for k, v in summ.items()},
+            }
+        if not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(args.config, args.cpu_batch)
+            except Exception as ex:  # noqa: BLE001
+                result["cpu_baseline"] = {"value": None, "error": repr(ex)}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

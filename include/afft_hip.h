@@ -145,8 +145,9 @@ int afft_add_rows_periodic(const float* x, int64_t ldx, const float* table, int6
 int afft_reduce_rows_periodic(const float* src, int64_t lds, int32_t rows, int32_t period, int32_t d,
                               float* out, int64_t ldo, void* stream);
 /* Nesterov-momentum SGD over one flat fp32 parameter buffer (conf/opt/optimizer/sgd.yaml, train.py:262):
- *   g += wd*p ; buf = mom*buf + g ; p -= lr*(g + mom*buf) ; grad is scaled by gscale first (1/world). */
-int afft_sgd_nesterov(float* p, const float* g, float* buf, int64_t n, float lr, float mom, float wd,
+ *   g = gscale*g + wd*p ; buf = mom*buf + g ; p -= lr*(g + mom*buf) ; gscale = 1/world after a summing
+ *   all-reduce; g may be fp32 or bf16 (bf16 gradient exchange). */
+int afft_sgd_nesterov(float* p, const void* g, int32_t g_dtype, float* buf, int64_t n, float lr, float mom, float wd,
                       float gscale, int32_t first_step, void* stream);
 
 #ifdef __cplusplus
