@@ -44,6 +44,7 @@ class GemmDesc(C.Structure):
 _SIGS = {
     "afft_version": ([], C.c_int),
     "afft_gemm": ([C.POINTER(GemmDesc), vp], C.c_int),
+    "afft_set_gemm_variant": ([C.c_int], C.c_int),
     "afft_layernorm_fwd": ([vp, i64, vp, vp, f32, i32, i32, vp, i64, i32, vp, vp, vp], C.c_int),
     "afft_layernorm_bwd_nparts": ([i32], C.c_int),
     "afft_layernorm_bwd": ([vp, i64, i32, vp, i64, vp, vp, vp, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp], C.c_int),
@@ -81,6 +82,8 @@ def lib():
             fn = getattr(_lib, name)
             fn.argtypes = args
             fn.restype = res
+        if os.environ.get("AFFT_GEMM_VARIANT"):
+            check(_lib.afft_set_gemm_variant(int(os.environ["AFFT_GEMM_VARIANT"])), "set_gemm_variant")
     return _lib
 
 

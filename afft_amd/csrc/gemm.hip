@@ -1,10 +1,20 @@
 // GEMM + fused epilogue for gfx950.
 //
-//  * gemm_bf16_kernel<NT|TN>: bf16 MFMA (v_mfma_f32_16x16x32_bf16), 128x128x64 tiles, 4 waves (2x2),
-//    wave tile 64x64 = 4x4 MFMA tiles, operands staged HBM->LDS with 16-byte LDS-DMA
-//    (global_load_lds_dwordx4), XOR-swizzled LDS images (conflict-free ds_read_b128 for the
-//    k-contiguous NT image, conflict-free ds_read_b64_tr_b16 for the k-strided TN image),
-//    double-buffered, XCD-aware grouped tile order.
+//  * gemm_bf16_kernel<WM, WN, STAGES, A_KS, B_KS>: bf16 MFMA (v_mfma_f32_16x16x32_bf16, fp32 accumulate).
+//    A workgroup of WM x WN waves owns a (64*WM) x (64*WN) output tile (each wave 64x64 = 4x4 MFMA tiles) and
+//    walks K in 64-deep steps through a STAGES-deep LDS ring that is filled by 16-byte LDS-DMA
+//    (global_load_lds_dwordx4) running STAGES-1 K-steps ahead: the loop waits with a COUNTED s_waitcnt vmcnt(N)
+//    (never 0 while more tiles are to come) and one raw s_barrier per K-step, so HBM/L2 latency hides under
+//    the MFMAs of the tiles in between.
+//      operand images in LDS (XOR-swizzled on the DMA source address, LDS writes stay lane-linear):
+//        k-contiguous operand ("row-major [rows][K]"): [rows][64 k], 128 B rows, conflict-free ds_read_b128
+//        k-strided operand    ("[K][cols]"):           [64 k][cols], conflict-free ds_read_b64_tr_b16 (transposed read)
+//      layouts: NT (A[M][K], B[N][K])  forward of nn.Linear, dgrad of HF Conv1D
+//               NN (A[M][K], B[K][N])  dgrad of nn.Linear, forward of HF Conv1D
+//               TN (A[K][M], B[K][N])  every weight gradient (reduction over the rows of both operands)
+//      shapes:  256x128 tile, 8 waves, 3 stages (144 KiB LDS, 1 workgroup/CU)   -- large GEMMs
+//               128x128 tile, 4 waves, 2 stages ( 64 KiB LDS, 2 workgroups/CU)  -- small grids / tails
+//    XCD-aware grouped tile order (workgroups b and b+8 share an XCD and its L2).
 //  * gemm_f32_kernel: exact fp32 (v_mfma_f32_32x32x2_f32), any strides / sizes; the parity mode
 //    and the fallback for shapes the fast path does not take.
 //
@@ -15,13 +25,12 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+constexpr int BK = 64;
 constexpr int GROUP_M = 8;
 
 struct GemmFast {
-  const bf16_t* A; int64_t lda;  // NT: A[M][K] ; TN: A[K][M]
-  const bf16_t* B; int64_t ldb;  // NT: B[N][K] ; TN: B[K][N]
+  const bf16_t* A; int64_t lda;  // k-contiguous: A[M][K] ; k-strided: A[K][M]
+  const bf16_t* B; int64_t ldb;  // k-contiguous: B[N][K] ; k-strided: B[K][N]
   int K;
   int tiles_m, tiles_n;
   EpiParams e;
@@ -44,12 +53,13 @@ __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int& tm, i
   tn = in_group / gsz;
 }
 
-// ----- NT image: tile [128 rows][64 k] bf16, 128 B per row, 16-B chunk c of row r stored at chunk c ^ ((r>>1)&7)
-__device__ __forceinline__ void stage_nt(const bf16_t* __restrict__ G, int64_t ld, int row0, int nrows, int k0,
+// ----- k-contiguous image: tile [ROWS][64 k] bf16, 128 B per row; 16-B chunk c of row r lives at chunk c ^ ((r>>1)&7)
+template <int ROWS, int NWAVES>
+__device__ __forceinline__ void stage_kc(const bf16_t* __restrict__ G, int64_t ld, int row0, int nrows, int k0,
                                          char* lds_tile, int wave, int lane) {
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const int j = wave * 4 + jj;          // 1-KiB piece = 8 rows
+  for (int jj = 0; jj < ROWS / 8 / NWAVES; ++jj) {
+    const int j = wave + jj * NWAVES;     // 1-KiB piece = 8 rows
     const int row = j * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     int grow = row0 + row;
@@ -58,35 +68,39 @@ __device__ __forceinline__ void stage_nt(const bf16_t* __restrict__ G, int64_t l
     __builtin_amdgcn_global_load_lds((const AFFT_GLOBAL void*)src, (AFFT_LDS void*)(lds_tile + j * 1024), 16, 0, 0);
   }
 }
-__device__ __forceinline__ bf16x8 frag_nt(const char* lds_tile, int row, int chunk) {
+__device__ __forceinline__ bf16x8 frag_kc(const char* lds_tile, int row, int chunk) {
   return *(const bf16x8*)(lds_tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
 
-// ----- TN image: tile [64 k][128 cols] bf16, 256 B per row, 32-B unit u of row r stored at unit u ^ f(r),
-//       f(r) = (r&3) | ((r>>3)&1)<<2  -> the two 4-row blocks a 32-lane half reads by ds_read_b64_tr_b16 hit 8 distinct units
-__device__ __forceinline__ int tn_f(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
-__device__ __forceinline__ void stage_tn(const bf16_t* __restrict__ G, int64_t ld, int col0, int k0,
+// ----- k-strided image: tile [64 k][COLS] bf16, 2*COLS B per row; 32-B unit u of row r lives at unit u ^ f(r),
+//       f(r) = (r&3) | ((r>>3)&1)<<2 : the two 4-row blocks a 32-lane half reads by ds_read_b64_tr_b16 hit 8 distinct units
+__device__ __forceinline__ int ks_f(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+template <int COLS, int NWAVES>
+__device__ __forceinline__ void stage_ks(const bf16_t* __restrict__ G, int64_t ld, int col0, int k0,
                                          char* lds_tile, int wave, int lane) {
+  constexpr int CH = COLS / 8;            // 16-B chunks per row (16 or 32)
+  constexpr int RPP = 64 / CH;            // rows per 1-KiB piece
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const int j = wave * 4 + jj;          // 1-KiB piece = 4 rows of 256 B
-    const int row = j * 4 + (lane >> 4);
-    const int c16 = lane & 15;
-    const int src_c16 = (((c16 >> 1) ^ tn_f(row)) << 1) | (c16 & 1);
+  for (int jj = 0; jj < COLS / 8 / NWAVES; ++jj) {
+    const int j = wave + jj * NWAVES;
+    const int row = j * RPP + lane / CH;
+    const int c16 = lane % CH;
+    const int src_c16 = (((c16 >> 1) ^ ks_f(row)) << 1) | (c16 & 1);
     int64_t col = col0 + src_c16 * 8;
     col = col < ld - 8 ? col : ld - 8;     // tail columns: stay inside the row, result discarded
     const bf16_t* src = G + (int64_t)(k0 + row) * ld + col;
     __builtin_amdgcn_global_load_lds((const AFFT_GLOBAL void*)src, (AFFT_LDS void*)(lds_tile + j * 1024), 16, 0, 0);
   }
 }
-// fragment for MFMA 16x16x32: lane (g = lane>>4, r = lane&15) needs tile[k = kb + 8g + j][col0 + r], j = 0..7
-__device__ __forceinline__ bf16x8 frag_tn(const char* lds_tile, int kb, int unit, int lane) {
+// fragment for MFMA 16x16x32: lane (g = lane>>4, r = lane&15) needs tile[k = kb + 8g + j][16*unit + r], j = 0..7
+template <int COLS>
+__device__ __forceinline__ bf16x8 frag_ks(const char* lds_tile, int kb, int unit, int lane) {
   const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
   const int r0 = kb + 8 * g + q, r1 = r0 + 4;
   const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (AFFT_LDS bf16x4*)(lds_tile + r0 * 256 + ((unit ^ tn_f(r0)) << 5) + p * 8));
+      (AFFT_LDS bf16x4*)(lds_tile + r0 * (2 * COLS) + ((unit ^ ks_f(r0)) << 5) + p * 8));
   const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (AFFT_LDS bf16x4*)(lds_tile + r1 * 256 + ((unit ^ tn_f(r1)) << 5) + p * 8));
+      (AFFT_LDS bf16x4*)(lds_tile + r1 * (2 * COLS) + ((unit ^ ks_f(r1)) << 5) + p * 8));
   bf16x8 f;
   f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
   f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
@@ -101,12 +115,24 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int TN>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmFast g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 16K | B 16K]
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt immediate");
+  // lgkmcnt(0): this wave's LDS reads of the stage about to be refilled have returned before it signals the barrier
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+
+template <int WM, int WN, int STAGES, bool A_KS, bool B_KS>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf16_kernel(const GemmFast g) {
+  constexpr int NW = WM * WN;
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int LPT = (BM / 8 + BN / 8) / NW;   // LDS-DMA instructions per wave per K-step
+  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "pieces must divide evenly over the waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [STAGES][A image | B image]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WN, wc = wave % WN;
   int tm, tn;
   tile_coords(g.tiles_m, g.tiles_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
@@ -118,40 +144,46 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmFast g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto stage = [&](int buf, int kt) {
-    char* a = smem + buf * (2 * TILE_BYTES);
-    char* b = a + TILE_BYTES;
-    if (TN) {
-      stage_tn(g.A, g.lda, m0, kt * BK, a, wave, lane);
-      stage_tn(g.B, g.ldb, n0, kt * BK, b, wave, lane);
-    } else {
-      stage_nt(g.A, g.lda, m0, M, kt * BK, a, wave, lane);
-      stage_nt(g.B, g.ldb, n0, N, kt * BK, b, wave, lane);
-    }
+  auto stage = [&](int kt) {
+    char* a = smem + (kt % STAGES) * STAGE_BYTES;
+    char* b = a + A_BYTES;
+    if constexpr (A_KS) stage_ks<BM, NW>(g.A, g.lda, m0, kt * BK, a, wave, lane);
+    else stage_kc<BM, NW>(g.A, g.lda, m0, M, kt * BK, a, wave, lane);
+    if constexpr (B_KS) stage_ks<BN, NW>(g.B, g.ldb, n0, kt * BK, b, wave, lane);
+    else stage_kc<BN, NW>(g.B, g.ldb, n0, N, kt * BK, b, wave, lane);
+  };
+  // wait until all but the `ahead` most recently issued tiles of this wave have landed, then rendezvous
+  auto wait_tiles_then_barrier = [&](int ahead) {
+    if constexpr (STAGES >= 4) { if (ahead >= 2) wait_vmcnt<2 * LPT>(); else if (ahead == 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>(); }
+    else if constexpr (STAGES == 3) { if (ahead >= 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>(); }
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
   };
 
   const int nk = g.K / BK;
-  stage(0, 0);
-  __syncthreads();  // an LDS-DMA is in flight -> the compiler's fence waits vmcnt(0) here
+  constexpr int D = STAGES - 1;  // prefetch distance in K-steps
+#pragma unroll
+  for (int t = 0; t < D; ++t)
+    if (t < nk) stage(t);
+  wait_tiles_then_barrier(min(D, nk) - 1);   // tile 0 landed everywhere
+
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const char* a = smem + cur * (2 * TILE_BYTES);
-    const char* b = a + TILE_BYTES;
+    if (kt + D < nk) stage(kt + D);         // refills the stage read in iteration kt-1 (all waves passed its barrier)
+    const char* a = smem + (kt % STAGES) * STAGE_BYTES;
+    const char* b = a + A_BYTES;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 af[4], bfr[4];
-      if (TN) {
+      const int chunk = s * 4 + (lane >> 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = frag_tn(a, 32 * s, wr * 4 + i, lane);
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (A_KS) af[i] = frag_ks<BM>(a, 32 * s, wr * 4 + i, lane);
+        else af[i] = frag_kc(a, wr * 64 + i * 16 + (lane & 15), chunk);
+      }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bfr[j] = frag_tn(b, 32 * s, wc * 4 + j, lane);
-      } else {
-        const int chunk = s * 4 + (lane >> 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = frag_nt(a, wr * 64 + i * 16 + (lane & 15), chunk);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bfr[j] = frag_nt(b, wc * 64 + j * 16 + (lane & 15), chunk);
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (B_KS) bfr[j] = frag_ks<BN>(b, 32 * s, wc * 4 + j, lane);
+        else bfr[j] = frag_kc(b, wc * 64 + j * 16 + (lane & 15), chunk);
       }
       // operands swapped on purpose: D[row = n][col = m] -> each lane owns 4 consecutive n of one row m
 #pragma unroll
@@ -160,7 +192,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmFast g) {
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
+    if (kt + 1 < nk) {
+      // tile kt+1 must have landed; tiles kt+2 .. min(kt+D, nk-1) may stay in flight across the barrier
+      const int ahead = min(kt + D, nk - 1) - (kt + 1);
+      wait_tiles_then_barrier(ahead);
+    }
   }
 
   static_for<0, 16>([&](auto idx) {
@@ -232,7 +268,52 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32 g) {
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+int g_variant = 0;  // 0 auto, 1 = 128x128 tile, 2 = 256x128 tile (tuning / tests)
+
+template <int WM, int WN, int STAGES, bool A_KS, bool B_KS>
+int launch_fast(GemmFast& g, hipStream_t stream) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr size_t lds = (size_t)STAGES * (BM + BN) * BK * 2;
+  g.tiles_m = (g.e.M + BM - 1) / BM;
+  g.tiles_n = (g.e.N + BN - 1) / BN;
+  auto kern = gemm_bf16_kernel<WM, WN, STAGES, A_KS, B_KS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      afft_set_error("afft_gemm: cannot reserve %zu bytes of LDS", lds);
+      (void)hipGetLastError();
+      return 2;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(64 * WM * WN), lds, stream, g);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
+template <bool A_KS, bool B_KS>
+int launch_layout(GemmFast& g, hipStream_t stream) {
+  int variant = g_variant;
+  if (variant == 0) {
+    // time ~ rounds x tile work / per-CU rate.  256x128 (1 workgroup/CU, deep prefetch) sustains ~1.4x the
+    // per-CU rate of 128x128 (2 workgroups/CU) when the grid fills the chip; pick by estimated makespan.
+    const int64_t t2 = (int64_t)((g.e.M + 255) / 256) * ((g.e.N + 127) / 128);
+    const int64_t t1 = (int64_t)((g.e.M + 127) / 128) * ((g.e.N + 127) / 128);
+    const double cost2 = (double)((t2 + 255) / 256) * 2.0 / 1.4;
+    const double cost1 = (double)((t1 + 511) / 512) * 2.0;
+    variant = (g.e.M >= 256 && cost2 <= cost1) ? 2 : 1;
+  }
+  if (variant == 2) return launch_fast<4, 2, 3, A_KS, B_KS>(g, stream);
+  return launch_fast<2, 2, 2, A_KS, B_KS>(g, stream);
+}
+
 }  // namespace
+
+extern "C" int afft_set_gemm_variant(int v) {
+  if (v < 0 || v > 2) { afft_set_error("afft_set_gemm_variant: %d not in 0..2", v); return 1; }
+  g_variant = v;
+  return 0;
+}
 
 extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -263,27 +344,24 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
            ok4(d->pre, d->ldpre, d->pre_dtype) && ok4(d->aux, d->ldaux, d->aux_dtype) &&
            ok4(d->residual, d->ldres, AFFT_F32) && ok4(d->bias, 4, AFFT_F32);
 
-  const bool nt = d->a_cs == 1 && d->b_rs == 1;
-  const bool tn = d->a_rs == 1 && d->b_cs == 1;
+  // operand layouts of the MFMA fast path: k-contiguous (unit stride along k) or k-strided (unit stride along m / n)
+  const bool a_kc = d->a_cs == 1, a_ks = d->a_rs == 1;
+  const bool b_kc = d->b_rs == 1, b_ks = d->b_cs == 1;
   bool fast = d->dtype == AFFT_BF16 && d->K >= BK && d->K % BK == 0 && aligned16(d->A) && aligned16(d->B);
-  if (fast && nt) fast = (d->a_rs % 8 == 0) && (d->b_cs % 8 == 0);
-  else if (fast && tn) fast = (d->a_cs % 8 == 0) && (d->b_rs % 8 == 0) && d->a_cs >= 8 && d->b_rs >= 8;
-  else fast = false;
+  const int64_t lda = a_kc ? d->a_rs : d->a_cs, ldb = b_kc ? d->b_cs : d->b_rs;
+  fast = fast && (a_kc || a_ks) && (b_kc || b_ks) && lda % 8 == 0 && ldb % 8 == 0 && lda >= 8 && ldb >= 8;
+  fast = fast && !(a_ks && !a_kc && b_kc && !b_ks);   // (A k-strided, B k-contiguous) does not occur on the path
 
   if (fast) {
     GemmFast g;
     g.A = (const bf16_t*)d->A; g.B = (const bf16_t*)d->B;
-    g.lda = nt ? d->a_rs : d->a_cs;
-    g.ldb = nt ? d->b_cs : d->b_rs;
+    g.lda = lda; g.ldb = ldb;
     g.K = d->K;
-    g.tiles_m = (d->M + BM - 1) / BM; g.tiles_n = (d->N + BN - 1) / BN;
     g.e = e;
-    const int grid = g.tiles_m * g.tiles_n;
-    const size_t lds = 4 * TILE_BYTES;
-    if (nt) hipLaunchKernelGGL(gemm_bf16_kernel<0>, dim3(grid), dim3(256), lds, stream, g);
-    else hipLaunchKernelGGL(gemm_bf16_kernel<1>, dim3(grid), dim3(256), lds, stream, g);
-    AFFT_LAUNCH_CHECK();
-    return 0;
+    const bool A_KS = !a_kc, B_KS = !b_kc;
+    if (!A_KS && !B_KS) return launch_layout<false, false>(g, stream);
+    if (!A_KS && B_KS) return launch_layout<false, true>(g, stream);
+    return launch_layout<true, true>(g, stream);
   }
   GemmF32 g;
   g.A = d->A; g.a_rs = d->a_rs; g.a_cs = d->a_cs;

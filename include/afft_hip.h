@@ -70,6 +70,8 @@ typedef struct {
   afft_dropout_t drop;               /* dropout / DropPath on the output (train mode), p = 0 -> off */
 } afft_gemm_t;
 int afft_gemm(const afft_gemm_t* g, void* stream);
+/* Tuning / test hook: force the bf16 tile shape (0 = auto, 1 = 128x128x64 2-stage, 2 = 256x128x64 3-stage). */
+int afft_set_gemm_variant(int variant);
 
 /* ------------------------------------------------------------------ LayerNorm
  * nn.LayerNorm(eps) fwd/bwd: models/fusion.py:281,362 ; transformerblock.py:122,127,150-152 ;

@@ -1,0 +1,47 @@
+"""Times the bf16 MFMA GEMM variants on the shapes of the cfg2 (B=64) step.  Usage: python tools/gemm_bench.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from afft_amd import _lib, ops  # noqa: E402
+
+
+def bench(layout, M, N, K, variant, iters=20):
+    dev = "cuda:0"
+    _lib.check(_lib.lib().afft_set_gemm_variant(variant))
+    g = torch.Generator().manual_seed(0)
+    if layout == "nt":
+        a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev); b = torch.randn(N, K, generator=g).to(torch.bfloat16).to(dev)
+        kw = dict(b_t=True)
+    elif layout == "nn":
+        a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev); b = torch.randn(K, N, generator=g).to(torch.bfloat16).to(dev)
+        kw = dict()
+    else:  # tn: a [K, M], b [K, N]
+        a = torch.randn(K, M, generator=g).to(torch.bfloat16).to(dev); b = torch.randn(K, N, generator=g).to(torch.bfloat16).to(dev)
+        kw = dict(a_t=True)
+    out = torch.empty(M, N, dtype=torch.bfloat16 if layout != "tn" else torch.float32, device=dev)
+    for _ in range(3):
+        ops.gemm(a, b, out, **kw)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        ops.gemm(a, b, out, **kw)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters
+    return ms, 2.0 * M * N * K / ms / 1e9
+
+
+if __name__ == "__main__":
+    shapes = [("nt", 5120, 6144, 2048), ("nt", 5120, 2048, 2048), ("nt", 5120, 8192, 2048), ("nt", 5120, 2048, 8192),
+              ("nn", 5120, 2048, 6144), ("nn", 5120, 8192, 2048), ("nn", 5120, 2048, 8192),
+              ("tn", 6144, 2048, 5120), ("tn", 8192, 2048, 5120), ("tn", 2048, 8192, 5120), ("tn", 2048, 2048, 5120),
+              ("nt", 1024, 6144, 2048), ("nt", 1024, 8192, 2048), ("nt", 1024, 2048, 8192), ("tn", 8192, 2048, 1024),
+              ("nt", 1088, 3840, 2048), ("nt", 8192, 8192, 8192)]
+    print(f"{'layout':6} {'M':>6} {'N':>6} {'K':>6} | {'v1 ms':>8} {'v1 TF':>7} | {'v2 ms':>8} {'v2 TF':>7}")
+    for lay, M, N, K in shapes:
+        r = [bench(lay, M, N, K, v) for v in (1, 2)]
+        print(f"{lay:6} {M:6d} {N:6d} {K:6d} | {r[0][0]:8.4f} {r[0][1]:7.1f} | {r[1][0]:8.4f} {r[1][1]:7.1f}")
