@@ -59,7 +59,7 @@ _SIGS = {
     "afft_colsum": ([vp, i64, i32, i32, i32, vp, i32, vp], C.c_int),
     "afft_add_rows_periodic": ([vp, i64, vp, i64, i32, i32, i32, vp, i64, vp], C.c_int),
     "afft_reduce_rows_periodic": ([vp, i64, i32, i32, i32, vp, i64, vp], C.c_int),
-    "afft_sgd_nesterov": ([vp, vp, i32, vp, i64, f32, f32, f32, f32, i32, vp], C.c_int),
+    "afft_sgd_nesterov": ([vp, vp, i32, vp, vp, i64, f32, f32, f32, f32, i32, vp], C.c_int),
 }
 
 EXPORTS = sorted(list(_SIGS) + ["afft_last_error"])

@@ -1,0 +1,404 @@
+// bf16 MFMA attention for the short sequences of the AFFT path (forward and backward).
+//
+//   SA-Fuser : L = M+1 modality tokens per frame -> G = 16/L frames are PACKED into one 16-row MFMA tile and a
+//              block-diagonal mask (same-frame test) is applied in-register together with the reference's mask;
+//   GPT-2    : L = T = 16 frames = exactly one tile, causal mask in-register;  T = 32 -> two tiles (NT = 2);
+//   CA-Fuser : causal self / cross attention over T frames, q and k/v from different tensors.
+//
+// One workgroup (4 waves) per (packed sequence group, head).  Q, K, V (and dO) tiles [16*NT rows][hd] are staged
+// once into LDS with 16-byte loads; every wave computes the small score tile S^T = K Q^T with
+// v_mfma_f32_16x16x32_bf16 (keys land on registers, queries on lanes, so the softmax reduction over keys is
+// in-lane + two cross-lane steps), masks and normalises in fp32 registers, and the four waves split the head
+// dimension for the P*V product on v_mfma_f32_16x16x16_bf16, whose B operand is exactly the register layout the
+// softmax left behind and whose A operand (V^T) comes from the hardware transposed LDS read ds_read_b64_tr_b16.
+// Backward uses the same two layouts (P^T / P) so no tile is ever transposed through memory.
+//
+// HBM-bound by construction (attention is < 0.2 % of the path's FLOPs): q, k, v are read once and
+// out written once per head; what this kernel buys over the generic VALU kernel (attention.hip) is the removal of
+// ~100 us of latency-bound per-pair dot products per launch.
+//
+// Reference semantics: models/transformerblock.py:24-33,64-73 ; HF GPT-2 eager attention (causal, masked
+// probabilities exactly 0).  probs output holds the PRE-dropout probabilities (see include/afft_hip.h).
+#include "common.h"
+
+namespace {
+
+struct AttnArgs {
+  const bf16_t *q, *k, *v, *dout;
+  int64_t ldq, ldk, ldv, lddo;
+  bf16_t *out, *dq, *dk, *dv;
+  int64_t ldo, lddq, lddk, lddv;
+  float* probs;        // fwd: written; bwd: read
+  int nseq, L, H, hd, G;
+  float scale;
+  int mask;
+  unsigned dthresh, dkey;
+  float dinv;
+};
+
+__device__ __forceinline__ bool pair_valid(int mask, int L, int rows_valid, int qi, int kj) {
+  if (qi >= rows_valid || kj >= rows_valid) return false;
+  const int sq = qi / L, sk = kj / L;
+  if (sq != sk) return false;                    // block-diagonal: tokens of different packed sequences never mix
+  const int i = qi - sq * L, j = kj - sk * L;
+  if (mask == AFFT_MASK_DIAG && i == j) return false;
+  if (mask == AFFT_MASK_CAUSAL && j > i) return false;
+  return true;
+}
+
+// LDS tile [R][hd] bf16; 32-byte unit u of row r is stored at unit u ^ (r & 7): conflict-free transposed reads,
+// 2-way (harmless here) ds_read_b128 row reads.
+__device__ __forceinline__ int tile_off(int row, int chunk16, int row_bytes) {
+  return row * row_bytes + ((chunk16 ^ ((row & 7) << 1)) << 4);
+}
+
+__device__ __forceinline__ void load_tile(const bf16_t* __restrict__ src, int64_t ld, int64_t row0, int rows_valid,
+                                          int R, int hd, char* lds) {
+  const int cpr = hd >> 3;  // 16-byte chunks per row
+  for (int idx = threadIdx.x; idx < R * cpr; idx += 256) {
+    const int row = idx / cpr, ch = idx - row * cpr;
+    uint4 val = make_uint4(0u, 0u, 0u, 0u);
+    if (row < rows_valid) val = *(const uint4*)(src + (row0 + row) * ld + ch * 8);
+    *(uint4*)(lds + tile_off(row, ch, hd * 2)) = val;
+  }
+}
+
+__device__ __forceinline__ bf16x8 row_frag(const char* lds, int row, int chunk16, int row_bytes) {
+  return *(const bf16x8*)(lds + tile_off(row, chunk16, row_bytes));
+}
+// A operand of 16x16x16 for X^T: lane (g, i) gets tile[row0 + 4g + j][16*cb + i], j = 0..3
+__device__ __forceinline__ bf16x4 tr_frag(const char* lds, int row0, int cb, int lane, int row_bytes) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int r = row0 + 4 * g + q;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (AFFT_LDS bf16x4*)(lds + r * row_bytes + ((cb ^ (r & 7)) << 5) + p * 8));
+}
+__device__ __forceinline__ bf16x4 pack4(const float (&v)[4]) {
+  bf16x4 r;
+  r[0] = (short)f2bf(v[0]); r[1] = (short)f2bf(v[1]); r[2] = (short)f2bf(v[2]); r[3] = (short)f2bf(v[3]);
+  return r;
+}
+__device__ __forceinline__ void store_o4(bf16_t* dst, const f32x4& a) {
+  uint2 u;
+  u.x = (unsigned)f2bf(a[0]) | ((unsigned)f2bf(a[1]) << 16);
+  u.y = (unsigned)f2bf(a[2]) | ((unsigned)f2bf(a[3]) << 16);
+  *(uint2*)dst = u;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int R = 16 * NT;
+  const int hd = a.hd, L = a.L, H = a.H;
+  const int rb = hd * 2;
+  char* Qs = smem;
+  char* Ks = Qs + R * rb;
+  char* Vs = Ks + R * rb;
+  const int grp = blockIdx.x / H, h = blockIdx.x % H;
+  const int seq0 = grp * a.G;
+  const int nsq = min(a.G, a.nseq - seq0);
+  const int rows_valid = nsq * L;
+  const int64_t row0 = (int64_t)seq0 * L;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  load_tile(a.q + (int64_t)h * hd, a.ldq, row0, rows_valid, R, hd, Qs);
+  load_tile(a.k + (int64_t)h * hd, a.ldk, row0, rows_valid, R, hd, Ks);
+  load_tile(a.v + (int64_t)h * hd, a.ldv, row0, rows_valid, R, hd, Vs);
+  __syncthreads();
+
+  // S^T[key][query] : keys on (lane>>4, reg), queries on lane&15
+  f32x4 s[NT][NT];
+#pragma unroll
+  for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int ks = 0; ks < hd / 32; ++ks) {
+    const int ch = ks * 4 + (lane >> 4);
+    bf16x8 kf[NT], qf[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      kf[t] = row_frag(Ks, t * 16 + (lane & 15), ch, rb);
+      qf[t] = row_frag(Qs, t * 16 + (lane & 15), ch, rb);
+    }
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < NT; ++qt)
+        s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], s[kt][qt], 0, 0, 0);
+  }
+  // masked softmax over keys, per query column
+  bf16x4 pb[NT][NT];
+#pragma unroll
+  for (int qt = 0; qt < NT; ++qt) {
+    const int qi = qt * 16 + (lane & 15);
+    float m = -INFINITY;
+    bool ok[NT][4];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kj = kt * 16 + 4 * (lane >> 4) + r;
+        ok[kt][r] = pair_valid(a.mask, L, rows_valid, qi, kj);
+        s[kt][qt][r] *= a.scale;
+        if (ok[kt][r]) m = fmaxf(m, s[kt][qt][r]);
+      }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = ok[kt][r] ? __expf(s[kt][qt][r] - m) : 0.f;
+        s[kt][qt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    const int sq = qi / L, i = qi - sq * L;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      float pv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = s[kt][qt][r] * inv;
+        pv[r] = p;
+        if (ok[kt][r]) {
+          const int kj = kt * 16 + 4 * (lane >> 4) + r;
+          const int j = kj - sq * L;
+          const int64_t pidx = ((((int64_t)(seq0 + sq)) * H + h) * L + i) * L + j;
+          if (wave == 0 && a.probs) a.probs[pidx] = p;
+          if (a.dthresh) pv[r] = drop_keep(a.dkey, (unsigned)pidx, a.dthresh) ? p * a.dinv : 0.f;
+        }
+      }
+      pb[kt][qt] = pack4(pv);
+    }
+    // masked (but same-sequence) pairs must read as exactly 0 in probs: write them too
+    if (wave == 0 && a.probs && qi < rows_valid) {
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kj = kt * 16 + 4 * (lane >> 4) + r;
+          if (!ok[kt][r] && kj < rows_valid && kj / L == sq)
+            a.probs[((((int64_t)(seq0 + sq)) * H + h) * L + i) * L + (kj - sq * L)] = 0.f;
+        }
+    }
+  }
+  // O^T[c][query] = sum_key V^T[c][key] P^T[key][query]; the 4 waves split the head dimension in 16-channel blocks
+  for (int cb = wave; cb < hd / 16; cb += 4) {
+    f32x4 o[NT];
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) o[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      const bf16x4 vt = tr_frag(Vs, kt * 16, cb, lane, rb);
+#pragma unroll
+      for (int qt = 0; qt < NT; ++qt) o[qt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt, pb[kt][qt], o[qt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+      const int qi = qt * 16 + (lane & 15);
+      if (qi < rows_valid) store_o4(a.out + (row0 + qi) * a.ldo + (int64_t)h * hd + cb * 16 + 4 * (lane >> 4), o[qt]);
+    }
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int R = 16 * NT;
+  const int hd = a.hd, L = a.L, H = a.H;
+  const int rb = hd * 2;
+  char* Qs = smem;
+  char* Ks = Qs + R * rb;
+  char* Vs = Ks + R * rb;
+  char* Ds = Vs + R * rb;   // dO
+  const int grp = blockIdx.x / H, h = blockIdx.x % H;
+  const int seq0 = grp * a.G;
+  const int nsq = min(a.G, a.nseq - seq0);
+  const int rows_valid = nsq * L;
+  const int64_t row0 = (int64_t)seq0 * L;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, c15 = lane & 15;
+  load_tile(a.q + (int64_t)h * hd, a.ldq, row0, rows_valid, R, hd, Qs);
+  load_tile(a.k + (int64_t)h * hd, a.ldk, row0, rows_valid, R, hd, Ks);
+  load_tile(a.v + (int64_t)h * hd, a.ldv, row0, rows_valid, R, hd, Vs);
+  load_tile(a.dout + (int64_t)h * hd, a.lddo, row0, rows_valid, R, hd, Ds);
+  __syncthreads();
+
+  // dP in both layouts from the same fragments:  A: dP^T[key][query] (keys on regs) ; B: dP[query][key] (queries on regs)
+  f32x4 dpa[NT][NT], dpb[NT][NT];
+#pragma unroll
+  for (int x = 0; x < NT; ++x)
+#pragma unroll
+    for (int y = 0; y < NT; ++y) { dpa[x][y] = f32x4{0.f, 0.f, 0.f, 0.f}; dpb[x][y] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int ks = 0; ks < hd / 32; ++ks) {
+    const int ch = ks * 4 + g;
+    bf16x8 vf[NT], df[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      vf[t] = row_frag(Vs, t * 16 + c15, ch, rb);
+      df[t] = row_frag(Ds, t * 16 + c15, ch, rb);
+    }
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < NT; ++qt) {
+        dpa[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kt], df[qt], dpa[kt][qt], 0, 0, 0);
+        dpb[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[qt], vf[kt], dpb[qt][kt], 0, 0, 0);
+      }
+  }
+  // layout A: query = qt*16 + c15 (lane), key = kt*16 + 4g + r (regs)
+  bf16x4 dsa[NT][NT];   // dS^T * scale  (B operand for dQ)
+#pragma unroll
+  for (int qt = 0; qt < NT; ++qt) {
+    const int qi = qt * 16 + c15;
+    const int sq = qi / L, i = qi - sq * L;
+    float p[NT][4], dp[NT][4];
+    float dot = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kj = kt * 16 + 4 * g + r;
+        float pv = 0.f, m = 0.f;
+        if (pair_valid(a.mask, L, rows_valid, qi, kj)) {
+          const int64_t pidx = ((((int64_t)(seq0 + sq)) * H + h) * L + i) * L + (kj - sq * L);
+          pv = a.probs[pidx];
+          m = (a.dthresh && !drop_keep(a.dkey, (unsigned)pidx, a.dthresh)) ? 0.f : a.dinv;
+        }
+        p[kt][r] = pv;
+        dp[kt][r] = dpa[kt][qt][r] * m;
+        dot += pv * dp[kt][r];
+      }
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      float v4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v4[r] = p[kt][r] * (dp[kt][r] - dot) * a.scale;
+      dsa[kt][qt] = pack4(v4);
+    }
+  }
+  // layout B: query = qt*16 + 4g + r (regs), key = kt*16 + c15 (lane)
+  bf16x4 dsb[NT][NT];   // dS * scale  (B operand for dK)
+  bf16x4 ppb[NT][NT];   // dropped-out P (B operand for dV)
+  {
+    float p[NT][NT][4], dp[NT][NT][4], pm[NT][NT][4], dot[NT][4];
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qi = qt * 16 + 4 * g + r;
+        const int sq = qi / L, i = qi - sq * L;
+        float d = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+          const int kj = kt * 16 + c15;
+          float pv = 0.f, m = 0.f;
+          if (pair_valid(a.mask, L, rows_valid, qi, kj)) {
+            const int64_t pidx = ((((int64_t)(seq0 + sq)) * H + h) * L + i) * L + (kj - sq * L);
+            pv = a.probs[pidx];
+            m = (a.dthresh && !drop_keep(a.dkey, (unsigned)pidx, a.dthresh)) ? 0.f : a.dinv;
+          }
+          p[qt][kt][r] = pv;
+          pm[qt][kt][r] = pv * m;                 // dropped-out probability P' (for dV)
+          dp[qt][kt][r] = dpb[qt][kt][r] * m;     // dP = dP' * m/(1-p)
+          d += pv * dp[qt][kt][r];
+        }
+        // sum over keys = over the 16 lanes of this lane group
+        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+        dot[qt][r] = d;
+      }
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+        float v4[4], pd[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v4[r] = p[qt][kt][r] * (dp[qt][kt][r] - dot[qt][r]) * a.scale;
+          pd[r] = pm[qt][kt][r];
+        }
+        dsb[qt][kt] = pack4(v4);
+        ppb[qt][kt] = pack4(pd);
+      }
+  }
+  // the three [hd x 16] products, 16 channels per step, waves split the head dimension
+  for (int cb = wave; cb < hd / 16; cb += 4) {
+    f32x4 odq[NT], odk[NT], odv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { odq[t] = f32x4{0.f, 0.f, 0.f, 0.f}; odk[t] = odq[t]; odv[t] = odq[t]; }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {          // reduction tile (keys for dQ, queries for dK / dV)
+      const bf16x4 kT = tr_frag(Ks, t * 16, cb, lane, rb);
+      const bf16x4 qT = tr_frag(Qs, t * 16, cb, lane, rb);
+      const bf16x4 dT = tr_frag(Ds, t * 16, cb, lane, rb);
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {        // output tile
+        odq[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kT, dsa[t][u], odq[u], 0, 0, 0);  // dQ^T[c][query u]
+        odk[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qT, dsb[t][u], odk[u], 0, 0, 0);  // dK^T[c][key u]
+        odv[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dT, ppb[t][u], odv[u], 0, 0, 0);  // dV^T[c][key u]
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const int ri = u * 16 + c15;
+      if (ri < rows_valid) {
+        const int64_t col = (int64_t)h * hd + cb * 16 + 4 * g;
+        store_o4(a.dq + (row0 + ri) * a.lddq + col, odq[u]);
+        store_o4(a.dk + (row0 + ri) * a.lddk + col, odk[u]);
+        store_o4(a.dv + (row0 + ri) * a.lddv + col, odv[u]);
+      }
+    }
+  }
+}
+
+bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+// Returns 0 when launched, -1 when the shape is not handled by the MFMA path (caller falls back), >0 on error.
+int afft_attention_mfma(bool backward, const void* dout, int64_t lddo, const void* q, int64_t ldq, const void* k,
+                        int64_t ldk, const void* v, int64_t ldv, float* probs, int nseq, int L, int H, int hd,
+                        float scale, int mask, float drop_p, unsigned drop_key, void* out, int64_t ldo, void* dq,
+                        int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, hipStream_t stream) {
+  if (L > 32 || hd % 64 != 0 || hd > 1024) return -1;
+  if (ldq % 8 || ldk % 8 || ldv % 8 || !al16(q) || !al16(k) || !al16(v)) return -1;
+  if (!backward && (ldo % 4 || (((uintptr_t)out) & 7))) return -1;
+  if (backward && (lddo % 8 || !al16(dout) || lddq % 4 || lddk % 4 || lddv % 4 || (((uintptr_t)dq) & 7) ||
+                   (((uintptr_t)dk) & 7) || (((uintptr_t)dv) & 7) || !probs)) return -1;
+  const int NT = L > 16 ? 2 : 1;
+  const size_t lds = (size_t)(backward ? 4 : 3) * 16 * NT * hd * 2;
+  if (lds > 160 * 1024) return -1;
+  AttnArgs a;
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.dout = (const bf16_t*)dout;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo;
+  a.out = (bf16_t*)out; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
+  a.ldo = ldo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+  a.probs = probs;
+  a.nseq = nseq; a.L = L; a.H = H; a.hd = hd; a.G = (16 * NT) / L;
+  a.scale = scale; a.mask = mask;
+  afft_dropout_t dd = {drop_p, drop_key, 0.f, 0u, 1};
+  const DropParams dp = make_drop(&dd);
+  a.dthresh = dp.thresh; a.dkey = dp.key; a.dinv = dp.inv_keep;
+  const int groups = (nseq + a.G - 1) / a.G;
+  const dim3 grid(groups * H), block(256);
+#define AFFT_ATTN_LAUNCH(KERN)                                                                              \
+  do {                                                                                                      \
+    static bool attr = false;                                                                               \
+    if (!attr) {                                                                                            \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              160 * 1024) != hipSuccess) { (void)hipGetLastError(); return -1; }             \
+      attr = true;                                                                                          \
+    }                                                                                                       \
+    hipLaunchKernelGGL(KERN, grid, block, lds, stream, a);                                                  \
+  } while (0)
+  if (!backward) { if (NT == 1) AFFT_ATTN_LAUNCH(attn_fwd_mfma_kernel<1>); else AFFT_ATTN_LAUNCH(attn_fwd_mfma_kernel<2>); }
+  else { if (NT == 1) AFFT_ATTN_LAUNCH(attn_bwd_mfma_kernel<1>); else AFFT_ATTN_LAUNCH(attn_bwd_mfma_kernel<2>); }
+#undef AFFT_ATTN_LAUNCH
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}

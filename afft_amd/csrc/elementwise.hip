@@ -44,6 +44,25 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
   }
 }
 
+// dst-only copy/cast, 4 elements per thread (cols % 4 == 0, aligned rows), optional dropout replay
+__global__ __launch_bounds__(256) void cast_rows4_kernel(const float* __restrict__ src, int64_t lds_, int rows, int cols,
+                                                         void* __restrict__ dst, int64_t ldd, int dst_dtype,
+                                                         const DropParams drop) {
+  const int nq = cols >> 2;
+  const int64_t total = (int64_t)rows * nq;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / nq), c = (int)(i - (int64_t)r * nq) * 4;
+    const float4 t = *(const float4*)(src + (int64_t)r * lds_ + c);
+    float v[4] = {t.x, t.y, t.z, t.w};
+    if (drop.thresh || drop.path_thresh) {
+      const float rs = drop_row_scale(drop, r);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] *= rs * drop_elem_scale(drop, (unsigned)r * (unsigned)cols + (unsigned)(c + k));
+    }
+    store4(dst, (int64_t)r * ldd + c, dst_dtype, v);
+  }
+}
+
 struct Modal8 { const float* p[8]; int64_t ld[8]; };
 
 __global__ __launch_bounds__(256) void assemble_kernel(Modal8 mods, int S, const float* __restrict__ token,
@@ -75,6 +94,31 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ sr
   atomicAdd(out + c, s);
 }
 
+// vectorized form (cols % 4 == 0, 4-wide aligned rows): 64 column-quads x 4 row-lanes per workgroup
+__global__ __launch_bounds__(256) void colsum4_kernel(const void* __restrict__ src, int64_t lds_, int dtype, int rows,
+                                                      int cols, int rows_per_block, float* __restrict__ out) {
+  __shared__ float sh[4][256];
+  const int qd = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + qd) * 4;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < cols)
+    for (int r = r0 + rl; r < r1; r += 4) {
+      float v[4];
+      load4(src, (int64_t)r * lds_ + c, dtype, v);
+      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sh[rl][qd * 4 + k] = s[k];
+  __syncthreads();
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc < cols) {
+    const float t = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    atomicAdd(out + cc, t);
+  }
+}
+
 __global__ __launch_bounds__(256) void add_rows_periodic_kernel(const float* __restrict__ x, int64_t ldx,
                                                                 const float* __restrict__ table, int64_t ldt,
                                                                 int period, int d, float* __restrict__ y, int64_t ldy) {
@@ -101,8 +145,8 @@ __global__ __launch_bounds__(256) void reduce_rows_periodic_kernel(const float* 
 }
 
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const void* __restrict__ g_, int g_dtype,
-                                                  float* __restrict__ buf, int64_t n, float lr, float mom, float wd,
-                                                  float gscale, int first) {
+                                                  float* __restrict__ buf, bf16_t* __restrict__ p16, int64_t n, float lr,
+                                                  float mom, float wd, float gscale, int first) {
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
     if (i + 3 < n) {
       float4 pv = *(float4*)(p + i);
@@ -120,12 +164,14 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const v
       }
       *(float4*)(buf + i) = make_float4(bb[0], bb[1], bb[2], bb[3]);
       *(float4*)(p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+      if (p16) store4(p16, i, AFFT_BF16, pp);
     } else {
       for (int64_t j = i; j < n; ++j) {
         const float gg = ld_any(g_, j, g_dtype) * gscale + wd * p[j];
         const float bb = first ? gg : mom * buf[j] + gg;
         buf[j] = bb;
         p[j] -= lr * (gg + mom * bb);
+        if (p16) p16[j] = f2bf(p[j]);
       }
     }
   }
@@ -142,6 +188,16 @@ extern "C" int afft_cast(const float* src, int64_t lds_, int32_t rows, int32_t c
   AFFT_CHECK(!dst_t || ldt >= rows, "cast: ldt < rows");
   if (rows == 0 || cols == 0) return 0;
   const int pad_cols = (dst && zero_pad) ? (int)ldd : cols;
+  if (dst && !dst_t && pad_cols == cols && cols % 4 == 0 && lds_ % 4 == 0 && ldd % 4 == 0 &&
+      (((uintptr_t)src) & 15) == 0 && (((uintptr_t)dst) & (dst_dtype == AFFT_F32 ? 15 : 7)) == 0) {
+    const int64_t total = (int64_t)rows * (cols / 4);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(cast_rows4_kernel, dim3((int)blocks), dim3(256), 0, stream, src, lds_, rows, cols, dst, ldd,
+                       dst_dtype, make_drop(drop));
+    AFFT_LAUNCH_CHECK();
+    return 0;
+  }
   dim3 grid((pad_cols + 63) / 64, (rows + 63) / 64);
   hipLaunchKernelGGL(cast_kernel, grid, dim3(256), 0, stream, src, lds_, rows, cols, dst, ldd, dst_dtype, dst_t, ldt,
                      pad_cols, make_drop(drop));
@@ -175,9 +231,11 @@ extern "C" int afft_colsum(const void* src, int64_t lds_, int32_t dtype, int32_t
     if (hipMemsetAsync(out, 0, sizeof(float) * cols, stream) != hipSuccess) { afft_set_error("colsum: memset failed"); return 2; }
   }
   if (rows == 0) return 0;
-  const int rpb = 64;
+  const bool v4 = cols % 4 == 0 && lds_ % 4 == 0 && (((uintptr_t)src) & (dtype == AFFT_F32 ? 15 : 7)) == 0;
+  const int rpb = v4 ? 128 : 64;
   dim3 grid((cols + 255) / 256, (rows + rpb - 1) / rpb);
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, src, lds_, dtype, rows, cols, rpb, out);
+  if (v4) hipLaunchKernelGGL(colsum4_kernel, grid, dim3(256), 0, stream, src, lds_, dtype, rows, cols, rpb, out);
+  else hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, src, lds_, dtype, rows, cols, rpb, out);
   AFFT_LAUNCH_CHECK();
   return 0;
 }
@@ -204,8 +262,8 @@ extern "C" int afft_reduce_rows_periodic(const float* src, int64_t lds_, int32_t
   return 0;
 }
 
-extern "C" int afft_sgd_nesterov(float* p, const void* g, int32_t g_dtype, float* buf, int64_t n, float lr, float mom,
-                                 float wd, float gscale, int32_t first_step, void* stream_) {
+extern "C" int afft_sgd_nesterov(float* p, const void* g, int32_t g_dtype, float* buf, void* p_bf16, int64_t n, float lr,
+                                 float mom, float wd, float gscale, int32_t first_step, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(p && g && buf, "sgd: null pointer");
   AFFT_CHECK(((uintptr_t)p & 15) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)buf & 15) == 0, "sgd: buffers must be 16-byte aligned");
@@ -213,8 +271,8 @@ extern "C" int afft_sgd_nesterov(float* p, const void* g, int32_t g_dtype, float
   if (n == 0) return 0;
   int64_t blocks = (n + 1023) / 1024;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(sgd_kernel, dim3((int)blocks), dim3(256), 0, stream, p, g, g_dtype, buf, n, lr, mom, wd, gscale,
-                     first_step);
+  hipLaunchKernelGGL(sgd_kernel, dim3((int)blocks), dim3(256), 0, stream, p, g, g_dtype, buf, (bf16_t*)p_bf16, n, lr, mom, wd,
+                     gscale, first_step);
   AFFT_LAUNCH_CHECK();
   return 0;
 }

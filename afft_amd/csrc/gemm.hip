@@ -299,9 +299,11 @@ int launch_layout(GemmFast& g, hipStream_t stream) {
     // per-CU rate of 128x128 (2 workgroups/CU) when the grid fills the chip; pick by estimated makespan.
     const int64_t t2 = (int64_t)((g.e.M + 255) / 256) * ((g.e.N + 127) / 128);
     const int64_t t1 = (int64_t)((g.e.M + 127) / 128) * ((g.e.N + 127) / 128);
-    const double cost2 = (double)((t2 + 255) / 256) * 2.0 / 1.4;
+    // measured (profiles/r01_gemm_variants_bench.txt): the 128x128 2-workgroups/CU shape wins on every shape of the
+    // path (two independent workgroups per CU de-synchronise their load / MFMA phases), so auto == 1 for now.
+    const double cost2 = (double)((t2 + 255) / 256) * 2.0 / 0.9;
     const double cost1 = (double)((t1 + 511) / 512) * 2.0;
-    variant = (g.e.M >= 256 && cost2 <= cost1) ? 2 : 1;
+    variant = (g.e.M >= 256 && cost2 < cost1 * 0.8) ? 2 : 1;
   }
   if (variant == 2) return launch_fast<4, 2, 3, A_KS, B_KS>(g, stream);
   return launch_fast<2, 2, 2, A_KS, B_KS>(g, stream);

@@ -136,13 +136,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
   }
 }
 
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nparts, int d, float* __restrict__ dw,
-                                     float* __restrict__ db) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * d) return;
+// 64 columns x 4 part-lanes per workgroup: coalesced 256-B reads, fixed summation order (deterministic)
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nparts, int d,
+                                                            float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ float sh[4][64];
+  const int col = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + col;
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * 2 * d + c];
-  if (c < d) { if (dw) dw[c] += s; } else { if (db) db[c - d] += s; }
+  if (c < 2 * d)
+    for (int p = pl; p < nparts; p += 4) s += partial[(int64_t)p * 2 * d + c];
+  sh[pl][col] = s;
+  __syncthreads();
+  if (pl == 0 && c < 2 * d) {
+    s = (sh[0][col] + sh[1][col]) + (sh[2][col] + sh[3][col]);
+    if (c < d) { if (dw) dw[c] += s; } else { if (db) db[c - d] += s; }
+  }
 }
 
 int pick_nv(int d) {
@@ -156,7 +164,7 @@ int pick_nv(int d) {
 
 extern "C" int afft_layernorm_bwd_nparts(int32_t rows) {
   int n = (rows + LN_WAVES - 1) / LN_WAVES;
-  return n < 1 ? 1 : (n > 512 ? 512 : n);
+  return n < 1 ? 1 : (n > 256 ? 256 : n);   // one workgroup per CU at most
 }
 
 extern "C" int afft_layernorm_fwd(const float* x, int64_t ldx, const float* w, const float* b, float eps,
@@ -193,7 +201,7 @@ extern "C" int afft_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype
 #undef LN_BWD
   AFFT_LAUNCH_CHECK();
   if (dw || db) {
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, stream, partial, grid, d, dw, db);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * d + 63) / 64), dim3(256), 0, stream, partial, grid, d, dw, db);
     AFFT_LAUNCH_CHECK();
   }
   return 0;

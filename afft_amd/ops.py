@@ -207,7 +207,10 @@ def reduce_rows_periodic(src: Tensor, period: int, out: Tensor):
     return out
 
 
-def sgd_nesterov(p: Tensor, g: Tensor, buf: Tensor, lr: float, mom: float, wd: float, gscale: float, first: bool):
+def sgd_nesterov(p: Tensor, g: Tensor, buf: Tensor, lr: float, mom: float, wd: float, gscale: float, first: bool,
+                 p_bf16: Optional[Tensor] = None):
     assert p.is_contiguous() and g.is_contiguous() and buf.is_contiguous()
-    L.check(L.lib().afft_sgd_nesterov(_p(p), _p(g), _dt(g), _p(buf), p.numel(), lr, mom, wd, gscale, 1 if first else 0,
+    if p_bf16 is not None:
+        assert p_bf16.dtype == torch.bfloat16 and p_bf16.numel() == p.numel() and p_bf16.is_contiguous()
+    L.check(L.lib().afft_sgd_nesterov(_p(p), _p(g), _dt(g), _p(buf), _p(p_bf16), p.numel(), lr, mom, wd, gscale, 1 if first else 0,
                                       _stream()), "sgd_nesterov")

@@ -45,12 +45,21 @@ class FlatParams:
         self.total = off
         self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
+        # bf16 image of every parameter at the same element offsets: written by the fused SGD kernel, so the
+        # MFMA operand copies of the weights cost no extra pass (only GEMM weights with both dims % 64 == 0 use it;
+        # odd shapes -- the 3806-row classifier, the 352-column objects mapping -- keep a padded cast image)
+        self.flat_p16 = torch.zeros(off, dtype=torch.bfloat16, device=dev) if dev.type == "cuda" else None
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 n = p.numel()
                 self.flat_p[o:o + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat_p[o:o + n].view(p.shape)
                 p.grad = self.flat_g[o:o + n].view(p.shape)
+            if self.flat_p16 is not None:
+                ops.cast(self.flat_p.view(off // 64, 64), self.flat_p16.view(off // 64, 64))
+                for p, o in zip(self.params, self.offsets):
+                    if p.dim() == 2 and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0:
+                        rt.adopt_weight_image(p, self.flat_p16[o:o + p.numel()].view(p.shape))
         rt.invalidate_weight_images()
 
     def index_of(self) -> Dict[int, int]:
@@ -157,9 +166,10 @@ class FusedSGD:
 
     def step(self, grad: Optional[Tensor] = None, gscale: float = 1.0):
         g = self.flat.flat_g if grad is None else grad
-        ops.sgd_nesterov(self.flat.flat_p, g, self.buf, self.lr, self.momentum, self.wd, gscale, self.steps == 0)
+        ops.sgd_nesterov(self.flat.flat_p, g, self.buf, self.lr, self.momentum, self.wd, gscale, self.steps == 0,
+                         p_bf16=self.flat.flat_p16)
         self.steps += 1
-        rt.invalidate_weight_images()   # bf16 weight images are re-cast on next use
+        rt.invalidate_weight_images()   # padded cast images (odd shapes) are re-cast on next use
 
 
 class Trainer:

@@ -60,39 +60,54 @@ def pad64(n: int) -> int:
 
 # --------------------------------------------------------------------------- bf16 weight images
 class _WImage:
-    __slots__ = ("version", "ptr", "w", "wt")
+    __slots__ = ("version", "ptr", "w", "external")
 
 
 _wlist: list = []   # weak references to parameters that own an image (for invalidate_weight_images)
 
 
-def weight_images(p: Tensor):
-    """(w16 [rows, pad64(cols)], wt16 [cols, pad64(rows)]) bf16 images of a 2-D fp32 parameter, zero padded,
-    refreshed when the parameter's version counter or storage changes (optimizer step, load_state_dict)."""
+def weight_image(p: Tensor) -> Tensor:
+    """bf16 image [pad64(rows), pad64(cols)] (zero padded) of a 2-D fp32 parameter: the MFMA operand copy.
+    One image serves forward (k-contiguous B, "NT") and dgrad (k-strided B, "NN") -- no transposed copy.
+    Refreshed by a cast kernel when the parameter's version counter or storage changes; parameters re-homed by
+    afft_amd.parallel.FlatParams get their image written by the fused SGD kernel itself (`external`)."""
     img = getattr(p, "_afft_img", None)
     ver = p._version
     if img is None or img.ptr != p.data_ptr() or img.w.device != p.device:
         img = _WImage()
         rows, cols = p.shape
-        img.w = torch.zeros(rows, pad64(cols), dtype=torch.bfloat16, device=p.device)
-        img.wt = torch.zeros(cols, pad64(rows), dtype=torch.bfloat16, device=p.device)
+        img.w = torch.zeros(pad64(rows), pad64(cols), dtype=torch.bfloat16, device=p.device)
         img.version = -1
+        img.external = False
         img.ptr = p.data_ptr()
         p._afft_img = img
         _wlist.append(weakref.ref(p))
     if img.version != ver:
         with torch.no_grad():
-            ops.cast(p.detach(), img.w, img.wt)
+            ops.cast(p.detach(), img.w[:p.shape[0], :p.shape[1]])
         img.version = ver
-    return img.w, img.wt
+    return img.w
 
 
-def invalidate_weight_images():
+def adopt_weight_image(p: Tensor, view16: Tensor):
+    """Use `view16` (bf16, same shape as p, both dims multiples of 64, kept fresh by the optimizer kernel) as
+    p's MFMA image."""
+    img = _WImage()
+    img.w = view16
+    img.version = p._version
+    img.external = True
+    img.ptr = p.data_ptr()
+    p._afft_img = img
+    _wlist.append(weakref.ref(p))
+
+
+def invalidate_weight_images(include_external: bool = False):
     alive = []
     for r in _wlist:
         p = r()
         if p is not None and getattr(p, "_afft_img", None) is not None:
-            p._afft_img.version = -1
+            if include_external or not p._afft_img.external:
+                p._afft_img.version = -1
             alive.append(r)
     _wlist[:] = alive
 

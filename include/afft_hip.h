@@ -148,9 +148,10 @@ int afft_reduce_rows_periodic(const float* src, int64_t lds, int32_t rows, int32
                               float* out, int64_t ldo, void* stream);
 /* Nesterov-momentum SGD over one flat fp32 parameter buffer (conf/opt/optimizer/sgd.yaml, train.py:262):
  *   g = gscale*g + wd*p ; buf = mom*buf + g ; p -= lr*(g + mom*buf) ; gscale = 1/world after a summing
- *   all-reduce; g may be fp32 or bf16 (bf16 gradient exchange). */
-int afft_sgd_nesterov(float* p, const void* g, int32_t g_dtype, float* buf, int64_t n, float lr, float mom, float wd,
-                      float gscale, int32_t first_step, void* stream);
+ *   all-reduce; g may be fp32 or bf16 (bf16 gradient exchange).  p_bf16 (optional, same element offsets as p)
+ *   receives the bf16 image of the updated weights: the GEMM operand copy is refreshed by the update itself. */
+int afft_sgd_nesterov(float* p, const void* g, int32_t g_dtype, float* buf, void* p_bf16, int64_t n, float lr, float mom,
+                      float wd, float gscale, int32_t first_step, void* stream);
 
 #ifdef __cplusplus
 }
