@@ -3,6 +3,8 @@
 // mask is applied in-register while the scores are produced.  HBM-bound by construction (reads q,k,v once
 // through L1/L2, writes out once): attention is < 0.2 % of the path's FLOPs.
 //   softmax(q k^T * hd^-0.5 + mask) v : models/transformerblock.py:24-33,64-73 ; HF GPT-2 eager attention.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -151,6 +153,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ dou
 
 }  // namespace
 
+// bf16 MFMA path (attention_mfma.hip); returns -1 when the shape is not handled
+int afft_attention_mfma(bool backward, const void* dout, int64_t lddo, const void* q, int64_t ldq, const void* k,
+                        int64_t ldk, const void* v, int64_t ldv, float* probs, int nseq, int L, int H, int hd,
+                        float scale, int mask, float drop_p, unsigned drop_key, void* out, int64_t ldo, void* dq,
+                        int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, hipStream_t stream);
+static bool use_mfma_attention() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("AFFT_ATTN_GENERIC"); v = (e && e[0] == '1') ? 0 : 1; }
+  return v == 1;
+}
+
 extern "C" int afft_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                                   int32_t dtype, int32_t nseq, int32_t L, int32_t H, int32_t hd, float scale,
                                   int32_t mask, float drop_p, uint32_t drop_key, void* out, int64_t ldo, float* probs,
@@ -162,6 +175,11 @@ extern "C" int afft_attention_fwd(const void* q, int64_t ldq, const void* k, int
   AFFT_CHECK(!(mask == AFFT_MASK_DIAG && L == 1), "attention_fwd: diagonal mask with L=1 masks every key");
   AFFT_CHECK(drop_p >= 0.f && drop_p < 1.f, "attention_fwd: dropout p outside [0,1)");
   if (nseq == 0) return 0;
+  if (dtype == AFFT_BF16 && use_mfma_attention()) {
+    const int rc = afft_attention_mfma(false, nullptr, 0, q, ldq, k, ldk, v, ldv, probs, nseq, L, H, hd, scale, mask,
+                                       drop_p, drop_key, out, ldo, nullptr, 0, nullptr, 0, nullptr, 0, stream);
+    if (rc >= 0) return rc;
+  }
   afft_dropout_t dd = {drop_p, drop_key, 0.f, 0u, 1};
   const DropParams dp = make_drop(&dd);
   const dim3 grid(nseq * H), block(256);
@@ -185,6 +203,11 @@ extern "C" int afft_attention_bwd(const void* dout, int64_t lddo, const void* q,
   AFFT_CHECK(L >= 1 && L <= LMAX, "attention_bwd: sequence length %d outside 1..%d", L, LMAX);
   AFFT_CHECK(drop_p >= 0.f && drop_p < 1.f, "attention_bwd: dropout p outside [0,1)");
   if (nseq == 0) return 0;
+  if (dtype == AFFT_BF16 && use_mfma_attention()) {
+    const int rc = afft_attention_mfma(true, dout, lddo, q, ldq, k, ldk, v, ldv, const_cast<float*>(probs), nseq, L, H, hd,
+                                       scale, 0, drop_p, drop_key, nullptr, 0, dq, lddq, dk, lddk, dv, lddv, stream);
+    if (rc >= 0) return rc;
+  }
   afft_dropout_t dd = {drop_p, drop_key, 0.f, 0u, 1};
   const DropParams dp = make_drop(&dd);
   const dim3 grid(nseq * H), block(256);

@@ -48,8 +48,11 @@ __device__ __forceinline__ bool pair_valid(int mask, int L, int rows_valid, int 
 
 // LDS tile [R][hd] bf16; 32-byte unit u of row r is stored at unit u ^ (r & 7): conflict-free transposed reads,
 // 2-way (harmless here) ds_read_b128 row reads.
+__device__ __forceinline__ int swz(int row, int row_bytes) {   // XOR stays inside the row: rows hold row_bytes/32 units
+  return row & 7 & ((row_bytes >> 5) - 1);
+}
 __device__ __forceinline__ int tile_off(int row, int chunk16, int row_bytes) {
-  return row * row_bytes + ((chunk16 ^ ((row & 7) << 1)) << 4);
+  return row * row_bytes + ((chunk16 ^ (swz(row, row_bytes) << 1)) << 4);
 }
 
 __device__ __forceinline__ void load_tile(const bf16_t* __restrict__ src, int64_t ld, int64_t row0, int rows_valid,
@@ -71,7 +74,7 @@ __device__ __forceinline__ bf16x4 tr_frag(const char* lds, int row0, int cb, int
   const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
   const int r = row0 + 4 * g + q;
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (AFFT_LDS bf16x4*)(lds + r * row_bytes + ((cb ^ (r & 7)) << 5) + p * 8));
+      (AFFT_LDS bf16x4*)(lds + r * row_bytes + ((cb ^ swz(r, row_bytes)) << 5) + p * 8));
 }
 __device__ __forceinline__ bf16x4 pack4(const float (&v)[4]) {
   bf16x4 r;

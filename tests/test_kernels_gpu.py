@@ -176,7 +176,10 @@ def test_layernorm_strided_token0_and_no_affine():
 
 
 ATTN_CASES = [(7, 5, 4, 16, 0, "f32"), (6, 5, 4, 64, 1, "f32"), (3, 16, 2, 64, 2, "f32"), (2, 32, 2, 32, 2, "f32"),
-              (9, 5, 4, 256, 0, "bf16"), (4, 16, 4, 512, 2, "bf16"), (3, 6, 4, 128, 1, "bf16"), (5, 1, 2, 32, 0, "f32")]
+              (9, 5, 4, 256, 0, "bf16"), (4, 16, 4, 512, 2, "bf16"), (3, 6, 4, 128, 1, "bf16"), (5, 1, 2, 32, 0, "f32"),
+              # bf16 with hd % 64 == 0 takes the MFMA path: packed frames (G=3, ragged last group), G=2, NT=2, T=10
+              (7, 5, 4, 512, 0, "bf16"), (64, 5, 4, 64, 1, "bf16"), (3, 8, 2, 64, 0, "bf16"), (2, 32, 2, 64, 2, "bf16"),
+              (5, 10, 4, 64, 2, "bf16"), (3, 17, 2, 128, 2, "bf16"), (4, 16, 2, 16, 2, "bf16")]
 
 
 @pytest.mark.parametrize("nseq,L,H,hd,mask,dt", ATTN_CASES)
@@ -211,6 +214,39 @@ def test_attention_fwd_bwd(nseq, L, H, hd, mask, dt):
     ops.attention_bwd(dout.to(tdt).to(dev()), q, k, v, probs, nseq, L, H, hd, scale, dg[:, :d], dg[:, d:2 * d], dg[:, 2 * d:])
     torch.cuda.synchronize()
     assert rel_l2(dg.float().cpu(), qr.grad.float()) < (3e-5 if dt == "f32" else 2e-2)
+
+
+def test_attention_dropout_mfma_matches_generic():
+    """The bf16 MFMA kernels and the generic fp32 kernels derive the dropout mask from the same (key, index):
+    with the same key they must agree (forward output and all three gradients)."""
+    from afft_amd import ops
+    nseq, L, H, hd, mask = 8, 5, 4, 64, 0
+    d = H * hd
+    scale = hd ** -0.5
+    qkv = bfr(rnd(nseq * L, 3 * d, seed=11))
+    dout = bfr(rnd(nseq * L, d, seed=12))
+    res = {}
+    for tdt in (torch.float32, torch.bfloat16):
+        g = qkv.to(tdt).to(dev())
+        q, k, v = g[:, :d], g[:, d:2 * d], g[:, 2 * d:]
+        out = torch.empty(nseq * L, d, dtype=tdt, device=dev())
+        probs = torch.empty(nseq, H, L, L, device=dev())
+        ops.attention_fwd(q, k, v, nseq, L, H, hd, scale, mask, out, probs, drop_p=0.3, drop_key=12345)
+        dg = torch.zeros(nseq * L, 3 * d, dtype=tdt, device=dev())
+        ops.attention_bwd(dout.to(tdt).to(dev()), q, k, v, probs, nseq, L, H, hd, scale, dg[:, :d], dg[:, d:2 * d],
+                          dg[:, 2 * d:], drop_p=0.3, drop_key=12345)
+        torch.cuda.synchronize()
+        res[tdt] = (out.float().cpu(), probs.cpu(), dg.float().cpu())
+    o32, p32, g32 = res[torch.float32]
+    o16, p16, g16 = res[torch.bfloat16]
+    assert rel_l2(p16, p32) < 2e-3          # pre-dropout probabilities
+    assert rel_l2(o16, o32) < 1.5e-2
+    assert rel_l2(g16, g32) < 3e-2
+    # dropout really happened: output differs from the p=0 output
+    g = qkv.to(dev())
+    out0 = torch.empty(nseq * L, d, device=dev())
+    ops.attention_fwd(g[:, :d], g[:, d:2 * d], g[:, 2 * d:], nseq, L, H, hd, scale, mask, out0, None)
+    assert rel_l2(out0.cpu(), o32) > 0.1
 
 
 @pytest.mark.parametrize("rows,C,soft", [(37, 3806, False), (20, 11, False), (33, 3806, True), (16, 7, True)])
