@@ -175,3 +175,54 @@ def test_train_mode_dropout_statistics():
     assert not torch.equal(outs[0], outs[1])
     for n, p in model.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
+
+
+def test_trainer_fused_sgd_and_weight_images():
+    """Trainer on one GPU: flat parameter/gradient buffers, fused Nesterov SGD equal to torch.optim.SGD on the same
+    gradients, bf16 weight images refreshed by the SGD kernel, loss goes down."""
+    import afft_amd
+    from afft_amd import runtime as rt
+    from afft_amd.config import make_model_cfg
+    from afft_amd.models.base_model import BaseModel
+    from afft_amd.parallel import Trainer
+    afft_amd.set_precision("bf16")
+    rt.set_grad_mode("sink")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    mods = {"rgb": 128, "objects": 40, "flow": 128}
+    cfg = make_model_cfg(mods, 128, 256, depth=2, fp_layers=2, fp_heads=4, drop=0.0)
+    model = BaseModel(cfg, {"action": 50}, {}).to(dev).eval()
+    B, T = 8, 8
+    feats = {m: torch.randn(B, T, C, 1, 1, 1, device=dev) for m, C in mods.items()}
+    tgt = {"action": torch.randint(0, 50, (B,), device=dev)}
+    sub = {"action": torch.randint(0, 50, (B, T, 1), device=dev)}
+    tr = Trainer(model, {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}, lr=0.05, momentum=0.9,
+                 weight_decay=1e-4)
+    p0 = tr.flat.flat_p.clone()
+    ref_p = torch.nn.Parameter(p0.clone())
+    ref_opt = torch.optim.SGD([ref_p], lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-4)
+    losses = []
+    for step in range(6):
+        loss, _ = tr.forward_backward(feats, tgt, sub)
+        losses.append(float(loss))
+        if step < 2:   # replay the same gradients through torch's optimizer
+            ref_p.data.copy_(tr.flat.flat_p)
+            ref_p.grad = tr.flat.flat_g.clone()
+        g, scale = tr.reducer.grad_for_optimizer()
+        tr.opt.step(g, scale)
+        if step < 2:
+            if step == 0:
+                ref_opt.step()
+            else:  # momentum buffer continuity
+                ref_opt.state[ref_p]["momentum_buffer"] = tr_prev_buf
+                ref_opt.step()
+            assert rel_l2(tr.flat.flat_p, ref_p.detach()) < 1e-6
+        tr_prev_buf = tr.opt.buf.clone()
+        # images written by the SGD kernel match a fresh cast of the weights
+        w = model.future_predictor.fuser.blocks[0].attn.qkv.weight
+        img = rt.weight_image(w)
+        assert torch.equal(img[:w.shape[0], :w.shape[1]], w.detach().to(torch.bfloat16))
+        wc = model.future_predictor.classifiers["action"]["all-fused"][1].weight   # 50 x 128: padded cast image
+        imgc = rt.weight_image(wc)
+        assert torch.equal(imgc[:50, :128], wc.detach().to(torch.bfloat16)) and float(imgc[50:].float().abs().max()) == 0
+    assert losses[-1] < losses[0] * 0.9, losses
