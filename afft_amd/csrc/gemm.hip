@@ -19,108 +19,13 @@
 //    and the fallback for shapes the fast path does not take.
 //
 // Replaces nn.Linear / HF Conv1D forward, dgrad and wgrad on the AFFT path (see include/afft_hip.h).
-#include <type_traits>
+#include "gemm_tiles.h"
 
-#include "common.h"
+using namespace afft_gemm_detail;
+
+int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream);
 
 namespace {
-
-constexpr int BK = 64;
-constexpr int GROUP_M = 8;
-
-struct GemmFast {
-  const bf16_t* A; int64_t lda;  // k-contiguous: A[M][K] ; k-strided: A[K][M]
-  const bf16_t* B; int64_t ldb;  // k-contiguous: B[N][K] ; k-strided: B[K][N]
-  int K;
-  int tiles_m, tiles_n;
-  EpiParams e;
-};
-
-__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int& tm, int& tn) {
-  // XCD-aware remap: workgroups b and b+8 share an XCD (and its L2); give each XCD a contiguous
-  // chunk of the tile list, then walk that chunk in GROUP_M-tall column groups so that co-resident
-  // tiles share A row-panels and B column-panels in that XCD's L2.
-  const int nwg = tiles_m * tiles_n;
-  const int bid = blockIdx.x;
-  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-  int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int width = GROUP_M * tiles_n;
-  const int group = id / width;
-  const int first_m = group * GROUP_M;
-  const int gsz = min(tiles_m - first_m, GROUP_M);
-  const int in_group = id - group * width;
-  tm = first_m + in_group % gsz;
-  tn = in_group / gsz;
-}
-
-// ----- k-contiguous image: tile [ROWS][64 k] bf16, 128 B per row; 16-B chunk c of row r lives at chunk c ^ ((r>>1)&7)
-template <int ROWS, int NWAVES>
-__device__ __forceinline__ void stage_kc(const bf16_t* __restrict__ G, int64_t ld, int row0, int nrows, int k0,
-                                         char* lds_tile, int wave, int lane) {
-#pragma unroll
-  for (int jj = 0; jj < ROWS / 8 / NWAVES; ++jj) {
-    const int j = wave + jj * NWAVES;     // 1-KiB piece = 8 rows
-    const int row = j * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    int grow = row0 + row;
-    grow = grow < nrows ? grow : nrows - 1;  // tail rows: re-read a valid row, result discarded by the epilogue
-    const bf16_t* src = G + (int64_t)grow * ld + k0 + chunk * 8;
-    __builtin_amdgcn_global_load_lds((const AFFT_GLOBAL void*)src, (AFFT_LDS void*)(lds_tile + j * 1024), 16, 0, 0);
-  }
-}
-__device__ __forceinline__ bf16x8 frag_kc(const char* lds_tile, int row, int chunk) {
-  return *(const bf16x8*)(lds_tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-}
-
-// ----- k-strided image: tile [64 k][COLS] bf16, 2*COLS B per row; 32-B unit u of row r lives at unit u ^ f(r),
-//       f(r) = (r&3) | ((r>>3)&1)<<2 : the two 4-row blocks a 32-lane half reads by ds_read_b64_tr_b16 hit 8 distinct units
-__device__ __forceinline__ int ks_f(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
-template <int COLS, int NWAVES>
-__device__ __forceinline__ void stage_ks(const bf16_t* __restrict__ G, int64_t ld, int col0, int k0,
-                                         char* lds_tile, int wave, int lane) {
-  constexpr int CH = COLS / 8;            // 16-B chunks per row (16 or 32)
-  constexpr int RPP = 64 / CH;            // rows per 1-KiB piece
-#pragma unroll
-  for (int jj = 0; jj < COLS / 8 / NWAVES; ++jj) {
-    const int j = wave + jj * NWAVES;
-    const int row = j * RPP + lane / CH;
-    const int c16 = lane % CH;
-    const int src_c16 = (((c16 >> 1) ^ ks_f(row)) << 1) | (c16 & 1);
-    int64_t col = col0 + src_c16 * 8;
-    col = col < ld - 8 ? col : ld - 8;     // tail columns: stay inside the row, result discarded
-    const bf16_t* src = G + (int64_t)(k0 + row) * ld + col;
-    __builtin_amdgcn_global_load_lds((const AFFT_GLOBAL void*)src, (AFFT_LDS void*)(lds_tile + j * 1024), 16, 0, 0);
-  }
-}
-// fragment for MFMA 16x16x32: lane (g = lane>>4, r = lane&15) needs tile[k = kb + 8g + j][16*unit + r], j = 0..7
-template <int COLS>
-__device__ __forceinline__ bf16x8 frag_ks(const char* lds_tile, int kb, int unit, int lane) {
-  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-  const int r0 = kb + 8 * g + q, r1 = r0 + 4;
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (AFFT_LDS bf16x4*)(lds_tile + r0 * (2 * COLS) + ((unit ^ ks_f(r0)) << 5) + p * 8));
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (AFFT_LDS bf16x4*)(lds_tile + r1 * (2 * COLS) + ((unit ^ ks_f(r1)) << 5) + p * 8));
-  bf16x8 f;
-  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
-  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-  return f;
-}
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N >= 0 && N < 64, "vmcnt immediate");
-  // lgkmcnt(0): this wave's LDS reads of the stage about to be refilled have returned before it signals the barrier
-  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
-}
 
 template <int WM, int WN, int STAGES, bool A_KS, bool B_KS>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf16_kernel(const GemmFast g) {
@@ -199,13 +104,27 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf1
     }
   }
 
+  // Epilogue through LDS (same scheme as gemm_pp.hip): accumulators -> fp32 [BM][BN] image with a 16-byte row pad
+  // (conflict-free scatter), then whole rows per wave with 16-byte LDS reads and fully coalesced global accesses.
+  constexpr int ESTRIDE = BN * 4 + 16;
+  __builtin_amdgcn_s_barrier();   // every wave is done reading the ring
   static_for<0, 16>([&](auto idx) {
     constexpr int i = decltype(idx)::value >> 2, j = decltype(idx)::value & 3;
-    const int m = m0 + wr * 64 + i * 16 + (lane & 15);
-    const int n = n0 + wc * 64 + j * 16 + 4 * (lane >> 4);
-    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-    epilogue4(g.e, m, n, v);
+    const int row = wr * 64 + i * 16 + (lane & 15);
+    const int col = wc * 64 + j * 16 + 4 * (lane >> 4);
+    *(f32x4*)(smem + row * ESTRIDE + col * 4) = acc[i][j];
   });
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  constexpr int LPR = BN / 4;            // lanes per row
+  constexpr int RPI = 64 / LPR;          // rows per wave-iteration
+  for (int it = 0; it < BM / NW / RPI; ++it) {
+    const int row = wave * (BM / NW) + it * RPI + lane / LPR;
+    const int c4 = lane % LPR;
+    const f32x4 t = *(const f32x4*)(smem + row * ESTRIDE + c4 * 16);
+    float o[4] = {t[0], t[1], t[2], t[3]};
+    epilogue4(g.e, m0 + row, n0 + 4 * c4, o);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -268,12 +187,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32 g) {
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-int g_variant = 0;  // 0 auto, 1 = 128x128 tile, 2 = 256x128 tile (tuning / tests)
+int g_variant = 0;  // 0 auto, 1 = 128x128 tile, 2 = 256x128 tile, 3 = 256x256 ping-pong (tuning / tests)
 
 template <int WM, int WN, int STAGES, bool A_KS, bool B_KS>
 int launch_fast(GemmFast& g, hipStream_t stream) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
-  constexpr size_t lds = (size_t)STAGES * (BM + BN) * BK * 2;
+  constexpr size_t ring = (size_t)STAGES * (BM + BN) * BK * 2, epi = (size_t)BM * (BN * 4 + 16);
+  constexpr size_t lds = ring > epi ? ring : epi;
   g.tiles_m = (g.e.M + BM - 1) / BM;
   g.tiles_n = (g.e.N + BN - 1) / BN;
   auto kern = gemm_bf16_kernel<WM, WN, STAGES, A_KS, B_KS>;
@@ -301,10 +221,14 @@ int launch_layout(GemmFast& g, hipStream_t stream) {
     const int64_t t1 = (int64_t)((g.e.M + 127) / 128) * ((g.e.N + 127) / 128);
     // measured (profiles/r01_gemm_variants_bench.txt): the 128x128 2-workgroups/CU shape wins on every shape of the
     // path (two independent workgroups per CU de-synchronise their load / MFMA phases), so auto == 1 for now.
-    const double cost2 = (double)((t2 + 255) / 256) * 2.0 / 0.9;
-    const double cost1 = (double)((t1 + 511) / 512) * 2.0;
-    variant = (g.e.M >= 256 && cost2 < cost1 * 0.8) ? 2 : 1;
+    (void)t2; (void)t1;
+    // measured (profiles/r01_gemm_variants_bench*.txt): the 256x256 ping-pong kernel wins once its grid covers
+    // >= ~60 % of the CUs; below that (GPT-2's M = 1024 GEMMs, small wgrads) two 128x128 workgroups per CU win.
+    const int64_t t3 = (int64_t)((g.e.M + 255) / 256) * ((g.e.N + 255) / 256);
+    variant = t3 >= 160 ? 3 : 1;
+    if (t3 < 256 && g.K < 4096 && !A_KS && !B_KS) variant = 1;   // short-K NT GEMM on a partial wave of 256x256 tiles
   }
+  if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream);
   if (variant == 2) return launch_fast<4, 2, 3, A_KS, B_KS>(g, stream);
   return launch_fast<2, 2, 2, A_KS, B_KS>(g, stream);
 }
@@ -312,7 +236,7 @@ int launch_layout(GemmFast& g, hipStream_t stream) {
 }  // namespace
 
 extern "C" int afft_set_gemm_variant(int v) {
-  if (v < 0 || v > 2) { afft_set_error("afft_set_gemm_variant: %d not in 0..2", v); return 1; }
+  if (v < 0 || v > 3) { afft_set_error("afft_set_gemm_variant: %d not in 0..3", v); return 1; }
   g_variant = v;
   return 0;
 }

@@ -1,0 +1,207 @@
+// 256x256x64 ping-pong bf16 MFMA GEMM (see the comment above the kernel). Split from gemm.hip to keep build times down.
+#include "gemm_tiles.h"
+
+using namespace afft_gemm_detail;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// 256x256x64 "ping-pong" kernel: 8 waves, one workgroup per CU, 128 KiB LDS.
+//
+// Why: a 128x128 tile needs 1 byte of L2->LDS fill per 64 FLOP and the per-CU LDS-fill path tops out near
+// 70 GB/s, which caps that shape around 1.1 PFLOP/s (profiles/r01_gemm_pmc_*.txt); 256x256 halves the bytes.
+// With one workgroup per CU the two waves that share a SIMD must not do the same thing at the same time, so the
+// 8 waves form two groups (waves 0-3 / 4-7, one of each per SIMD) that run the SAME phase program one barrier
+// apart: while one group issues its 16 MFMAs of a phase, the other reads the next phase's fragments from LDS and
+// issues LDS-DMA.  Per K-tile (64 deep) a wave runs 4 phases = the 4 quadrants of its 128x64 output, and its rows /
+// columns are interleaved over the two 128-row halves of the A and B tiles, so a K-tile is consumed half-tile by
+// half-tile (A0,B0 | B1 | A1 | -) and staged half-tile by half-tile, LEAD = 6 half-tiles (12 LDS-DMA instructions
+// per wave) ahead, behind a counted s_waitcnt vmcnt(8).
+//
+//   stream of half-tiles (16 KiB each): index m = 4*kt + q, q: 0 = A rows 0-127, 1 = B rows 0-127,
+//   2 = B rows 128-255, 3 = A rows 128-255; ring slot = ((kt & 1) * 4 + q).
+//   phase n = 4*kt + p:  L(n): read the fragments phase n needs, issue half-tile n + LEAD, wait until half-tile
+//   n + 2 has landed (this wave's pieces), s_barrier;  C(n): 16 MFMAs, s_barrier.
+//   slot 2n:   group 0 runs L(n),  group 1 runs C(n-1)      slot 2n+1: group 0 runs C(n),  group 1 runs L(n)
+//   RAW: half-tile m is first read in L(m - (m&3 ? 1 : 0) ...) >= two slots after every wave's wait for it;
+//   WAR: half-tile m overwrites m - 8, whose last reader (group 1) finished >= 3 slots earlier (LEAD <= 7).
+template <bool A_KS, bool B_KS>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g) {
+  constexpr int HB = 128 * BK * 2;   // half-tile bytes (16 KiB)
+  constexpr int LEAD = 6;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int gp = wave >> 2, wc = wave & 3;
+  int tm, tn;
+  tile_coords(g.tiles_m, g.tiles_n, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int M = g.e.M, N = g.e.N;
+  const int nk = g.K / BK, NH = 4 * nk;
+
+  f32x4 acc[2][2][4][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 aF[4][2], bF[2][2][2];   // A fragments of the live half; B fragments of both halves
+
+  auto issue = [&](int m, int q) {   // q = m & 3 (compile-time at every call site)
+    if (m >= NH) return;
+    const int kt = m >> 2;
+    char* dst = smem + ((kt & 1) * 4 + q) * HB;
+    if (q == 0 || q == 3) {
+      const int r0 = m0 + (q == 3 ? 128 : 0);
+      if constexpr (A_KS) stage_ks<128, 8>(g.A, g.lda, r0, kt * BK, dst, wave, lane);
+      else stage_kc<128, 8>(g.A, g.lda, r0, M, kt * BK, dst, wave, lane);
+    } else {
+      const int c0 = n0 + (q == 2 ? 128 : 0);
+      if constexpr (B_KS) stage_ks<128, 8>(g.B, g.ldb, c0, kt * BK, dst, wave, lane);
+      else stage_kc<128, 8>(g.B, g.ldb, c0, N, kt * BK, dst, wave, lane);
+    }
+  };
+  auto load_a = [&](int kt, int ih) {
+    const char* base = smem + ((kt & 1) * 4 + (ih ? 3 : 0)) * HB;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (A_KS) aF[i][s] = frag_ks<128>(base, 32 * s, gp * 4 + i, lane);
+        else aF[i][s] = frag_kc(base, gp * 64 + i * 16 + (lane & 15), s * 4 + (lane >> 4));
+      }
+  };
+  auto load_b = [&](int kt, int jh) {
+    const char* base = smem + ((kt & 1) * 4 + 1 + jh) * HB;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if constexpr (B_KS) bF[jh][j][s] = frag_ks<128>(base, 32 * s, wc * 2 + j, lane);
+        else bF[jh][j][s] = frag_kc(base, wc * 32 + j * 16 + (lane & 15), s * 4 + (lane >> 4));
+      }
+  };
+  // end of an L segment: this wave's pieces of every half-tile <= n + 2 have landed, its LDS reads have returned
+  auto wait_then_barrier = [&](int n) {
+    const int last = min(n + LEAD, NH - 1);
+    const int out = last - (n + 2);           // half-tiles allowed to stay in flight
+    // no lgkmcnt here: the LDS reads of this segment only have to be back before this wave's own MFMAs (the
+    // compiler's wait after the barrier), so their latency overlaps the barrier; the ring slot they read is not
+    // refilled until >= 3 barriers later, each of which this wave passes with lgkmcnt already drained.
+    if (out >= 4) wait_vmcnt_only<8>();
+    else if (out == 3) wait_vmcnt_only<6>();
+    else if (out == 2) wait_vmcnt_only<4>();
+    else if (out == 1) wait_vmcnt_only<2>();
+    else wait_vmcnt_only<0>();
+    __builtin_amdgcn_s_barrier();
+  };
+  auto compute = [&](auto ihc, auto jhc) {
+    constexpr int ih = decltype(ihc)::value, jh = decltype(jhc)::value;
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[ih][jh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bF[jh][j][s], aF[i][s], acc[ih][jh][i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  // prologue = "L(-1)": half-tiles 0 .. LEAD-1
+  issue(0, 0); issue(1, 1); issue(2, 2); issue(3, 3); issue(4, 0); issue(5, 1);
+  wait_then_barrier(-1);
+  if (gp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one slot behind group 0
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int n = 4 * kt;
+    // phase 0: quadrant (rows half 0, cols half 0)
+    load_a(kt, 0); load_b(kt, 0);
+    issue(n + 0 + LEAD, 2);
+    wait_then_barrier(n + 0);
+    compute(I0{}, I0{});
+    // phase 1: (0, 1)
+    load_b(kt, 1);
+    issue(n + 1 + LEAD, 3);
+    wait_then_barrier(n + 1);
+    compute(I0{}, I1{});
+    // phase 2: (1, 1)
+    load_a(kt, 1);
+    issue(n + 2 + LEAD, 0);
+    wait_then_barrier(n + 2);
+    compute(I1{}, I1{});
+    // phase 3: (1, 0)
+    issue(n + 3 + LEAD, 1);
+    wait_then_barrier(n + 3);
+    compute(I1{}, I0{});
+  }
+  if (gp == 0) __builtin_amdgcn_s_barrier();
+
+  // Epilogue through LDS (the ring is free now): two passes of 128 rows.  Accumulators are scattered into an fp32
+  // [128][256] image (row stride 1040 B = 1 KiB + 16 B, so the 16 rows a lane group writes fall in 16 different
+  // 16-byte slots), then every wave walks 16 whole rows: one conflict-free 16-byte LDS read per lane and fully
+  // coalesced global accesses (bias, residual, pre-activation, outputs) in a runtime loop -- no 32-fold unrolled
+  // epilogue, no 32-byte store segments.
+  constexpr int ESTRIDE = 1040;
+  static_for<0, 2>([&](auto ihc) {
+    constexpr int ih = decltype(ihc)::value;
+    __builtin_amdgcn_s_barrier();   // pass 0: every wave is done with the ring; pass 1: pass 0 has been read back
+    static_for<0, 16>([&](auto idx) {
+      constexpr int v = decltype(idx)::value;
+      constexpr int jh = v >> 3, i = (v >> 1) & 3, j = v & 1;
+      const int row = gp * 64 + i * 16 + (lane & 15);
+      const int col = jh * 128 + wc * 32 + j * 16 + 4 * (lane >> 4);
+      *(f32x4*)(smem + row * ESTRIDE + col * 4) = acc[ih][jh][i][j];
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int rr = 0; rr < 16; ++rr) {
+      const int row = wave * 16 + rr;
+      const f32x4 t = *(const f32x4*)(smem + row * ESTRIDE + lane * 16);
+      float o[4] = {t[0], t[1], t[2], t[3]};
+      epilogue4(g.e, m0 + ih * 128 + row, n0 + 4 * lane, o);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  });
+}
+
+template <bool A_KS, bool B_KS>
+int launch_pp(GemmFast& g, hipStream_t stream) {
+  constexpr size_t lds = 128 * 1040;          // ring: 2 K-tiles x 4 half-tiles x 16 KiB = 128 KiB; epilogue image: 130 KiB
+  g.tiles_m = (g.e.M + 255) / 256;
+  g.tiles_n = (g.e.N + 255) / 256;
+  auto kern = gemm_bf16_pp_kernel<A_KS, B_KS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      afft_set_error("afft_gemm: cannot reserve %zu bytes of LDS", lds);
+      (void)hipGetLastError();
+      return 2;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), lds, stream, g);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
+
+}  // namespace
+
+int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream) {
+  if (!a_ks && !b_ks) return launch_pp<false, false>(g, stream);
+#ifndef AFFT_PP_NT_ONLY   // development switch: build only the NT instantiation (compile time)
+  if (!a_ks && b_ks) return launch_pp<false, true>(g, stream);
+  if (a_ks && b_ks) return launch_pp<true, true>(g, stream);
+#endif
+  afft_set_error("afft_gemm: layout (A k-strided, B k-contiguous) is not built");
+  return 1;
+}

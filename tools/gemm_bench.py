@@ -41,7 +41,8 @@ if __name__ == "__main__":
               ("tn", 6144, 2048, 5120), ("tn", 8192, 2048, 5120), ("tn", 2048, 8192, 5120), ("tn", 2048, 2048, 5120),
               ("nt", 1024, 6144, 2048), ("nt", 1024, 8192, 2048), ("nt", 1024, 2048, 8192), ("tn", 8192, 2048, 1024),
               ("nt", 1088, 3840, 2048), ("nt", 8192, 8192, 8192)]
-    print(f"{'layout':6} {'M':>6} {'N':>6} {'K':>6} | {'v1 ms':>8} {'v1 TF':>7} | {'v2 ms':>8} {'v2 TF':>7}")
+    variants = [int(v) for v in os.environ.get("VARIANTS", "1,3").split(",")]
+    print(f"{'layout':6} {'M':>6} {'N':>6} {'K':>6} | " + " | ".join(f"v{v} ms    v{v} TF" for v in variants))
     for lay, M, N, K in shapes:
-        r = [bench(lay, M, N, K, v) for v in (1, 2)]
-        print(f"{lay:6} {M:6d} {N:6d} {K:6d} | {r[0][0]:8.4f} {r[0][1]:7.1f} | {r[1][0]:8.4f} {r[1][1]:7.1f}")
+        r = [bench(lay, M, N, K, v) for v in variants]
+        print(f"{lay:6} {M:6d} {N:6d} {K:6d} | " + " | ".join(f"{x[0]:8.4f} {x[1]:7.1f}" for x in r))
