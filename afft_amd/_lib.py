@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libafft_hip.so")
+LIB_PATH = os.environ.get("AFFT_LIB") or os.path.join(_HERE, "lib", "libafft_hip.so")   # AFFT_LIB: kernel-tuning builds
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_DGELU_ERF, ACT_DGELU_TANH = 0, 1, 2, 3, 4
@@ -45,6 +45,7 @@ _SIGS = {
     "afft_version": ([], C.c_int),
     "afft_gemm": ([C.POINTER(GemmDesc), vp], C.c_int),
     "afft_set_gemm_variant": ([C.c_int], C.c_int),
+    "afft_gemm_variant_for": ([C.c_int, C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
     "afft_layernorm_fwd": ([vp, i64, vp, vp, f32, i32, i32, vp, i64, i32, vp, vp, vp], C.c_int),
     "afft_layernorm_bwd_nparts": ([i32], C.c_int),
     "afft_layernorm_bwd": ([vp, i64, i32, vp, i64, vp, vp, vp, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp], C.c_int),

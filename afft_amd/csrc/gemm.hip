@@ -211,29 +211,32 @@ int launch_fast(GemmFast& g, hipStream_t stream) {
   return 0;
 }
 
+int choose_variant(int M, int N, int K, bool A_KS, bool B_KS);
+
 template <bool A_KS, bool B_KS>
 int launch_layout(GemmFast& g, hipStream_t stream) {
-  int variant = g_variant;
-  if (variant == 0) {
-    // time ~ rounds x tile work / per-CU rate.  256x128 (1 workgroup/CU, deep prefetch) sustains ~1.4x the
-    // per-CU rate of 128x128 (2 workgroups/CU) when the grid fills the chip; pick by estimated makespan.
-    const int64_t t2 = (int64_t)((g.e.M + 255) / 256) * ((g.e.N + 127) / 128);
-    const int64_t t1 = (int64_t)((g.e.M + 127) / 128) * ((g.e.N + 127) / 128);
-    // measured (profiles/r01_gemm_variants_bench.txt): the 128x128 2-workgroups/CU shape wins on every shape of the
-    // path (two independent workgroups per CU de-synchronise their load / MFMA phases), so auto == 1 for now.
-    (void)t2; (void)t1;
-    // measured (profiles/r01_gemm_variants_bench*.txt): the 256x256 ping-pong kernel wins once its grid covers
-    // >= ~60 % of the CUs; below that (GPT-2's M = 1024 GEMMs, small wgrads) two 128x128 workgroups per CU win.
-    const int64_t t3 = (int64_t)((g.e.M + 255) / 256) * ((g.e.N + 255) / 256);
-    variant = t3 >= 160 ? 3 : 1;
-    if (t3 < 256 && g.K < 4096 && !A_KS && !B_KS) variant = 1;   // short-K NT GEMM on a partial wave of 256x256 tiles
-  }
+  const int variant = choose_variant(g.e.M, g.e.N, g.K, A_KS, B_KS);
   if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream);
   if (variant == 2) return launch_fast<4, 2, 3, A_KS, B_KS>(g, stream);
   return launch_fast<2, 2, 2, A_KS, B_KS>(g, stream);
 }
 
+int choose_variant(int M, int N, int K, bool A_KS, bool B_KS) {
+  if (g_variant != 0) return g_variant;
+  // measured (profiles/r01_gemm_variants_bench2.txt): the 256x256 ping-pong kernel (1 workgroup/CU) wins once its
+  // grid covers >= ~60 % of the CUs; below that (GPT-2's M = 1024 GEMMs, small weight gradients) two independent
+  // 128x128 workgroups per CU win.  The 256x128 3-stage shape (variant 2) never wins and is kept for reference.
+  const int64_t t3 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
+  if (t3 < 160) return 1;
+  if (t3 < 256 && K < 4096 && !A_KS && !B_KS) return 1;   // short-K NT GEMM on a partial wave of 256x256 tiles
+  return 3;
+}
+
 }  // namespace
+
+extern "C" int afft_gemm_variant_for(int M, int N, int K, int a_kstrided, int b_kstrided) {
+  return choose_variant(M, N, K, a_kstrided != 0, b_kstrided != 0);
+}
 
 extern "C" int afft_set_gemm_variant(int v) {
   if (v < 0 || v > 3) { afft_set_error("afft_set_gemm_variant: %d not in 0..3", v); return 1; }

@@ -25,10 +25,29 @@ namespace {
 //   slot 2n:   group 0 runs L(n),  group 1 runs C(n-1)      slot 2n+1: group 0 runs C(n),  group 1 runs L(n)
 //   RAW: half-tile m is first read in L(m - (m&3 ? 1 : 0) ...) >= two slots after every wave's wait for it;
 //   WAR: half-tile m overwrites m - 8, whose last reader (group 1) finished >= 3 slots earlier (LEAD <= 7).
+#ifdef AFFT_PP_STAMP   // diagnostic build only: per-segment cycle sums of workgroup 0 (see tools/pp_stamp.py)
+unsigned long long* g_pp_stamp = nullptr;
+#define STAMP(var) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); } while (0)
+#else
+#define STAMP(var) do { } while (0)
+#endif
+
 template <bool A_KS, bool B_KS>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g) {
+__global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
+#ifdef AFFT_PP_STAMP
+    , unsigned long long* stamp_out
+#endif
+) {
   constexpr int HB = 128 * BK * 2;   // half-tile bytes (16 KiB)
-  constexpr int LEAD = 6;
+#ifndef AFFT_PP_LEAD
+#define AFFT_PP_LEAD 7
+#endif
+#ifndef AFFT_PP_DMA_IN_C
+#define AFFT_PP_DMA_IN_C 0
+#endif
+  constexpr int LEAD = AFFT_PP_LEAD;             // half-tiles of look-ahead of the LDS-DMA stream (<= 7)
+  constexpr bool DMA_IN_C = AFFT_PP_DMA_IN_C;    // issue the LDS-DMA after the MFMAs (C segment) instead of in L
+  constexpr int ISSUED_AT_L_END = LEAD - (DMA_IN_C ? 1 : 0);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -85,8 +104,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g) 
       }
   };
   // end of an L segment: this wave's pieces of every half-tile <= n + 2 have landed, its LDS reads have returned
+  unsigned long long sL = 0, sW = 0, sB1 = 0, sC = 0, sB2 = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+  (void)sL; (void)sW; (void)sB1; (void)sC; (void)sB2; (void)t0; (void)t1; (void)t2; (void)t3; (void)t4; (void)t5;
   auto wait_then_barrier = [&](int n) {
-    const int last = min(n + LEAD, NH - 1);
+    STAMP(t1);
+    const int last = min(n + ISSUED_AT_L_END, NH - 1);
     const int out = last - (n + 2);           // half-tiles allowed to stay in flight
     // no lgkmcnt here: the LDS reads of this segment only have to be back before this wave's own MFMAs (the
     // compiler's wait after the barrier), so their latency overlaps the barrier; the ring slot they read is not
@@ -96,9 +118,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g) 
     else if (out == 2) wait_vmcnt_only<4>();
     else if (out == 1) wait_vmcnt_only<2>();
     else wait_vmcnt_only<0>();
+    STAMP(t2);
     __builtin_amdgcn_s_barrier();
+    STAMP(t3);
+    sL += t1 - t0; sW += t2 - t1; sB1 += t3 - t2;
   };
-  auto compute = [&](auto ihc, auto jhc) {
+  auto compute = [&](auto ihc, auto jhc, int dma_m, auto dma_q) {
     constexpr int ih = decltype(ihc)::value, jh = decltype(jhc)::value;
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
@@ -111,39 +136,56 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g) 
           acc[ih][jh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bF[jh][j][s], aF[i][s], acc[ih][jh][i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DMA_IN_C) issue(dma_m, decltype(dma_q)::value);
+    STAMP(t4);
     __builtin_amdgcn_s_barrier();
+    STAMP(t5);
+    sC += t4 - t3; sB2 += t5 - t4; t0 = t5;
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
 
-  // prologue = "L(-1)": half-tiles 0 .. LEAD-1
-  issue(0, 0); issue(1, 1); issue(2, 2); issue(3, 3); issue(4, 0); issue(5, 1);
+  // prologue = "L(-1)": the half-tiles every later wait rule assumes are already issued
+  static_for<0, ISSUED_AT_L_END>([&](auto mc) { issue(decltype(mc)::value, decltype(mc)::value & 3); });
   wait_then_barrier(-1);
   if (gp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one slot behind group 0
+  STAMP(t0);
+  sL = sW = sB1 = sC = sB2 = 0;
+  unsigned long long tstart = t0; (void)tstart;
 
+  using Q0 = std::integral_constant<int, (0 + LEAD) & 3>;
+  using Q1 = std::integral_constant<int, (1 + LEAD) & 3>;
+  using Q2 = std::integral_constant<int, (2 + LEAD) & 3>;
+  using Q3 = std::integral_constant<int, (3 + LEAD) & 3>;
   for (int kt = 0; kt < nk; ++kt) {
     const int n = 4 * kt;
     // phase 0: quadrant (rows half 0, cols half 0)
     load_a(kt, 0); load_b(kt, 0);
-    issue(n + 0 + LEAD, 2);
+    if constexpr (!DMA_IN_C) issue(n + 0 + LEAD, Q0::value);
     wait_then_barrier(n + 0);
-    compute(I0{}, I0{});
+    compute(I0{}, I0{}, n + 0 + LEAD, Q0{});
     // phase 1: (0, 1)
     load_b(kt, 1);
-    issue(n + 1 + LEAD, 3);
+    if constexpr (!DMA_IN_C) issue(n + 1 + LEAD, Q1::value);
     wait_then_barrier(n + 1);
-    compute(I0{}, I1{});
+    compute(I0{}, I1{}, n + 1 + LEAD, Q1{});
     // phase 2: (1, 1)
     load_a(kt, 1);
-    issue(n + 2 + LEAD, 0);
+    if constexpr (!DMA_IN_C) issue(n + 2 + LEAD, Q2::value);
     wait_then_barrier(n + 2);
-    compute(I1{}, I1{});
+    compute(I1{}, I1{}, n + 2 + LEAD, Q2{});
     // phase 3: (1, 0)
-    issue(n + 3 + LEAD, 1);
+    if constexpr (!DMA_IN_C) issue(n + 3 + LEAD, Q3::value);
     wait_then_barrier(n + 3);
-    compute(I1{}, I0{});
+    compute(I1{}, I0{}, n + 3 + LEAD, Q3{});
   }
   if (gp == 0) __builtin_amdgcn_s_barrier();
+#ifdef AFFT_PP_STAMP
+  if (stamp_out && blockIdx.x == 0 && lane == 0) {
+    unsigned long long* o = stamp_out + wave * 8;
+    o[0] = sL; o[1] = sW; o[2] = sB1; o[3] = sC; o[4] = sB2; o[5] = t0 - tstart; o[6] = (unsigned long long)nk;
+  }
+#endif
 
   // Epilogue through LDS (the ring is free now): two passes of 128 rows.  Accumulators are scattered into an fp32
   // [128][256] image (row stride 1040 B = 1 KiB + 16 B, so the 16 rows a lane group writes fall in 16 different
@@ -188,13 +230,21 @@ int launch_pp(GemmFast& g, hipStream_t stream) {
     }
     attr_set = true;
   }
+#ifdef AFFT_PP_STAMP
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), lds, stream, g, g_pp_stamp);
+#else
   hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), lds, stream, g);
+#endif
   AFFT_LAUNCH_CHECK();
   return 0;
 }
 
 
 }  // namespace
+
+#ifdef AFFT_PP_STAMP
+extern "C" void afft_debug_pp_stamp(void* p) { g_pp_stamp = (unsigned long long*)p; }
+#endif
 
 int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream) {
   if (!a_ks && !b_ks) return launch_pp<false, false>(g, stream);

@@ -113,10 +113,58 @@ def _bgrad(dy: Tensor, bias: Optional[Tensor]) -> Optional[Tensor]:
     return g
 
 
+class _Side:
+    """`with _Side(dev):` enqueues the enclosed kernels on the device's side stream, ordered after everything
+    already on the current stream.  Weight-gradient GEMMs (and bias column sums) are independent of the
+    data-gradient chain of the same backward, so running them there lets their workgroups fill the CUs that a
+    partial wave of the dgrad kernel leaves idle (256x256 tiles run one workgroup per CU).  join_side() at the end
+    of the backward orders the current stream after them again (buffers are released only after that)."""
+
+    def __init__(self, device):
+        self.on = rt.overlap_wgrad() and device.type == "cuda"
+        self.device = device
+
+    def __enter__(self):
+        if self.on:
+            ev = torch.cuda.Event()
+            ev.record()
+            st = rt.aux_stream(self.device)
+            st.wait_event(ev)
+            self.ctx = torch.cuda.stream(st)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def join_side(device):
+    if rt.overlap_wgrad() and device.type == "cuda":
+        ev = torch.cuda.Event()
+        ev.record(rt.aux_stream(device))
+        torch.cuda.current_stream().wait_event(ev)
+
+
+_PENDING_READY: list = []
+
+
 def _ready(p: Tensor):
+    """The gradient of p has been enqueued.  Notification is deferred to the end of the running backward
+    (flush_ready) so that a consumer -- bucket all-reduce, per-bucket SGD on a side stream -- is ordered after
+    every kernel of this backward that still READS the parameter (e.g. the dgrad GEMM reads the weight image the
+    optimizer is about to overwrite)."""
+    if rt.SINK.on_grad_ready is not None:
+        _PENDING_READY.append(p)
+
+
+def flush_ready():
     cb = rt.SINK.on_grad_ready
     if cb is not None:
-        cb(p)
+        for p in _PENDING_READY:
+            cb(p)
+    _PENDING_READY.clear()
 
 
 def _ln_bwd(dy: Tensor, x: Tensor, w: Optional[Tensor], b: Optional[Tensor], mean, rstd, dx_in: Optional[Tensor],
@@ -207,15 +255,17 @@ class AttnSublayer(torch.autograd.Function):
         dy = dy.contiguous()
         od = _out_drop(drop)
         dya = to_act(dy, od)
-        g_wp = _wgrad(dya, ao, w_proj, conv1d)
-        g_bp = _bgrad(dy if od is None else dya.live, b_proj)
+        with _Side(dev):
+            g_wp = _wgrad(dya, ao, w_proj, conv1d)
+            g_bp = _bgrad(dy if od is None else dya.live, b_proj)
         dao = Act(R, d, dev)
         _lin_dgrad(dya, w_proj, conv1d, dao.live)
         dqkv = Act(R, 3 * d, dev)
         ops.attention_bwd(dao.live, qkv.cols(0, d), qkv.cols(d, 2 * d), qkv.cols(2 * d, 3 * d), probs, nseq, L, H, hd,
                           scale, dqkv.cols(0, d), dqkv.cols(d, 2 * d), dqkv.cols(2 * d, 3 * d), *(_attn_drop(drop)))
-        g_wq = _wgrad(dqkv, xn, w_qkv, conv1d)
-        g_bq = _bgrad(dqkv.live, b_qkv)
+        with _Side(dev):
+            g_wq = _wgrad(dqkv, xn, w_qkv, conv1d)
+            g_bq = _bgrad(dqkv.live, b_qkv)
         if pre_ln:
             dxn = Act(R, d, dev)
             _lin_dgrad(dqkv, w_qkv, conv1d, dxn.live)
@@ -224,7 +274,9 @@ class AttnSublayer(torch.autograd.Function):
             dx = torch.empty(R, d, dtype=torch.float32, device=dev)
             _lin_dgrad(dqkv, w_qkv, conv1d, dx)
             g_lw = g_lb = None
+        join_side(dev)
         ctx.acts = None
+        flush_ready()
         return dx, g_lw, g_lb, g_wq, g_bq, g_wp, g_bp, None, None, None, None, None, None, None, None
 
 
@@ -263,12 +315,14 @@ class MLPSublayer(torch.autograd.Function):
         dy = dy.contiguous()
         od = _out_drop(drop)
         dya = to_act(dy, od)
-        g_w2 = _wgrad(dya, h, w2, conv1d)
-        g_b2 = _bgrad(dy if od is None else dya.live, b2)
+        with _Side(dev):
+            g_w2 = _wgrad(dya, h, w2, conv1d)
+            g_b2 = _bgrad(dy if od is None else dya.live, b2)
         du = Act(R, hidden, dev)
         _lin_dgrad(dya, w2, conv1d, du.live, act=_GELU[gelu][1], aux=u.live)
-        g_w1 = _wgrad(du, xn, w1, conv1d)
-        g_b1 = _bgrad(du.live, b1)
+        with _Side(dev):
+            g_w1 = _wgrad(du, xn, w1, conv1d)
+            g_b1 = _bgrad(du.live, b1)
         if pre_ln:
             dxn = Act(R, d, dev)
             _lin_dgrad(du, w1, conv1d, dxn.live)
@@ -277,7 +331,9 @@ class MLPSublayer(torch.autograd.Function):
             dx = torch.empty(R, d, dtype=torch.float32, device=dev)
             _lin_dgrad(du, w1, conv1d, dx)
             g_lw = g_lb = None
+        join_side(dev)
         ctx.acts = None
+        flush_ready()
         return dx, g_lw, g_lb, g_w1, g_b1, g_w2, g_b2, None, None, None, None, None
 
 
@@ -327,16 +383,18 @@ class CrossAttnSublayer(torch.autograd.Function):
         dy = dy.contiguous()
         od = _out_drop(drop)
         dya = to_act(dy, od)
-        g_wp = _wgrad(dya, ao, w_proj, False)
-        g_bp = _bgrad(dy if od is None else dya.live, b_proj)
+        with _Side(dev):
+            g_wp = _wgrad(dya, ao, w_proj, False)
+            g_bp = _bgrad(dy if od is None else dya.live, b_proj)
         dao = Act(R, d, dev)
         _lin_dgrad(dya, w_proj, False, dao.live)
         dq, dk, dv = Act(R, d, dev), Act(R, d, dev), Act(R, d, dev)
         ops.attention_bwd(dao.live, q.live, k.live, v.live, probs, nseq, L, H, hd, scale, dq.live, dk.live, dv.live,
                           *(_attn_drop(drop)))
-        g_q = _wgrad(dq, xq, w_q, False)
-        g_k = _wgrad(dk, mkv, w_k, False)
-        g_v = _wgrad(dv, mkv, w_v, False)
+        with _Side(dev):
+            g_q = _wgrad(dq, xq, w_q, False)
+            g_k = _wgrad(dk, mkv, w_k, False)
+            g_v = _wgrad(dv, mkv, w_v, False)
         dmkv = torch.empty(R, d, dtype=torch.float32, device=dev)
         _lin_dgrad(dk, w_k, False, dmkv)
         _lin_dgrad(dv, w_v, False, dmkv, accumulate=True)
@@ -349,7 +407,9 @@ class CrossAttnSublayer(torch.autograd.Function):
             dx = torch.empty(R, d, dtype=torch.float32, device=dev)
             _lin_dgrad(dq, w_q, False, dx)
             dmem, g_qw, g_qb, g_kw, g_kb = dmkv, None, None, None, None
+        join_side(dev)
         ctx.acts = None
+        flush_ready()
         return dx, dmem, g_qw, g_qb, g_kw, g_kb, g_q, g_k, g_v, g_wp, g_bp, None, None, None, None, None, None, None
 
 
@@ -376,15 +436,18 @@ class Linear(torch.autograd.Function):
         W, b = ctx.saved_tensors
         xa = ctx.xa
         dya = to_act(dy)
-        g_w = _wgrad(dya, xa, W, False)
-        g_b = _bgrad(dya.live if rt.precision() == "fp32" else dy if dy.stride(1) == 1 else dy.contiguous(), b)
+        with _Side(dy.device):
+            g_w = _wgrad(dya, xa, W, False)
+            g_b = _bgrad(dya.live if rt.precision() == "fp32" else dy if dy.stride(1) == 1 else dy.contiguous(), b)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(xa.rows, W.shape[1], dtype=torch.float32, device=dy.device)
             _lin_dgrad(dya, W, False, dx)
             if ctx.in_drop is not None:
                 ops.cast(dx, dx, drop=ctx.in_drop)   # replay the input mask on the gradient (in place)
+        join_side(dy.device)
         ctx.xa = None
+        flush_ready()
         return dx, g_w, g_b, None
 
 
@@ -418,6 +481,7 @@ class LayerNormRows(torch.autograd.Function):
             dX = torch.zeros_like(X)
             _, gw, gb = _ln_bwd(dy, X.view(rows, s * d)[:, :d], w, b, mean, rstd, dx_in=None,
                                 dx_out=dX.view(rows, s * d)[:, :d])
+        flush_ready()
         return dX, gw, gb, None, None
 
 
@@ -468,6 +532,7 @@ class AssembleTokens(torch.autograd.Function):
             if sink:
                 _ready(mod_embed)
         gf = [dX3[:, (i + 1) * d:(i + 2) * d] if n else None for i, n in enumerate(needs)]
+        flush_ready()
         return (g_tok, g_emb, None, None, *gf)
 
 
@@ -498,6 +563,7 @@ class AddRowTable(torch.autograd.Function):
             return dy, None, None, None
         g = torch.zeros_like(table)
         ops.reduce_rows_periodic(dy, period, g[offset:offset + period])
+        flush_ready()
         return dy, g, None, None
 
 
@@ -517,6 +583,7 @@ class ElementDropout(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(dy)
         ops.cast(dy, dx, drop=ctx.desc)
+        flush_ready()
         return dx, None
 
 
@@ -539,6 +606,7 @@ class SoftmaxCE(torch.autograd.Function):
         rows, C = lg.shape
         d = torch.empty(rows, C, dtype=torch.float32, device=lg.device)
         ops.softmax_ce(lg, C, labels=labels, soft=soft, keep=keep, dlogits=d, row_g=g_rows.contiguous())
+        flush_ready()
         return d, None, None, None
 
 
@@ -560,4 +628,5 @@ class MSE(torch.autograd.Function):
         da = torch.zeros(rows, d, dtype=torch.float32, device=a.device)
         db = torch.zeros(rows, d, dtype=torch.float32, device=a.device)
         ops.mse(a, b, 1.0 / (rows * d), None, da, db, g_dev=g.contiguous())
+        flush_ready()
         return da, db

@@ -5,16 +5,17 @@ GPU, one exchange per step -- the gradient sum -- carried by RCCL over xGMI (tor
 Replaces the reference's torch DDP wrapper + per-parameter SGD groups (train.py:189-225,352,364-368,251-265):
 
   * parameters, gradients and momentum live in three flat fp32 buffers (views handed back to the modules), so
-    the optimizer is ONE fused Nesterov-SGD kernel launch and a bucket is a contiguous slice;
+    the optimizer is a fused Nesterov-SGD kernel over contiguous slices and a bucket is a contiguous slice;
   * weight-gradient GEMMs write straight into the flat gradient buffer (afft_amd.runtime.GradSink); when the last
-    gradient of a bucket has been produced the bucket's all-reduce is enqueued on a side stream.  xGMI is
-    point-to-point (7 links/GPU), so buckets are large (>= 64 MB) and few, and the payload can be sent as bf16
-    (``comm_dtype``) to halve the per-link bytes;
+    gradient of a bucket has been produced the bucket is handed to a SIDE STREAM: (world > 1) its all-reduce --
+    xGMI is point-to-point (7 links/GPU), so buckets are large (>= 128 MB) and few, and the payload can be sent
+    as bf16 (``comm_dtype``) to halve the per-link bytes -- followed immediately by the SGD update of exactly that
+    slice (HBM-bound, it overlaps the MFMA-bound backward GEMMs of the earlier layers) which also rewrites the bf16
+    weight images of the slice;
   * nothing in the data path needs a collective besides that sum (clips are independent).
 """
 from __future__ import annotations
 
-import os
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -67,7 +68,8 @@ class FlatParams:
 
 
 class GradReducer:
-    """Bucketed, backward-overlapped gradient all-reduce over the flat gradient buffer."""
+    """Bucketed, backward-overlapped gradient all-reduce over the flat gradient buffer.  `on_bucket` (optional) is
+    called on the side stream right after a bucket's gradient is final (reduced): the per-bucket optimizer hook."""
 
     def __init__(self, flat: FlatParams, group=None, bucket_elems: int = 32 * 1024 * 1024, comm_dtype: str = "fp32"):
         self.flat = flat
@@ -92,9 +94,10 @@ class GradReducer:
         self._launched = [False] * len(self.buckets)
         self._handles: List = []
         self._use_cuda = flat.flat_g.is_cuda
-        self.comm_stream = torch.cuda.Stream() if (self._use_cuda and self.world > 1) else None
+        self.side_stream = torch.cuda.Stream() if self._use_cuda else None
         self.flat_g16 = (torch.empty(flat.total, dtype=torch.bfloat16, device=flat.flat_g.device)
                          if (comm_dtype == "bf16" and self.world > 1) else None)
+        self.on_bucket: Optional[Callable[[int, int, Tensor, float], None]] = None
 
     # ---- step protocol
     def begin_step(self):
@@ -102,7 +105,8 @@ class GradReducer:
         self._launched = [False] * len(self.buckets)
         self._handles = []
         rt.SINK.begin_step()
-        rt.SINK.on_grad_ready = self._on_ready if self.world > 1 else None
+        early = self.world > 1 or self.on_bucket is not None
+        rt.SINK.on_grad_ready = self._on_ready if early else None
 
     def _on_ready(self, p: Tensor):
         i = self._pidx.get(id(p))
@@ -113,40 +117,47 @@ class GradReducer:
         if self.expected is not None and not self._launched[b] and self._count[b] == self.expected[b]:
             self._launch(b)
 
+    def _grad_slice(self, s: int, e: int):
+        if self.flat_g16 is not None:
+            return self.flat_g16[s:e]
+        return self.flat.flat_g[s:e]
+
     def _launch(self, b: int):
         self._launched[b] = True
         s, e = self.buckets[b]
-        if self._use_cuda:
-            ev = torch.cuda.Event()
-            ev.record()
-            self.comm_stream.wait_event(ev)
-            with torch.cuda.stream(self.comm_stream):
+        if not self._use_cuda:
+            if self.world > 1:
+                self._handles.append(dist.all_reduce(self.flat.flat_g[s:e], group=self.group, async_op=True))
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        self.side_stream.wait_event(ev)
+        with torch.cuda.stream(self.side_stream):
+            if self.world > 1:
                 if self.flat_g16 is not None:
                     n = e - s
                     ops.cast(self.flat.flat_g[s:e].view(n // 64, 64), self.flat_g16[s:e].view(n // 64, 64))
-                    h = dist.all_reduce(self.flat_g16[s:e], group=self.group, async_op=True)
-                else:
-                    h = dist.all_reduce(self.flat.flat_g[s:e], group=self.group, async_op=True)
-        else:
-            h = dist.all_reduce(self.flat.flat_g[s:e], group=self.group, async_op=True)
-        self._handles.append(h)
+                # RCCL enqueues behind the work already on this stream; later work on this stream follows it
+                dist.all_reduce(self._grad_slice(s, e), group=self.group)
+            if self.on_bucket is not None:
+                self.on_bucket(s, e, self._grad_slice(s, e), 1.0 / self.world)
 
     def finish_step(self):
-        """Call after backward: zero untouched grads, launch whatever is still pending, wait for all buckets."""
+        """Call after backward: zero untouched grads, hand over whatever is still pending, join the side stream."""
         rt.SINK.on_grad_ready = None
         rt.SINK.finish_step(self.flat.params)
-        if self.world <= 1:
+        if self.world <= 1 and self.on_bucket is None:
             return
         if self.expected is None:
             self.expected = list(self._count)
-        # fixed order on every rank: buckets are launched last-to-first (the order backward completes them)
+        # fixed order on every rank: buckets are handed over last-to-first (the order backward completes them)
         for b in reversed(range(len(self.buckets))):
             if not self._launched[b]:
                 self._launch(b)
         for h in self._handles:
             h.wait()
         if self._use_cuda:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            torch.cuda.current_stream().wait_stream(self.side_stream)
 
     def grad_for_optimizer(self):
         """(flat gradient tensor, scale): summed over ranks; the optimizer applies 1/world."""
@@ -157,26 +168,37 @@ class GradReducer:
 
 class FusedSGD:
     """Nesterov-momentum SGD over the flat buffers (conf/opt/optimizer/sgd.yaml + expts/01: lr 1e-3,
-    momentum 0.9, nesterov, wd 1e-6) -- one kernel launch for all 151 parameter tensors."""
+    momentum 0.9, nesterov, wd 1e-6): one kernel launch per contiguous slice instead of 151 parameter groups;
+    the same kernel writes the bf16 weight images of the slice."""
 
     def __init__(self, flat: FlatParams, lr: float = 1e-3, momentum: float = 0.9, weight_decay: float = 1e-6):
         self.flat, self.lr, self.momentum, self.wd = flat, lr, momentum, weight_decay
         self.buf = torch.zeros_like(flat.flat_p)
         self.steps = 0
 
-    def step(self, grad: Optional[Tensor] = None, gscale: float = 1.0):
-        g = self.flat.flat_g if grad is None else grad
-        ops.sgd_nesterov(self.flat.flat_p, g, self.buf, self.lr, self.momentum, self.wd, gscale, self.steps == 0,
-                         p_bf16=self.flat.flat_p16)
+    def step_range(self, s: int, e: int, grad: Tensor, gscale: float):
+        p16 = self.flat.flat_p16[s:e] if self.flat.flat_p16 is not None else None
+        ops.sgd_nesterov(self.flat.flat_p[s:e], grad, self.buf[s:e], self.lr, self.momentum, self.wd, gscale,
+                         self.steps == 0, p_bf16=p16)
+
+    def end_step(self):
         self.steps += 1
         rt.invalidate_weight_images()   # padded cast images (odd shapes) are re-cast on next use
 
+    def step(self, grad: Optional[Tensor] = None, gscale: float = 1.0):
+        g = self.flat.flat_g if grad is None else grad
+        self.step_range(0, self.flat.total, g, gscale)
+        self.end_step()
+
 
 class Trainer:
-    """fwd + loss + bwd (+ overlapped gradient all-reduce) + fused SGD for a BaseModel."""
+    """fwd + loss + bwd (+ overlapped gradient all-reduce) + fused SGD for a BaseModel.  With `overlap_optimizer`
+    the update of a bucket runs on the side stream as soon as that bucket's gradient is final, under the
+    backward GEMMs of the layers below it."""
 
     def __init__(self, model, loss_wts: Dict[str, float], lr=1e-3, momentum=0.9, weight_decay=1e-6,
-                 comm_dtype: str = "fp32", bucket_elems: int = 32 * 1024 * 1024, group=None):
+                 comm_dtype: str = "fp32", bucket_elems: int = 32 * 1024 * 1024, group=None,
+                 overlap_optimizer: bool = True):
         from .common.runner import BasicLossAccuracy, Runner
         self.model = model
         self.flat = FlatParams(model)
@@ -185,8 +207,10 @@ class Trainer:
         self.loss_fn = BasicLossAccuracy(compute_metrics=False)
         self._reduce = Runner._reduce_loss
         self.loss_wts = loss_wts
+        self.overlap_optimizer = overlap_optimizer and self.flat.flat_p.is_cuda
 
-    def forward_backward(self, feats: Dict[str, Tensor], target, target_subclips):
+    def forward_backward(self, feats: Dict[str, Tensor], target, target_subclips, optimize_in_backward: bool = False):
+        self.reducer.on_bucket = self.opt.step_range if optimize_in_backward else None
         self.reducer.begin_step()
         outputs, out_t = self.model(feats, mixup_fn=None, target=target, target_subclips=target_subclips,
                                     target_subclips_ignore_index=None)
@@ -194,11 +218,14 @@ class Trainer:
         loss, parts = self._reduce(losses, self.loss_wts, sync=False)
         loss.backward()
         self.reducer.finish_step()
+        if optimize_in_backward:
+            self.opt.end_step()
         return loss.detach(), parts
 
     def step(self, feats, target, target_subclips, optimize: bool = True):
-        loss, parts = self.forward_backward(feats, target, target_subclips)
-        if optimize:
+        fused = optimize and self.overlap_optimizer
+        loss, parts = self.forward_backward(feats, target, target_subclips, optimize_in_backward=fused)
+        if optimize and not fused:
             g, scale = self.reducer.grad_for_optimizer()
             self.opt.step(g, scale)
         return loss, parts

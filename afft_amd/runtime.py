@@ -146,6 +146,29 @@ class GradSink:
 SINK = GradSink()
 
 
+_AUX_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+_OVERLAP_WGRAD = os.environ.get("AFFT_OVERLAP_WGRAD", "1") != "0"
+
+
+def aux_stream(device) -> "torch.cuda.Stream":
+    """Per-device side stream on which weight-gradient GEMMs run beside the data-gradient chain."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _AUX_STREAMS.get(idx)
+    if st is None:
+        st = torch.cuda.Stream(device=idx)
+        _AUX_STREAMS[idx] = st
+    return st
+
+
+def overlap_wgrad() -> bool:
+    return _OVERLAP_WGRAD
+
+
+def set_overlap_wgrad(on: bool):
+    global _OVERLAP_WGRAD
+    _OVERLAP_WGRAD = bool(on)
+
+
 def empty(*shape, dtype=torch.float32, device=None) -> Tensor:
     return torch.empty(*shape, dtype=dtype, device=device)
 

@@ -77,7 +77,7 @@ class GemmTimer:
         self.records = []
 
     def __enter__(self):
-        from afft_amd import ops
+        from afft_amd import _lib, ops
         self.ops = ops
         self.orig = ops.gemm
         timer = self
@@ -87,9 +87,14 @@ class GemmTimer:
             M, K = (a.shape[1], a.shape[0]) if a_t else (a.shape[0], a.shape[1])
             N = b.shape[0] if b_t else b.shape[1]
             fast = a.dtype == torch.bfloat16 and K % 64 == 0
-            kind = "tn" if (a_t and not b_t) else ("nt" if (not a_t and b_t) else "other")
-            if not fast:
-                kind = "f32path"
+            a_ks, b_ks = bool(a_t), not bool(b_t)
+            if not fast or (a_ks and not b_ks):
+                kind = "gemm_f32_kernel"
+            else:
+                var = _lib.lib().afft_gemm_variant_for(M, N, K, int(a_ks), int(b_ks))
+                lay = "%s, %s" % ("true" if a_ks else "false", "true" if b_ks else "false")
+                kind = ("gemm_bf16_pp_kernel<%s>" % lay) if var == 3 else \
+                    ("gemm_bf16_kernel<%s, %s>" % ("2, 2, 2" if var == 1 else "4, 2, 3", lay))
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             r = timer.orig(a, b, out, **kw)
@@ -235,14 +240,15 @@ def main():
             with GemmTimer() as gt:
                 trainer.step(feats, tgt, sub, optimize=False)
             summ = gt.summary()
-            dom = "nt" if "nt" in summ else max(summ, key=lambda k: summ[k]["ms"])
+            dom = max(summ, key=lambda k: summ[k]["ms"])   # dominant kernel symbol by total time
             d = summ[dom]
             avg_ms = d["ms"] / d["launches"]
             avg_fl = d["flops"] / d["launches"]
             ach = avg_fl / (avg_ms * 1e-3) / 1e12
             dtype_peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3
             result["roofline"] = {
-                "kernel": "gemm_bf16_kernel<NT> (forward + dgrad GEMMs, v_mfma_f32_16x16x32_bf16)" if dom == "nt" else dom,
+                "kernel": dom + " (bf16 MFMA GEMM, v_mfma_f32_16x16x32_bf16; <A k-strided, B k-strided>: "
+                          "false,false = NT forward/dgrad)",
                 "bound": "mfma", "achieved": round(ach, 1), "peak": dtype_peak, "unit": "TFLOP/s",
                 "frac": round(ach / dtype_peak, 4), "traffic": None,
                 "launches_per_step": d["launches"], "avg_launch_ms": round(avg_ms, 4),

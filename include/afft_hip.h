@@ -72,6 +72,9 @@ typedef struct {
 int afft_gemm(const afft_gemm_t* g, void* stream);
 /* Tuning / test hook: force the bf16 tile shape (0 = auto, 1 = 128x128x64 2-stage, 2 = 256x128x64 3-stage). */
 int afft_set_gemm_variant(int variant);
+/* Which bf16 tile shape afft_gemm picks for a fast-path problem (1 / 2 / 3 as above); used by bench.py to attribute
+ * launches to kernel symbols. */
+int afft_gemm_variant_for(int M, int N, int K, int a_kstrided, int b_kstrided);
 
 /* ------------------------------------------------------------------ LayerNorm
  * nn.LayerNorm(eps) fwd/bwd: models/fusion.py:281,362 ; transformerblock.py:122,127,150-152 ;
