@@ -45,6 +45,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
 #ifndef AFFT_PP_DMA_IN_C
 #define AFFT_PP_DMA_IN_C 0
 #endif
+#ifndef AFFT_PP_DMA_FIRST
+#define AFFT_PP_DMA_FIRST 1
+#endif
   constexpr int LEAD = AFFT_PP_LEAD;             // half-tiles of look-ahead of the LDS-DMA stream (<= 7)
   constexpr bool DMA_IN_C = AFFT_PP_DMA_IN_C;    // issue the LDS-DMA after the MFMAs (C segment) instead of in L
   constexpr int ISSUED_AT_L_END = LEAD - (DMA_IN_C ? 1 : 0);
@@ -160,18 +163,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
   for (int kt = 0; kt < nk; ++kt) {
     const int n = 4 * kt;
     // phase 0: quadrant (rows half 0, cols half 0)
+    if constexpr (!DMA_IN_C && AFFT_PP_DMA_FIRST) issue(n + 0 + LEAD, Q0::value);
     load_a(kt, 0); load_b(kt, 0);
-    if constexpr (!DMA_IN_C) issue(n + 0 + LEAD, Q0::value);
+    if constexpr (!DMA_IN_C && !AFFT_PP_DMA_FIRST) issue(n + 0 + LEAD, Q0::value);
     wait_then_barrier(n + 0);
     compute(I0{}, I0{}, n + 0 + LEAD, Q0{});
     // phase 1: (0, 1)
+    if constexpr (!DMA_IN_C && AFFT_PP_DMA_FIRST) issue(n + 1 + LEAD, Q1::value);
     load_b(kt, 1);
-    if constexpr (!DMA_IN_C) issue(n + 1 + LEAD, Q1::value);
+    if constexpr (!DMA_IN_C && !AFFT_PP_DMA_FIRST) issue(n + 1 + LEAD, Q1::value);
     wait_then_barrier(n + 1);
     compute(I0{}, I1{}, n + 1 + LEAD, Q1{});
     // phase 2: (1, 1)
+    if constexpr (!DMA_IN_C && AFFT_PP_DMA_FIRST) issue(n + 2 + LEAD, Q2::value);
     load_a(kt, 1);
-    if constexpr (!DMA_IN_C) issue(n + 2 + LEAD, Q2::value);
+    if constexpr (!DMA_IN_C && !AFFT_PP_DMA_FIRST) issue(n + 2 + LEAD, Q2::value);
     wait_then_barrier(n + 2);
     compute(I1{}, I1{}, n + 2 + LEAD, Q2{});
     // phase 3: (1, 0)
