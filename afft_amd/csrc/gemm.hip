@@ -49,13 +49,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf1
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  const int nk = g.K / BK / g.splitk;          // K-steps of this slice
+  const int kbase = blockIdx.y * nk * BK;      // split-K: slice z = blockIdx.y
   auto stage = [&](int kt) {
     char* a = smem + (kt % STAGES) * STAGE_BYTES;
     char* b = a + A_BYTES;
-    if constexpr (A_KS) stage_ks<BM, NW>(g.A, g.lda, m0, kt * BK, a, wave, lane);
-    else stage_kc<BM, NW>(g.A, g.lda, m0, M, kt * BK, a, wave, lane);
-    if constexpr (B_KS) stage_ks<BN, NW>(g.B, g.ldb, n0, kt * BK, b, wave, lane);
-    else stage_kc<BN, NW>(g.B, g.ldb, n0, N, kt * BK, b, wave, lane);
+    if constexpr (A_KS) stage_ks<BM, NW>(g.A, g.lda, m0, kbase + kt * BK, a, wave, lane);
+    else stage_kc<BM, NW>(g.A, g.lda, m0, M, kbase + kt * BK, a, wave, lane);
+    if constexpr (B_KS) stage_ks<BN, NW>(g.B, g.ldb, n0, kbase + kt * BK, b, wave, lane);
+    else stage_kc<BN, NW>(g.B, g.ldb, n0, N, kbase + kt * BK, b, wave, lane);
   };
   // wait until all but the `ahead` most recently issued tiles of this wave have landed, then rendezvous
   auto wait_tiles_then_barrier = [&](int ahead) {
@@ -65,7 +67,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf1
     __builtin_amdgcn_s_barrier();
   };
 
-  const int nk = g.K / BK;
   constexpr int D = STAGES - 1;  // prefetch distance in K-steps
 #pragma unroll
   for (int t = 0; t < D; ++t)
@@ -123,7 +124,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf1
     const int c4 = lane % LPR;
     const f32x4 t = *(const f32x4*)(smem + row * ESTRIDE + c4 * 16);
     float o[4] = {t[0], t[1], t[2], t[3]};
-    epilogue4(g.e, m0 + row, n0 + 4 * c4, o);
+    if (g.splitk > 1 && blockIdx.y != 0) {   // bias and residual are added once, by slice 0
+      EpiParams le = g.e;
+      le.bias = nullptr; le.residual = nullptr;
+      epilogue4(le, m0 + row, n0 + 4 * c4, o);
+    } else {
+      epilogue4(g.e, m0 + row, n0 + 4 * c4, o);
+    }
   }
 }
 
@@ -187,6 +194,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32 g) {
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+int g_splitk_enabled = 0;   // measured slower than the plain launch on every small-grid shape (profiles/r01_gemm_variants_bench2.txt)
 int g_variant = 0;  // 0 auto, 1 = 128x128 tile, 2 = 256x128 tile, 3 = 256x256 ping-pong (tuning / tests)
 
 template <int WM, int WN, int STAGES, bool A_KS, bool B_KS>
@@ -206,7 +214,7 @@ int launch_fast(GemmFast& g, hipStream_t stream) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(64 * WM * WN), lds, stream, g);
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.splitk), dim3(64 * WM * WN), lds, stream, g);
   AFFT_LAUNCH_CHECK();
   return 0;
 }
@@ -216,7 +224,26 @@ int choose_variant(int M, int N, int K, bool A_KS, bool B_KS);
 template <bool A_KS, bool B_KS>
 int launch_layout(GemmFast& g, hipStream_t stream) {
   const int variant = choose_variant(g.e.M, g.e.N, g.K, A_KS, B_KS);
+  g.splitk = 1;
+  g.e.atomic = 0;
   if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream);
+  if (variant == 1 && g_splitk_enabled) {
+    // small grids: <= 128 tiles of 128x128 leave half the CUs idle and one workgroup per CU; cut K in 2 (4 for
+    // K >= 8192) and let the slices add fp32 partials with atomics into a zeroed output.  Needs a linear epilogue.
+    const int64_t t1 = (int64_t)((g.e.M + 127) / 128) * ((g.e.N + 127) / 128);
+    const EpiParams& e = g.e;
+    const bool linear = e.act == AFFT_ACT_NONE && !e.pre && !e.out2 && e.out_dtype == AFFT_F32 && !e.accumulate;
+    int s = (t1 <= 128 && g.K >= 2048) ? (g.K >= 8192 ? 4 : 2) : 1;
+    if (s > 1 && linear && (g.K / BK) % s == 0) {
+      if (hipMemset2DAsync(e.out, (size_t)e.ldo * 4, 0, (size_t)e.N * 4, (size_t)e.M, stream) != hipSuccess) {
+        afft_set_error("afft_gemm: split-K memset failed");
+        (void)hipGetLastError();
+        return 2;
+      }
+      g.splitk = s;
+      g.e.atomic = 1;
+    }
+  }
   if (variant == 2) return launch_fast<4, 2, 3, A_KS, B_KS>(g, stream);
   return launch_fast<2, 2, 2, A_KS, B_KS>(g, stream);
 }
@@ -237,6 +264,8 @@ int choose_variant(int M, int N, int K, bool A_KS, bool B_KS) {
 extern "C" int afft_gemm_variant_for(int M, int N, int K, int a_kstrided, int b_kstrided) {
   return choose_variant(M, N, K, a_kstrided != 0, b_kstrided != 0);
 }
+
+extern "C" int afft_set_gemm_splitk(int on) { g_splitk_enabled = on ? 1 : 0; return 0; }
 
 extern "C" int afft_set_gemm_variant(int v) {
   if (v < 0 || v > 3) { afft_set_error("afft_set_gemm_variant: %d not in 0..3", v); return 1; }
@@ -262,6 +291,7 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
   e.accumulate = d->accumulate;
   e.out = d->out; e.ldo = d->ldo; e.out_dtype = d->out_dtype;
   e.out2 = d->out2; e.ldo2 = d->ldo2; e.out2_dtype = d->out2_dtype;
+  e.atomic = 0;
   AFFT_CHECK(d->drop.p >= 0.f && d->drop.p < 1.f && d->drop.path_p >= 0.f && d->drop.path_p < 1.f, "afft_gemm: dropout p outside [0,1)");
   e.drop = make_drop(&d->drop);
   auto ok4 = [](const void* p, int64_t ld, int dtype) {

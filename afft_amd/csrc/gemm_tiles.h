@@ -16,6 +16,7 @@ struct GemmFast {
   const bf16_t* B; int64_t ldb;  // k-contiguous: B[N][K] ; k-strided: B[K][N]
   int K;
   int tiles_m, tiles_n;
+  int splitk;   // K is cut into `splitk` slices along gridDim.y (128x128 kernel only); 1 = off
   EpiParams e;
 };
 

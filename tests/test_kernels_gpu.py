@@ -52,6 +52,10 @@ GEMM_CASES = [
     ("tn_bf16_tails_acc", 3806, 200, 192, "bf16", "tn", dict(out_f32=True, accumulate=True, lda_pad=3840, ldb_pad=256)),
     ("tn_bf16_small", 24, 64, 64, "bf16", "tn", dict(out_f32=True)),
     ("nt_bf16_fallback_k", 70, 50, 24, "bf16", "nt", dict(bias=True, out_f32=True)),   # K % 64 != 0 -> fp32-MFMA path
+    # small grids: split-K with fp32 atomics (K >= 2048: 2 slices, K >= 8192: 4), linear epilogue only
+    ("nt_bf16_splitk2", 256, 384, 2048, "bf16", "nt", dict(bias=True, residual=True, out_f32=True, rowscale=True)),
+    ("nn_bf16_splitk4", 200, 256, 8192, "bf16", "nn", dict(bias=True, out_f32=True)),
+    ("nt_bf16_nosplit_gelu", 256, 256, 2048, "bf16", "nt", dict(bias=True, act=1)),
     ("nt_f32", 150, 130, 100, "f32", "nt", dict(bias=True, act=1, pre=True)),
     ("nn_f32", 96, 200, 77, "f32", "nn", dict(bias=True, residual=True, out_f32=True)),
     ("tn_f32", 66, 70, 130, "f32", "tn", dict(accumulate=True, out_f32=True)),
@@ -64,6 +68,8 @@ GEMM_CASES = [
 def test_gemm(case):
     from afft_amd import ops
     name, M, N, K, dt, layout, ep = case
+    from afft_amd import _lib
+    _lib.check(_lib.lib().afft_set_gemm_splitk(1 if "splitk" in name else 0))   # off by default (slower), tested anyway
     tdt = torch.bfloat16 if dt == "bf16" else torch.float32
     a_t, b_t = layout[0] == "t", layout[1] == "t"
     lda_pad, ldb_pad = ep.get("lda_pad"), ep.get("ldb_pad")
