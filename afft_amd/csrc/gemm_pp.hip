@@ -46,7 +46,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
 #define AFFT_PP_DMA_IN_C 0
 #endif
 #ifndef AFFT_PP_DMA_FIRST
-#define AFFT_PP_DMA_FIRST 1
+#define AFFT_PP_DMA_FIRST 0
 #endif
   constexpr int LEAD = AFFT_PP_LEAD;             // half-tiles of look-ahead of the LDS-DMA stream (<= 7)
   constexpr bool DMA_IN_C = AFFT_PP_DMA_IN_C;    // issue the LDS-DMA after the MFMAs (C segment) instead of in L

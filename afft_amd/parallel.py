@@ -71,10 +71,13 @@ class GradReducer:
     """Bucketed, backward-overlapped gradient all-reduce over the flat gradient buffer.  `on_bucket` (optional) is
     called on the side stream right after a bucket's gradient is final (reduced): the per-bucket optimizer hook."""
 
-    def __init__(self, flat: FlatParams, group=None, bucket_elems: int = 32 * 1024 * 1024, comm_dtype: str = "fp32"):
+    def __init__(self, flat: FlatParams, group=None, bucket_elems: int = 32 * 1024 * 1024, comm_dtype: str = "fp32",
+                 force_comm: bool = False):
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # force_comm: run the collective path even in a 1-rank group (exercises RCCL + the bf16 payload on one GPU)
+        self.comm = self.world > 1 or (force_comm and dist.is_available() and dist.is_initialized())
         self.comm_dtype = comm_dtype
         self.buckets: List[tuple] = []        # (start, end) element ranges, in parameter order
         self.bucket_of: List[int] = []        # param index -> bucket index
@@ -96,7 +99,7 @@ class GradReducer:
         self._use_cuda = flat.flat_g.is_cuda
         self.side_stream = torch.cuda.Stream() if self._use_cuda else None
         self.flat_g16 = (torch.empty(flat.total, dtype=torch.bfloat16, device=flat.flat_g.device)
-                         if (comm_dtype == "bf16" and self.world > 1) else None)
+                         if (comm_dtype == "bf16" and self.comm) else None)
         self.on_bucket: Optional[Callable[[int, int, Tensor, float], None]] = None
 
     # ---- step protocol
@@ -105,7 +108,7 @@ class GradReducer:
         self._launched = [False] * len(self.buckets)
         self._handles = []
         rt.SINK.begin_step()
-        early = self.world > 1 or self.on_bucket is not None
+        early = self.comm or self.on_bucket is not None
         rt.SINK.on_grad_ready = self._on_ready if early else None
 
     def _on_ready(self, p: Tensor):
@@ -126,14 +129,14 @@ class GradReducer:
         self._launched[b] = True
         s, e = self.buckets[b]
         if not self._use_cuda:
-            if self.world > 1:
+            if self.comm:
                 self._handles.append(dist.all_reduce(self.flat.flat_g[s:e], group=self.group, async_op=True))
             return
         ev = torch.cuda.Event()
         ev.record()
         self.side_stream.wait_event(ev)
         with torch.cuda.stream(self.side_stream):
-            if self.world > 1:
+            if self.comm:
                 if self.flat_g16 is not None:
                     n = e - s
                     ops.cast(self.flat.flat_g[s:e].view(n // 64, 64), self.flat_g16[s:e].view(n // 64, 64))
@@ -146,7 +149,7 @@ class GradReducer:
         """Call after backward: zero untouched grads, hand over whatever is still pending, join the side stream."""
         rt.SINK.on_grad_ready = None
         rt.SINK.finish_step(self.flat.params)
-        if self.world <= 1 and self.on_bucket is None:
+        if not self.comm and self.on_bucket is None:
             return
         if self.expected is None:
             self.expected = list(self._count)
@@ -198,11 +201,12 @@ class Trainer:
 
     def __init__(self, model, loss_wts: Dict[str, float], lr=1e-3, momentum=0.9, weight_decay=1e-6,
                  comm_dtype: str = "fp32", bucket_elems: int = 32 * 1024 * 1024, group=None,
-                 overlap_optimizer: bool = True):
+                 overlap_optimizer: bool = True, force_comm: bool = False):
         from .common.runner import BasicLossAccuracy, Runner
         self.model = model
         self.flat = FlatParams(model)
-        self.reducer = GradReducer(self.flat, group=group, bucket_elems=bucket_elems, comm_dtype=comm_dtype)
+        self.reducer = GradReducer(self.flat, group=group, bucket_elems=bucket_elems, comm_dtype=comm_dtype,
+                                   force_comm=force_comm)
         self.opt = FusedSGD(self.flat, lr, momentum, weight_decay)
         self.loss_fn = BasicLossAccuracy(compute_metrics=False)
         self._reduce = Runner._reduce_loss

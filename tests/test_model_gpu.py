@@ -268,3 +268,48 @@ def test_overlapped_optimizer_and_wgrad_streams_equal_serial():
     print(f"serial-vs-serial noise {noise:.2e}, overlap-vs-serial {d:.2e}")
     assert d < 5 * noise + 1e-6, (d, noise)
     assert abs(l_s - l_o) < 1e-3 * max(1.0, abs(l_s)), (l_s, l_o)
+
+
+def test_rccl_path_single_rank():
+    """The collective path of the trainer (bucket -> side stream -> bf16 cast -> RCCL all-reduce -> per-bucket SGD on
+    bf16 gradients) run in a 1-rank "nccl" (= RCCL) group on one GPU: must equal the no-communication result up to the
+    bf16 rounding of the gradient payload."""
+    import os
+    import torch.distributed as dist
+    import afft_amd
+    from afft_amd import runtime as rt
+    from afft_amd.config import make_model_cfg
+    from afft_amd.models.base_model import BaseModel
+    from afft_amd.parallel import Trainer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dev = torch.device("cuda:0")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        afft_amd.set_precision("bf16")
+        rt.set_grad_mode("sink")
+        mods = {"rgb": 128, "flow": 128}
+        g = torch.Generator().manual_seed(9)
+        B, T = 8, 8
+        feats = {m: torch.randn(B, T, C, 1, 1, 1, generator=g).to(dev) for m, C in mods.items()}
+        tgt = {"action": torch.randint(0, 31, (B,), generator=g).to(dev)}
+        sub = {"action": torch.randint(0, 31, (B, T, 1), generator=g).to(dev)}
+        out = {}
+        for mode in ("none", "fp32", "bf16"):
+            torch.manual_seed(1)
+            cfg = make_model_cfg(mods, 128, 128, depth=2, fp_layers=2, fp_heads=4, drop=0.0)
+            model = BaseModel(cfg, {"action": 31}, {}).to(dev).eval()
+            tr = Trainer(model, {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}, lr=0.01,
+                         bucket_elems=1 << 16, comm_dtype="fp32" if mode == "none" else mode, force_comm=(mode != "none"))
+            for _ in range(3):
+                loss, _ = tr.step(feats, tgt, sub)
+            torch.cuda.synchronize()
+            out[mode] = tr.flat.flat_p.clone()
+        assert rel_l2(out["fp32"], out["none"]) < 5e-5
+        assert rel_l2(out["bf16"], out["none"]) < 2e-3      # bf16 rounding of the gradient payload
+    finally:
+        if created:
+            dist.destroy_process_group()
