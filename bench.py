@@ -250,11 +250,19 @@ def main():
             avg_fl = d["flops"] / d["launches"]
             ach = avg_fl / (avg_ms * 1e-3) / 1e12
             dtype_peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3
+            traffic = None
+            try:   # HBM-side bytes per launch from separate rocprofv3 --pmc passes (tools/traffic_summary.py), committed
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic_pmc.json")))
+                traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
             result["roofline"] = {
                 "kernel": dom + " (bf16 MFMA GEMM, v_mfma_f32_16x16x32_bf16; <A k-strided, B k-strided>: "
                           "false,false = NT forward/dgrad)",
                 "bound": "mfma", "achieved": round(ach, 1), "peak": dtype_peak, "unit": "TFLOP/s",
-                "frac": round(ach / dtype_peak, 4), "traffic": None,
+                "frac": round(ach / dtype_peak, 4), "traffic": traffic,
+                "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate --pmc passes of this command "
+                                "(profiles/r01_gemm_hbm_traffic_pmc.json); fabric-side, includes Infinity-Cache hits",
                 "launches_per_step": d["launches"], "avg_launch_ms": round(avg_ms, 4),
                 "avg_algorithmic_gflop_per_launch": round(avg_fl / 1e9, 2),
                 "by_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
