@@ -3,6 +3,10 @@
 
 using namespace afft_gemm_detail;
 
+#ifndef AFFT_PP_DIAG
+#define AFFT_PP_DIAG 0    // diagnostic builds only (wrong results): 1 = no fragment reads, 2 = no LDS-DMA in the loop, 4 = no MFMA
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -42,15 +46,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
 #ifndef AFFT_PP_LEAD
 #define AFFT_PP_LEAD 7
 #endif
-#ifndef AFFT_PP_DMA_IN_C
-#define AFFT_PP_DMA_IN_C 0
-#endif
-#ifndef AFFT_PP_DMA_FIRST
-#define AFFT_PP_DMA_FIRST 0
-#endif
   constexpr int LEAD = AFFT_PP_LEAD;             // half-tiles of look-ahead of the LDS-DMA stream (<= 7)
-  constexpr bool DMA_IN_C = AFFT_PP_DMA_IN_C;    // issue the LDS-DMA after the MFMAs (C segment) instead of in L
-  constexpr int ISSUED_AT_L_END = LEAD - (DMA_IN_C ? 1 : 0);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -58,6 +54,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
   int tm, tn;
   tile_coords(g.tiles_m, g.tiles_n, tm, tn);
   const int m0 = tm * 256, n0 = tn * 256;
+#ifdef AFFT_PP_SAMETILE   // diagnostic build only: every workgroup stages tile (0,0) -> all L2 hits (results are wrong)
+  const int m0l = 0, n0l = 0;
+#else
+  const int m0l = m0, n0l = n0;
+#endif
   const int M = g.e.M, N = g.e.N;
   const int nk = g.K / BK, NH = 4 * nk;
 
@@ -71,22 +72,71 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 aF[4][2], bF[2][2][2];   // A fragments of the live half; B fragments of both halves
+  if (AFFT_PP_DIAG & 1) {
+    for (int i = 0; i < 4; ++i) for (int s = 0; s < 2; ++s) for (int e = 0; e < 8; ++e) aF[i][s][e] = (short)(lane * 37 + i);
+    for (int a = 0; a < 2; ++a) for (int j = 0; j < 2; ++j) for (int s = 0; s < 2; ++s) for (int e = 0; e < 8; ++e) bF[a][j][s][e] = (short)(lane * 11 + j);
+  }
 
+  // ---- LDS-DMA staging, scalar-base form: global_load_lds_dwordx4 voff32, s[base:base+1] with M0 = LDS destination.
+  // Every lane-dependent part of a source address is one loop-invariant 32-bit VGPR per operand (row-in-piece * pitch
+  // + swizzled 16-byte chunk); the piece's first row, the K offset and the edge clamps are wave-uniform SALU work.
+  // (The per-lane 64-bit pointers the builtin needs cost 2 VGPRs per piece kind and pushed the kernel into scratch.)
+  const unsigned lds0 = (unsigned)(size_t)(AFFT_LDS char*)smem;
+  const unsigned lda2 = (unsigned)(g.lda * 2), ldb2 = (unsigned)(g.ldb * 2);
+  // k-contiguous image: piece j = rows 8j..8j+7, lane -> row (lane>>3), chunk (lane&7) ^ ((row>>1)&7)
+  const unsigned kc_row = lane >> 3;
+  const unsigned kc_chunk16 = (unsigned)(((lane & 7) ^ (((wave & 1) << 2) + (lane >> 4))) << 4);
+  // k-strided image: piece j = k-rows 4j..4j+3 of 128 columns, lane -> row (lane>>4), 16-B chunk c16 = lane&15 at
+  // source chunk ((c16>>1) ^ f(row)) << 1 | (c16&1), f(row) = (row&3) | ((row>>3)&1) << 2
+  const unsigned ks_row = lane >> 4;
+  const unsigned ks_c16 = (unsigned)((((((lane & 15) >> 1) ^ ((lane >> 4) | (((wave >> 1) & 1) << 2))) << 1) | (lane & 1)) << 4);
+  const unsigned voffA = A_KS ? ks_row * lda2 + ks_c16 : kc_row * lda2 + kc_chunk16;
+  const unsigned voffB = B_KS ? ks_row * ldb2 + ks_c16 : kc_row * ldb2 + kc_chunk16;
+  auto glds = [&](const char* sbase, unsigned voff, unsigned dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(dst) : "memory");
+  };
+  auto stage_half_kc = [&](const bf16_t* G, int64_t ld, unsigned ld2, unsigned voff_full, int row0, int nrows, int k0,
+                           unsigned dst) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = wave + jj * 8;
+      const int pb = min(row0 + j * 8, nrows - 1);          // tail pieces re-read valid rows; the epilogue drops them
+      const int lim = nrows - 1 - pb;
+      const char* sbase = (const char*)(G + (int64_t)pb * ld + k0);
+      unsigned voff = voff_full;
+      if (lim < 7) voff = min(kc_row, (unsigned)lim) * ld2 + kc_chunk16;
+      glds(sbase, voff, dst + j * 1024);
+    }
+  };
+  auto stage_half_ks = [&](const bf16_t* G, int64_t ld, unsigned ld2, unsigned voff_full, int col0, int k0, unsigned dst) {
+    const int limc = ((int)ld - 8 - col0) * 2;              // last 16-byte chunk that stays inside the row
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = wave + jj * 8;
+      const char* sbase = (const char*)(G + (int64_t)(k0 + j * 4) * ld + col0);
+      unsigned voff = voff_full;
+      if (limc < 240) voff = ks_row * ld2 + min(ks_c16, (unsigned)max(limc, 0));
+      glds(sbase, voff, dst + j * 1024);
+    }
+  };
+  bool in_loop = false; (void)in_loop;
   auto issue = [&](int m, int q) {   // q = m & 3 (compile-time at every call site)
     if (m >= NH) return;
+    if ((AFFT_PP_DIAG & 2) && in_loop) return;
     const int kt = m >> 2;
-    char* dst = smem + ((kt & 1) * 4 + q) * HB;
+    const unsigned dst = lds0 + ((kt & 1) * 4 + q) * HB;
     if (q == 0 || q == 3) {
-      const int r0 = m0 + (q == 3 ? 128 : 0);
-      if constexpr (A_KS) stage_ks<128, 8>(g.A, g.lda, r0, kt * BK, dst, wave, lane);
-      else stage_kc<128, 8>(g.A, g.lda, r0, M, kt * BK, dst, wave, lane);
+      const int r0 = m0l + (q == 3 ? 128 : 0);
+      if constexpr (A_KS) stage_half_ks(g.A, g.lda, lda2, voffA, r0, kt * BK, dst);
+      else stage_half_kc(g.A, g.lda, lda2, voffA, r0, M, kt * BK, dst);
     } else {
-      const int c0 = n0 + (q == 2 ? 128 : 0);
-      if constexpr (B_KS) stage_ks<128, 8>(g.B, g.ldb, c0, kt * BK, dst, wave, lane);
-      else stage_kc<128, 8>(g.B, g.ldb, c0, N, kt * BK, dst, wave, lane);
+      const int c0 = n0l + (q == 2 ? 128 : 0);
+      if constexpr (B_KS) stage_half_ks(g.B, g.ldb, ldb2, voffB, c0, kt * BK, dst);
+      else stage_half_kc(g.B, g.ldb, ldb2, voffB, c0, N, kt * BK, dst);
     }
   };
   auto load_a = [&](int kt, int ih) {
+    if (AFFT_PP_DIAG & 1) return;
     const char* base = smem + ((kt & 1) * 4 + (ih ? 3 : 0)) * HB;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -96,23 +146,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
         else aF[i][s] = frag_kc(base, gp * 64 + i * 16 + (lane & 15), s * 4 + (lane >> 4));
       }
   };
-  auto load_b = [&](int kt, int jh) {
+  auto load_b = [&](int kt, int jh, auto slotc) {   // B half jh of K-tile kt -> fragment slot
+    constexpr int slot = decltype(slotc)::value;
+    if (AFFT_PP_DIAG & 1) return;
     const char* base = smem + ((kt & 1) * 4 + 1 + jh) * HB;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        if constexpr (B_KS) bF[jh][j][s] = frag_ks<128>(base, 32 * s, wc * 2 + j, lane);
-        else bF[jh][j][s] = frag_kc(base, wc * 32 + j * 16 + (lane & 15), s * 4 + (lane >> 4));
+        if constexpr (B_KS) bF[slot][j][s] = frag_ks<128>(base, 32 * s, wc * 2 + j, lane);
+        else bF[slot][j][s] = frag_kc(base, wc * 32 + j * 16 + (lane & 15), s * 4 + (lane >> 4));
       }
   };
-  // end of an L segment: this wave's pieces of every half-tile <= n + 2 have landed, its LDS reads have returned
+  // end of an L segment: this wave's pieces of every half-tile <= n + 3 have landed
   unsigned long long sL = 0, sW = 0, sB1 = 0, sC = 0, sB2 = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
   (void)sL; (void)sW; (void)sB1; (void)sC; (void)sB2; (void)t0; (void)t1; (void)t2; (void)t3; (void)t4; (void)t5;
   auto wait_then_barrier = [&](int n) {
     STAMP(t1);
-    const int last = min(n + ISSUED_AT_L_END, NH - 1);
-    const int out = last - (n + 2);           // half-tiles allowed to stay in flight
+    const int last = min(n + LEAD, NH - 1);
+    const int out = last - (n + 3);           // half-tiles allowed to stay in flight
     // no lgkmcnt here: the LDS reads of this segment only have to be back before this wave's own MFMAs (the
     // compiler's wait after the barrier), so their latency overlaps the barrier; the ring slot they read is not
     // refilled until >= 3 barriers later, each of which this wave passes with lgkmcnt already drained.
@@ -126,20 +178,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
     STAMP(t3);
     sL += t1 - t0; sW += t2 - t1; sB1 += t3 - t2;
   };
-  auto compute = [&](auto ihc, auto jhc, int dma_m, auto dma_q) {
-    constexpr int ih = decltype(ihc)::value, jh = decltype(jhc)::value;
+  auto compute = [&](auto ihc, auto jhc, auto slotc) {
+    constexpr int ih = decltype(ihc)::value, jh = decltype(jhc)::value, slot = decltype(slotc)::value;
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
+    if (!(AFFT_PP_DIAG & 4))
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[ih][jh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bF[jh][j][s], aF[i][s], acc[ih][jh][i][j], 0, 0, 0);
+          acc[ih][jh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bF[slot][j][s], aF[i][s], acc[ih][jh][i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DMA_IN_C) issue(dma_m, decltype(dma_q)::value);
     STAMP(t4);
     __builtin_amdgcn_s_barrier();
     STAMP(t5);
@@ -149,41 +201,31 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
   using I1 = std::integral_constant<int, 1>;
 
   // prologue = "L(-1)": the half-tiles every later wait rule assumes are already issued
-  static_for<0, ISSUED_AT_L_END>([&](auto mc) { issue(decltype(mc)::value, decltype(mc)::value & 3); });
+  static_for<0, LEAD>([&](auto mc) { issue(decltype(mc)::value, decltype(mc)::value & 3); });
   wait_then_barrier(-1);
+  load_b(0, 0, I0{});                          // K-tile 0's first B fragments (later ones are read a phase early)
   if (gp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one slot behind group 0
   STAMP(t0);
   sL = sW = sB1 = sC = sB2 = 0;
   unsigned long long tstart = t0; (void)tstart;
 
-  using Q0 = std::integral_constant<int, (0 + LEAD) & 3>;
-  using Q1 = std::integral_constant<int, (1 + LEAD) & 3>;
-  using Q2 = std::integral_constant<int, (2 + LEAD) & 3>;
-  using Q3 = std::integral_constant<int, (3 + LEAD) & 3>;
-  for (int kt = 0; kt < nk; ++kt) {
+  // One K-tile = 4 phases = the 4 quadrants of the wave's 128x64 output, in the order (0,0) (0,1) (1,1) (1,0).
+  // The two B fragment slots swap roles every K-tile (P = parity: B half 0 lives in slot P, half 1 in slot 1-P) so
+  // that the next K-tile's first B fragments can be read during phase 3, whose own operands are all resident:
+  // LDS reads per phase 8 / 4 / 8 / 4 instead of 12 / 4 / 8 / 0 (the L segment has to fit under 16 MFMAs).
+  in_loop = true;
+  auto ktile = [&](auto Pc, int kt) {
+    using SP = std::integral_constant<int, decltype(Pc)::value>;
+    using SQ = std::integral_constant<int, 1 - decltype(Pc)::value>;
     const int n = 4 * kt;
-    // phase 0: quadrant (rows half 0, cols half 0)
-    if constexpr (!DMA_IN_C && AFFT_PP_DMA_FIRST) issue(n + 0 + LEAD, Q0::value);
-    load_a(kt, 0); load_b(kt, 0);
-    if constexpr (!DMA_IN_C && !AFFT_PP_DMA_FIRST) issue(n + 0 + LEAD, Q0::value);
-    wait_then_barrier(n + 0);
-    compute(I0{}, I0{}, n + 0 + LEAD, Q0{});
-    // phase 1: (0, 1)
-    if constexpr (!DMA_IN_C && AFFT_PP_DMA_FIRST) issue(n + 1 + LEAD, Q1::value);
-    load_b(kt, 1);
-    if constexpr (!DMA_IN_C && !AFFT_PP_DMA_FIRST) issue(n + 1 + LEAD, Q1::value);
-    wait_then_barrier(n + 1);
-    compute(I0{}, I1{}, n + 1 + LEAD, Q1{});
-    // phase 2: (1, 1)
-    if constexpr (!DMA_IN_C && AFFT_PP_DMA_FIRST) issue(n + 2 + LEAD, Q2::value);
-    load_a(kt, 1);
-    if constexpr (!DMA_IN_C && !AFFT_PP_DMA_FIRST) issue(n + 2 + LEAD, Q2::value);
-    wait_then_barrier(n + 2);
-    compute(I1{}, I1{}, n + 2 + LEAD, Q2{});
-    // phase 3: (1, 0)
-    if constexpr (!DMA_IN_C) issue(n + 3 + LEAD, Q3::value);
-    wait_then_barrier(n + 3);
-    compute(I1{}, I0{}, n + 3 + LEAD, Q3{});
+    load_a(kt, 0);                       issue(n + 0 + LEAD, (0 + LEAD) & 3); wait_then_barrier(n + 0); compute(I0{}, I0{}, SP{});
+    load_b(kt, 1, SQ{});                 issue(n + 1 + LEAD, (1 + LEAD) & 3); wait_then_barrier(n + 1); compute(I0{}, I1{}, SQ{});
+    load_a(kt, 1);                       issue(n + 2 + LEAD, (2 + LEAD) & 3); wait_then_barrier(n + 2); compute(I1{}, I1{}, SQ{});
+    load_b(kt + 1, 0, SQ{});             issue(n + 3 + LEAD, (3 + LEAD) & 3); wait_then_barrier(n + 3); compute(I1{}, I0{}, SP{});
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    ktile(I0{}, kt);
+    if (kt + 1 < nk) ktile(I1{}, kt + 1);
   }
   if (gp == 0) __builtin_amdgcn_s_barrier();
 #ifdef AFFT_PP_STAMP

@@ -70,20 +70,24 @@ def to_act(x: Tensor, drop=None) -> Act:
 def _lin_fwd(x: Act, W: Tensor, conv1d: bool, out: Tensor, **ep) -> Tensor:
     """out[rows, n_out] = epilogue(x @ W^T) (nn.Linear, W [out,in]) or x @ W (HF Conv1D, W [in,out])."""
     if rt.precision() == "bf16":
-        w16 = rt.weight_image(W)             # [pad(rows), pad(cols)] bf16 image of W
-        if conv1d:                           # W [in, out]: B is k-strided ("NN")
-            return ops.gemm(x.k, w16[:, :W.shape[1]], out, **ep)
-        return ops.gemm(x.k, w16[:W.shape[0]], out, b_t=True, **ep)   # W [out, in]: B is k-contiguous ("NT")
+        w16, wt16 = rt.weight_images(W)      # [pad(rows), pad(cols)] and its transpose
+        if not conv1d:                       # W [out, in] is B stored [N, K]: "NT"
+            return ops.gemm(x.k, w16[:W.shape[0]], out, b_t=True, **ep)
+        if wt16 is not None:                 # W^T [out, in]: "NT"
+            return ops.gemm(x.k, wt16[:W.shape[1]], out, b_t=True, **ep)
+        return ops.gemm(x.k, w16[:, :W.shape[1]], out, **ep)             # W [in, out] = [K, N]: "NN"
     return ops.gemm(x.live, W, out, b_t=not conv1d, **ep)
 
 
 def _lin_dgrad(dy: Act, W: Tensor, conv1d: bool, out: Tensor, **ep) -> Tensor:
     """out[rows, n_in] = epilogue(dy @ W) (nn.Linear) or dy @ W^T (Conv1D)."""
     if rt.precision() == "bf16":
-        w16 = rt.weight_image(W)
-        if conv1d:                           # dx = dy W^T, W [in, out] is B stored [N, K] ("NT")
+        w16, wt16 = rt.weight_images(W)
+        if conv1d:                           # dx = dy W^T, W [in, out] is B stored [N, K]: "NT"
             return ops.gemm(dy.k, w16[:W.shape[0]], out, b_t=True, **ep)
-        return ops.gemm(dy.k, w16[:, :W.shape[1]], out, **ep)         # dx = dy W, W [out, in] = [K, N] ("NN")
+        if wt16 is not None:                 # dx = dy W, W^T [in, out] is B stored [N, K]: "NT"
+            return ops.gemm(dy.k, wt16[:W.shape[1]], out, b_t=True, **ep)
+        return ops.gemm(dy.k, w16[:, :W.shape[1]], out, **ep)            # W [out, in] = [K, N]: "NN"
     return ops.gemm(dy.live, W, out, b_t=conv1d, **ep)
 
 

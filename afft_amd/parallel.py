@@ -50,6 +50,10 @@ class FlatParams:
         # MFMA operand copies of the weights cost no extra pass (only GEMM weights with both dims % 64 == 0 use it;
         # odd shapes -- the 3806-row classifier, the 352-column objects mapping -- keep a padded cast image)
         self.flat_p16 = torch.zeros(off, dtype=torch.bfloat16, device=dev) if dev.type == "cuda" else None
+        # transposed bf16 images (same offsets): with both images every forward / dgrad GEMM is the k-contiguous "NT"
+        # layout; refreshed by a transpose-cast queued behind the SGD kernel of the bucket (see FusedSGD.step_range)
+        self.flat_pT16 = torch.zeros(off, dtype=torch.bfloat16, device=dev) if dev.type == "cuda" else None
+        self.transposed: List[tuple] = []     # (offset, param, transposed view) for the 2-D GEMM weights
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 n = p.numel()
@@ -60,8 +64,17 @@ class FlatParams:
                 ops.cast(self.flat_p.view(off // 64, 64), self.flat_p16.view(off // 64, 64))
                 for p, o in zip(self.params, self.offsets):
                     if p.dim() == 2 and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0:
-                        rt.adopt_weight_image(p, self.flat_p16[o:o + p.numel()].view(p.shape))
+                        vt = self.flat_pT16[o:o + p.numel()].view(p.shape[1], p.shape[0])
+                        ops.cast(p.detach(), None, vt)
+                        rt.adopt_weight_image(p, self.flat_p16[o:o + p.numel()].view(p.shape), vt)
+                        self.transposed.append((o, p, vt))
         rt.invalidate_weight_images()
+
+    def refresh_transposed(self, s: int, e: int):
+        """Re-cast the transposed bf16 images of the weights that live in flat range [s, e)."""
+        for o, p, vt in self.transposed:
+            if s <= o < e:
+                ops.cast(p.detach(), None, vt)
 
     def index_of(self) -> Dict[int, int]:
         return {id(p): i for i, p in enumerate(self.params)}
@@ -183,6 +196,7 @@ class FusedSGD:
         p16 = self.flat.flat_p16[s:e] if self.flat.flat_p16 is not None else None
         ops.sgd_nesterov(self.flat.flat_p[s:e], grad, self.buf[s:e], self.lr, self.momentum, self.wd, gscale,
                          self.steps == 0, p_bf16=p16)
+        self.flat.refresh_transposed(s, e)
 
     def end_step(self):
         self.steps += 1

@@ -60,23 +60,27 @@ def pad64(n: int) -> int:
 
 # --------------------------------------------------------------------------- bf16 weight images
 class _WImage:
-    __slots__ = ("version", "ptr", "w", "external")
+    __slots__ = ("version", "ptr", "w", "wt", "external")
 
 
 _wlist: list = []   # weak references to parameters that own an image (for invalidate_weight_images)
 
 
-def weight_image(p: Tensor) -> Tensor:
-    """bf16 image [pad64(rows), pad64(cols)] (zero padded) of a 2-D fp32 parameter: the MFMA operand copy.
-    One image serves forward (k-contiguous B, "NT") and dgrad (k-strided B, "NN") -- no transposed copy.
-    Refreshed by a cast kernel when the parameter's version counter or storage changes; parameters re-homed by
-    afft_amd.parallel.FlatParams get their image written by the fused SGD kernel itself (`external`)."""
+def weight_images(p: Tensor):
+    """(w16, wt16): bf16 images of a 2-D fp32 parameter, zero padded to multiples of 64 --
+    w16 [pad(rows), pad(cols)] and its transpose wt16 [pad(cols), pad(rows)] (may be None).
+    With both images every forward and dgrad GEMM runs in the k-contiguous "NT" layout (the fastest operand
+    path: one ds_read_b128 per fragment); without wt16 the k-strided "NN" layout is used instead.
+    Refreshed by one cast kernel when the parameter's version counter or storage changes; parameters re-homed by
+    afft_amd.parallel.FlatParams have w16 written by the fused SGD kernel and wt16 by a transpose-cast queued right
+    behind it on the optimizer's side stream (`external`)."""
     img = getattr(p, "_afft_img", None)
     ver = p._version
     if img is None or img.ptr != p.data_ptr() or img.w.device != p.device:
         img = _WImage()
         rows, cols = p.shape
         img.w = torch.zeros(pad64(rows), pad64(cols), dtype=torch.bfloat16, device=p.device)
+        img.wt = torch.zeros(pad64(cols), pad64(rows), dtype=torch.bfloat16, device=p.device)
         img.version = -1
         img.external = False
         img.ptr = p.data_ptr()
@@ -84,16 +88,17 @@ def weight_image(p: Tensor) -> Tensor:
         _wlist.append(weakref.ref(p))
     if img.version != ver:
         with torch.no_grad():
-            ops.cast(p.detach(), img.w[:p.shape[0], :p.shape[1]])
+            ops.cast(p.detach(), img.w[:p.shape[0], :p.shape[1]], img.wt[:p.shape[1], :p.shape[0]])
         img.version = ver
-    return img.w
+    return img.w, img.wt
 
 
-def adopt_weight_image(p: Tensor, view16: Tensor):
-    """Use `view16` (bf16, same shape as p, both dims multiples of 64, kept fresh by the optimizer kernel) as
-    p's MFMA image."""
+def adopt_weight_image(p: Tensor, view16: Tensor, view16_t: Optional[Tensor] = None):
+    """Use `view16` (bf16, same shape as p, both dims multiples of 64, kept fresh by the optimizer kernel) and
+    optionally its transpose `view16_t` as p's MFMA images."""
     img = _WImage()
     img.w = view16
+    img.wt = view16_t
     img.version = p._version
     img.external = True
     img.ptr = p.data_ptr()

@@ -35,14 +35,41 @@ def bench(layout, M, N, K, variant, iters=20):
     return ms, 2.0 * M * N * K / ms / 1e9
 
 
+def bench_blas(layout, M, N, K, iters=20):
+    """The vendor library (torch.mm -> hipBLASLt/rocBLAS) on the same operands: a yardstick, never the product path."""
+    dev = "cuda:0"
+    if layout == "nt":
+        a = torch.randn(M, K, device=dev).to(torch.bfloat16); b = torch.randn(N, K, device=dev).to(torch.bfloat16).t()
+    elif layout == "nn":
+        a = torch.randn(M, K, device=dev).to(torch.bfloat16); b = torch.randn(K, N, device=dev).to(torch.bfloat16)
+    else:
+        a = torch.randn(K, M, device=dev).to(torch.bfloat16).t(); b = torch.randn(K, N, device=dev).to(torch.bfloat16)
+    for _ in range(3):
+        torch.mm(a, b)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        torch.mm(a, b)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters
+    return ms, 2.0 * M * N * K / ms / 1e9
+
+
 if __name__ == "__main__":
     shapes = [("nt", 5120, 6144, 2048), ("nt", 5120, 2048, 2048), ("nt", 5120, 8192, 2048), ("nt", 5120, 2048, 8192),
               ("nn", 5120, 2048, 6144), ("nn", 5120, 8192, 2048), ("nn", 5120, 2048, 8192),
               ("tn", 6144, 2048, 5120), ("tn", 8192, 2048, 5120), ("tn", 2048, 8192, 5120), ("tn", 2048, 2048, 5120),
               ("nt", 1024, 6144, 2048), ("nt", 1024, 8192, 2048), ("nt", 1024, 2048, 8192), ("tn", 8192, 2048, 1024),
+              ("nt", 1024, 2048, 2048), ("tn", 2048, 2048, 1024), ("tn", 6144, 2048, 1024), ("nt", 1024, 3840, 2048),
               ("nt", 1088, 3840, 2048), ("nt", 8192, 8192, 8192)]
     variants = [int(v) for v in os.environ.get("VARIANTS", "1,3").split(",")]
-    print(f"{'layout':6} {'M':>6} {'N':>6} {'K':>6} | " + " | ".join(f"v{v} ms    v{v} TF" for v in variants))
+    blas = os.environ.get("BLAS", "0") == "1"
+    print(f"{'layout':6} {'M':>6} {'N':>6} {'K':>6} | " + " | ".join(f"v{v} ms    v{v} TF" for v in variants)
+          + (" | blas ms  blas TF" if blas else ""))
     for lay, M, N, K in shapes:
         r = [bench(lay, M, N, K, v) for v in variants]
+        if blas:
+            r.append(bench_blas(lay, M, N, K))
         print(f"{lay:6} {M:6d} {N:6d} {K:6d} | " + " | ".join(f"{x[0]:8.4f} {x[1]:7.1f}" for x in r))
