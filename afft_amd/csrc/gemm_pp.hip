@@ -3,6 +3,12 @@
 
 using namespace afft_gemm_detail;
 
+#ifndef AFFT_PP_DMA_FIRST
+#define AFFT_PP_DMA_FIRST 0   // experiment: issue the LDS-DMA before the fragment reads of an L segment
+#endif
+#ifndef AFFT_PP_PRIO
+#define AFFT_PP_PRIO 1        // experiment: 1 = MFMA segments at raised priority, 0 = no priority change, 2 = L segments raised
+#endif
 #ifndef AFFT_PP_DIAG
 #define AFFT_PP_DIAG 0    // diagnostic builds only (wrong results): 1 = no fragment reads, 2 = no LDS-DMA in the loop, 4 = no MFMA
 #endif
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
   auto compute = [&](auto ihc, auto jhc, auto slotc) {
     constexpr int ih = decltype(ihc)::value, jh = decltype(jhc)::value, slot = decltype(slotc)::value;
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
+    if (AFFT_PP_PRIO == 1) __builtin_amdgcn_s_setprio(1);
     if (!(AFFT_PP_DIAG & 4))
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[ih][jh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bF[slot][j][s], aF[i][s], acc[ih][jh][i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+    if (AFFT_PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     STAMP(t4);
     __builtin_amdgcn_s_barrier();
@@ -218,10 +224,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
     using SP = std::integral_constant<int, decltype(Pc)::value>;
     using SQ = std::integral_constant<int, 1 - decltype(Pc)::value>;
     const int n = 4 * kt;
-    load_a(kt, 0);                       issue(n + 0 + LEAD, (0 + LEAD) & 3); wait_then_barrier(n + 0); compute(I0{}, I0{}, SP{});
-    load_b(kt, 1, SQ{});                 issue(n + 1 + LEAD, (1 + LEAD) & 3); wait_then_barrier(n + 1); compute(I0{}, I1{}, SQ{});
-    load_a(kt, 1);                       issue(n + 2 + LEAD, (2 + LEAD) & 3); wait_then_barrier(n + 2); compute(I1{}, I1{}, SQ{});
-    load_b(kt + 1, 0, SQ{});             issue(n + 3 + LEAD, (3 + LEAD) & 3); wait_then_barrier(n + 3); compute(I1{}, I0{}, SP{});
+    auto L = [&](auto reads, int m, int q) {
+      if (AFFT_PP_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+      if (AFFT_PP_DMA_FIRST) { issue(m, q); reads(); } else { reads(); issue(m, q); }
+      if (AFFT_PP_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+    };
+    L([&] { load_a(kt, 0); }, n + 0 + LEAD, (0 + LEAD) & 3);            wait_then_barrier(n + 0); compute(I0{}, I0{}, SP{});
+    L([&] { load_b(kt, 1, SQ{}); }, n + 1 + LEAD, (1 + LEAD) & 3);      wait_then_barrier(n + 1); compute(I0{}, I1{}, SQ{});
+    L([&] { load_a(kt, 1); }, n + 2 + LEAD, (2 + LEAD) & 3);            wait_then_barrier(n + 2); compute(I1{}, I1{}, SQ{});
+    L([&] { load_b(kt + 1, 0, SQ{}); }, n + 3 + LEAD, (3 + LEAD) & 3);  wait_then_barrier(n + 3); compute(I1{}, I0{}, SP{});
   };
   for (int kt = 0; kt < nk; kt += 2) {
     ktile(I0{}, kt);

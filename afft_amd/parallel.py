@@ -52,7 +52,8 @@ class FlatParams:
         self.flat_p16 = torch.zeros(off, dtype=torch.bfloat16, device=dev) if dev.type == "cuda" else None
         # transposed bf16 images (same offsets): with both images every forward / dgrad GEMM is the k-contiguous "NT"
         # layout; refreshed by a transpose-cast queued behind the SGD kernel of the bucket (see FusedSGD.step_range)
-        self.flat_pT16 = torch.zeros(off, dtype=torch.bfloat16, device=dev) if dev.type == "cuda" else None
+        use_t = dev.type == "cuda" and rt.transposed_images()
+        self.flat_pT16 = torch.zeros(off, dtype=torch.bfloat16, device=dev) if use_t else None
         self.transposed: List[tuple] = []     # (offset, param, transposed view) for the 2-D GEMM weights
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
@@ -64,10 +65,12 @@ class FlatParams:
                 ops.cast(self.flat_p.view(off // 64, 64), self.flat_p16.view(off // 64, 64))
                 for p, o in zip(self.params, self.offsets):
                     if p.dim() == 2 and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0:
-                        vt = self.flat_pT16[o:o + p.numel()].view(p.shape[1], p.shape[0])
-                        ops.cast(p.detach(), None, vt)
+                        vt = None
+                        if use_t:
+                            vt = self.flat_pT16[o:o + p.numel()].view(p.shape[1], p.shape[0])
+                            ops.cast(p.detach(), None, vt)
+                            self.transposed.append((o, p, vt))
                         rt.adopt_weight_image(p, self.flat_p16[o:o + p.numel()].view(p.shape), vt)
-                        self.transposed.append((o, p, vt))
         rt.invalidate_weight_images()
 
     def refresh_transposed(self, s: int, e: int):

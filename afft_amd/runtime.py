@@ -93,6 +93,16 @@ def weight_images(p: Tensor):
     return img.w, img.wt
 
 
+_TRANSPOSED_IMAGES = os.environ.get("AFFT_WT_IMAGES", "0") != "0"
+
+
+def transposed_images() -> bool:
+    """Keep a transposed bf16 image beside every GEMM weight of a Trainer (all forward / dgrad GEMMs then run NT) at
+    the price of one transpose-cast per weight per optimizer step.  Off by default: measured on cfg2 the casts cost
+    0.5 ms/step more than NT saves over the k-strided NN layout (21.6 vs 21.1 ms/step); AFFT_WT_IMAGES=1 turns it on."""
+    return _TRANSPOSED_IMAGES
+
+
 def adopt_weight_image(p: Tensor, view16: Tensor, view16_t: Optional[Tensor] = None):
     """Use `view16` (bf16, same shape as p, both dims multiples of 64, kept fresh by the optimizer kernel) and
     optionally its transpose `view16_t` as p's MFMA images."""
