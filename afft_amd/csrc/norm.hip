@@ -58,87 +58,114 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
-// backward: each wave walks rows r = part*4+wave, += 4*nparts; keeps dw/db partial sums for its columns
-// in registers, combined across the 4 waves through LDS, one [2][d] slab per workgroup.
-template <int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, int64_t lddy, int dy_dtype,
-                                                     const float* __restrict__ x, int64_t ldx,
-                                                     const float* __restrict__ w, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, int rows, int d,
-                                                     const float* __restrict__ dx_in, float* __restrict__ dx_out,
-                                                     int64_t lddx, bf16_t* __restrict__ dx_bf16,
-                                                     float* __restrict__ partial) {
+// backward: a workgroup is 16 waves = 4 row groups x 4 column slices.  Wave (rg, cs) owns the columns of slice cs
+// (d/4 wide) of rows base + rg, base += 4 * gridDim.x: a quarter of a row per wave keeps the per-lane state small
+// (16 waves per CU and more stay resident, their loads overlap), the two per-row sums are combined over the 4 slices
+// through a double-buffered LDS cell with one barrier per row step, and the dw/db column partials stay in registers
+// until the end, when the 4 row groups add them into one [2][d] LDS slab in a fixed order (deterministic).
+constexpr int LNB_RG = 4, LNB_CS = 4;
+
+template <int NV>  // float4 chunks per lane inside a slice: d/4 <= LNB_CS * 64 * NV
+__global__ __launch_bounds__(1024) void ln_bwd_kernel(const void* __restrict__ dy, int64_t lddy, int dy_dtype,
+                                                      const float* __restrict__ x, int64_t ldx,
+                                                      const float* __restrict__ w, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, int rows, int d,
+                                                      const float* __restrict__ dx_in, float* __restrict__ dx_out,
+                                                      int64_t lddx, bf16_t* __restrict__ dx_bf16,
+                                                      float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = (float*)smem;  // [4 waves][2][d]
+  float* slab = (float*)smem;                      // [2][d]
+  float* cell = slab + 2 * d;                      // [2 buffers][LNB_RG][LNB_CS][2]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nq = d >> 2;
-  float4 pw[NV], pb[NV];
-#pragma unroll
-  for (int t = 0; t < NV; ++t) pw[t] = pb[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float inv_d = 1.0f / (float)d;
-  for (int row = blockIdx.x * LN_WAVES + wave; row < rows; row += gridDim.x * LN_WAVES) {
-    const float mu = mean[row], rs = rstd[row];
-    const float* xr = x + (int64_t)row * ldx;
-    float g[NV][4], xh[NV][4];
-    float c1 = 0.f, c2 = 0.f;
-#pragma unroll
-    for (int t = 0; t < NV; ++t) {
-      const int q = lane + 64 * t;
-      if (q < nq) {
-        float dyv[4];
-        load4(dy, (int64_t)row * lddy + 4 * q, dy_dtype, dyv);
-        const float4 xv = *(const float4*)(xr + 4 * q);
-        float4 ww = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (w) ww = *(const float4*)(w + 4 * q);
-        xh[t][0] = (xv.x - mu) * rs; xh[t][1] = (xv.y - mu) * rs; xh[t][2] = (xv.z - mu) * rs; xh[t][3] = (xv.w - mu) * rs;
-        g[t][0] = dyv[0] * ww.x; g[t][1] = dyv[1] * ww.y; g[t][2] = dyv[2] * ww.z; g[t][3] = dyv[3] * ww.w;
-        pw[t].x += dyv[0] * xh[t][0]; pw[t].y += dyv[1] * xh[t][1]; pw[t].z += dyv[2] * xh[t][2]; pw[t].w += dyv[3] * xh[t][3];
-        pb[t].x += dyv[0]; pb[t].y += dyv[1]; pb[t].z += dyv[2]; pb[t].w += dyv[3];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { c1 += g[t][r]; c2 += g[t][r] * xh[t][r]; }
-      }
-    }
-    c1 = wave_sum(c1) * inv_d;
-    c2 = wave_sum(c2) * inv_d;
-#pragma unroll
-    for (int t = 0; t < NV; ++t) {
-      const int q = lane + 64 * t;
-      if (q < nq) {
-        float o[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = rs * (g[t][r] - c1 - xh[t][r] * c2);
-        const int64_t idx = (int64_t)row * lddx + 4 * q;
-        if (dx_in) {
-          const float4 a = *(const float4*)(dx_in + idx);
-          o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w;
-        }
-        *(float4*)(dx_out + idx) = make_float4(o[0], o[1], o[2], o[3]);
-        if (dx_bf16) store4(dx_bf16, idx, AFFT_BF16, o);
-      }
-    }
-  }
-  // combine the 4 waves' column partials
+  const int rg = wave >> 2, cs = wave & 3;
+  const int nq = d >> 2, qs = (nq + LNB_CS - 1) / LNB_CS;
+  const int q0 = cs * qs, q1 = min(nq, q0 + qs);
+  float4 pw[NV], pb[NV], ww[NV];
 #pragma unroll
   for (int t = 0; t < NV; ++t) {
-    const int q = lane + 64 * t;
-    if (q < nq) {
-      *(float4*)(red + (wave * 2 + 0) * d + 4 * q) = pw[t];
-      *(float4*)(red + (wave * 2 + 1) * d + 4 * q) = pb[t];
+    pw[t] = pb[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int q = q0 + lane + 64 * t;
+    ww[t] = (w && q < q1) ? *(const float4*)(w + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
+  }
+  const float inv_d = 1.0f / (float)d;
+  int buf = 0;
+  for (int base = blockIdx.x * LNB_RG; base < rows; base += gridDim.x * LNB_RG, buf ^= 1) {
+    const int row = base + rg;
+    const bool live = row < rows;
+    float g[NV][4], xh[NV][4];
+    float c1 = 0.f, c2 = 0.f, rs = 0.f;
+    if (live) {
+      const float mu = mean[row];
+      rs = rstd[row];
+      const float* xr = x + (int64_t)row * ldx;
+#pragma unroll
+      for (int t = 0; t < NV; ++t) {
+        const int q = q0 + lane + 64 * t;
+        if (q < q1) {
+          float dyv[4];
+          load4(dy, (int64_t)row * lddy + 4 * q, dy_dtype, dyv);
+          const float4 xv = *(const float4*)(xr + 4 * q);
+          xh[t][0] = (xv.x - mu) * rs; xh[t][1] = (xv.y - mu) * rs; xh[t][2] = (xv.z - mu) * rs; xh[t][3] = (xv.w - mu) * rs;
+          g[t][0] = dyv[0] * ww[t].x; g[t][1] = dyv[1] * ww[t].y; g[t][2] = dyv[2] * ww[t].z; g[t][3] = dyv[3] * ww[t].w;
+          pw[t].x += dyv[0] * xh[t][0]; pw[t].y += dyv[1] * xh[t][1]; pw[t].z += dyv[2] * xh[t][2]; pw[t].w += dyv[3] * xh[t][3];
+          pb[t].x += dyv[0]; pb[t].y += dyv[1]; pb[t].z += dyv[2]; pb[t].w += dyv[3];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { c1 += g[t][r]; c2 += g[t][r] * xh[t][r]; }
+        }
+      }
+    }
+    c1 = wave_sum(c1);
+    c2 = wave_sum(c2);
+    float* my = cell + ((buf * LNB_RG + rg) * LNB_CS) * 2;
+    if (lane == 0) { my[cs * 2] = c1; my[cs * 2 + 1] = c2; }
+    __syncthreads();
+    c1 = ((my[0] + my[2]) + (my[4] + my[6])) * inv_d;
+    c2 = ((my[1] + my[3]) + (my[5] + my[7])) * inv_d;
+    if (live) {
+#pragma unroll
+      for (int t = 0; t < NV; ++t) {
+        const int q = q0 + lane + 64 * t;
+        if (q < q1) {
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = rs * (g[t][r] - c1 - xh[t][r] * c2);
+          const int64_t idx = (int64_t)row * lddx + 4 * q;
+          if (dx_in) {
+            const float4 a = *(const float4*)(dx_in + idx);
+            o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w;
+          }
+          *(float4*)(dx_out + idx) = make_float4(o[0], o[1], o[2], o[3]);
+          if (dx_bf16) store4(dx_bf16, idx, AFFT_BF16, o);
+        }
+      }
     }
   }
-  __syncthreads();
-  for (int c = threadIdx.x; c < 2 * d; c += 256) {
-    const int which = c / d, col = c - which * d;
-    float s = 0.f;
+  // the 4 row groups add their column partials into the slab one after the other
+  for (int r = 0; r < LNB_RG; ++r) {
+    if (rg == r) {
 #pragma unroll
-    for (int wv = 0; wv < LN_WAVES; ++wv) s += red[(wv * 2 + which) * d + col];
-    partial[(int64_t)blockIdx.x * 2 * d + c] = s;
+      for (int t = 0; t < NV; ++t) {
+        const int q = q0 + lane + 64 * t;
+        if (q < q1) {
+          float4 a = pw[t], c = pb[t];
+          if (r) {
+            const float4 sa = *(const float4*)(slab + 4 * q), sc = *(const float4*)(slab + d + 4 * q);
+            a.x += sa.x; a.y += sa.y; a.z += sa.z; a.w += sa.w;
+            c.x += sc.x; c.y += sc.y; c.z += sc.z; c.w += sc.w;
+          }
+          *(float4*)(slab + 4 * q) = a;
+          *(float4*)(slab + d + 4 * q) = c;
+        }
+      }
+    }
+    __syncthreads();
   }
+  for (int c = threadIdx.x; c < 2 * d; c += 1024) partial[(int64_t)blockIdx.x * 2 * d + c] = slab[c];
 }
 
 // 64 columns x 4 part-lanes per workgroup: coalesced 256-B reads, fixed summation order (deterministic)
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nparts, int d,
-                                                            float* __restrict__ dw, float* __restrict__ db) {
+                                                            float* __restrict__ dw, float* __restrict__ db, int accumulate) {
   __shared__ float sh[4][64];
   const int col = threadIdx.x & 63, pl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + col;
@@ -149,7 +176,8 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
   __syncthreads();
   if (pl == 0 && c < 2 * d) {
     s = (sh[0][col] + sh[1][col]) + (sh[2][col] + sh[3][col]);
-    if (c < d) { if (dw) dw[c] += s; } else { if (db) db[c - d] += s; }
+    float* dst = c < d ? (dw ? dw + c : nullptr) : (db ? db + (c - d) : nullptr);
+    if (dst) *dst = accumulate ? *dst + s : s;
   }
 }
 
@@ -163,8 +191,8 @@ int pick_nv(int d) {
 }  // namespace
 
 extern "C" int afft_layernorm_bwd_nparts(int32_t rows) {
-  int n = (rows + LN_WAVES - 1) / LN_WAVES;
-  return n < 1 ? 1 : (n > 256 ? 256 : n);   // one workgroup per CU at most
+  int n = ((rows + LNB_RG - 1) / LNB_RG + 1) / 2;   // >= 2 row steps per workgroup amortise its column-partial slab
+  return n < 1 ? 1 : (n > 256 ? 256 : n);           // one workgroup (16 waves) per CU at most
 }
 
 extern "C" int afft_layernorm_fwd(const float* x, int64_t ldx, const float* w, const float* b, float eps,
@@ -187,21 +215,22 @@ extern "C" int afft_layernorm_fwd(const float* x, int64_t ldx, const float* w, c
 extern "C" int afft_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx,
                                   const float* w, const float* mean, const float* rstd, int32_t rows, int32_t d,
                                   const float* dx_in, float* dx_out, int64_t lddx, void* dx_bf16, float* dw,
-                                  float* db, float* partial, void* stream_) {
+                                  float* db, int32_t accumulate, float* partial, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(dy && x && mean && rstd && dx_out && partial, "layernorm_bwd: null pointer");
   AFFT_CHECK(d > 0 && d % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "layernorm_bwd: d/ld must be multiples of 4");
-  const int nv = pick_nv(d);
-  AFFT_CHECK(nv != 0 && d <= 4096, "layernorm_bwd: d=%d exceeds 4096", d);
+  AFFT_CHECK(d <= 4096, "layernorm_bwd: d=%d exceeds 4096", d);
   if (rows == 0) return 0;
+  const int qs = (d / 4 + LNB_CS - 1) / LNB_CS;
+  const int nv = qs <= 64 ? 1 : qs <= 128 ? 2 : 4;
   const int grid = afft_layernorm_bwd_nparts(rows);
-  const size_t lds = (size_t)LN_WAVES * 2 * d * sizeof(float);
-#define LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(grid), dim3(256), lds, stream, dy, lddy, dy_dtype, x, ldx, w, mean, rstd, rows, d, dx_in, dx_out, lddx, (bf16_t*)dx_bf16, partial)
-  switch (nv) { case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; case 4: LN_BWD(4); break; case 8: LN_BWD(8); break; default: LN_BWD(16); }
+  const size_t lds = (size_t)2 * d * sizeof(float) + 2 * LNB_RG * LNB_CS * 2 * sizeof(float);
+#define LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(grid), dim3(1024), lds, stream, dy, lddy, dy_dtype, x, ldx, w, mean, rstd, rows, d, dx_in, dx_out, lddx, (bf16_t*)dx_bf16, partial)
+  switch (nv) { case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; default: LN_BWD(4); }
 #undef LN_BWD
   AFFT_LAUNCH_CHECK();
   if (dw || db) {
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * d + 63) / 64), dim3(256), 0, stream, partial, grid, d, dw, db);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * d + 63) / 64), dim3(256), 0, stream, partial, grid, d, dw, db, accumulate);
     AFFT_LAUNCH_CHECK();
   }
   return 0;

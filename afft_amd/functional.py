@@ -179,23 +179,24 @@ def _ln_bwd(dy: Tensor, x: Tensor, w: Optional[Tensor], b: Optional[Tensor], mea
         dx_out = torch.empty(rows, d, dtype=torch.float32, device=x.device)
     if rt.grad_mode() == "sink":
         gw = gb = None
+        acc_w = acc_b = True
         if w is not None:
-            gw, acc = rt.SINK.grad_buffer(w)
-            if not acc:
-                gw.zero_()
+            gw, acc_w = rt.SINK.grad_buffer(w)
         if b is not None:
-            gb, acc = rt.SINK.grad_buffer(b)
-            if not acc:
-                gb.zero_()
-        ops.layernorm_bwd(dy, x, w, mean, rstd, dx_out, dx_in=dx_in, dw=gw, db=gb)
+            gb, acc_b = rt.SINK.grad_buffer(b)
+        if w is not None and b is not None and acc_w != acc_b:   # mixed first-touch state: fall back to a zero fill
+            (gw if not acc_w else gb).zero_()
+            acc_w = acc_b = True
+        ops.layernorm_bwd(dy, x, w, mean, rstd, dx_out, dx_in=dx_in, dw=gw, db=gb,
+                          accumulate=acc_w if w is not None else acc_b)
         if w is not None:
             _ready(w)
         if b is not None:
             _ready(b)
         return dx_out, None, None
-    gw = torch.zeros_like(w) if w is not None else None
-    gb = torch.zeros_like(b) if b is not None else None
-    ops.layernorm_bwd(dy, x, w, mean, rstd, dx_out, dx_in=dx_in, dw=gw, db=gb)
+    gw = torch.empty_like(w) if w is not None else None
+    gb = torch.empty_like(b) if b is not None else None
+    ops.layernorm_bwd(dy, x, w, mean, rstd, dx_out, dx_in=dx_in, dw=gw, db=gb, accumulate=False)
     return dx_out, gw, gb
 
 

@@ -96,7 +96,8 @@ def layernorm_fwd(x: Tensor, w: Optional[Tensor], b: Optional[Tensor], eps: floa
 
 def layernorm_bwd(dy: Tensor, x: Tensor, w: Optional[Tensor], mean: Tensor, rstd: Tensor, dx_out: Tensor,
                   dx_in: Optional[Tensor] = None, dx_bf16: Optional[Tensor] = None, dw: Optional[Tensor] = None,
-                  db: Optional[Tensor] = None) -> Tensor:
+                  db: Optional[Tensor] = None, accumulate: bool = True) -> Tensor:
+    """dw / db (optional) receive the weight / bias gradients: added to when `accumulate`, else overwritten."""
     rows, d = x.shape
     nparts = L.lib().afft_layernorm_bwd_nparts(rows)
     partial = torch.empty(nparts * 2 * d, dtype=torch.float32, device=x.device)
@@ -107,7 +108,7 @@ def layernorm_bwd(dy: Tensor, x: Tensor, w: Optional[Tensor], mean: Tensor, rstd
         assert dx_bf16.dtype == torch.bfloat16 and _rowmajor(dx_bf16, "dx_bf16") == lddx
     L.check(L.lib().afft_layernorm_bwd(_p(dy), _rowmajor(dy, "dy"), _dt(dy), _p(x), _rowmajor(x, "x"), _p(w),
                                        _p(mean), _p(rstd), rows, d, _p(dx_in), _p(dx_out), lddx, _p(dx_bf16),
-                                       _p(dw), _p(db), _p(partial), _stream()), "layernorm_bwd")
+                                       _p(dw), _p(db), 1 if accumulate else 0, _p(partial), _stream()), "layernorm_bwd")
     return dx_out
 
 

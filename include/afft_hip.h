@@ -87,14 +87,15 @@ int afft_gemm_variant_for(int M, int N, int K, int a_kstrided, int b_kstrided);
 int afft_layernorm_fwd(const float* x, int64_t ldx, const float* w, const float* b,
                        float eps, int32_t rows, int32_t d, void* y, int64_t ldy, int32_t y_dtype,
                        float* mean, float* rstd, void* stream);
-/* dx_out[r] = (dx_in ? dx_in[r] : 0) + LN'(dy)[r]; dw/db are ACCUMULATED into (+=).  dy dtype selectable.
+/* dx_out[r] = (dx_in ? dx_in[r] : 0) + LN'(dy)[r]; dw/db are written (accumulate = 0) or added to (+=).
+ * dy dtype selectable.
  * dx_bf16 (optional) receives a bf16 copy of dx_out (feeds the next dgrad/wgrad GEMMs).
  * partial: fp32 workspace of at least 2*d*afft_layernorm_bwd_nparts(rows) floats. */
 int afft_layernorm_bwd_nparts(int32_t rows);
 int afft_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx,
                        const float* w, const float* mean, const float* rstd,
                        int32_t rows, int32_t d, const float* dx_in, float* dx_out, int64_t lddx,
-                       void* dx_bf16, float* dw, float* db, float* partial, void* stream);
+                       void* dx_bf16, float* dw, float* db, int32_t accumulate, float* partial, void* stream);
 
 /* ------------------------------------------------------------------ small-sequence attention
  * softmax(q k^T * scale + mask) v per (sequence, head); L <= 32 tokens per sequence.

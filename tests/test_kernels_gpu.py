@@ -169,6 +169,10 @@ def test_layernorm_fwd_bwd(rows, d, dt):
     assert rel_l2(dxb.float().cpu(), xr.grad.float() + dx_in) < 5e-3
     assert rel_l2(dw.cpu() - 0.5, wr.grad.float()) < 3e-5
     assert rel_l2(db.cpu() + 0.25, br.grad.float()) < 3e-5
+    # accumulate = False overwrites whatever the gradient buffers held
+    ops.layernorm_bwd(dy.to(ydt).to(dev()), xg, w.to(dev()), mean, rstd, dx, dx_in=dx_in.to(dev()), dw=dw, db=db,
+                      accumulate=False)
+    assert rel_l2(dw.cpu(), wr.grad.float()) < 3e-5 and rel_l2(db.cpu(), br.grad.float()) < 3e-5
 
 
 def test_layernorm_strided_token0_and_no_affine():
