@@ -256,6 +256,11 @@ extern "C" int afft_reduce_rows_periodic(const float* src, int64_t lds_, int32_t
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(src && out && period > 0, "reduce_rows_periodic: bad argument");
   if (rows == 0 || d == 0) return 0;
+  // dense rows: row r = k * period + p is row k, columns p*d.. of the [rows/period, period*d] view, so the sums are the
+  // column sums of that view (many workgroups, coalesced); period 1 is a plain column sum at any row stride
+  if (period == 1) return afft_colsum(src, lds_, AFFT_F32, rows, d, out, 1, stream_);
+  if (lds_ == d && ldo == d && rows % period == 0)
+    return afft_colsum(src, (int64_t)period * d, AFFT_F32, rows / period, period * d, out, 1, stream_);
   dim3 grid((d + 255) / 256, period);
   hipLaunchKernelGGL(reduce_rows_periodic_kernel, grid, dim3(256), 0, stream, src, lds_, rows, period, d, out, ldo);
   AFFT_LAUNCH_CHECK();

@@ -72,18 +72,18 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const void* __restrict__ d
                                                       const float* __restrict__ rstd, int rows, int d,
                                                       const float* __restrict__ dx_in, float* __restrict__ dx_out,
                                                       int64_t lddx, bf16_t* __restrict__ dx_bf16,
-                                                      float* __restrict__ partial) {
+                                                      const DropParams drop, int nslab, float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* slab = (float*)smem;                      // [2][d]
-  float* cell = slab + 2 * d;                      // [2 buffers][LNB_RG][LNB_CS][2]
+  float* slab = (float*)smem;                      // [nslab][d]: dw, db (, column sums of the masked copy)
+  float* cell = slab + nslab * d;                  // [2 buffers][LNB_RG][LNB_CS][2]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rg = wave >> 2, cs = wave & 3;
   const int nq = d >> 2, qs = (nq + LNB_CS - 1) / LNB_CS;
   const int q0 = cs * qs, q1 = min(nq, q0 + qs);
-  float4 pw[NV], pb[NV], ww[NV];
+  float4 pw[NV], pb[NV], pc[NV], ww[NV];
 #pragma unroll
   for (int t = 0; t < NV; ++t) {
-    pw[t] = pb[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    pw[t] = pb[t] = pc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int q = q0 + lane + 64 * t;
     ww[t] = (w && q < q1) ? *(const float4*)(w + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
   }
@@ -135,7 +135,15 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const void* __restrict__ d
             o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w;
           }
           *(float4*)(dx_out + idx) = make_float4(o[0], o[1], o[2], o[3]);
-          if (dx_bf16) store4(dx_bf16, idx, AFFT_BF16, o);
+          if (dx_bf16 || nslab == 3) {   // the copy the upstream GEMMs consume: their output-dropout mask replayed
+            if (drop.thresh || drop.path_thresh) {
+              const float prs = drop_row_scale(drop, row);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[r] *= prs * drop_elem_scale(drop, (unsigned)row * (unsigned)d + (unsigned)(4 * q + r));
+            }
+            if (dx_bf16) store4(dx_bf16, idx, AFFT_BF16, o);
+            pc[t].x += o[0]; pc[t].y += o[1]; pc[t].z += o[2]; pc[t].w += o[3];
+          }
         }
       }
     }
@@ -147,37 +155,45 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const void* __restrict__ d
       for (int t = 0; t < NV; ++t) {
         const int q = q0 + lane + 64 * t;
         if (q < q1) {
-          float4 a = pw[t], c = pb[t];
+          float4 a = pw[t], c = pb[t], e = pc[t];
           if (r) {
             const float4 sa = *(const float4*)(slab + 4 * q), sc = *(const float4*)(slab + d + 4 * q);
             a.x += sa.x; a.y += sa.y; a.z += sa.z; a.w += sa.w;
             c.x += sc.x; c.y += sc.y; c.z += sc.z; c.w += sc.w;
+            if (nslab == 3) {
+              const float4 se = *(const float4*)(slab + 2 * d + 4 * q);
+              e.x += se.x; e.y += se.y; e.z += se.z; e.w += se.w;
+            }
           }
           *(float4*)(slab + 4 * q) = a;
           *(float4*)(slab + d + 4 * q) = c;
+          if (nslab == 3) *(float4*)(slab + 2 * d + 4 * q) = e;
         }
       }
     }
     __syncthreads();
   }
-  for (int c = threadIdx.x; c < 2 * d; c += 1024) partial[(int64_t)blockIdx.x * 2 * d + c] = slab[c];
+  for (int c = threadIdx.x; c < nslab * d; c += 1024) partial[(int64_t)blockIdx.x * nslab * d + c] = slab[c];
 }
 
 // 64 columns x 4 part-lanes per workgroup: coalesced 256-B reads, fixed summation order (deterministic)
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nparts, int d,
-                                                            float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nparts, int d, int nslab,
+                                                            float* __restrict__ dw, float* __restrict__ db, int accumulate,
+                                                            float* __restrict__ dcol, int dcol_accumulate) {
   __shared__ float sh[4][64];
   const int col = threadIdx.x & 63, pl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + col;
   float s = 0.f;
-  if (c < 2 * d)
-    for (int p = pl; p < nparts; p += 4) s += partial[(int64_t)p * 2 * d + c];
+  if (c < nslab * d)
+    for (int p = pl; p < nparts; p += 4) s += partial[(int64_t)p * nslab * d + c];
   sh[pl][col] = s;
   __syncthreads();
-  if (pl == 0 && c < 2 * d) {
+  if (pl == 0 && c < nslab * d) {
     s = (sh[0][col] + sh[1][col]) + (sh[2][col] + sh[3][col]);
-    float* dst = c < d ? (dw ? dw + c : nullptr) : (db ? db + (c - d) : nullptr);
-    if (dst) *dst = accumulate ? *dst + s : s;
+    const int which = c / d, k = c - which * d;
+    float* dst = which == 0 ? dw : which == 1 ? db : dcol;
+    const int acc = which == 2 ? dcol_accumulate : accumulate;
+    if (dst) dst[k] = acc ? dst[k] + s : s;
   }
 }
 
@@ -214,8 +230,9 @@ extern "C" int afft_layernorm_fwd(const float* x, int64_t ldx, const float* w, c
 
 extern "C" int afft_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx,
                                   const float* w, const float* mean, const float* rstd, int32_t rows, int32_t d,
-                                  const float* dx_in, float* dx_out, int64_t lddx, void* dx_bf16, float* dw,
-                                  float* db, int32_t accumulate, float* partial, void* stream_) {
+                                  const float* dx_in, float* dx_out, int64_t lddx, void* dx_bf16,
+                                  const afft_dropout_t* copy_drop, float* dw, float* db, int32_t accumulate,
+                                  float* dcol, int32_t dcol_accumulate, float* partial, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(dy && x && mean && rstd && dx_out && partial, "layernorm_bwd: null pointer");
   AFFT_CHECK(d > 0 && d % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "layernorm_bwd: d/ld must be multiples of 4");
@@ -224,13 +241,16 @@ extern "C" int afft_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype
   const int qs = (d / 4 + LNB_CS - 1) / LNB_CS;
   const int nv = qs <= 64 ? 1 : qs <= 128 ? 2 : 4;
   const int grid = afft_layernorm_bwd_nparts(rows);
-  const size_t lds = (size_t)2 * d * sizeof(float) + 2 * LNB_RG * LNB_CS * 2 * sizeof(float);
-#define LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(grid), dim3(1024), lds, stream, dy, lddy, dy_dtype, x, ldx, w, mean, rstd, rows, d, dx_in, dx_out, lddx, (bf16_t*)dx_bf16, partial)
+  const int nslab = dcol ? 3 : 2;
+  const DropParams drop = make_drop(copy_drop);
+  const size_t lds = (size_t)nslab * d * sizeof(float) + 2 * LNB_RG * LNB_CS * 2 * sizeof(float);
+#define LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(grid), dim3(1024), lds, stream, dy, lddy, dy_dtype, x, ldx, w, mean, rstd, rows, d, dx_in, dx_out, lddx, (bf16_t*)dx_bf16, drop, nslab, partial)
   switch (nv) { case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; default: LN_BWD(4); }
 #undef LN_BWD
   AFFT_LAUNCH_CHECK();
-  if (dw || db) {
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * d + 63) / 64), dim3(256), 0, stream, partial, grid, d, dw, db, accumulate);
+  if (dw || db || dcol) {
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((nslab * d + 63) / 64), dim3(256), 0, stream, partial, grid, d, nslab, dw, db,
+                       accumulate, dcol, dcol_accumulate);
     AFFT_LAUNCH_CHECK();
   }
   return 0;

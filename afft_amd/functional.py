@@ -8,7 +8,7 @@ probabilities, losses, master weights and gradients are fp32; GEMM operands are 
 """
 from __future__ import annotations
 
-from typing import List, Optional, Tuple
+from typing import NamedTuple, List, Optional, Tuple
 
 import torch
 
@@ -171,13 +171,95 @@ def flush_ready():
     _PENDING_READY.clear()
 
 
+# --------------------------------------------------------------------------- gradient hand-over between sub-layers
+# The residual-stream gradient dx a sub-layer's backward returns is the dy of the sub-layer that ran before it in the
+# forward pass, whose first two steps are "cast dy to bf16 with my output-dropout mask replayed" and "column-sum that
+# for my output bias".  The LayerNorm-backward kernel that writes dx can emit both on the way (it has the row in
+# registers), which saves a read of dy, a cast kernel and a column-sum kernel per sub-layer.  Who that upstream
+# sub-layer is, is noted in the forward pass (_note_output / _upstream_of, matched on the tensor the two share); the
+# emitted pieces travel in a single-slot hand-over (_SHADOW) that the upstream backward accepts only for the very
+# tensor (storage, shape, version counter) it was made from -- anything else (summed gradients, hooks, a different
+# graph) falls back to the separate kernels.
+class _Up(NamedTuple):
+    ptr: int
+    shape: tuple
+    od: object          # _lib.Dropout or None: the upstream sub-layer's output dropout
+    bias: object        # its output bias parameter (or None)
+
+
+class _Shadow(NamedTuple):
+    ptr: int
+    shape: tuple
+    version: int
+    od: object
+    bias: object
+    act: Act
+    gbias: object       # autograd mode: the bias gradient tensor; sink mode: None (already accumulated)
+
+
+_LAST_OUT: Optional[_Up] = None
+_SHADOW: Optional[_Shadow] = None
+
+
+def _same_drop(a, b) -> bool:
+    if a is None or b is None:
+        return a is None and b is None
+    return (a.p, a.key, a.path_p, a.path_key, a.path_group) == (b.p, b.key, b.path_p, b.path_key, b.path_group)
+
+
+def _note_output(y: Tensor, od, bias):
+    global _LAST_OUT
+    _LAST_OUT = _Up(y.data_ptr(), tuple(y.shape), od, bias) if rt.precision() == "bf16" else None
+
+
+def _upstream_of(x: Tensor) -> Optional[_Up]:
+    u = _LAST_OUT
+    if u is not None and u.ptr == x.data_ptr() and u.shape == tuple(x.shape) and rt.handover():
+        return u
+    return None
+
+
+def _take_shadow(dy: Tensor, od, bias) -> Optional[_Shadow]:
+    global _SHADOW
+    sh, _SHADOW = _SHADOW, None
+    if (sh is not None and sh.ptr == dy.data_ptr() and sh.shape == tuple(dy.shape) and sh.version == dy._version
+            and sh.bias is bias and _same_drop(sh.od, od)):
+        return sh
+    return None
+
+
+def _drop_shadow():
+    global _SHADOW
+    _SHADOW = None
+
+
+def _forget_output():
+    """Called by the forward of every op that is not a sub-layer: the next sub-layer has no sub-layer upstream."""
+    global _LAST_OUT
+    _LAST_OUT = None
+
+
 def _ln_bwd(dy: Tensor, x: Tensor, w: Optional[Tensor], b: Optional[Tensor], mean, rstd, dx_in: Optional[Tensor],
-            dx_out: Optional[Tensor] = None):
-    """returns (dx, dw, db) with dw/db None in sink mode (accumulated in place)."""
+            dx_out: Optional[Tensor] = None, up: Optional[_Up] = None):
+    """returns (dx, dw, db) with dw/db None in sink mode (accumulated in place).  `up`: the sub-layer that consumes dx
+    (see above); its bf16 operand and bias gradient are emitted by the same kernel and left in _SHADOW."""
+    global _SHADOW
     rows, d = x.shape
     if dx_out is None:
         dx_out = torch.empty(rows, d, dtype=torch.float32, device=x.device)
-    if rt.grad_mode() == "sink":
+    sink = rt.grad_mode() == "sink"
+    extra = {}
+    dxa = gbu = None
+    if up is not None and d % 64 == 0 and dx_out.stride(0) == d:
+        dxa = Act(rows, d, x.device)
+        extra = dict(dx_bf16=dxa.live, copy_drop=up.od)
+        if up.bias is not None:
+            if sink:
+                gbu, accu = rt.SINK.grad_buffer(up.bias)
+            else:
+                gbu, accu = torch.empty_like(up.bias), False
+            extra.update(dcol=gbu, dcol_accumulate=accu)
+    if sink:
         gw = gb = None
         acc_w = acc_b = True
         if w is not None:
@@ -188,15 +270,21 @@ def _ln_bwd(dy: Tensor, x: Tensor, w: Optional[Tensor], b: Optional[Tensor], mea
             (gw if not acc_w else gb).zero_()
             acc_w = acc_b = True
         ops.layernorm_bwd(dy, x, w, mean, rstd, dx_out, dx_in=dx_in, dw=gw, db=gb,
-                          accumulate=acc_w if w is not None else acc_b)
+                          accumulate=acc_w if w is not None else acc_b, **extra)
         if w is not None:
             _ready(w)
         if b is not None:
             _ready(b)
-        return dx_out, None, None
-    gw = torch.empty_like(w) if w is not None else None
-    gb = torch.empty_like(b) if b is not None else None
-    ops.layernorm_bwd(dy, x, w, mean, rstd, dx_out, dx_in=dx_in, dw=gw, db=gb, accumulate=False)
+        if gbu is not None:
+            _ready(up.bias)
+        gw = gb = None
+    else:
+        gw = torch.empty_like(w) if w is not None else None
+        gb = torch.empty_like(b) if b is not None else None
+        ops.layernorm_bwd(dy, x, w, mean, rstd, dx_out, dx_in=dx_in, dw=gw, db=gb, accumulate=False, **extra)
+    if dxa is not None:
+        _SHADOW = _Shadow(dx_out.data_ptr(), tuple(dx_out.shape), dx_out._version, up.od, up.bias, dxa,
+                          None if sink else gbu)
     return dx_out, gw, gb
 
 
@@ -228,6 +316,7 @@ class AttnSublayer(torch.autograd.Function):
         R, d = x.shape
         nseq, hd = R // L, d // H
         dev = x.device
+        ctx.up = _upstream_of(x) if pre_ln else None
         mean, rstd = _stats(R if pre_ln else 0, dev)
         if pre_ln:
             xn = Act(R, d, dev)
@@ -247,6 +336,7 @@ class AttnSublayer(torch.autograd.Function):
         ctx.acts = (xn, qkv, ao)
         ctx.cfg = (L, H, scale, conv1d, pre_ln, drop)
         ctx.mark_non_differentiable(probs)
+        _note_output(y, _out_drop(drop), b_proj)
         return y, probs
 
     @staticmethod
@@ -259,10 +349,11 @@ class AttnSublayer(torch.autograd.Function):
         dev = x.device
         dy = dy.contiguous()
         od = _out_drop(drop)
-        dya = to_act(dy, od)
+        sh = _take_shadow(dy, od, b_proj)
+        dya = sh.act if sh is not None else to_act(dy, od)
         with _Side(dev):
             g_wp = _wgrad(dya, ao, w_proj, conv1d)
-            g_bp = _bgrad(dy if od is None else dya.live, b_proj)
+            g_bp = sh.gbias if sh is not None else _bgrad(dy if od is None else dya.live, b_proj)
         dao = Act(R, d, dev)
         _lin_dgrad(dya, w_proj, conv1d, dao.live)
         dqkv = Act(R, 3 * d, dev)
@@ -274,7 +365,7 @@ class AttnSublayer(torch.autograd.Function):
         if pre_ln:
             dxn = Act(R, d, dev)
             _lin_dgrad(dqkv, w_qkv, conv1d, dxn.live)
-            dx, g_lw, g_lb = _ln_bwd(dxn.live, x, ln_w, ln_b, mean, rstd, dx_in=dy)
+            dx, g_lw, g_lb = _ln_bwd(dxn.live, x, ln_w, ln_b, mean, rstd, dx_in=dy, up=ctx.up)
         else:
             dx = torch.empty(R, d, dtype=torch.float32, device=dev)
             _lin_dgrad(dqkv, w_qkv, conv1d, dx)
@@ -295,6 +386,7 @@ class MLPSublayer(torch.autograd.Function):
         dev = x.device
         hidden = w1.shape[1] if conv1d else w1.shape[0]
         d_out = w2.shape[1] if conv1d else w2.shape[0]
+        ctx.up = _upstream_of(x) if pre_ln else None
         mean, rstd = _stats(R if pre_ln else 0, dev)
         if pre_ln:
             xn = Act(R, d, dev)
@@ -308,6 +400,7 @@ class MLPSublayer(torch.autograd.Function):
         ctx.save_for_backward(x, ln_w, ln_b, w1, b1, w2, b2, mean, rstd)
         ctx.acts = (xn, u, h)
         ctx.cfg = (gelu, conv1d, hidden, pre_ln, drop)
+        _note_output(y, _out_drop(drop), b2)
         return y
 
     @staticmethod
@@ -319,10 +412,11 @@ class MLPSublayer(torch.autograd.Function):
         dev = x.device
         dy = dy.contiguous()
         od = _out_drop(drop)
-        dya = to_act(dy, od)
+        sh = _take_shadow(dy, od, b2)
+        dya = sh.act if sh is not None else to_act(dy, od)
         with _Side(dev):
             g_w2 = _wgrad(dya, h, w2, conv1d)
-            g_b2 = _bgrad(dy if od is None else dya.live, b2)
+            g_b2 = sh.gbias if sh is not None else _bgrad(dy if od is None else dya.live, b2)
         du = Act(R, hidden, dev)
         _lin_dgrad(dya, w2, conv1d, du.live, act=_GELU[gelu][1], aux=u.live)
         with _Side(dev):
@@ -331,7 +425,7 @@ class MLPSublayer(torch.autograd.Function):
         if pre_ln:
             dxn = Act(R, d, dev)
             _lin_dgrad(du, w1, conv1d, dxn.live)
-            dx, g_lw, g_lb = _ln_bwd(dxn.live, x, ln_w, ln_b, mean, rstd, dx_in=dy)
+            dx, g_lw, g_lb = _ln_bwd(dxn.live, x, ln_w, ln_b, mean, rstd, dx_in=dy, up=ctx.up)
         else:
             dx = torch.empty(R, d, dtype=torch.float32, device=dev)
             _lin_dgrad(du, w1, conv1d, dx)
@@ -353,6 +447,7 @@ class CrossAttnSublayer(torch.autograd.Function):
         R, d = x.shape
         nseq, hd = R // L, d // H
         dev = x.device
+        ctx.up = _upstream_of(x) if pre_ln else None
         mq, rq = _stats(R if pre_ln else 0, dev)
         mk, rk = _stats(R if pre_ln else 0, dev)
         if pre_ln:
@@ -375,6 +470,7 @@ class CrossAttnSublayer(torch.autograd.Function):
         ctx.save_for_backward(x, mem, nq_w, nq_b, nkv_w, nkv_b, w_q, w_k, w_v, w_proj, b_proj, mq, rq, mk, rk, probs)
         ctx.acts = (xq, mkv, q, k, v, ao)
         ctx.cfg = (L, H, scale, pre_ln, drop)
+        _note_output(y, _out_drop(drop), b_proj)
         return y
 
     @staticmethod
@@ -387,10 +483,11 @@ class CrossAttnSublayer(torch.autograd.Function):
         dev = x.device
         dy = dy.contiguous()
         od = _out_drop(drop)
-        dya = to_act(dy, od)
+        sh = _take_shadow(dy, od, b_proj)
+        dya = sh.act if sh is not None else to_act(dy, od)
         with _Side(dev):
             g_wp = _wgrad(dya, ao, w_proj, False)
-            g_bp = _bgrad(dy if od is None else dya.live, b_proj)
+            g_bp = sh.gbias if sh is not None else _bgrad(dy if od is None else dya.live, b_proj)
         dao = Act(R, d, dev)
         _lin_dgrad(dya, w_proj, False, dao.live)
         dq, dk, dv = Act(R, d, dev), Act(R, d, dev), Act(R, d, dev)
@@ -406,8 +503,8 @@ class CrossAttnSublayer(torch.autograd.Function):
         if pre_ln:
             dxq = Act(R, d, dev)
             _lin_dgrad(dq, w_q, False, dxq.live)
-            dx, g_qw, g_qb = _ln_bwd(dxq.live, x, nq_w, nq_b, mq, rq, dx_in=dy)
             dmem, g_kw, g_kb = _ln_bwd(dmkv, mem, nkv_w, nkv_b, mk, rk, dx_in=None)
+            dx, g_qw, g_qb = _ln_bwd(dxq.live, x, nq_w, nq_b, mq, rq, dx_in=dy, up=ctx.up)
         else:
             dx = torch.empty(R, d, dtype=torch.float32, device=dev)
             _lin_dgrad(dq, w_q, False, dx)
@@ -427,6 +524,7 @@ class Linear(torch.autograd.Function):
     def forward(ctx, x, W, b, in_drop=None):
         rows = x.shape[0]
         n_out = W.shape[0]
+        _forget_output()
         xa = to_act(x, in_drop)   # Dropout(p) on the input: classifier (future_prediction.py:108)
         ctx.in_drop = in_drop
         ybuf = torch.empty(rows, rt.pad64(n_out) if n_out % 4 else n_out, dtype=torch.float32, device=x.device)
@@ -440,6 +538,7 @@ class Linear(torch.autograd.Function):
     def backward(ctx, dy):
         W, b = ctx.saved_tensors
         xa = ctx.xa
+        _drop_shadow()
         dya = to_act(dy)
         with _Side(dy.device):
             g_w = _wgrad(dya, xa, W, False)
@@ -465,6 +564,7 @@ class LayerNormRows(torch.autograd.Function):
     def forward(ctx, X, w, b, eps, stride_rows):
         Rall, d = X.shape
         rows = Rall // stride_rows
+        _forget_output()
         xv = X.view(rows, stride_rows * d)[:, :d]
         mean, rstd = _stats(rows, X.device)
         y = torch.empty(rows, d, dtype=torch.float32, device=X.device)
@@ -476,6 +576,7 @@ class LayerNormRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         X, w, b, mean, rstd = ctx.saved_tensors
+        _drop_shadow()
         s = ctx.stride_rows
         Rall, d = X.shape
         rows = Rall // s
@@ -498,6 +599,7 @@ class AssembleTokens(torch.autograd.Function):
     def forward(ctx, token, mod_embed, T, frame_level, *feats):
         BT, d = feats[0].shape
         S = len(feats) + 1
+        _forget_output()
         X = torch.empty(BT * S, d, dtype=torch.float32, device=feats[0].device)
         tok2d = token.view(-1, d)
         ops.assemble_tokens(list(feats), tok2d, d if frame_level else 0,
@@ -510,6 +612,7 @@ class AssembleTokens(torch.autograd.Function):
     def backward(ctx, dX):
         token, mod_embed = ctx.saved_tensors
         T, frame_level, S, BT, d, needs = ctx.cfg
+        _drop_shadow()
         dX = dX.contiguous()
         dX3 = dX.view(BT, S * d)
         g_tok = g_emb = None
@@ -548,6 +651,7 @@ class AddRowTable(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, table, period, offset):
+        _forget_output()
         y = torch.empty_like(x)
         ops.add_rows_periodic(x, table[offset:offset + period], period, y)
         ctx.save_for_backward(table)
@@ -558,6 +662,7 @@ class AddRowTable(torch.autograd.Function):
     def backward(ctx, dy):
         (table,) = ctx.saved_tensors
         period, offset = ctx.cfg
+        _drop_shadow()
         dy = dy.contiguous()
         if rt.grad_mode() == "sink":
             g, acc = rt.SINK.grad_buffer(table)
@@ -578,6 +683,7 @@ class ElementDropout(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, desc):
+        _forget_output()
         y = torch.empty_like(x)
         ops.cast(x, y, drop=desc)
         ctx.desc = desc

@@ -96,11 +96,13 @@ def layernorm_fwd(x: Tensor, w: Optional[Tensor], b: Optional[Tensor], eps: floa
 
 def layernorm_bwd(dy: Tensor, x: Tensor, w: Optional[Tensor], mean: Tensor, rstd: Tensor, dx_out: Tensor,
                   dx_in: Optional[Tensor] = None, dx_bf16: Optional[Tensor] = None, dw: Optional[Tensor] = None,
-                  db: Optional[Tensor] = None, accumulate: bool = True) -> Tensor:
-    """dw / db (optional) receive the weight / bias gradients: added to when `accumulate`, else overwritten."""
+                  db: Optional[Tensor] = None, accumulate: bool = True, copy_drop: Optional["L.Dropout"] = None,
+                  dcol: Optional[Tensor] = None, dcol_accumulate: bool = True) -> Tensor:
+    """dw / db (optional) receive the weight / bias gradients: added to when `accumulate`, else overwritten.
+    dx_bf16 (optional): bf16 copy of dx_out with the mask `copy_drop` replayed; dcol (optional): its column sums."""
     rows, d = x.shape
     nparts = L.lib().afft_layernorm_bwd_nparts(rows)
-    partial = torch.empty(nparts * 2 * d, dtype=torch.float32, device=x.device)
+    partial = torch.empty(nparts * 3 * d, dtype=torch.float32, device=x.device)
     lddx = _rowmajor(dx_out, "dx_out")
     if dx_in is not None:
         assert _rowmajor(dx_in, "dx_in") == lddx
@@ -108,7 +110,9 @@ def layernorm_bwd(dy: Tensor, x: Tensor, w: Optional[Tensor], mean: Tensor, rstd
         assert dx_bf16.dtype == torch.bfloat16 and _rowmajor(dx_bf16, "dx_bf16") == lddx
     L.check(L.lib().afft_layernorm_bwd(_p(dy), _rowmajor(dy, "dy"), _dt(dy), _p(x), _rowmajor(x, "x"), _p(w),
                                        _p(mean), _p(rstd), rows, d, _p(dx_in), _p(dx_out), lddx, _p(dx_bf16),
-                                       _p(dw), _p(db), 1 if accumulate else 0, _p(partial), _stream()), "layernorm_bwd")
+                                       C.byref(copy_drop) if copy_drop is not None else None,
+                                       _p(dw), _p(db), 1 if accumulate else 0, _p(dcol), 1 if dcol_accumulate else 0,
+                                       _p(partial), _stream()), "layernorm_bwd")
     return dx_out
 
 

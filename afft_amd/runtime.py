@@ -184,6 +184,20 @@ def set_overlap_wgrad(on: bool):
     _OVERLAP_WGRAD = bool(on)
 
 
+_HANDOVER = os.environ.get("AFFT_HANDOVER", "1") != "0"
+
+
+def handover() -> bool:
+    """Let a sub-layer's LayerNorm-backward kernel also emit the bf16 operand and the output-bias gradient of the
+    sub-layer upstream of it (afft_amd/functional.py, "gradient hand-over"); off: separate cast / column-sum kernels."""
+    return _HANDOVER
+
+
+def set_handover(on: bool):
+    global _HANDOVER
+    _HANDOVER = bool(on)
+
+
 def empty(*shape, dtype=torch.float32, device=None) -> Tensor:
     return torch.empty(*shape, dtype=dtype, device=device)
 

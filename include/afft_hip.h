@@ -89,13 +89,17 @@ int afft_layernorm_fwd(const float* x, int64_t ldx, const float* w, const float*
                        float* mean, float* rstd, void* stream);
 /* dx_out[r] = (dx_in ? dx_in[r] : 0) + LN'(dy)[r]; dw/db are written (accumulate = 0) or added to (+=).
  * dy dtype selectable.
- * dx_bf16 (optional) receives a bf16 copy of dx_out (feeds the next dgrad/wgrad GEMMs).
- * partial: fp32 workspace of at least 2*d*afft_layernorm_bwd_nparts(rows) floats. */
+ * dx_bf16 (optional) receives a bf16 copy of dx_out with the dropout / DropPath mask `copy_drop` (optional) replayed
+ * on it: the operand of the dgrad/wgrad GEMMs of the sub-layer that produced this LayerNorm's input, whose output
+ * dropout it is.  dcol (optional, fp32 [d]) receives the column sums of that masked copy (= that sub-layer's output
+ * bias gradient), written or added to per dcol_accumulate.
+ * partial: fp32 workspace of at least 3*d*afft_layernorm_bwd_nparts(rows) floats. */
 int afft_layernorm_bwd_nparts(int32_t rows);
 int afft_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx,
                        const float* w, const float* mean, const float* rstd,
                        int32_t rows, int32_t d, const float* dx_in, float* dx_out, int64_t lddx,
-                       void* dx_bf16, float* dw, float* db, int32_t accumulate, float* partial, void* stream);
+                       void* dx_bf16, const afft_dropout_t* copy_drop, float* dw, float* db, int32_t accumulate,
+                       float* dcol, int32_t dcol_accumulate, float* partial, void* stream);
 
 /* ------------------------------------------------------------------ small-sequence attention
  * softmax(q k^T * scale + mask) v per (sequence, head); L <= 32 tokens per sequence.

@@ -347,6 +347,18 @@ def test_mse_and_elementwise():
     acc = torch.ones(T, dd, device=dev())
     ops.reduce_rows_periodic(x.to(dev()), T, acc)
     assert rel_l2(acc.cpu() - 1.0, x.view(B, T, dd).sum(0)) < 1e-5
+    # strided source rows (token 0 of every frame), period 1 and period T; ragged row count (rows % period != 0)
+    xs = rnd(B * T, 3 * dd, seed=33)
+    acc1 = torch.zeros(1, dd, device=dev())
+    ops.reduce_rows_periodic(xs.to(dev())[:, :dd], 1, acc1)
+    assert rel_l2(acc1.cpu()[0], xs[:, :dd].sum(0)) < 1e-5
+    accT = torch.zeros(T, dd, device=dev())
+    ops.reduce_rows_periodic(xs.to(dev())[:, :dd], T, accT)
+    assert rel_l2(accT.cpu(), xs[:, :dd].reshape(B, T, dd).sum(0)) < 1e-5
+    accR = torch.zeros(T, dd, device=dev())
+    ops.reduce_rows_periodic(x.to(dev())[:B * T - 3], T, accR)
+    refR = torch.cat([x[:B * T - 3], torch.zeros(3, dd)]).view(B, T, dd).sum(0)
+    assert rel_l2(accR.cpu(), refR) < 1e-5
 
     # Nesterov SGD vs torch.optim.SGD
     n = 1000 + 3

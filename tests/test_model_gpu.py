@@ -138,6 +138,52 @@ def test_autograd_grad_mode_equals_sink():
         assert rel_l2(grads["autograd"][k], grads["sink"][k]) < 1e-5, k
 
 
+@pytest.mark.parametrize("name,train", [("t0_sa", True), ("t0_sa", False), ("t1_ca", True), ("t3_m5", False)])
+def test_gradient_handover_equals_separate_kernels(name, train):
+    """The LayerNorm-backward kernel emitting the upstream sub-layer's bf16 operand (dropout mask replayed) and its
+    output-bias gradient must give the same parameter gradients as the separate cast / column-sum kernels."""
+    import afft_amd
+    from afft_amd import dropout as D_, functional as F_, runtime as rt
+    from afft_amd.common.runner import BasicLossAccuracy, Runner
+    c, state, data, tgt, sub = case_tensors(name)
+    dev = torch.device("cuda:0")
+    grads = {}
+    taken = {}
+    real_take = F_._take_shadow
+    try:
+        for on in (True, False):
+            rt.set_handover(on)
+            rt.set_grad_mode("sink")
+            model = build(c, "bf16")
+            model.load_state_dict(state)
+            model = model.cuda()
+            model.train(train)
+            D_.manual_seed(11)
+            hits = []
+
+            def counting_take(dy, od, bias, _hits=hits):
+                sh = real_take(dy, od, bias)
+                _hits.append(sh is not None)
+                return sh
+            F_._take_shadow = counting_take
+            rt.SINK.begin_step()
+            out, out_t = model({m: d.to(dev) for m, d in data.items()}, mixup_fn=None, target={"action": tgt.to(dev)},
+                               target_subclips={"action": sub.to(dev)}, target_subclips_ignore_index=None)
+            losses, _ = BasicLossAccuracy(False)(out, out_t["target"], out_t["target_subclips"])
+            total, _ = Runner._reduce_loss(losses, {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}, sync=False)
+            total.backward()
+            rt.SINK.finish_step(list(model.parameters()))
+            grads[on] = {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters()}
+            taken[on] = sum(hits)
+    finally:
+        F_._take_shadow = real_take
+        rt.set_handover(True)
+    assert taken[True] > 0 and taken[False] == 0      # the fused path really ran (and only when enabled)
+    for k in grads[True]:
+        tol = 3e-3 if k.endswith("bias") else 2e-5    # bias: fp32 sums of the masked row vs sums of its bf16 rounding
+        assert rel_l2(grads[True][k], grads[False][k]) < tol, (k, rel_l2(grads[True][k], grads[False][k]))
+
+
 def test_train_mode_dropout_statistics():
     """Train mode: dropout/DropPath are active (outputs differ from eval, differ between steps), finite, and the
     backward pass replays the forward masks (checked on a Linear with input dropout by finite differences)."""
