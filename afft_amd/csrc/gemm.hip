@@ -51,13 +51,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf1
 
   const int nk = g.K / BK / g.splitk;          // K-steps of this slice
   const int kbase = blockIdx.y * nk * BK;      // split-K: slice z = blockIdx.y
+  static_assert(BM == 128 && BN == 128, "staging helpers assume 128-row / 128-column operand tiles");
+  const unsigned lds0 = lds_addr(smem);
+  const unsigned lda2 = (unsigned)(g.lda * 2), ldb2 = (unsigned)(g.ldb * 2);
+  const LaneOffsets lo = lane_offsets(wave, lane);
+  const unsigned voffA = A_KS ? lo.ks_row * lda2 + lo.ks_c16 : lo.kc_row * lda2 + lo.kc_chunk16;
+  const unsigned voffB = B_KS ? lo.ks_row * ldb2 + lo.ks_c16 : lo.kc_row * ldb2 + lo.kc_chunk16;
   auto stage = [&](int kt) {
-    char* a = smem + (kt % STAGES) * STAGE_BYTES;
-    char* b = a + A_BYTES;
-    if constexpr (A_KS) stage_ks<BM, NW>(g.A, g.lda, m0, kbase + kt * BK, a, wave, lane);
-    else stage_kc<BM, NW>(g.A, g.lda, m0, M, kbase + kt * BK, a, wave, lane);
-    if constexpr (B_KS) stage_ks<BN, NW>(g.B, g.ldb, n0, kbase + kt * BK, b, wave, lane);
-    else stage_kc<BN, NW>(g.B, g.ldb, n0, N, kbase + kt * BK, b, wave, lane);
+    const unsigned a = lds0 + (kt % STAGES) * STAGE_BYTES;
+    const unsigned b = a + A_BYTES;
+    if constexpr (A_KS) stage_ks<NW, 16 / NW>(g.A, g.lda, lda2, voffA, lo, m0, kbase + kt * BK, a, wave);
+    else stage_kc<NW, 16 / NW>(g.A, g.lda, lda2, voffA, lo, m0, M, kbase + kt * BK, a, wave);
+    if constexpr (B_KS) stage_ks<NW, 16 / NW>(g.B, g.ldb, ldb2, voffB, lo, n0, kbase + kt * BK, b, wave);
+    else stage_kc<NW, 16 / NW>(g.B, g.ldb, ldb2, voffB, lo, n0, N, kbase + kt * BK, b, wave);
   };
   // wait until all but the `ahead` most recently issued tiles of this wave have landed, then rendezvous
   auto wait_tiles_then_barrier = [&](int ahead) {
@@ -244,7 +250,6 @@ int launch_layout(GemmFast& g, hipStream_t stream) {
       g.e.atomic = 1;
     }
   }
-  if (variant == 2) return launch_fast<4, 2, 3, A_KS, B_KS>(g, stream);
   return launch_fast<2, 2, 2, A_KS, B_KS>(g, stream);
 }
 
@@ -268,7 +273,7 @@ extern "C" int afft_gemm_variant_for(int M, int N, int K, int a_kstrided, int b_
 extern "C" int afft_set_gemm_splitk(int on) { g_splitk_enabled = on ? 1 : 0; return 0; }
 
 extern "C" int afft_set_gemm_variant(int v) {
-  if (v < 0 || v > 3) { afft_set_error("afft_set_gemm_variant: %d not in 0..3", v); return 1; }
+  if (v != 0 && v != 1 && v != 3) { afft_set_error("afft_set_gemm_variant: %d is not 0 (auto), 1 (128x128) or 3 (256x256 ping-pong)", v); return 1; }
   g_variant = v;
   return 0;
 }

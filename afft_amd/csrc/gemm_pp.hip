@@ -83,48 +83,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
     for (int a = 0; a < 2; ++a) for (int j = 0; j < 2; ++j) for (int s = 0; s < 2; ++s) for (int e = 0; e < 8; ++e) bF[a][j][s][e] = (short)(lane * 11 + j);
   }
 
-  // ---- LDS-DMA staging, scalar-base form: global_load_lds_dwordx4 voff32, s[base:base+1] with M0 = LDS destination.
-  // Every lane-dependent part of a source address is one loop-invariant 32-bit VGPR per operand (row-in-piece * pitch
-  // + swizzled 16-byte chunk); the piece's first row, the K offset and the edge clamps are wave-uniform SALU work.
-  // (The per-lane 64-bit pointers the builtin needs cost 2 VGPRs per piece kind and pushed the kernel into scratch.)
-  const unsigned lds0 = (unsigned)(size_t)(AFFT_LDS char*)smem;
+  // LDS-DMA staging (gemm_tiles.h): one lane-offset VGPR per operand, scalar bases
+  const unsigned lds0 = lds_addr(smem);
   const unsigned lda2 = (unsigned)(g.lda * 2), ldb2 = (unsigned)(g.ldb * 2);
-  // k-contiguous image: piece j = rows 8j..8j+7, lane -> row (lane>>3), chunk (lane&7) ^ ((row>>1)&7)
-  const unsigned kc_row = lane >> 3;
-  const unsigned kc_chunk16 = (unsigned)(((lane & 7) ^ (((wave & 1) << 2) + (lane >> 4))) << 4);
-  // k-strided image: piece j = k-rows 4j..4j+3 of 128 columns, lane -> row (lane>>4), 16-B chunk c16 = lane&15 at
-  // source chunk ((c16>>1) ^ f(row)) << 1 | (c16&1), f(row) = (row&3) | ((row>>3)&1) << 2
-  const unsigned ks_row = lane >> 4;
-  const unsigned ks_c16 = (unsigned)((((((lane & 15) >> 1) ^ ((lane >> 4) | (((wave >> 1) & 1) << 2))) << 1) | (lane & 1)) << 4);
-  const unsigned voffA = A_KS ? ks_row * lda2 + ks_c16 : kc_row * lda2 + kc_chunk16;
-  const unsigned voffB = B_KS ? ks_row * ldb2 + ks_c16 : kc_row * ldb2 + kc_chunk16;
-  auto glds = [&](const char* sbase, unsigned voff, unsigned dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(dst) : "memory");
-  };
-  auto stage_half_kc = [&](const bf16_t* G, int64_t ld, unsigned ld2, unsigned voff_full, int row0, int nrows, int k0,
-                           unsigned dst) {
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-      const int j = wave + jj * 8;
-      const int pb = min(row0 + j * 8, nrows - 1);          // tail pieces re-read valid rows; the epilogue drops them
-      const int lim = nrows - 1 - pb;
-      const char* sbase = (const char*)(G + (int64_t)pb * ld + k0);
-      unsigned voff = voff_full;
-      if (lim < 7) voff = min(kc_row, (unsigned)lim) * ld2 + kc_chunk16;
-      glds(sbase, voff, dst + j * 1024);
-    }
-  };
-  auto stage_half_ks = [&](const bf16_t* G, int64_t ld, unsigned ld2, unsigned voff_full, int col0, int k0, unsigned dst) {
-    const int limc = ((int)ld - 8 - col0) * 2;              // last 16-byte chunk that stays inside the row
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-      const int j = wave + jj * 8;
-      const char* sbase = (const char*)(G + (int64_t)(k0 + j * 4) * ld + col0);
-      unsigned voff = voff_full;
-      if (limc < 240) voff = ks_row * ld2 + min(ks_c16, (unsigned)max(limc, 0));
-      glds(sbase, voff, dst + j * 1024);
-    }
-  };
+  const LaneOffsets lo = lane_offsets(wave, lane);
+  const unsigned voffA = A_KS ? lo.ks_row * lda2 + lo.ks_c16 : lo.kc_row * lda2 + lo.kc_chunk16;
+  const unsigned voffB = B_KS ? lo.ks_row * ldb2 + lo.ks_c16 : lo.kc_row * ldb2 + lo.kc_chunk16;
   bool in_loop = false; (void)in_loop;
   auto issue = [&](int m, int q) {   // q = m & 3 (compile-time at every call site)
     if (m >= NH) return;
@@ -133,12 +97,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
     const unsigned dst = lds0 + ((kt & 1) * 4 + q) * HB;
     if (q == 0 || q == 3) {
       const int r0 = m0l + (q == 3 ? 128 : 0);
-      if constexpr (A_KS) stage_half_ks(g.A, g.lda, lda2, voffA, r0, kt * BK, dst);
-      else stage_half_kc(g.A, g.lda, lda2, voffA, r0, M, kt * BK, dst);
+      if constexpr (A_KS) stage_ks<8, 2>(g.A, g.lda, lda2, voffA, lo, r0, kt * BK, dst, wave);
+      else stage_kc<8, 2>(g.A, g.lda, lda2, voffA, lo, r0, M, kt * BK, dst, wave);
     } else {
       const int c0 = n0l + (q == 2 ? 128 : 0);
-      if constexpr (B_KS) stage_half_ks(g.B, g.ldb, ldb2, voffB, c0, kt * BK, dst);
-      else stage_half_kc(g.B, g.ldb, ldb2, voffB, c0, N, kt * BK, dst);
+      if constexpr (B_KS) stage_ks<8, 2>(g.B, g.ldb, ldb2, voffB, lo, c0, kt * BK, dst, wave);
+      else stage_kc<8, 2>(g.B, g.ldb, ldb2, voffB, lo, c0, N, kt * BK, dst, wave);
     }
   };
   auto load_a = [&](int kt, int ih) {

@@ -37,45 +37,69 @@ __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int& tm, i
   tn = in_group / gsz;
 }
 
-// ----- k-contiguous image: tile [ROWS][64 k] bf16, 128 B per row; 16-B chunk c of row r lives at chunk c ^ ((r>>1)&7)
-template <int ROWS, int NWAVES>
-__device__ __forceinline__ void stage_kc(const bf16_t* __restrict__ G, int64_t ld, int row0, int nrows, int k0,
-                                         char* lds_tile, int wave, int lane) {
+// ----- LDS-DMA staging, scalar-base form: global_load_lds_dwordx4 voff32, s[base:base+1] with M0 = LDS destination.
+// A 1-KiB piece is one wave-instruction (64 lanes x 16 B, lane-linear in LDS).  Everything lane-dependent in a source
+// address is ONE loop-invariant 32-bit VGPR per operand (row-in-piece * pitch + swizzled 16-byte chunk); the piece's
+// first row, the K offset and the edge clamps are wave-uniform SALU work.  (Per-lane 64-bit pointers, which the
+// __builtin_amdgcn_global_load_lds form needs, cost 2 VGPRs per piece kind and 2 VALU per piece.)
+// Pieces are dealt to the NW waves of the workgroup round-robin: wave w stages pieces w, w + NW, ...
+//
+// k-contiguous image: tile [ROWS][64 k] bf16, 128 B per row; 16-B chunk c of row r lives at chunk c ^ ((r>>1)&7);
+//   piece j = rows 8j..8j+7, lane -> row (lane>>3), chunk (lane&7)
+// k-strided image: tile [64 k][128 cols] bf16, 256 B per row; 32-B unit u of row r lives at unit u ^ f(r),
+//   f(r) = (r&3) | ((r>>3)&1)<<2 (the two 4-row blocks a 32-lane half reads by ds_read_b64_tr_b16 hit 8 distinct units);
+//   piece j = k-rows 4j..4j+3, lane -> row (lane>>4), 16-B chunk (lane&15)
+struct LaneOffsets {
+  unsigned kc_row, kc_chunk16;   // k-contiguous: row inside the piece, byte offset of the (swizzled) source chunk
+  unsigned ks_row, ks_c16;       // k-strided:    k-row inside the piece, byte offset of the (swizzled) source chunk
+};
+__device__ __forceinline__ LaneOffsets lane_offsets(int wave, int lane) {   // NW even: (j & 1), ((j >> 1) & 1) = wave's
+  LaneOffsets o;
+  o.kc_row = lane >> 3;
+  o.kc_chunk16 = (unsigned)(((lane & 7) ^ (((wave & 1) << 2) + (lane >> 4))) << 4);
+  o.ks_row = lane >> 4;
+  o.ks_c16 = (unsigned)((((((lane & 15) >> 1) ^ ((lane >> 4) | (((wave >> 1) & 1) << 2))) << 1) | (lane & 1)) << 4);
+  return o;
+}
+__device__ __forceinline__ void glds16(const char* sbase, unsigned voff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(AFFT_LDS const char*)p; }
+
+// rows row0.. of a k-contiguous operand G[nrows][ld], K offset k0 -> PIECES pieces of this wave at LDS address dst
+template <int NW, int PIECES>
+__device__ __forceinline__ void stage_kc(const bf16_t* __restrict__ G, int64_t ld, unsigned ld2, unsigned voff_full,
+                                         const LaneOffsets& lo, int row0, int nrows, int k0, unsigned dst, int wave) {
 #pragma unroll
-  for (int jj = 0; jj < ROWS / 8 / NWAVES; ++jj) {
-    const int j = wave + jj * NWAVES;     // 1-KiB piece = 8 rows
-    const int row = j * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    int grow = row0 + row;
-    grow = grow < nrows ? grow : nrows - 1;  // tail rows: re-read a valid row, result discarded by the epilogue
-    const bf16_t* src = G + (int64_t)grow * ld + k0 + chunk * 8;
-    __builtin_amdgcn_global_load_lds((const AFFT_GLOBAL void*)src, (AFFT_LDS void*)(lds_tile + j * 1024), 16, 0, 0);
+  for (int jj = 0; jj < PIECES; ++jj) {
+    const int j = wave + jj * NW;
+    const int pb = min(row0 + j * 8, nrows - 1);          // tail pieces re-read valid rows; the epilogue drops them
+    const int lim = nrows - 1 - pb;
+    const char* sbase = (const char*)(G + (int64_t)pb * ld + k0);
+    unsigned voff = voff_full;
+    if (lim < 7) voff = min(lo.kc_row, (unsigned)lim) * ld2 + lo.kc_chunk16;
+    glds16(sbase, voff, dst + j * 1024);
+  }
+}
+// columns col0..col0+127 of a k-strided operand G[K][ld], K rows k0..k0+63
+template <int NW, int PIECES>
+__device__ __forceinline__ void stage_ks(const bf16_t* __restrict__ G, int64_t ld, unsigned ld2, unsigned voff_full,
+                                         const LaneOffsets& lo, int col0, int k0, unsigned dst, int wave) {
+  const int limc = ((int)ld - 8 - col0) * 2;              // last 16-byte chunk that stays inside the row
+#pragma unroll
+  for (int jj = 0; jj < PIECES; ++jj) {
+    const int j = wave + jj * NW;
+    const char* sbase = (const char*)(G + (int64_t)(k0 + j * 4) * ld + col0);
+    unsigned voff = voff_full;
+    if (limc < 240) voff = lo.ks_row * ld2 + min(lo.ks_c16, (unsigned)max(limc, 0));
+    glds16(sbase, voff, dst + j * 1024);
   }
 }
 __device__ __forceinline__ bf16x8 frag_kc(const char* lds_tile, int row, int chunk) {
   return *(const bf16x8*)(lds_tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
 
-// ----- k-strided image: tile [64 k][COLS] bf16, 2*COLS B per row; 32-B unit u of row r lives at unit u ^ f(r),
-//       f(r) = (r&3) | ((r>>3)&1)<<2 : the two 4-row blocks a 32-lane half reads by ds_read_b64_tr_b16 hit 8 distinct units
 __device__ __forceinline__ int ks_f(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
-template <int COLS, int NWAVES>
-__device__ __forceinline__ void stage_ks(const bf16_t* __restrict__ G, int64_t ld, int col0, int k0,
-                                         char* lds_tile, int wave, int lane) {
-  constexpr int CH = COLS / 8;            // 16-B chunks per row (16 or 32)
-  constexpr int RPP = 64 / CH;            // rows per 1-KiB piece
-#pragma unroll
-  for (int jj = 0; jj < COLS / 8 / NWAVES; ++jj) {
-    const int j = wave + jj * NWAVES;
-    const int row = j * RPP + lane / CH;
-    const int c16 = lane % CH;
-    const int src_c16 = (((c16 >> 1) ^ ks_f(row)) << 1) | (c16 & 1);
-    int64_t col = col0 + src_c16 * 8;
-    col = col < ld - 8 ? col : ld - 8;     // tail columns: stay inside the row, result discarded
-    const bf16_t* src = G + (int64_t)(k0 + row) * ld + col;
-    __builtin_amdgcn_global_load_lds((const AFFT_GLOBAL void*)src, (AFFT_LDS void*)(lds_tile + j * 1024), 16, 0, 0);
-  }
-}
 // fragment for MFMA 16x16x32: lane (g = lane>>4, r = lane&15) needs tile[k = kb + 8g + j][16*unit + r], j = 0..7
 template <int COLS>
 __device__ __forceinline__ bf16x8 frag_ks(const char* lds_tile, int kb, int unit, int lane) {

@@ -70,12 +70,12 @@ typedef struct {
   afft_dropout_t drop;               /* dropout / DropPath on the output (train mode), p = 0 -> off */
 } afft_gemm_t;
 int afft_gemm(const afft_gemm_t* g, void* stream);
-/* Tuning / test hook: force the bf16 tile shape (0 = auto, 1 = 128x128x64 2-stage, 2 = 256x128x64 3-stage). */
+/* Tuning / test hook: force the bf16 tile shape (0 = auto, 1 = 128x128x64 2-stage, 3 = 256x256x64 ping-pong). */
 int afft_set_gemm_variant(int variant);
 /* Split-K for small grids (fp32 outputs with a linear epilogue; partial sums via float atomics).  Off by default:
  * measured 10-60 % slower than the plain launch on the GPT-2 shapes (atomic traffic + zero-fill). */
 int afft_set_gemm_splitk(int on);
-/* Which bf16 tile shape afft_gemm picks for a fast-path problem (1 / 2 / 3 as above); used by bench.py to attribute
+/* Which bf16 tile shape afft_gemm picks for a fast-path problem (1 / 3 as above); used by bench.py to attribute
  * launches to kernel symbols. */
 int afft_gemm_variant_for(int M, int N, int K, int a_kstrided, int b_kstrided);
 

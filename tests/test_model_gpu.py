@@ -312,11 +312,13 @@ def test_overlapped_optimizer_and_wgrad_streams_equal_serial():
     p_s, l_s = results["serial"]
     p_o, l_o = results["overlap"]
     # bias-gradient column sums and loss sums use fp32 atomics, so two runs of the SAME schedule differ in the last
-    # bits (and a flipped bf16 rounding of a weight image amplifies that); calibrate on serial-vs-serial
+    # bits, and one flipped bf16 rounding of a weight image turns that into a ~1e-5 relative difference (observed
+    # bimodal: 1e-10 or 1e-5 between identical schedules); calibrate on serial-vs-serial with that floor.  A missing
+    # stream dependency shows up orders of magnitude above it.
     noise = max(rel_l2(results["serial2"][0], p_s), rel_l2(results["overlap2"][0], p_o), 1e-7)
     d = rel_l2(p_o, p_s)
     print(f"serial-vs-serial noise {noise:.2e}, overlap-vs-serial {d:.2e}")
-    assert d < 5 * noise + 1e-6, (d, noise)
+    assert d < 5 * noise + 3e-5, (d, noise)
     assert abs(l_s - l_o) < 1e-3 * max(1.0, abs(l_s)), (l_s, l_o)
 
 
