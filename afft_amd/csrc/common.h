@@ -143,7 +143,6 @@ struct EpiParams {
   void* out; int64_t ldo; int out_dtype;
   void* out2; int64_t ldo2; int out2_dtype;
   int vec4;  // host-verified: every ld % 4 == 0 and bases 16-byte aligned -> 4-wide accesses legal
-  int atomic;  // split-K: fp32 `out` was zeroed by the launcher; every K-slice adds its partial with float atomics
   DropParams drop;  // dropout on the (activated) GEMM output + DropPath row scale, before the residual add
 };
 
@@ -214,12 +213,6 @@ __device__ __forceinline__ void epilogue4(const EpiParams& e, int m, int n, floa
       float4 t = *(const float4*)((const float*)e.out + (int64_t)m * e.ldo + n);
       v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
     }
-    if (e.atomic) {
-      float* o = (float*)e.out + (int64_t)m * e.ldo + n;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(o + r, v[r]);
-      return;
-    }
     store4(e.out, (int64_t)m * e.ldo + n, e.out_dtype, v);
     if (e.out2) store4(e.out2, (int64_t)m * e.ldo2 + n, e.out2_dtype, v);
   } else {
@@ -237,7 +230,6 @@ __device__ __forceinline__ void epilogue4(const EpiParams& e, int m, int n, floa
       x *= rs;
       if (e.residual) x += e.residual[(int64_t)m * e.ldres + nn];
       if (e.accumulate) x += ((const float*)e.out)[(int64_t)m * e.ldo + nn];
-      if (e.atomic) { atomicAdd((float*)e.out + (int64_t)m * e.ldo + nn, x); continue; }
       st_any(e.out, (int64_t)m * e.ldo + nn, e.out_dtype, x);
       if (e.out2) st_any(e.out2, (int64_t)m * e.ldo2 + nn, e.out2_dtype, x);
     }

@@ -19,6 +19,9 @@
 //    and the fallback for shapes the fast path does not take.
 //
 // Replaces nn.Linear / HF Conv1D forward, dgrad and wgrad on the AFFT path (see include/afft_hip.h).
+#include <mutex>
+#include <unordered_map>
+
 #include "gemm_tiles.h"
 
 using namespace afft_gemm_detail;
@@ -111,6 +114,48 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf1
     }
   }
 
+  // Split-K (small grids): every slice parks its fp32 partial tile in the workspace and counts itself in; the slice
+  // that arrives LAST (no workgroup ever waits for another, so nothing can deadlock) adds the partials up in slice
+  // order -- bitwise the same sum whoever is last -- and runs the ordinary epilogue, so any epilogue works.
+  if (g.splitk > 1) {
+    constexpr int NT = 64 * NW;
+    const int S = g.splitk, me = blockIdx.y;
+    float* tile_ws = g.ws + (int64_t)blockIdx.x * S * (BM * BN);
+    float* mine = tile_ws + (int64_t)me * (BM * BN);
+    // Partials travel through memory with system-scope (write-through / cache-bypassing) accesses instead of
+    // release/acquire fences: an agent-scope release writes the whole L2 back and an acquire invalidates it, which
+    // costs every other workgroup of the launch its cached operand tiles (measured: +30 us per GEMM).
+    static_for<0, 16>([&](auto idx) {
+      constexpr int v = decltype(idx)::value;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        __hip_atomic_store(mine + (v * 4 + r) * NT + tid, acc[v >> 2][v & 3][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's partial has been written through
+    __syncthreads();                                   // (also: every wave is done reading the ring -> smem is free)
+    if (tid == 0) *(volatile int*)smem = __hip_atomic_fetch_add(g.counters + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int arrived = *(volatile int*)smem;
+    if (arrived != S - 1) return;
+    f32x4 sum[16];
+    static_for<0, 16>([&](auto idx) { sum[decltype(idx)::value] = f32x4{0.f, 0.f, 0.f, 0.f}; });
+    for (int sl = 0; sl < S; ++sl) {
+      const float* src = tile_ws + (int64_t)sl * (BM * BN);
+      static_for<0, 16>([&](auto idx) {
+        constexpr int v = decltype(idx)::value;
+        f32x4 t = acc[v >> 2][v & 3];
+        if (sl != me) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            t[r] = __hip_atomic_load(src + (v * 4 + r) * NT + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        sum[v] += t;
+      });
+    }
+    static_for<0, 16>([&](auto idx) { acc[decltype(idx)::value >> 2][decltype(idx)::value & 3] = sum[decltype(idx)::value]; });
+    if (tid == 0) __hip_atomic_store(g.counters + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+  }
+
   // Epilogue through LDS (same scheme as gemm_pp.hip): accumulators -> fp32 [BM][BN] image with a 16-byte row pad
   // (conflict-free scatter), then whole rows per wave with 16-byte LDS reads and fully coalesced global accesses.
   constexpr int ESTRIDE = BN * 4 + 16;
@@ -130,13 +175,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf1
     const int c4 = lane % LPR;
     const f32x4 t = *(const f32x4*)(smem + row * ESTRIDE + c4 * 16);
     float o[4] = {t[0], t[1], t[2], t[3]};
-    if (g.splitk > 1 && blockIdx.y != 0) {   // bias and residual are added once, by slice 0
-      EpiParams le = g.e;
-      le.bias = nullptr; le.residual = nullptr;
-      epilogue4(le, m0 + row, n0 + 4 * c4, o);
-    } else {
-      epilogue4(g.e, m0 + row, n0 + 4 * c4, o);
-    }
+    epilogue4(g.e, m0 + row, n0 + 4 * c4, o);
   }
 }
 
@@ -200,7 +239,40 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32 g) {
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-int g_splitk_enabled = 0;   // measured slower than the plain launch on every small-grid shape (profiles/r01_gemm_variants_bench2.txt)
+int g_splitk_mode = 1;   // 0 off, 1 auto, 2 / 4: force that many slices wherever the shape allows (tests, tuning)
+
+// Split-K workspace: per stream (two streams may run small GEMMs at the same time), grown on demand, never freed.
+struct SplitWs { float* ws = nullptr; size_t bytes = 0; int* counters = nullptr; };
+constexpr int kMaxSplitTiles = 1024;
+std::mutex g_ws_mu;
+std::unordered_map<hipStream_t, SplitWs> g_ws;
+
+int splitk_workspace(hipStream_t stream, size_t bytes, GemmFast& g) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  SplitWs& w = g_ws[stream];
+  if (!w.counters) {
+    if (hipMalloc((void**)&w.counters, kMaxSplitTiles * sizeof(int)) != hipSuccess ||
+        hipMemset(w.counters, 0, kMaxSplitTiles * sizeof(int)) != hipSuccess) {
+      afft_set_error("afft_gemm: split-K counter allocation failed");
+      (void)hipGetLastError();
+      return 2;
+    }
+  }
+  if (w.bytes < bytes) {
+    // a launch still using the old buffer may be in flight on this stream: drain it before the buffer goes away
+    if (w.ws) { (void)hipStreamSynchronize(stream); (void)hipFree(w.ws); w.ws = nullptr; w.bytes = 0; }
+    if (hipMalloc((void**)&w.ws, bytes) != hipSuccess) {
+      afft_set_error("afft_gemm: split-K workspace allocation (%zu bytes) failed", bytes);
+      (void)hipGetLastError();
+      return 2;
+    }
+    w.bytes = bytes;
+  }
+  g.ws = w.ws;
+  g.counters = w.counters;
+  return 0;
+}
+
 int g_variant = 0;  // 0 auto, 1 = 128x128 tile, 2 = 256x128 tile, 3 = 256x256 ping-pong (tuning / tests)
 
 template <int WM, int WN, int STAGES, bool A_KS, bool B_KS>
@@ -231,25 +303,24 @@ template <bool A_KS, bool B_KS>
 int launch_layout(GemmFast& g, hipStream_t stream) {
   const int variant = choose_variant(g.e.M, g.e.N, g.K, A_KS, B_KS);
   g.splitk = 1;
-  g.e.atomic = 0;
+  g.ws = nullptr;
+  g.counters = nullptr;
   if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream);
-  if (variant == 1 && g_splitk_enabled) {
-    // small grids: <= 128 tiles of 128x128 leave half the CUs idle and one workgroup per CU; cut K in 2 (4 for
-    // K >= 8192) and let the slices add fp32 partials with atomics into a zeroed output.  Needs a linear epilogue.
+  if (g_splitk_mode) {
+    // Small grids: <= 128 tiles of 128x128 leave half of the CUs without a workgroup, and what bounds such a launch
+    // is the LDS fill rate of the CUs that have one -- more CUs pulling is the lever.  Cut K in 2 (4 when K is long).
     const int64_t t1 = (int64_t)((g.e.M + 127) / 128) * ((g.e.N + 127) / 128);
-    const EpiParams& e = g.e;
-    const bool linear = e.act == AFFT_ACT_NONE && !e.pre && !e.out2 && e.out_dtype == AFFT_F32 && !e.accumulate;
-    int s = (t1 <= 128 && g.K >= 2048) ? (g.K >= 8192 ? 4 : 2) : 1;
-    if (s > 1 && linear && (g.K / BK) % s == 0) {
-      if (hipMemset2DAsync(e.out, (size_t)e.ldo * 4, 0, (size_t)e.N * 4, (size_t)e.M, stream) != hipSuccess) {
-        afft_set_error("afft_gemm: split-K memset failed");
-        (void)hipGetLastError();
-        return 2;
-      }
+    const int nk = g.K / BK;
+    int s = 1;
+    if (g_splitk_mode == 1) s = (t1 <= 128 && nk >= 32) ? ((nk >= 96 && t1 * 4 <= 512) ? 4 : 2) : 1;
+    else if (t1 * g_splitk_mode <= kMaxSplitTiles && nk >= 2 * g_splitk_mode) s = g_splitk_mode;
+    while (s > 1 && nk % s != 0) s >>= 1;
+    if (s > 1 && t1 <= kMaxSplitTiles) {
+      if (int rc = splitk_workspace(stream, (size_t)t1 * s * 128 * 128 * sizeof(float), g)) return rc;
       g.splitk = s;
-      g.e.atomic = 1;
     }
   }
+  if (variant == 4) return launch_fast<2, 2, 4, A_KS, B_KS>(g, stream);
   return launch_fast<2, 2, 2, A_KS, B_KS>(g, stream);
 }
 
@@ -270,10 +341,14 @@ extern "C" int afft_gemm_variant_for(int M, int N, int K, int a_kstrided, int b_
   return choose_variant(M, N, K, a_kstrided != 0, b_kstrided != 0);
 }
 
-extern "C" int afft_set_gemm_splitk(int on) { g_splitk_enabled = on ? 1 : 0; return 0; }
+extern "C" int afft_set_gemm_splitk(int mode) {
+  if (mode != 0 && mode != 1 && mode != 2 && mode != 4) { afft_set_error("afft_set_gemm_splitk: %d is not 0, 1, 2 or 4", mode); return 1; }
+  g_splitk_mode = mode;
+  return 0;
+}
 
 extern "C" int afft_set_gemm_variant(int v) {
-  if (v != 0 && v != 1 && v != 3) { afft_set_error("afft_set_gemm_variant: %d is not 0 (auto), 1 (128x128) or 3 (256x256 ping-pong)", v); return 1; }
+  if (v != 0 && v != 1 && v != 3 && v != 4) { afft_set_error("afft_set_gemm_variant: %d is not 0 (auto), 1 (128x128) or 3 (256x256 ping-pong)", v); return 1; }
   g_variant = v;
   return 0;
 }
@@ -296,7 +371,6 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
   e.accumulate = d->accumulate;
   e.out = d->out; e.ldo = d->ldo; e.out_dtype = d->out_dtype;
   e.out2 = d->out2; e.ldo2 = d->ldo2; e.out2_dtype = d->out2_dtype;
-  e.atomic = 0;
   AFFT_CHECK(d->drop.p >= 0.f && d->drop.p < 1.f && d->drop.path_p >= 0.f && d->drop.path_p < 1.f, "afft_gemm: dropout p outside [0,1)");
   e.drop = make_drop(&d->drop);
   auto ok4 = [](const void* p, int64_t ld, int dtype) {

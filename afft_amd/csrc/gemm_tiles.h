@@ -17,6 +17,8 @@ struct GemmFast {
   int K;
   int tiles_m, tiles_n;
   int splitk;   // K is cut into `splitk` slices along gridDim.y (128x128 kernel only); 1 = off
+  float* ws;    // split-K: fp32 partial tiles [tile][slice][128*128]
+  int* counters;  // split-K: arrivals per tile (zero between launches)
   EpiParams e;
 };
 

@@ -72,9 +72,10 @@ typedef struct {
 int afft_gemm(const afft_gemm_t* g, void* stream);
 /* Tuning / test hook: force the bf16 tile shape (0 = auto, 1 = 128x128x64 2-stage, 3 = 256x256x64 ping-pong). */
 int afft_set_gemm_variant(int variant);
-/* Split-K for small grids (fp32 outputs with a linear epilogue; partial sums via float atomics).  Off by default:
- * measured 10-60 % slower than the plain launch on the GPT-2 shapes (atomic traffic + zero-fill). */
-int afft_set_gemm_splitk(int on);
+/* Split-K for small grids of the 128x128 kernel (<= 128 tiles, K >= 2048): K is cut into 2 or 4 slices, every slice
+ * parks its fp32 partial tile in a per-stream workspace and the slice that arrives last adds them up in slice order
+ * and runs the epilogue (no waiting, any epilogue, bitwise repeatable).  mode: 0 off, 1 auto (default), 2 / 4 force. */
+int afft_set_gemm_splitk(int mode);
 /* Which bf16 tile shape afft_gemm picks for a fast-path problem (1 / 3 as above); used by bench.py to attribute
  * launches to kernel symbols. */
 int afft_gemm_variant_for(int M, int N, int K, int a_kstrided, int b_kstrided);

@@ -52,9 +52,11 @@ GEMM_CASES = [
     ("tn_bf16_tails_acc", 3806, 200, 192, "bf16", "tn", dict(out_f32=True, accumulate=True, lda_pad=3840, ldb_pad=256)),
     ("tn_bf16_small", 24, 64, 64, "bf16", "tn", dict(out_f32=True)),
     ("nt_bf16_fallback_k", 70, 50, 24, "bf16", "nt", dict(bias=True, out_f32=True)),   # K % 64 != 0 -> fp32-MFMA path
-    # small grids: split-K with fp32 atomics (K >= 2048: 2 slices, K >= 8192: 4), linear epilogue only
+    # small grids: split-K (K >= 2048: 2 slices, K >= 6144: 4), the last-arriving slice sums and runs the epilogue
     ("nt_bf16_splitk2", 256, 384, 2048, "bf16", "nt", dict(bias=True, residual=True, out_f32=True, rowscale=True)),
     ("nn_bf16_splitk4", 200, 256, 8192, "bf16", "nn", dict(bias=True, out_f32=True)),
+    ("nt_bf16_splitk2_gelu", 256, 256, 2048, "bf16", "nt", dict(bias=True, act=1, pre=True)),
+    ("tn_bf16_splitk4_acc", 200, 130, 6144, "bf16", "tn", dict(out_f32=True, accumulate=True, lda_pad=256, ldb_pad=192)),
     ("nt_bf16_nosplit_gelu", 256, 256, 2048, "bf16", "nt", dict(bias=True, act=1)),
     ("nt_f32", 150, 130, 100, "f32", "nt", dict(bias=True, act=1, pre=True)),
     ("nn_f32", 96, 200, 77, "f32", "nn", dict(bias=True, residual=True, out_f32=True)),
@@ -69,7 +71,7 @@ def test_gemm(case):
     from afft_amd import ops
     name, M, N, K, dt, layout, ep = case
     from afft_amd import _lib
-    _lib.check(_lib.lib().afft_set_gemm_splitk(1 if "splitk" in name else 0))   # off by default (slower), tested anyway
+    _lib.check(_lib.lib().afft_set_gemm_splitk(0 if "nosplit" in name else 1))   # 1 = auto (the default)
     tdt = torch.bfloat16 if dt == "bf16" else torch.float32
     a_t, b_t = layout[0] == "t", layout[1] == "t"
     lda_pad, ldb_pad = ep.get("lda_pad"), ep.get("ldb_pad")
@@ -134,6 +136,15 @@ def test_gemm(case):
         assert rel_l2(out2.float().cpu(), ref) < 1e-2
     if ldo != N:  # padding columns untouched
         assert float(out_buf[:, N:].abs().max()) == 0.0
+    _lib.check(_lib.lib().afft_set_gemm_splitk(1))
+    if "splitk" in name and not ep.get("accumulate"):   # the sum is taken in slice order whoever arrives last: bitwise repeatable
+        first = out.clone()
+        for _ in range(3):
+            ops.gemm(a_store, b_store, out, a_t=a_t, b_t=b_t, bias=None if bias is None else bias.to(dev()), act=act,
+                     aux=None if aux is None else aux.to(tdt).to(dev()), pre=pre,
+                     rowscale=None if rowscale is None else rowscale.to(dev()),
+                     residual=None if res is None else res.to(dev()), out2=out2, alpha=alpha)
+            assert torch.equal(out, first)
 
 
 @pytest.mark.parametrize("rows,d,dt", [(37, 64, "f32"), (300, 1024, "bf16"), (130, 2048, "f32"), (5, 128, "bf16")])
