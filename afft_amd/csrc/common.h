@@ -143,6 +143,7 @@ struct EpiParams {
   void* out; int64_t ldo; int out_dtype;
   void* out2; int64_t ldo2; int out2_dtype;
   int vec4;  // host-verified: every ld % 4 == 0 and bases 16-byte aligned -> 4-wide accesses legal
+  int vec8;  // host-verified: every ld % 8 == 0 and bases 16-byte aligned -> 8-wide accesses legal (16-B bf16 stores)
   DropParams drop;  // dropout on the (activated) GEMM output + DropPath row scale, before the residual add
 };
 
@@ -234,4 +235,82 @@ __device__ __forceinline__ void epilogue4(const EpiParams& e, int m, int n, floa
       if (e.out2) st_any(e.out2, (int64_t)m * e.ldo2 + nn, e.out2_dtype, x);
     }
   }
+}
+
+// 8-wide accesses: one 16-byte access per bf16 tensor (half the store instructions of two 4-wide calls -- the
+// epilogue of a 256x256 tile is bound by store issue and by every CU writing at once), two per fp32 tensor.
+__device__ __forceinline__ void store8(void* base, int64_t idx, int dtype, const float (&v)[8]) {
+  if (dtype == AFFT_F32) {
+    *(float4*)((float*)base + idx) = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)((float*)base + idx + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    uint4 u;
+    u.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+    u.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    u.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
+    u.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+    *(uint4*)((bf16_t*)base + idx) = u;
+  }
+}
+__device__ __forceinline__ void load8(const void* base, int64_t idx, int dtype, float (&v)[8]) {
+  if (dtype == AFFT_F32) {
+    const float4 a = *(const float4*)((const float*)base + idx), b = *(const float4*)((const float*)base + idx + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+    const uint4 u = *(const uint4*)((const bf16_t*)base + idx);
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+  }
+}
+
+// v[0..7] = accumulators for C[m, n..n+7], n % 8 == 0
+__device__ __forceinline__ void epilogue8(const EpiParams& e, int m, int n, float (&v)[8]) {
+  if (m >= e.M || n >= e.N) return;
+  if (!(e.vec8 && n + 7 < e.N)) {
+    float lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
+    epilogue4(e, m, n, lo);
+    epilogue4(e, m, n + 4, hi);
+    return;
+  }
+  const float rs = (e.rowscale ? e.rowscale[m] : 1.0f) * drop_row_scale(e.drop, m);
+  const bool scaled = e.rowscale || e.drop.path_thresh;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] *= e.alpha;
+  if (e.bias) {
+    float b[8];
+    load8(e.bias, n, AFFT_F32, b);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] += b[r];
+  }
+  if (e.pre) store8(e.pre, (int64_t)m * e.ldpre + n, e.pre_dtype, v);
+  if (e.act != AFFT_ACT_NONE) {
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (e.act >= AFFT_ACT_DGELU_ERF) load8(e.aux, (int64_t)m * e.ldaux + n, e.aux_dtype, a);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = apply_act(e.act, v[r], a[r]);
+  }
+  if (e.drop.thresh) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] *= drop_elem_scale(e.drop, (unsigned)m * (unsigned)e.N + (unsigned)(n + r));
+  }
+  if (scaled) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] *= rs;
+  }
+  if (e.residual) {
+    float t[8];
+    load8(e.residual, (int64_t)m * e.ldres + n, AFFT_F32, t);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] += t[r];
+  }
+  if (e.accumulate) {
+    float t[8];
+    load8(e.out, (int64_t)m * e.ldo + n, AFFT_F32, t);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] += t[r];
+  }
+  store8(e.out, (int64_t)m * e.ldo + n, e.out_dtype, v);
+  if (e.out2) store8(e.out2, (int64_t)m * e.ldo2 + n, e.out2_dtype, v);
 }

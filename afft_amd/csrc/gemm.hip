@@ -168,14 +168,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf1
   });
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  constexpr int LPR = BN / 4;            // lanes per row
+  constexpr int LPR = BN / 8;            // lanes per row (8 columns each: 16-byte bf16 stores)
   constexpr int RPI = 64 / LPR;          // rows per wave-iteration
   for (int it = 0; it < BM / NW / RPI; ++it) {
     const int row = wave * (BM / NW) + it * RPI + lane / LPR;
-    const int c4 = lane % LPR;
-    const f32x4 t = *(const f32x4*)(smem + row * ESTRIDE + c4 * 16);
-    float o[4] = {t[0], t[1], t[2], t[3]};
-    epilogue4(g.e, m0 + row, n0 + 4 * c4, o);
+    const int c8 = lane % LPR;
+    const f32x4 t0 = *(const f32x4*)(smem + row * ESTRIDE + c8 * 32);
+    const f32x4 t1 = *(const f32x4*)(smem + row * ESTRIDE + c8 * 32 + 16);
+    float o[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+    epilogue8(g.e, m0 + row, n0 + 8 * c8, o);
   }
 }
 
@@ -378,6 +379,9 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
     const uintptr_t align = dtype == AFFT_F32 ? 16 : 8;
     return (ld % 4 == 0) && ((((uintptr_t)p) & (align - 1)) == 0);
   };
+  auto ok8 = [](const void* p, int64_t ld) { return !p || ((ld % 8 == 0) && ((((uintptr_t)p) & 15) == 0)); };
+  e.vec8 = ok8(d->out, d->ldo) && ok8(d->out2, d->ldo2) && ok8(d->pre, d->ldpre) && ok8(d->aux, d->ldaux) &&
+           ok8(d->residual, d->ldres) && ok8(d->bias, 8);
   e.vec4 = ok4(d->out, d->ldo, d->out_dtype) && ok4(d->out2, d->ldo2, d->out2_dtype) &&
            ok4(d->pre, d->ldpre, d->pre_dtype) && ok4(d->aux, d->ldaux, d->aux_dtype) &&
            ok4(d->residual, d->ldres, AFFT_F32) && ok4(d->bias, 4, AFFT_F32);

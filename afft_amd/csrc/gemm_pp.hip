@@ -10,7 +10,8 @@ using namespace afft_gemm_detail;
 #define AFFT_PP_PRIO 1        // experiment: 1 = MFMA segments at raised priority, 0 = no priority change, 2 = L segments raised
 #endif
 #ifndef AFFT_PP_DIAG
-#define AFFT_PP_DIAG 0    // diagnostic builds only (wrong results): 1 = no fragment reads, 2 = no LDS-DMA in the loop, 4 = no MFMA
+#define AFFT_PP_DIAG 0    // diagnostic builds only (wrong results): 1 = no fragment reads, 2 = no LDS-DMA in the loop, 4 = no MFMA,
+                          // 8 = no global accesses in the epilogue, 16 = no epilogue at all
 #endif
 
 namespace {
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
   // coalesced global accesses (bias, residual, pre-activation, outputs) in a runtime loop -- no 32-fold unrolled
   // epilogue, no 32-byte store segments.
   constexpr int ESTRIDE = 1040;
+  if (AFFT_PP_DIAG & 16) return;
   static_for<0, 2>([&](auto ihc) {
     constexpr int ih = decltype(ihc)::value;
     __builtin_amdgcn_s_barrier();   // pass 0: every wave is done with the ring; pass 1: pass 0 has been read back
@@ -228,11 +230,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
     });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    for (int rr = 0; rr < 16; ++rr) {
-      const int row = wave * 16 + rr;
-      const f32x4 t = *(const f32x4*)(smem + row * ESTRIDE + lane * 16);
-      float o[4] = {t[0], t[1], t[2], t[3]};
-      epilogue4(g.e, m0 + ih * 128 + row, n0 + 4 * lane, o);
+    for (int rr = 0; rr < 8; ++rr) {     // two rows per step: a lane owns 8 consecutive columns (16-byte bf16 stores)
+      const int row = wave * 16 + rr * 2 + (lane >> 5);
+      const int c8 = lane & 31;
+      const f32x4 t0 = *(const f32x4*)(smem + row * ESTRIDE + c8 * 32);
+      const f32x4 t1 = *(const f32x4*)(smem + row * ESTRIDE + c8 * 32 + 16);
+      float o[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+      if (!(AFFT_PP_DIAG & 8)) epilogue8(g.e, m0 + ih * 128 + row, n0 + 8 * c8, o);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   });
