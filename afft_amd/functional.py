@@ -91,9 +91,19 @@ def _lin_dgrad(dy: Act, W: Tensor, conv1d: bool, out: Tensor, **ep) -> Tensor:
     return ops.gemm(dy.live, W, out, b_t=conv1d, **ep)
 
 
+def _on_side(t: Tensor) -> Tensor:
+    """The tensor is about to be read by a kernel on the auxiliary stream: tell the caching allocator, so that its
+    memory is not handed out again (to main-stream allocations) before that kernel has run."""
+    if t.is_cuda and rt.overlap_wgrad() and torch.cuda.current_stream() != torch.cuda.default_stream():
+        t.record_stream(torch.cuda.current_stream())
+    return t
+
+
 def _wgrad(dy: Act, x: Act, W: Tensor, conv1d: bool) -> Optional[Tensor]:
     """dW = dy^T x (nn.Linear) or x^T dy (Conv1D); accumulated into W.grad (sink mode) or returned."""
     a, b = (x, dy) if conv1d else (dy, x)
+    _on_side(a.buf)
+    _on_side(b.buf)
     if rt.grad_mode() == "sink":
         g, acc = rt.SINK.grad_buffer(W)
         ops.gemm(a.tn, b.tn, g, a_t=True, accumulate=acc)
@@ -107,6 +117,7 @@ def _wgrad(dy: Act, x: Act, W: Tensor, conv1d: bool) -> Optional[Tensor]:
 def _bgrad(dy: Tensor, bias: Optional[Tensor]) -> Optional[Tensor]:
     if bias is None:
         return None
+    _on_side(dy)
     if rt.grad_mode() == "sink":
         g, acc = rt.SINK.grad_buffer(bias)
         ops.colsum(dy, g, accumulate=acc)
@@ -118,11 +129,13 @@ def _bgrad(dy: Tensor, bias: Optional[Tensor]) -> Optional[Tensor]:
 
 
 class _Side:
-    """`with _Side(dev):` enqueues the enclosed kernels on the device's side stream, ordered after everything
+    """`with _Side(dev):` enqueues the enclosed kernels on the device's auxiliary stream, ordered after everything
     already on the current stream.  Weight-gradient GEMMs (and bias column sums) are independent of the
     data-gradient chain of the same backward, so running them there lets their workgroups fill the CUs that a
-    partial wave of the dgrad kernel leaves idle (256x256 tiles run one workgroup per CU).  join_side() at the end
-    of the backward orders the current stream after them again (buffers are released only after that)."""
+    partial wave of the dgrad kernel leaves idle (256x256 tiles run one workgroup per CU).  Nothing on the main
+    stream waits for them until the whole backward pass is over (join_side): their inputs are kept away from the
+    allocator by record_stream (_on_side), and the optimizer / all-reduce stream orders itself behind the auxiliary
+    stream when it picks up a bucket (parallel.GradReducer._launch)."""
 
     def __init__(self, device):
         self.on = rt.overlap_wgrad() and device.type == "cuda"
@@ -144,11 +157,33 @@ class _Side:
         return False
 
 
+_JOIN_QUEUED = False
+
+
 def join_side(device):
-    if rt.overlap_wgrad() and device.type == "cuda":
-        ev = torch.cuda.Event()
-        ev.record(rt.aux_stream(device))
-        torch.cuda.current_stream().wait_event(ev)
+    """Order the current stream after the auxiliary stream.  Sink mode: once, when the running backward pass ends
+    (an autograd-engine callback) -- a per-sub-layer join would stall the dgrad chain behind every weight gradient
+    and costs a cross-stream bubble each time.  Autograd mode: right away (the gradients returned to autograd are
+    consumed on the current stream)."""
+    global _JOIN_QUEUED
+    if not (rt.overlap_wgrad() and device.type == "cuda"):
+        return
+    main, aux = torch.cuda.current_stream(), rt.aux_stream(device)
+    if rt.grad_mode() == "sink":
+        if not _JOIN_QUEUED:
+            def _final(main=main, aux=aux):
+                global _JOIN_QUEUED
+                _JOIN_QUEUED = False
+                main.wait_stream(aux)
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(_final)
+                _JOIN_QUEUED = True
+                return
+            except RuntimeError:      # not inside a backward pass (a Function.backward called by hand)
+                pass
+        else:
+            return
+    main.wait_stream(aux)
 
 
 _PENDING_READY: list = []

@@ -151,6 +151,8 @@ class GradReducer:
         ev = torch.cuda.Event()
         ev.record()
         self.side_stream.wait_event(ev)
+        if rt.overlap_wgrad():    # weight gradients of this bucket were enqueued on the auxiliary stream
+            self.side_stream.wait_stream(rt.aux_stream(self.flat.flat_g.device))
         with torch.cuda.stream(self.side_stream):
             if self.comm:
                 if self.flat_g16 is not None:
