@@ -114,46 +114,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf1
     }
   }
 
-  // Split-K (small grids): every slice parks its fp32 partial tile in the workspace and counts itself in; the slice
-  // that arrives LAST (no workgroup ever waits for another, so nothing can deadlock) adds the partials up in slice
-  // order -- bitwise the same sum whoever is last -- and runs the ordinary epilogue, so any epilogue works.
+  // Split-K (small grids): see splitk_combine (gemm_tiles.h); the last-arriving slice runs the ordinary epilogue.
   if (g.splitk > 1) {
-    constexpr int NT = 64 * NW;
-    const int S = g.splitk, me = blockIdx.y;
-    float* tile_ws = g.ws + (int64_t)blockIdx.x * S * (BM * BN);
-    float* mine = tile_ws + (int64_t)me * (BM * BN);
-    // Partials travel through memory with system-scope (write-through / cache-bypassing) accesses instead of
-    // release/acquire fences: an agent-scope release writes the whole L2 back and an acquire invalidates it, which
-    // costs every other workgroup of the launch its cached operand tiles (measured: +30 us per GEMM).
-    static_for<0, 16>([&](auto idx) {
-      constexpr int v = decltype(idx)::value;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        __hip_atomic_store(mine + (v * 4 + r) * NT + tid, acc[v >> 2][v & 3][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's partial has been written through
-    __syncthreads();                                   // (also: every wave is done reading the ring -> smem is free)
-    if (tid == 0) *(volatile int*)smem = __hip_atomic_fetch_add(g.counters + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int arrived = *(volatile int*)smem;
-    if (arrived != S - 1) return;
-    f32x4 sum[16];
-    static_for<0, 16>([&](auto idx) { sum[decltype(idx)::value] = f32x4{0.f, 0.f, 0.f, 0.f}; });
-    for (int sl = 0; sl < S; ++sl) {
-      const float* src = tile_ws + (int64_t)sl * (BM * BN);
-      static_for<0, 16>([&](auto idx) {
-        constexpr int v = decltype(idx)::value;
-        f32x4 t = acc[v >> 2][v & 3];
-        if (sl != me) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            t[r] = __hip_atomic_load(src + (v * 4 + r) * NT + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        sum[v] += t;
-      });
-    }
-    static_for<0, 16>([&](auto idx) { acc[decltype(idx)::value >> 2][decltype(idx)::value & 3] = sum[decltype(idx)::value]; });
-    if (tid == 0) __hip_atomic_store(g.counters + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+    __syncthreads();   // every wave is done reading the ring -> smem is free
+    if (!splitk_combine<16, 64 * NW>(reinterpret_cast<f32x4(&)[16]>(acc), g.ws, g.counters, blockIdx.x, g.splitk, blockIdx.y, tid, smem))
+      return;
   }
 
   // Epilogue through LDS (same scheme as gemm_pp.hip): accumulators -> fp32 [BM][BN] image with a 16-byte row pad
@@ -241,6 +206,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32 g) {
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 int g_splitk_mode = 1;   // 0 off, 1 auto, 2 / 4: force that many slices wherever the shape allows (tests, tuning)
+int g_pp_split_min_nk = [] { const char* e = getenv("AFFT_PP_SPLIT_MIN_NK"); return e ? atoi(e) : (1 << 30); }();
 
 // Split-K workspace: per stream (two streams may run small GEMMs at the same time), grown on demand, never freed.
 struct SplitWs { float* ws = nullptr; size_t bytes = 0; int* counters = nullptr; };
@@ -306,7 +272,23 @@ int launch_layout(GemmFast& g, hipStream_t stream) {
   g.splitk = 1;
   g.ws = nullptr;
   g.counters = nullptr;
-  if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream);
+  if (variant == 3) {
+    // 256x256 tiles: a grid that leaves more than a third of the CUs without a tile (160 tiles: every N = 2048 GEMM
+    // of the fuser at B = 64) CAN be cut into 3 K-slices -- 480 workgroups = 2 rounds of a third of K each instead of
+    // 1 round of all of it.  Measured (5120x2048x8192): 194 -> 240 us, the 256-KiB partial tiles (164 MB written and
+    // read back per launch) cost more than the idle CUs; so the automatic mode never picks it (AFFT_PP_SPLIT_MIN_NK
+    // lowers the threshold for experiments) and it stays as a tested path for shapes with much longer K.
+    const int64_t t3 = (int64_t)((g.e.M + 255) / 256) * ((g.e.N + 255) / 256);
+    const int nk = g.K / BK;
+    int s = 1;
+    if (g_splitk_mode == 1) s = (t3 * 3 <= 512 && t3 > 128 && nk >= g_pp_split_min_nk) ? 3 : 1;
+    else if (g_splitk_mode > 1 && nk >= 2 * g_splitk_mode) s = g_splitk_mode == 4 ? 3 : 2;
+    if (s > 1 && t3 <= kMaxSplitTiles) {
+      if (int rc = splitk_workspace(stream, (size_t)t3 * s * 256 * 256 * sizeof(float), g)) return rc;
+      g.splitk = s;
+    }
+    return afft_gemm_launch_pp(A_KS, B_KS, g, stream);
+  }
   if (g_splitk_mode) {
     // Small grids: <= 128 tiles of 128x128 leave half of the CUs without a workgroup, and what bounds such a launch
     // is the LDS fill rate of the CUs that have one -- more CUs pulling is the lever.  Cut K in 2 (4 when K is long).

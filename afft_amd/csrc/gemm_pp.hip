@@ -67,7 +67,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
   const int m0l = m0, n0l = n0;
 #endif
   const int M = g.e.M, N = g.e.N;
-  const int nk = g.K / BK, NH = 4 * nk;
+  // split-K (grids that leave > 1/3 of the CUs without a tile): slice blockIdx.y owns K-tiles [kt_lo, kt_lo + nk)
+  const int nk_all = g.K / BK;
+  const int kt_lo = (int)(((int64_t)blockIdx.y * nk_all) / g.splitk);
+  const int nk = (int)(((int64_t)(blockIdx.y + 1) * nk_all) / g.splitk) - kt_lo, NH = 4 * nk;
 
   f32x4 acc[2][2][4][2];
 #pragma unroll
@@ -98,12 +101,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
     const unsigned dst = lds0 + ((kt & 1) * 4 + q) * HB;
     if (q == 0 || q == 3) {
       const int r0 = m0l + (q == 3 ? 128 : 0);
-      if constexpr (A_KS) stage_ks<8, 2>(g.A, g.lda, lda2, voffA, lo, r0, kt * BK, dst, wave);
-      else stage_kc<8, 2>(g.A, g.lda, lda2, voffA, lo, r0, M, kt * BK, dst, wave);
+      if constexpr (A_KS) stage_ks<8, 2>(g.A, g.lda, lda2, voffA, lo, r0, (kt_lo + kt) * BK, dst, wave);
+      else stage_kc<8, 2>(g.A, g.lda, lda2, voffA, lo, r0, M, (kt_lo + kt) * BK, dst, wave);
     } else {
       const int c0 = n0l + (q == 2 ? 128 : 0);
-      if constexpr (B_KS) stage_ks<8, 2>(g.B, g.ldb, ldb2, voffB, lo, c0, kt * BK, dst, wave);
-      else stage_kc<8, 2>(g.B, g.ldb, ldb2, voffB, lo, c0, N, kt * BK, dst, wave);
+      if constexpr (B_KS) stage_ks<8, 2>(g.B, g.ldb, ldb2, voffB, lo, c0, (kt_lo + kt) * BK, dst, wave);
+      else stage_kc<8, 2>(g.B, g.ldb, ldb2, voffB, lo, c0, N, (kt_lo + kt) * BK, dst, wave);
     }
   };
   auto load_a = [&](int kt, int ih) {
@@ -211,6 +214,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
   }
 #endif
 
+  if (g.splitk > 1) {   // see splitk_combine (gemm_tiles.h): only the last-arriving slice of a tile goes on
+    __syncthreads();    // every wave is done with the ring -> smem is free
+    if (!splitk_combine<32, 512>(reinterpret_cast<f32x4(&)[32]>(acc), g.ws, g.counters, blockIdx.x, g.splitk, blockIdx.y, tid, smem))
+      return;
+  }
+
   // Epilogue through LDS (the ring is free now): two passes of 128 rows.  Accumulators are scattered into an fp32
   // [128][256] image (row stride 1040 B = 1 KiB + 16 B, so the 16 rows a lane group writes fall in 16 different
   // 16-byte slots), then every wave walks 16 whole rows: one conflict-free 16-byte LDS read per lane and fully
@@ -258,9 +267,9 @@ int launch_pp(GemmFast& g, hipStream_t stream) {
     attr_set = true;
   }
 #ifdef AFFT_PP_STAMP
-  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), lds, stream, g, g_pp_stamp);
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.splitk), dim3(512), lds, stream, g, g_pp_stamp);
 #else
-  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), lds, stream, g);
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.splitk), dim3(512), lds, stream, g);
 #endif
   AFFT_LAUNCH_CHECK();
   return 0;

@@ -8,6 +8,14 @@
 namespace afft_gemm_detail {
 
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 constexpr int BK = 64;
 constexpr int GROUP_M = 8;
 
@@ -16,7 +24,7 @@ struct GemmFast {
   const bf16_t* B; int64_t ldb;  // k-contiguous: B[N][K] ; k-strided: B[K][N]
   int K;
   int tiles_m, tiles_n;
-  int splitk;   // K is cut into `splitk` slices along gridDim.y (128x128 kernel only); 1 = off
+  int splitk;   // K is cut into `splitk` slices along gridDim.y; 1 = off
   float* ws;    // split-K: fp32 partial tiles [tile][slice][128*128]
   int* counters;  // split-K: arrivals per tile (zero between launches)
   EpiParams e;
@@ -117,18 +125,54 @@ __device__ __forceinline__ bf16x8 frag_ks(const char* lds_tile, int kb, int unit
   return f;
 }
 
+// ----- split-K hand-over ("last arriver"): every slice of a tile parks its fp32 partial (NV f32x4 per thread, NT threads)
+// in the workspace with system-scope (write-through) stores and counts itself in; the slice whose count completes the
+// tile adds the partials in slice order -- bitwise the same sum whoever it is -- and returns true (it runs the
+// epilogue); the others return false and exit.  No workgroup waits for another, so nothing can deadlock, and there is
+// no release/acquire fence: an agent-scope release writes the whole L2 back and an acquire invalidates it, which costs
+// every other workgroup of the launch its cached operand tiles (measured +30 us per GEMM).
+// smem: at least 4 bytes of LDS nobody else touches between the two barriers inside.
+template <int NV, int NT>
+__device__ __forceinline__ bool splitk_combine(f32x4 (&acc)[NV], float* ws, int* counters, int tile, int S, int me, int tid,
+                                               char* smem) {
+  float* tile_ws = ws + (int64_t)tile * S * (NV * NT * 4);
+  float* mine = tile_ws + (int64_t)me * (NV * NT * 4);
+  static_for<0, NV>([&](auto idx) {
+    constexpr int v = decltype(idx)::value;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      __hip_atomic_store(mine + (v * 4 + r) * NT + tid, acc[v][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  });
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's partial has been written through
+  __syncthreads();
+  if (tid == 0) *(volatile int*)smem = __hip_atomic_fetch_add(counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int arrived = *(volatile int*)smem;
+  if (arrived != S - 1) return false;
+  f32x4 sum[NV];
+  static_for<0, NV>([&](auto idx) { sum[decltype(idx)::value] = f32x4{0.f, 0.f, 0.f, 0.f}; });
+  for (int sl = 0; sl < S; ++sl) {
+    const float* src = tile_ws + (int64_t)sl * (NV * NT * 4);
+    static_for<0, NV>([&](auto idx) {
+      constexpr int v = decltype(idx)::value;
+      f32x4 t = acc[v];
+      if (sl != me) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          t[r] = __hip_atomic_load(src + (v * 4 + r) * NT + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      sum[v] += t;
+    });
+  }
+  static_for<0, NV>([&](auto idx) { acc[decltype(idx)::value] = sum[decltype(idx)::value]; });
+  if (tid == 0) __hip_atomic_store(counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+  return true;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_only() {
   static_assert(N >= 0 && N < 64, "vmcnt immediate");
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
 }
 
 template <int N>

@@ -58,6 +58,11 @@ GEMM_CASES = [
     ("nt_bf16_splitk2_gelu", 256, 256, 2048, "bf16", "nt", dict(bias=True, act=1, pre=True)),
     ("tn_bf16_splitk4_acc", 200, 130, 6144, "bf16", "tn", dict(out_f32=True, accumulate=True, lda_pad=256, ldb_pad=192)),
     ("nt_bf16_nosplit_gelu", 256, 256, 2048, "bf16", "nt", dict(bias=True, act=1)),
+    # 256x256 ping-pong kernel forced, 3 uneven K-slices (10 K-tiles -> 3 + 3 + 4), every layout
+    ("nt_bf16_pp_splitk3", 512, 520, 640, "bf16", "nt", dict(bias=True, act=1, pre=True)),
+    ("nn_bf16_pp_splitk3", 300, 512, 640, "bf16", "nn", dict(bias=True, residual=True, out_f32=True)),
+    ("tn_bf16_pp_splitk3", 512, 264, 704, "bf16", "tn", dict(out_f32=True)),
+    ("nt_bf16_pp", 300, 520, 192, "bf16", "nt", dict(bias=True, act=2, out2=True)),
     ("nt_f32", 150, 130, 100, "f32", "nt", dict(bias=True, act=1, pre=True)),
     ("nn_f32", 96, 200, 77, "f32", "nn", dict(bias=True, residual=True, out_f32=True)),
     ("tn_f32", 66, 70, 130, "f32", "tn", dict(accumulate=True, out_f32=True)),
@@ -71,7 +76,8 @@ def test_gemm(case):
     from afft_amd import ops
     name, M, N, K, dt, layout, ep = case
     from afft_amd import _lib
-    _lib.check(_lib.lib().afft_set_gemm_splitk(0 if "nosplit" in name else 1))   # 1 = auto (the default)
+    _lib.check(_lib.lib().afft_set_gemm_splitk(0 if "nosplit" in name else 4 if "pp_splitk3" in name else 1))   # 1 = auto (default)
+    _lib.check(_lib.lib().afft_set_gemm_variant(3 if "_pp" in name else 0))
     tdt = torch.bfloat16 if dt == "bf16" else torch.float32
     a_t, b_t = layout[0] == "t", layout[1] == "t"
     lda_pad, ldb_pad = ep.get("lda_pad"), ep.get("ldb_pad")
@@ -136,7 +142,6 @@ def test_gemm(case):
         assert rel_l2(out2.float().cpu(), ref) < 1e-2
     if ldo != N:  # padding columns untouched
         assert float(out_buf[:, N:].abs().max()) == 0.0
-    _lib.check(_lib.lib().afft_set_gemm_splitk(1))
     if "splitk" in name and not ep.get("accumulate"):   # the sum is taken in slice order whoever arrives last: bitwise repeatable
         first = out.clone()
         for _ in range(3):
@@ -145,6 +150,8 @@ def test_gemm(case):
                      rowscale=None if rowscale is None else rowscale.to(dev()),
                      residual=None if res is None else res.to(dev()), out2=out2, alpha=alpha)
             assert torch.equal(out, first)
+    _lib.check(_lib.lib().afft_set_gemm_splitk(1))
+    _lib.check(_lib.lib().afft_set_gemm_variant(0))
 
 
 @pytest.mark.parametrize("rows,d,dt", [(37, 64, "f32"), (300, 1024, "bf16"), (130, 2048, "f32"), (5, 128, "bf16")])
