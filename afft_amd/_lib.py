@@ -62,7 +62,9 @@ _SIGS = {
     "afft_colsum": ([vp, i64, i32, i32, i32, vp, i32, vp], C.c_int),
     "afft_add_rows_periodic": ([vp, i64, vp, i64, i32, i32, i32, vp, i64, vp], C.c_int),
     "afft_reduce_rows_periodic": ([vp, i64, i32, i32, i32, vp, i64, vp], C.c_int),
-    "afft_sgd_nesterov": ([vp, vp, i32, vp, vp, i64, f32, f32, f32, f32, i32, vp], C.c_int),
+    "afft_sgd_nesterov": ([vp, vp, i32, vp, vp, i64, f32, f32, f32, f32, vp, i32, vp], C.c_int),
+    "afft_sumsq": ([vp, i32, i64, f32, vp, vp], C.c_int),
+    "afft_clip_coef": ([vp, f32, vp, vp, vp], C.c_int),
 }
 
 EXPORTS = sorted(list(_SIGS) + ["afft_last_error"])

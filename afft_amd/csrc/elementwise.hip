@@ -146,7 +146,9 @@ __global__ __launch_bounds__(256) void reduce_rows_periodic_kernel(const float* 
 
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const void* __restrict__ g_, int g_dtype,
                                                   float* __restrict__ buf, bf16_t* __restrict__ p16, int64_t n, float lr,
-                                                  float mom, float wd, float gscale, int first) {
+                                                  float mom, float wd, float gscale, const float* __restrict__ gscale_dev,
+                                                  int first) {
+  if (gscale_dev) gscale *= *gscale_dev;   // clip coefficient computed on the device (afft_clip_coef)
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
     if (i + 3 < n) {
       float4 pv = *(float4*)(p + i);
@@ -267,8 +269,58 @@ extern "C" int afft_reduce_rows_periodic(const float* src, int64_t lds_, int32_t
   return 0;
 }
 
+// sum of squares of a flat gradient buffer (fp32 or bf16), added to *out: one float atomic per workgroup
+__global__ __launch_bounds__(256) void sumsq_kernel(const void* __restrict__ x, int dtype, int64_t n, float scale,
+                                                    float* __restrict__ out) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      float v[4];
+      load4(x, i, dtype, v);
+      s += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    } else {
+      for (int64_t j = i; j < n; ++j) { const float v = ld_any(x, j, dtype); s += v * v; }
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, ((sh[0] + sh[1]) + (sh[2] + sh[3])) * scale);
+}
+
+__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ coef,
+                                 float* __restrict__ norm_out) {
+  const float norm = sqrtf(*sumsq);
+  if (norm_out) *norm_out = norm;
+  const float c = max_norm / (norm + 1e-6f);    // torch.nn.utils.clip_grad_norm_: clamped to 1
+  *coef = c < 1.0f ? c : 1.0f;
+}
+
+extern "C" int afft_sumsq(const void* x, int32_t dtype, int64_t n, float scale, float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(x && out, "sumsq: null pointer");
+  AFFT_CHECK(dtype == AFFT_F32 || dtype == AFFT_BF16, "sumsq: bad dtype");
+  AFFT_CHECK((((uintptr_t)x) & 15) == 0, "sumsq: buffer must be 16-byte aligned");
+  if (n == 0) return 0;
+  int64_t blocks = (n + 1023) / 1024;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((int)blocks), dim3(256), 0, stream, x, dtype, n, scale, out);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int afft_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(sumsq && coef && max_norm > 0.f, "clip_coef: bad argument");
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, stream, sumsq, max_norm, coef, norm_out);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int afft_sgd_nesterov(float* p, const void* g, int32_t g_dtype, float* buf, void* p_bf16, int64_t n, float lr,
-                                 float mom, float wd, float gscale, int32_t first_step, void* stream_) {
+                                 float mom, float wd, float gscale, const float* gscale_dev, int32_t first_step,
+                                 void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(p && g && buf, "sgd: null pointer");
   AFFT_CHECK(((uintptr_t)p & 15) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)buf & 15) == 0, "sgd: buffers must be 16-byte aligned");
@@ -277,7 +329,7 @@ extern "C" int afft_sgd_nesterov(float* p, const void* g, int32_t g_dtype, float
   int64_t blocks = (n + 1023) / 1024;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(sgd_kernel, dim3((int)blocks), dim3(256), 0, stream, p, g, g_dtype, buf, (bf16_t*)p_bf16, n, lr, mom, wd,
-                     gscale, first_step);
+                     gscale, gscale_dev, first_step);
   AFFT_LAUNCH_CHECK();
   return 0;
 }

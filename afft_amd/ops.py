@@ -213,9 +213,22 @@ def reduce_rows_periodic(src: Tensor, period: int, out: Tensor):
 
 
 def sgd_nesterov(p: Tensor, g: Tensor, buf: Tensor, lr: float, mom: float, wd: float, gscale: float, first: bool,
-                 p_bf16: Optional[Tensor] = None):
+                 p_bf16: Optional[Tensor] = None, gscale_dev: Optional[Tensor] = None):
     assert p.is_contiguous() and g.is_contiguous() and buf.is_contiguous()
     if p_bf16 is not None:
         assert p_bf16.dtype == torch.bfloat16 and p_bf16.numel() == p.numel() and p_bf16.is_contiguous()
-    L.check(L.lib().afft_sgd_nesterov(_p(p), _p(g), _dt(g), _p(buf), _p(p_bf16), p.numel(), lr, mom, wd, gscale, 1 if first else 0,
-                                      _stream()), "sgd_nesterov")
+    L.check(L.lib().afft_sgd_nesterov(_p(p), _p(g), _dt(g), _p(buf), _p(p_bf16), p.numel(), lr, mom, wd, gscale,
+                                      _p(gscale_dev), 1 if first else 0, _stream()), "sgd_nesterov")
+
+
+def sumsq(x: Tensor, out: Tensor, scale: float = 1.0):
+    """out[0] += scale * sum(x^2) over a flat fp32 / bf16 buffer."""
+    assert x.is_contiguous() and out.dtype == torch.float32
+    L.check(L.lib().afft_sumsq(_p(x), _dt(x), x.numel(), scale, _p(out), _stream()), "sumsq")
+    return out
+
+
+def clip_coef(sumsq_: Tensor, max_norm: float, coef: Tensor, norm_out: Optional[Tensor] = None):
+    """coef[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) on the device (no host sync)."""
+    L.check(L.lib().afft_clip_coef(_p(sumsq_), float(max_norm), _p(coef), _p(norm_out), _stream()), "clip_coef")
+    return coef

@@ -197,19 +197,29 @@ class FusedSGD:
         self.buf = torch.zeros_like(flat.flat_p)
         self.steps = 0
 
-    def step_range(self, s: int, e: int, grad: Tensor, gscale: float):
+    def step_range(self, s: int, e: int, grad: Tensor, gscale: float, gscale_dev: Optional[Tensor] = None):
         p16 = self.flat.flat_p16[s:e] if self.flat.flat_p16 is not None else None
         ops.sgd_nesterov(self.flat.flat_p[s:e], grad, self.buf[s:e], self.lr, self.momentum, self.wd, gscale,
-                         self.steps == 0, p_bf16=p16)
+                         self.steps == 0, p_bf16=p16, gscale_dev=gscale_dev)
         self.flat.refresh_transposed(s, e)
 
     def end_step(self):
         self.steps += 1
         rt.invalidate_weight_images()   # padded cast images (odd shapes) are re-cast on next use
 
-    def step(self, grad: Optional[Tensor] = None, gscale: float = 1.0):
+    def step(self, grad: Optional[Tensor] = None, gscale: float = 1.0, grad_clip: Optional[float] = None):
+        """grad_clip: clip by global L2 norm first (train.py:254-260 = torch.nn.utils.clip_grad_norm_): the norm, the
+        coefficient min(1, c / (norm + 1e-6)) and its use all stay on the device (no host sync); the norm of the step
+        is left in self.last_grad_norm (device scalar)."""
         g = self.flat.flat_g if grad is None else grad
-        self.step_range(0, self.flat.total, g, gscale)
+        coef = None
+        if grad_clip is not None and g.is_cuda:
+            ss = torch.zeros(1, dtype=torch.float32, device=g.device)
+            coef = torch.empty(1, dtype=torch.float32, device=g.device)
+            self.last_grad_norm = torch.empty(1, dtype=torch.float32, device=g.device)
+            ops.sumsq(g, ss, gscale * gscale)
+            ops.clip_coef(ss, grad_clip, coef, self.last_grad_norm)
+        self.step_range(0, self.flat.total, g, gscale, coef)
         self.end_step()
 
 
@@ -220,7 +230,7 @@ class Trainer:
 
     def __init__(self, model, loss_wts: Dict[str, float], lr=1e-3, momentum=0.9, weight_decay=1e-6,
                  comm_dtype: str = "fp32", bucket_elems: int = 32 * 1024 * 1024, group=None,
-                 overlap_optimizer: bool = True, force_comm: bool = False):
+                 overlap_optimizer: bool = True, force_comm: bool = False, grad_clip: Optional[float] = None):
         from .common.runner import BasicLossAccuracy, Runner
         self.model = model
         self.flat = FlatParams(model)
@@ -230,7 +240,8 @@ class Trainer:
         self.loss_fn = BasicLossAccuracy(compute_metrics=False)
         self._reduce = Runner._reduce_loss
         self.loss_wts = loss_wts
-        self.overlap_optimizer = overlap_optimizer and self.flat.flat_p.is_cuda
+        self.grad_clip = grad_clip     # opt.grad_clip of the reference's config; needs the whole gradient first
+        self.overlap_optimizer = overlap_optimizer and self.flat.flat_p.is_cuda and grad_clip is None
 
     def forward_backward(self, feats: Dict[str, Tensor], target, target_subclips, optimize_in_backward: bool = False):
         self.reducer.on_bucket = self.opt.step_range if optimize_in_backward else None
@@ -250,5 +261,5 @@ class Trainer:
         loss, parts = self.forward_backward(feats, target, target_subclips, optimize_in_backward=fused)
         if optimize and not fused:
             g, scale = self.reducer.grad_for_optimizer()
-            self.opt.step(g, scale)
+            self.opt.step(g, scale, grad_clip=self.grad_clip)
         return loss, parts

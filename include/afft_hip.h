@@ -161,9 +161,15 @@ int afft_reduce_rows_periodic(const float* src, int64_t lds, int32_t rows, int32
 /* Nesterov-momentum SGD over one flat fp32 parameter buffer (conf/opt/optimizer/sgd.yaml, train.py:262):
  *   g = gscale*g + wd*p ; buf = mom*buf + g ; p -= lr*(g + mom*buf) ; gscale = 1/world after a summing
  *   all-reduce; g may be fp32 or bf16 (bf16 gradient exchange).  p_bf16 (optional, same element offsets as p)
- *   receives the bf16 image of the updated weights: the GEMM operand copy is refreshed by the update itself. */
+ *   receives the bf16 image of the updated weights: the GEMM operand copy is refreshed by the update itself.
+ *   gscale_dev (optional device scalar) multiplies gscale: the gradient-clipping coefficient of afft_clip_coef. */
 int afft_sgd_nesterov(float* p, const void* g, int32_t g_dtype, float* buf, void* p_bf16, int64_t n, float lr, float mom,
-                      float wd, float gscale, int32_t first_step, void* stream);
+                      float wd, float gscale, const float* gscale_dev, int32_t first_step, void* stream);
+/* Gradient clipping by global norm (train.py:254-260, torch.nn.utils.clip_grad_norm_), without a host sync:
+ *   afft_sumsq: *out += scale * sum x[i]^2 over a flat fp32/bf16 buffer (scale = gscale^2 of the optimizer);
+ *   afft_clip_coef: *coef = min(1, max_norm / (sqrt(*sumsq) + 1e-6)), *norm_out (optional) = sqrt(*sumsq). */
+int afft_sumsq(const void* x, int32_t dtype, int64_t n, float scale, float* out, void* stream);
+int afft_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -378,6 +378,31 @@ def test_mse_and_elementwise():
     refR = torch.cat([x[:B * T - 3], torch.zeros(3, dd)]).view(B, T, dd).sum(0)
     assert rel_l2(accR.cpu(), refR) < 1e-5
 
+    # gradient clipping by global norm, coefficient kept on the device
+    gfl = rnd(5000 + 7, seed=43) * 3.0
+    for dt_, tol_ in ((torch.float32, 1e-6), (torch.bfloat16, 1e-6)):
+        gdev = gfl.to(dt_).to(dev())
+        ss = torch.zeros(1, device=dev())
+        ops.sumsq(gdev, ss, 0.25)
+        coef, nrm = torch.empty(1, device=dev()), torch.empty(1, device=dev())
+        ops.clip_coef(ss, 2.0, coef, nrm)
+        ref_norm = float((gdev.float().cpu() * 0.5).norm())
+        assert abs(float(nrm) - ref_norm) < 1e-4 * ref_norm
+        assert abs(float(coef) - min(1.0, 2.0 / (ref_norm + 1e-6))) < 1e-5
+    p0_c = rnd(1003, seed=44)
+    pc = torch.nn.Parameter(p0_c.clone())
+    optc = torch.optim.SGD([pc], lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-3)
+    gcl = rnd(1003, seed=45) * 5.0
+    pc.grad = gcl.clone()
+    torch.nn.utils.clip_grad_norm_([pc], 1.5)
+    optc.step()
+    pgc, bufc = p0_c.clone().to(dev()), torch.empty(1003, device=dev())
+    ssc, coefc = torch.zeros(1, device=dev()), torch.empty(1, device=dev())
+    ops.sumsq(gcl.to(dev()), ssc)
+    ops.clip_coef(ssc, 1.5, coefc)
+    ops.sgd_nesterov(pgc, gcl.to(dev()), bufc, 0.1, 0.9, 1e-3, 1.0, True, gscale_dev=coefc)
+    assert rel_l2(pgc.cpu(), pc.detach()) < 1e-6
+
     # Nesterov SGD vs torch.optim.SGD
     n = 1000 + 3
     p0, g0, g1 = rnd(n, seed=40), rnd(n, seed=41), rnd(n, seed=42)

@@ -278,6 +278,43 @@ def test_trainer_fused_sgd_and_weight_images():
     assert losses[-1] < losses[0], losses
 
 
+def test_trainer_gradient_clipping_matches_torch():
+    """opt.grad_clip (train.py:254-260): global-norm clipping with the coefficient kept on the device equals
+    torch.nn.utils.clip_grad_norm_ followed by torch's Nesterov SGD."""
+    import afft_amd
+    from afft_amd import runtime as rt
+    from afft_amd.config import make_model_cfg
+    from afft_amd.models.base_model import BaseModel
+    from afft_amd.parallel import Trainer
+    afft_amd.set_precision("bf16")
+    rt.set_grad_mode("sink")
+    dev = torch.device("cuda:0")
+    mods = {"rgb": 128, "flow": 128}
+    B, T = 8, 8
+    g = torch.Generator().manual_seed(21)
+    feats = {m: torch.randn(B, T, C, 1, 1, 1, generator=g).to(dev) for m, C in mods.items()}
+    tgt = {"action": torch.randint(0, 31, (B,), generator=g).to(dev)}
+    sub = {"action": torch.randint(0, 31, (B, T, 1), generator=g).to(dev)}
+    torch.manual_seed(6)
+    model = BaseModel(make_model_cfg(mods, 128, 256, depth=2, fp_layers=2, fp_heads=4, drop=0.0), {"action": 31}, {}).to(dev).eval()
+    clip = 0.05
+    tr = Trainer(model, {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}, lr=0.05, momentum=0.9,
+                 weight_decay=1e-4, grad_clip=clip)
+    assert not tr.overlap_optimizer            # the whole gradient is needed before the first update
+    p0 = tr.flat.flat_p.clone()
+    tr.forward_backward(feats, tgt, sub)
+    grad = tr.flat.flat_g.clone()
+    assert float(grad.norm()) > clip           # the clip is active
+    ref_p = torch.nn.Parameter(p0.clone())
+    ref_p.grad = grad.clone()
+    torch.nn.utils.clip_grad_norm_([ref_p], clip)
+    torch.optim.SGD([ref_p], lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-4).step()
+    gflat, scale = tr.reducer.grad_for_optimizer()
+    tr.opt.step(gflat, scale, grad_clip=clip)
+    assert rel_l2(tr.flat.flat_p, ref_p.detach()) < 1e-6
+    assert abs(float(tr.opt.last_grad_norm) - float(grad.norm())) < 1e-4 * float(grad.norm())
+
+
 def test_overlapped_optimizer_and_wgrad_streams_equal_serial():
     """Per-bucket SGD on the side stream (under backward) and weight-gradient GEMMs on the auxiliary stream must give
     the same parameters as the fully serial schedule (same kernels, same order of accumulation)."""
