@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("AFFT_LIB") or os.path.join(_HERE, "lib", "libafft_hip
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_DGELU_ERF, ACT_DGELU_TANH = 0, 1, 2, 3, 4
-MASK_NONE, MASK_DIAG, MASK_CAUSAL = 0, 1, 2
+MASK_NONE, MASK_DIAG, MASK_CAUSAL, MASK_BLOCKCAUSAL = 0, 1, 2, 3
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -51,7 +51,7 @@ _SIGS = {
     "afft_layernorm_bwd_nparts": ([i32], C.c_int),
     "afft_layernorm_bwd": ([vp, i64, i32, vp, i64, vp, vp, vp, i32, i32, vp, vp, i64, vp, C.POINTER(Dropout), vp, vp, i32,
                             vp, i32, vp, vp], C.c_int),
-    "afft_attention_fwd": ([vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, i32, f32, C.c_uint32,
+    "afft_attention_fwd": ([vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, i32, i32, f32, C.c_uint32,
                             vp, i64, vp, vp], C.c_int),
     "afft_attention_bwd": ([vp, i64, vp, i64, vp, i64, vp, i64, i32, vp, i32, i32, i32, i32, f32, f32, C.c_uint32,
                             vp, i64, vp, i64, vp, i64, vp], C.c_int),
@@ -64,6 +64,8 @@ _SIGS = {
     "afft_reduce_rows_periodic": ([vp, i64, i32, i32, i32, vp, i64, vp], C.c_int),
     "afft_sgd_nesterov": ([vp, vp, i32, vp, vp, i64, f32, f32, f32, f32, vp, i32, vp], C.c_int),
     "afft_sumsq": ([vp, i32, i64, f32, vp, vp], C.c_int),
+    "afft_group_sum": ([vp, i32, i32, i64, f32, vp, vp], C.c_int),
+    "afft_group_bcast": ([vp, i32, i32, i64, f32, vp, vp], C.c_int),
     "afft_clip_coef": ([vp, f32, vp, vp, vp], C.c_int),
 }
 

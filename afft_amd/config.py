@@ -25,6 +25,14 @@ def make_model_cfg(modal_dims: Dict[str, int], common_dim: int, fp_inter_dim: in
     elif fuser == "ca":
         fz = dict(_target_="models.fusion.TemporalCrossAttentFuser", dim=common_dim, modalities=dict(modal_dims),
                   num_heads=num_heads, embd_drop_rate=drop, drop_rate=drop, attn_drop_rate=drop, drop_path_rate=drop)
+    elif fuser == "cm":      # conf/model/fuser/CMFuser.yaml: SA-Fuser without modality token
+        fz = dict(_target_="models.fusion.CMFuser", dim=common_dim, depth=depth, num_heads=num_heads,
+                  embd_drop_rate=drop, drop_rate=drop, attn_drop_rate=drop, drop_path_rate=drop, cross_attn=cross_attn)
+    elif fuser == "tsa":     # conf/model/fuser/T-SA-Fuser.yaml
+        fz = dict(_target_="models.fusion.TemporalCMFuser", dim=common_dim, depth=depth, num_heads=num_heads,
+                  embd_drop_rate=drop, drop_rate=drop, attn_drop_rate=drop, drop_path_rate=drop,
+                  modalities=dict(modal_dims), modal_encoding=modal_encoding, frame_level_token=frame_level_token,
+                  temporal_sequence_length=T if frame_level_token else None)
     else:
         raise ValueError(fuser)
     cfg = dict(

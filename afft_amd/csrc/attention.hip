@@ -1,6 +1,7 @@
 // Small-sequence attention, forward and backward, generic over storage type (fp32 parity mode / bf16).
-// One workgroup per (sequence, head); L <= 32 tokens, so the whole score matrix lives in LDS and the
-// mask is applied in-register while the scores are produced.  HBM-bound by construction (reads q,k,v once
+// One workgroup per (sequence, head); L <= 128 tokens (the T-SA-Fuser attends over M*T tokens: models/fusion.py:121-215),
+// so the whole score matrix lives in LDS (template LM = 32 / 64 / 128 rows) and the mask is applied in-register while
+// the scores are produced.  HBM-bound by construction (reads q,k,v once
 // through L1/L2, writes out once): attention is < 0.2 % of the path's FLOPs.
 //   softmax(q k^T * hd^-0.5 + mask) v : models/transformerblock.py:24-33,64-73 ; HF GPT-2 eager attention.
 #include <stdlib.h>
@@ -9,19 +10,21 @@
 
 namespace {
 
-constexpr int LMAX = 32;
+constexpr int LMAX = 128;
 
-__device__ __forceinline__ bool masked(int mask, int i, int j) {
-  return (mask == AFFT_MASK_DIAG && i == j) || (mask == AFFT_MASK_CAUSAL && j > i);
+__device__ __forceinline__ bool masked(int mask, int period, int i, int j) {
+  return (mask == AFFT_MASK_DIAG && i == j) || (mask == AFFT_MASK_CAUSAL && j > i) ||
+         (mask == AFFT_MASK_BLOCKCAUSAL && (j % period) > (i % period));
 }
 
-template <typename T>
+template <typename T, int LM>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, int64_t ldq, const T* __restrict__ k,
                                                        int64_t ldk, const T* __restrict__ v, int64_t ldv, int L, int H,
-                                                       int hd, float scale, int mask, unsigned dthresh, unsigned dkey,
-                                                       float dinv, T* __restrict__ out, int64_t ldo,
+                                                       int hd, float scale, int mask, int period, unsigned dthresh,
+                                                       unsigned dkey, float dinv, T* __restrict__ out, int64_t ldo,
                                                        float* __restrict__ probs) {
-  __shared__ float sc[LMAX][LMAX + 1];
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float (*sc)[LM + 1] = reinterpret_cast<float (*)[LM + 1]>(smem_raw);
   const int seq = blockIdx.x / H, h = blockIdx.x % H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t row0 = (int64_t)seq * L;
@@ -32,7 +35,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, 
   for (int idx = wave; idx < L * L; idx += 4) {
     const int i = idx / L, j = idx - i * L;
     float s = 0.f;
-    if (!masked(mask, i, j)) {
+    if (!masked(mask, period, i, j)) {
       for (int c = lane; c < hd; c += 64) s += Elem<T>::ld(qh + i * ldq + c) * Elem<T>::ld(kh + j * ldk + c);
       s = wave_sum(s) * scale;
     } else {
@@ -62,19 +65,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, 
   }
   __syncthreads();
   for (int c = tid; c < hd; c += 256) {
-    float vc[LMAX];
+    float vc[LM];
 #pragma unroll
-    for (int j = 0; j < LMAX; ++j) vc[j] = j < L ? Elem<T>::ld(vh + j * ldv + c) : 0.f;
+    for (int j = 0; j < LM; ++j) vc[j] = j < L ? Elem<T>::ld(vh + j * ldv + c) : 0.f;
     for (int i = 0; i < L; ++i) {
       float o = 0.f;
 #pragma unroll
-      for (int j = 0; j < LMAX; ++j) o += (j < L ? sc[i][j] : 0.f) * vc[j];
+      for (int j = 0; j < LM; ++j) o += (j < L ? sc[i][j] : 0.f) * vc[j];
       Elem<T>::st(out + (row0 + i) * ldo + (int64_t)h * hd + c, o);
     }
   }
 }
 
-template <typename T>
+template <typename T, int LM>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ dout, int64_t lddo, const T* __restrict__ q,
                                                        int64_t ldq, const T* __restrict__ k, int64_t ldk,
                                                        const T* __restrict__ v, int64_t ldv,
@@ -82,8 +85,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ dou
                                                        unsigned dthresh, unsigned dkey, float dinv,
                                                        T* __restrict__ dq, int64_t lddq, T* __restrict__ dk, int64_t lddk,
                                                        T* __restrict__ dv, int64_t lddv) {
-  __shared__ float pp[LMAX][LMAX + 1];  // probabilities (pre-dropout), later the dropped-out P' used by dV
-  __shared__ float ds[LMAX][LMAX + 1];  // dP, then dS*scale
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float (*pp)[LM + 1] = reinterpret_cast<float (*)[LM + 1]>(smem_raw);                  // probabilities (pre-dropout), later the dropped-out P' used by dV
+  float (*ds)[LM + 1] = reinterpret_cast<float (*)[LM + 1]>(smem_raw) + LM;             // dP, then dS*scale
   const int seq = blockIdx.x / H, h = blockIdx.x % H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t row0 = (int64_t)seq * L;
@@ -120,35 +124,76 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ dou
   }
   __syncthreads();
   for (int c = tid; c < hd; c += 256) {
-    float a[LMAX];
+    float a[LM];
     // dV[j][c] = sum_i P[i][j] dO[i][c]
 #pragma unroll
-    for (int i = 0; i < LMAX; ++i) a[i] = i < L ? Elem<T>::ld(doh + i * lddo + c) : 0.f;
+    for (int i = 0; i < LM; ++i) a[i] = i < L ? Elem<T>::ld(doh + i * lddo + c) : 0.f;
     for (int j = 0; j < L; ++j) {
       float o = 0.f;
 #pragma unroll
-      for (int i = 0; i < LMAX; ++i) o += (i < L ? pp[i][j] : 0.f) * a[i];
+      for (int i = 0; i < LM; ++i) o += (i < L ? pp[i][j] : 0.f) * a[i];
       Elem<T>::st(dv + (row0 + j) * lddv + (int64_t)h * hd + c, o);
     }
     // dQ[i][c] = sum_j dS[i][j] k[j][c]
 #pragma unroll
-    for (int j = 0; j < LMAX; ++j) a[j] = j < L ? Elem<T>::ld(kh + j * ldk + c) : 0.f;
+    for (int j = 0; j < LM; ++j) a[j] = j < L ? Elem<T>::ld(kh + j * ldk + c) : 0.f;
     for (int i = 0; i < L; ++i) {
       float o = 0.f;
 #pragma unroll
-      for (int j = 0; j < LMAX; ++j) o += (j < L ? ds[i][j] : 0.f) * a[j];
+      for (int j = 0; j < LM; ++j) o += (j < L ? ds[i][j] : 0.f) * a[j];
       Elem<T>::st(dq + (row0 + i) * lddq + (int64_t)h * hd + c, o);
     }
     // dK[j][c] = sum_i dS[i][j] q[i][c]
 #pragma unroll
-    for (int i = 0; i < LMAX; ++i) a[i] = i < L ? Elem<T>::ld(qh + i * ldq + c) : 0.f;
+    for (int i = 0; i < LM; ++i) a[i] = i < L ? Elem<T>::ld(qh + i * ldq + c) : 0.f;
     for (int j = 0; j < L; ++j) {
       float o = 0.f;
 #pragma unroll
-      for (int i = 0; i < LMAX; ++i) o += (i < L ? ds[i][j] : 0.f) * a[i];
+      for (int i = 0; i < LM; ++i) o += (i < L ? ds[i][j] : 0.f) * a[i];
       Elem<T>::st(dk + (row0 + j) * lddk + (int64_t)h * hd + c, o);
     }
   }
+}
+
+
+
+template <typename T, int LM>
+int launch_fwd(dim3 grid, hipStream_t stream, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+               int L, int H, int hd, float scale, int mask, int period, const DropParams& dp, void* out, int64_t ldo,
+               float* probs) {
+  constexpr size_t lds = sizeof(float) * LM * (LM + 1);
+  auto kern = attn_fwd_kernel<T, LM>;
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      afft_set_error("attention_fwd: cannot reserve %zu bytes of LDS", lds);
+      (void)hipGetLastError();
+      return 2;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv, L, H, hd, scale,
+                     mask, period, dp.thresh, dp.key, dp.inv_keep, (T*)out, ldo, probs);
+  return 0;
+}
+template <typename T, int LM>
+int launch_bwd(dim3 grid, hipStream_t stream, const void* dout, int64_t lddo, const void* q, int64_t ldq, const void* k,
+               int64_t ldk, const void* v, int64_t ldv, const float* probs, int L, int H, int hd, float scale,
+               const DropParams& dp, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv) {
+  constexpr size_t lds = sizeof(float) * 2 * LM * (LM + 1);
+  auto kern = attn_bwd_kernel<T, LM>;
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      afft_set_error("attention_bwd: cannot reserve %zu bytes of LDS", lds);
+      (void)hipGetLastError();
+      return 2;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)dout, lddo, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
+                     probs, L, H, hd, scale, dp.thresh, dp.key, dp.inv_keep, (T*)dq, lddq, (T*)dk, lddk, (T*)dv, lddv);
+  return 0;
 }
 
 }  // namespace
@@ -166,30 +211,32 @@ static bool use_mfma_attention() {
 
 extern "C" int afft_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                                   int32_t dtype, int32_t nseq, int32_t L, int32_t H, int32_t hd, float scale,
-                                  int32_t mask, float drop_p, uint32_t drop_key, void* out, int64_t ldo, float* probs,
-                                  void* stream_) {
+                                  int32_t mask, int32_t mask_period, float drop_p, uint32_t drop_key, void* out,
+                                  int64_t ldo, float* probs, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(q && k && v && out, "attention_fwd: null pointer");
   AFFT_CHECK(L >= 1 && L <= LMAX, "attention_fwd: sequence length %d outside 1..%d", L, LMAX);
-  AFFT_CHECK(mask >= AFFT_MASK_NONE && mask <= AFFT_MASK_CAUSAL, "attention_fwd: bad mask %d", mask);
+  AFFT_CHECK(mask >= AFFT_MASK_NONE && mask <= AFFT_MASK_BLOCKCAUSAL, "attention_fwd: bad mask %d", mask);
+  AFFT_CHECK(mask != AFFT_MASK_BLOCKCAUSAL || (mask_period >= 1 && L % mask_period == 0),
+             "attention_fwd: block-causal mask needs a period that divides L (L=%d, period=%d)", L, mask_period);
   AFFT_CHECK(!(mask == AFFT_MASK_DIAG && L == 1), "attention_fwd: diagonal mask with L=1 masks every key");
   AFFT_CHECK(drop_p >= 0.f && drop_p < 1.f, "attention_fwd: dropout p outside [0,1)");
   if (nseq == 0) return 0;
-  if (dtype == AFFT_BF16 && use_mfma_attention()) {
+  if (dtype == AFFT_BF16 && use_mfma_attention() && mask <= AFFT_MASK_CAUSAL) {
     const int rc = afft_attention_mfma(false, nullptr, 0, q, ldq, k, ldk, v, ldv, probs, nseq, L, H, hd, scale, mask,
                                        drop_p, drop_key, out, ldo, nullptr, 0, nullptr, 0, nullptr, 0, stream);
     if (rc >= 0) return rc;
   }
   afft_dropout_t dd = {drop_p, drop_key, 0.f, 0u, 1};
   const DropParams dp = make_drop(&dd);
-  const dim3 grid(nseq * H), block(256);
-  if (dtype == AFFT_F32)
-    hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, 0, stream, (const float*)q, ldq, (const float*)k, ldk,
-                       (const float*)v, ldv, L, H, hd, scale, mask, dp.thresh, dp.key, dp.inv_keep, (float*)out, ldo, probs);
-  else if (dtype == AFFT_BF16)
-    hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
-                       (const bf16_t*)v, ldv, L, H, hd, scale, mask, dp.thresh, dp.key, dp.inv_keep, (bf16_t*)out, ldo, probs);
-  else AFFT_CHECK(false, "attention_fwd: bad dtype %d", dtype);
+  const dim3 grid(nseq * H);
+  AFFT_CHECK(dtype == AFFT_F32 || dtype == AFFT_BF16, "attention_fwd: bad dtype %d", dtype);
+  int rc;
+#define FWD(T, LM) launch_fwd<T, LM>(grid, stream, q, ldq, k, ldk, v, ldv, L, H, hd, scale, mask, mask_period, dp, out, ldo, probs)
+  if (dtype == AFFT_F32) rc = L <= 32 ? FWD(float, 32) : L <= 64 ? FWD(float, 64) : FWD(float, 128);
+  else rc = L <= 32 ? FWD(bf16_t, 32) : L <= 64 ? FWD(bf16_t, 64) : FWD(bf16_t, 128);
+#undef FWD
+  if (rc) return rc;
   AFFT_LAUNCH_CHECK();
   return 0;
 }
@@ -210,16 +257,14 @@ extern "C" int afft_attention_bwd(const void* dout, int64_t lddo, const void* q,
   }
   afft_dropout_t dd = {drop_p, drop_key, 0.f, 0u, 1};
   const DropParams dp = make_drop(&dd);
-  const dim3 grid(nseq * H), block(256);
-  if (dtype == AFFT_F32)
-    hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, block, 0, stream, (const float*)dout, lddo, (const float*)q, ldq,
-                       (const float*)k, ldk, (const float*)v, ldv, probs, L, H, hd, scale, dp.thresh, dp.key, dp.inv_keep,
-                       (float*)dq, lddq, (float*)dk, lddk, (float*)dv, lddv);
-  else if (dtype == AFFT_BF16)
-    hipLaunchKernelGGL(attn_bwd_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)dout, lddo, (const bf16_t*)q, ldq,
-                       (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, probs, L, H, hd, scale, dp.thresh, dp.key, dp.inv_keep,
-                       (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv);
-  else AFFT_CHECK(false, "attention_bwd: bad dtype %d", dtype);
+  const dim3 grid(nseq * H);
+  AFFT_CHECK(dtype == AFFT_F32 || dtype == AFFT_BF16, "attention_bwd: bad dtype %d", dtype);
+  int rc;
+#define BWD(T, LM) launch_bwd<T, LM>(grid, stream, dout, lddo, q, ldq, k, ldk, v, ldv, probs, L, H, hd, scale, dp, dq, lddq, dk, lddk, dv, lddv)
+  if (dtype == AFFT_F32) rc = L <= 32 ? BWD(float, 32) : L <= 64 ? BWD(float, 64) : BWD(float, 128);
+  else rc = L <= 32 ? BWD(bf16_t, 32) : L <= 64 ? BWD(bf16_t, 64) : BWD(bf16_t, 128);
+#undef BWD
+  if (rc) return rc;
   AFFT_LAUNCH_CHECK();
   return 0;
 }

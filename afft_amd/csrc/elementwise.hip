@@ -269,6 +269,50 @@ extern "C" int afft_reduce_rows_periodic(const float* src, int64_t lds_, int32_t
   return 0;
 }
 
+// y[g, :] = scale * sum_s x[g, s, :]  (x fp32 [G, S, W], W % 4 == 0): the token mean of the fusers without a modality
+// token (models/fusion.py:114-116 CMFuser, :207-210 T-SA-Fuser); and its backward, a broadcast
+__global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict__ x, int S, int64_t W, float scale,
+                                                        float* __restrict__ y) {
+  const int64_t g = blockIdx.y;
+  const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= W) return;
+  const float* xg = x + g * S * W + c;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < S; ++s) {
+    const float4 t = *(const float4*)(xg + (int64_t)s * W);
+    a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+  }
+  *(float4*)(y + g * W + c) = make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale);
+}
+__global__ __launch_bounds__(256) void group_bcast_kernel(const float* __restrict__ dy, int S, int64_t W, float scale,
+                                                          float* __restrict__ dx) {
+  const int64_t g = blockIdx.y;
+  const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= W) return;
+  float4 t = *(const float4*)(dy + g * W + c);
+  t = make_float4(t.x * scale, t.y * scale, t.z * scale, t.w * scale);
+  for (int s = 0; s < S; ++s) *(float4*)(dx + (g * S + s) * W + c) = t;
+}
+
+extern "C" int afft_group_sum(const float* x, int32_t G, int32_t S, int64_t W, float scale, float* y, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(x && y && S >= 1, "group_sum: bad argument");
+  AFFT_CHECK(W % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, "group_sum: W must be a multiple of 4, buffers 16-byte aligned");
+  if (G == 0 || W == 0) return 0;
+  hipLaunchKernelGGL(group_sum_kernel, dim3((unsigned)((W / 4 + 255) / 256), G), dim3(256), 0, stream, x, S, W, scale, y);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int afft_group_bcast(const float* dy, int32_t G, int32_t S, int64_t W, float scale, float* dx, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(dy && dx && S >= 1, "group_bcast: bad argument");
+  AFFT_CHECK(W % 4 == 0 && (((uintptr_t)dy | (uintptr_t)dx) & 15) == 0, "group_bcast: W must be a multiple of 4, buffers 16-byte aligned");
+  if (G == 0 || W == 0) return 0;
+  hipLaunchKernelGGL(group_bcast_kernel, dim3((unsigned)((W / 4 + 255) / 256), G), dim3(256), 0, stream, dy, S, W, scale, dx);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
 // sum of squares of a flat gradient buffer (fp32 or bf16), added to *out: one float atomic per workgroup
 __global__ __launch_bounds__(256) void sumsq_kernel(const void* __restrict__ x, int dtype, int64_t n, float scale,
                                                     float* __restrict__ out) {

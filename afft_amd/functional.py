@@ -13,8 +13,8 @@ from typing import NamedTuple, List, Optional, Tuple
 import torch
 
 from . import ops, runtime as rt
-from ._lib import (ACT_DGELU_ERF, ACT_DGELU_TANH, ACT_GELU_ERF, ACT_GELU_TANH, ACT_NONE, MASK_CAUSAL, MASK_DIAG,
-                   MASK_NONE)
+from ._lib import (ACT_DGELU_ERF, ACT_DGELU_TANH, ACT_GELU_ERF, ACT_GELU_TANH, ACT_NONE, MASK_BLOCKCAUSAL, MASK_CAUSAL,
+                   MASK_DIAG, MASK_NONE)
 
 Tensor = torch.Tensor
 
@@ -336,7 +336,14 @@ def _out_drop(drop):
 
 
 _GELU = {"erf": (ACT_GELU_ERF, ACT_DGELU_ERF), "tanh": (ACT_GELU_TANH, ACT_DGELU_TANH)}
-_MASK = {"none": MASK_NONE, "diag": MASK_DIAG, "causal": MASK_CAUSAL}
+_MASK = {"none": MASK_NONE, "diag": MASK_DIAG, "causal": MASK_CAUSAL, "blockcausal": MASK_BLOCKCAUSAL}
+
+
+def _mask_args(mask):
+    """'none' | 'diag' | 'causal' | ('blockcausal', T)  ->  (kernel mask id, period)"""
+    if isinstance(mask, str):
+        return _MASK[mask], 0
+    return _MASK[mask[0]], int(mask[1])
 
 
 # --------------------------------------------------------------------------- pre-LN self-attention sub-layer
@@ -363,8 +370,9 @@ class AttnSublayer(torch.autograd.Function):
         ao = Act(R, d, dev)
         probs = torch.empty(nseq, H, L, L, dtype=torch.float32, device=dev)
         scale = float(scale) if scale else float(hd) ** -0.5
+        mk, per = _mask_args(mask)
         ops.attention_fwd(qkv.cols(0, d), qkv.cols(d, 2 * d), qkv.cols(2 * d, 3 * d), nseq, L, H, hd, scale,
-                          _MASK[mask], ao.live, probs, *(_attn_drop(drop)))
+                          mk, ao.live, probs, *(_attn_drop(drop)), mask_period=per)
         y = torch.empty(R, d, dtype=torch.float32, device=dev)
         _lin_fwd(ao, w_proj, conv1d, y, bias=b_proj, residual=x if pre_ln else None, drop=_out_drop(drop))
         ctx.save_for_backward(x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, mean, rstd, probs)
@@ -498,8 +506,9 @@ class CrossAttnSublayer(torch.autograd.Function):
         ao = Act(R, d, dev)
         probs = torch.empty(nseq, H, L, L, dtype=torch.float32, device=dev)
         scale = float(scale) if scale else float(hd) ** -0.5
-        ops.attention_fwd(q.live, k.live, v.live, nseq, L, H, hd, scale, _MASK[mask], ao.live, probs,
-                          *(_attn_drop(drop)))
+        mask_id, per = _mask_args(mask)
+        ops.attention_fwd(q.live, k.live, v.live, nseq, L, H, hd, scale, mask_id, ao.live, probs,
+                          *(_attn_drop(drop)), mask_period=per)
         y = torch.empty(R, d, dtype=torch.float32, device=dev)
         _lin_fwd(ao, w_proj, False, y, bias=b_proj, residual=x if pre_ln else None, drop=_out_drop(drop))
         ctx.save_for_backward(x, mem, nq_w, nq_b, nkv_w, nkv_b, w_q, w_k, w_v, w_proj, b_proj, mq, rq, mk, rk, probs)
@@ -699,7 +708,7 @@ class AddRowTable(torch.autograd.Function):
         period, offset = ctx.cfg
         _drop_shadow()
         dy = dy.contiguous()
-        if rt.grad_mode() == "sink":
+        if rt.grad_mode() == "sink" and table.is_leaf:   # a computed table (T-SA-Fuser) hands its gradient to autograd
             g, acc = rt.SINK.grad_buffer(table)
             if not acc:
                 g.zero_()
@@ -710,6 +719,76 @@ class AddRowTable(torch.autograd.Function):
         ops.reduce_rows_periodic(dy, period, g[offset:offset + period])
         flush_ready()
         return dy, g, None, None
+
+
+class SinkParam(torch.autograd.Function):
+    """Identity on a (small) parameter that is consumed by torch glue ops (slicing / repeat of an embedding table):
+    its gradient comes back through autograd and is routed into the gradient sink here, like every other parameter
+    gradient of the path (first touch of a step overwrites, later ones add; readiness is notified), instead of being
+    accumulated onto last step's value by autograd's AccumulateGrad."""
+
+    @staticmethod
+    def forward(ctx, p):
+        ctx.save_for_backward(p)
+        return p.view_as(p)
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        if rt.grad_mode() != "sink":
+            return g
+        buf, acc = rt.SINK.grad_buffer(p)
+        if acc:
+            buf.add_(g)
+        else:
+            buf.copy_(g)
+        _ready(p)
+        flush_ready()
+        return None
+
+
+class ScatterTokens(torch.autograd.Function):
+    """X[g, s, :] = feats[s][g, :]: the modality features as the tokens of one sequence, without a modality token
+    (models/fusion.py:107 CMFuser: (B*T, n, C); :176 T-SA-Fuser: (B, n*T, C) with rows = whole clips)."""
+
+    @staticmethod
+    def forward(ctx, *feats):
+        G, W = feats[0].shape
+        S = len(feats)
+        _forget_output()
+        X = torch.empty(G, S * W, dtype=torch.float32, device=feats[0].device)
+        for i, f in enumerate(feats):
+            ops.cast(f if f.stride(1) == 1 else f.contiguous(), X[:, i * W:(i + 1) * W])
+        ctx.cfg = (S, W, [f.requires_grad for f in feats])
+        return X
+
+    @staticmethod
+    def backward(ctx, dX):
+        S, W, needs = ctx.cfg
+        _drop_shadow()
+        return tuple(dX[:, i * W:(i + 1) * W] if n else None for i, n in enumerate(needs))
+
+
+class GroupMean(torch.autograd.Function):
+    """y[g, :] = mean_s x[g, s, :] for x fp32 [G, S, W] (models/fusion.py:114, :207-210)."""
+
+    @staticmethod
+    def forward(ctx, x, G, S, W):
+        _forget_output()
+        ctx.in_shape = tuple(x.shape)
+        x = x.contiguous()
+        y = torch.empty(G, W, dtype=torch.float32, device=x.device)
+        ops.group_sum(x, G, S, W, 1.0 / S, y)
+        ctx.cfg = (G, S, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        G, S, W = ctx.cfg
+        _drop_shadow()
+        dx = torch.empty(G * S, W, dtype=torch.float32, device=dy.device)
+        ops.group_bcast(dy.contiguous(), G, S, W, 1.0 / S, dx)
+        return dx.view(ctx.in_shape), None, None, None
 
 
 class ElementDropout(torch.autograd.Function):

@@ -107,6 +107,115 @@ class ModalTokenCMFuser(nn.Module):
         return z.view(B, T, C), torch.stack(attn_weights).transpose(0, 1)
 
 
+class CMFuser(nn.Module):
+    """Corresponds to SA-Fuser without modality token in the paper (models/fusion.py:61-118): the M modality features
+    of a frame attend to each other, the fused feature is the MEAN of the M output tokens."""
+
+    def __init__(self, dim, depth=1, num_heads=4, mlp_ratio=4., qkv_bias=False, qk_scale=None, embd_drop_rate=0.,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0., act_layer=nn.GELU, norm_layer=None,
+                 cross_attn=False):
+        super().__init__()
+        from functools import partial
+        norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]  # stochastic depth decay rule
+        self.blocks = nn.ModuleList([
+            Block(dim=dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                  drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[i], act_layer=act_layer,
+                  norm_layer=norm_layer) for i in range(depth)])
+        self.norm = norm_layer(dim)
+        self.embd_drop = nn.Dropout(embd_drop_rate)
+        self.cross_attn = cross_attn
+        self.apply(_init_weights)
+
+    @staticmethod
+    def generate_cross_attention_mask(sz):
+        mask = torch.eye(sz)
+        return mask.masked_fill(mask == 1, float('-inf'))
+
+    def forward(self, modal_feats: Dict[str, Tensor], ordered_feature_list: Callable) -> Tuple[Tensor, Tensor]:
+        B, T, C = _check_same_shape(modal_feats)
+        feats = ordered_feature_list(modal_feats)
+        S = len(feats)
+        BT = B * T
+        X = F_.ScatterTokens.apply(*[_rows(f, BT, C) for f in feats]).view(BT * S, C)     # n * (B,T,C) -> (B*T, n, C)
+        if self.training and self.embd_drop.p > 0:
+            X = F_.ElementDropout.apply(X, D_.elementwise(self.embd_drop.p))
+        mask = "diag" if self.cross_attn else "none"
+        attn_weights = []
+        for blk in self.blocks:
+            X, probs = blk.forward_rows(X, S, mask)
+            attn_weights.append(probs.view(B, T, *probs.shape[1:]))
+        X = F_.LayerNormRows.apply(X, self.norm.weight, self.norm.bias, self.norm.eps, 1)
+        z = F_.GroupMean.apply(X, BT, S, C)                                                # torch.mean(x, dim=1)
+        return z.view(-1, T, C), torch.stack(attn_weights).transpose(0, 1)
+
+
+class TemporalCMFuser(nn.Module):
+    """Corresponds to T-SA-Fuser in the paper (models/fusion.py:121-215): temporal (causal) and multi-modal attention
+    at the same time -- one sequence of num_mods * T tokens per clip, modality-major, under the causal T x T mask tiled
+    over the modalities; frame position + modality embeddings."""
+
+    def __init__(self, dim, depth=1, num_heads=4, mlp_ratio=4., qkv_bias=False, qk_scale=None, embd_drop_rate=0.,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0., act_layer=nn.GELU, norm_layer=None,
+                 modalities=None, modal_encoding=True, frame_level_token=False, temporal_sequence_length=None,
+                 max_position_embeddings=64):
+        super().__init__()
+        from functools import partial
+        norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]  # stochastic depth decay rule
+        self.blocks = nn.ModuleList([
+            Block(dim=dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                  drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[i], act_layer=act_layer,
+                  norm_layer=norm_layer) for i in range(depth)])
+        self.norm = norm_layer(dim)
+        # frame position embedding and modality embedding
+        self.num_mods = len(modalities) + 1 if frame_level_token else len(modalities)
+        self.modality_embedding = nn.Parameter(torch.zeros(self.num_mods, dim)) if modal_encoding else None
+        self.position_embeddings = nn.Embedding(max_position_embeddings, dim)
+        self.embd_drop = nn.Dropout(embd_drop_rate)
+        self.frame_level_token = frame_level_token
+        self.temporal_sequence_length = temporal_sequence_length
+        self.modal_token = None        # modality agnostic token
+        if frame_level_token:
+            assert temporal_sequence_length is not None, "Temporal sequence length must be provided!"
+            self.modal_token = nn.Parameter(torch.zeros(1, temporal_sequence_length, dim))
+        if self.modal_token is not None:
+            trunc_normal_(self.modal_token, std=.02)
+        if self.modality_embedding is not None:
+            trunc_normal_(self.modality_embedding, std=.02)
+        self.apply(_init_weights)
+
+    def forward(self, modal_feats: Dict[str, Tensor], ordered_feature_list: Callable) -> Tuple[Tensor, Tensor]:
+        B, T, C = _check_same_shape(modal_feats)
+        n = self.num_mods
+        L = n * T
+        if L > 128:
+            raise NotImplementedError(f"afft_amd: T-SA-Fuser sequences of {L} tokens (> 128) are not built")
+        feats = [_rows(f, B, T * C) for f in ordered_feature_list(modal_feats)]           # each (B, T*C)
+        if self.frame_level_token:
+            assert self.temporal_sequence_length == T, \
+                f"Temporal sequence length not valid {self.temporal_sequence_length} vs {T}"
+            feats = [F_.SinkParam.apply(self.modal_token).reshape(1, T * C).expand(B, -1)] + feats
+        X = F_.ScatterTokens.apply(*feats).view(B * L, C)                                   # (B, n*T, C), modality-major
+        # position embedding of the frame + modality embedding: one [n*T, C] table added to every clip
+        table = F_.SinkParam.apply(self.position_embeddings.weight)[:T].repeat(n, 1)
+        if self.modality_embedding is not None:
+            table = table + F_.SinkParam.apply(self.modality_embedding).repeat_interleave(T, dim=0)
+        X = F_.AddRowTable.apply(X, table, L, 0)
+        if self.training and self.embd_drop.p > 0:
+            X = F_.ElementDropout.apply(X, D_.elementwise(self.embd_drop.p))
+        attn_weights = []
+        for blk in self.blocks:
+            X, probs = blk.forward_rows(X, L, ("blockcausal", T))                          # probs [B, H, L, L]
+            attn_weights.append(probs)
+        X = F_.LayerNormRows.apply(X, self.norm.weight, self.norm.bias, self.norm.eps, 1)
+        if self.frame_level_token:
+            z = X.view(B, L, C)[:, :T, :]       # the outputs of the frame-level modal tokens
+        else:
+            z = F_.GroupMean.apply(X, B, n, T * C).view(B, T, C)    # mean over the modality tokens of each frame
+        return z, torch.stack(attn_weights).transpose(0, 1)
+
+
 class TemporalCrossAttentFuser(nn.Module):
     """Corresponds to CA-Fuser in the paper: rgb is the query stream, every other modality a memory;
     depth = number of modalities - 1."""

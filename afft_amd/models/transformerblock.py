@@ -22,11 +22,16 @@ Tensor = torch.Tensor
 MaskArg = Union[None, str, Tensor]
 
 
-def mask_kind(attn_mask: MaskArg, n: int) -> str:
-    """The HIP attention kernel applies its mask in-register from a kind ('none' | 'diag' | 'causal').
-    The reference passes additive -inf tensors (models/fusion.py:30-32,313-317); recognise those."""
+def mask_kind(attn_mask: MaskArg, n: int):
+    """The HIP attention kernels apply their mask in-register from a kind: 'none' | 'diag' | 'causal' |
+    ('blockcausal', T).  The reference passes additive -inf tensors (models/fusion.py:30-32,170-171,313-317);
+    recognise those."""
     if attn_mask is None:
         return "none"
+    if isinstance(attn_mask, tuple):
+        if len(attn_mask) != 2 or attn_mask[0] != "blockcausal" or n % int(attn_mask[1]) != 0:
+            raise ValueError(f"unknown mask kind {attn_mask!r}")
+        return ("blockcausal", int(attn_mask[1]))
     if isinstance(attn_mask, str):
         if attn_mask not in ("none", "diag", "causal"):
             raise ValueError(f"unknown mask kind {attn_mask!r}")
@@ -36,13 +41,18 @@ def mask_kind(attn_mask: MaskArg, n: int) -> str:
         raise ValueError(f"attn_mask must be ({n},{n}), got {tuple(m.shape)}")
     if torch.equal(m, torch.zeros(n, n)):
         return "none"
-    if torch.equal(m, torch.triu(torch.full((n, n), float("-inf")), diagonal=1)):
+    causal = lambda t: torch.triu(torch.full((t, t), float("-inf")), diagonal=1)   # noqa: E731
+    if torch.equal(m, causal(n)):
         return "causal"
     eye = torch.zeros(n, n)
     eye.fill_diagonal_(float("-inf"))
     if torch.equal(m, eye):
         return "diag"
-    raise NotImplementedError("afft_amd: only the reference's masks (none / -inf diagonal / causal) are supported")
+    for t in range(1, n):            # T-SA-Fuser: the causal T x T mask tiled over the modalities
+        if n % t == 0 and torch.equal(m, causal(t).repeat(n // t, n // t)):
+            return ("blockcausal", t)
+    raise NotImplementedError("afft_amd: only the reference's masks (none / -inf diagonal / causal / causal tiled "
+                              "over the modalities) are supported")
 
 
 def _flat(x: Tensor):

@@ -117,10 +117,11 @@ def layernorm_bwd(dy: Tensor, x: Tensor, w: Optional[Tensor], mean: Tensor, rstd
 
 
 def attention_fwd(q: Tensor, k: Tensor, v: Tensor, nseq: int, L_: int, H: int, hd: int, scale: float, mask: int,
-                  out: Tensor, probs: Optional[Tensor], drop_p: float = 0.0, drop_key: int = 0) -> Tensor:
+                  out: Tensor, probs: Optional[Tensor], drop_p: float = 0.0, drop_key: int = 0,
+                  mask_period: int = 0) -> Tensor:
     assert q.dtype == k.dtype == v.dtype == out.dtype
     L.check(L.lib().afft_attention_fwd(_p(q), _rowmajor(q, "q"), _p(k), _rowmajor(k, "k"), _p(v), _rowmajor(v, "v"),
-                                       _dt(q), nseq, L_, H, hd, scale, mask, drop_p, drop_key, _p(out),
+                                       _dt(q), nseq, L_, H, hd, scale, mask, mask_period, drop_p, drop_key, _p(out),
                                        _rowmajor(out, "out"), _p(probs), _stream()), "attention_fwd")
     return out
 
@@ -232,3 +233,17 @@ def clip_coef(sumsq_: Tensor, max_norm: float, coef: Tensor, norm_out: Optional[
     """coef[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) on the device (no host sync)."""
     L.check(L.lib().afft_clip_coef(_p(sumsq_), float(max_norm), _p(coef), _p(norm_out), _stream()), "clip_coef")
     return coef
+
+
+def group_sum(x: Tensor, G: int, S: int, W: int, scale: float, y: Tensor):
+    """y[g, :] = scale * sum_s x[g, s, :] for contiguous fp32 x [G, S, W]."""
+    assert x.is_contiguous() and y.is_contiguous() and x.dtype == y.dtype == torch.float32
+    L.check(L.lib().afft_group_sum(_p(x), G, S, W, scale, _p(y), _stream()), "group_sum")
+    return y
+
+
+def group_bcast(dy: Tensor, G: int, S: int, W: int, scale: float, dx: Tensor):
+    """dx[g, s, :] = scale * dy[g, :]."""
+    assert dy.is_contiguous() and dx.is_contiguous() and dy.dtype == dx.dtype == torch.float32
+    L.check(L.lib().afft_group_bcast(_p(dy), G, S, W, scale, _p(dx), _stream()), "group_bcast")
+    return dx

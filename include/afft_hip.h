@@ -25,7 +25,7 @@ enum { AFFT_F32 = 0, AFFT_BF16 = 1 };
 enum { AFFT_ACT_NONE = 0, AFFT_ACT_GELU_ERF = 1, AFFT_ACT_GELU_TANH = 2,
        AFFT_ACT_DGELU_ERF = 3,   /* v *= d/du gelu_erf(aux[m,n])  (backward of nn.GELU)  */
        AFFT_ACT_DGELU_TANH = 4 };/* v *= d/du gelu_new(aux[m,n])  (backward of HF gelu_new) */
-enum { AFFT_MASK_NONE = 0, AFFT_MASK_DIAG = 1, AFFT_MASK_CAUSAL = 2 };
+enum { AFFT_MASK_NONE = 0, AFFT_MASK_DIAG = 1, AFFT_MASK_CAUSAL = 2, AFFT_MASK_BLOCKCAUSAL = 3 };
 
 /* Dropout description shared by the kernels that apply or replay a dropout mask.  keep(idx) is a pure
  * function of (key, element index), so backward passes regenerate the forward mask instead of storing it.
@@ -103,17 +103,21 @@ int afft_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const flo
                        float* dcol, int32_t dcol_accumulate, float* partial, void* stream);
 
 /* ------------------------------------------------------------------ small-sequence attention
- * softmax(q k^T * scale + mask) v per (sequence, head); L <= 32 tokens per sequence.
+ * softmax(q k^T * scale + mask) v per (sequence, head); L <= 128 tokens per sequence (bf16 MFMA kernel for
+ * L <= 32 and the first three masks, a generic kernel otherwise).
  *   SA-Fuser: L = M+1 modality tokens of one frame  (models/transformerblock.py:24-33, fusion.py:338-349)
  *   GPT-2:    L = T frames, causal                   (HF modeling_gpt2.py eager_attention_forward)
  *   CA-Fuser: causal self and cross attention        (models/transformerblock.py:56-76)
+ *   T-SA-Fuser: L = M*T tokens, AFFT_MASK_BLOCKCAUSAL with mask_period = T: key j is hidden from query i when
+ *               (j mod T) > (i mod T) = generate_square_subsequent_mask(T).repeat(M, M)  (models/fusion.py:170-171)
  * q/k/v: [nseq*L, *] with row strides ldq/ldk/ldv, head h at columns h*hd..; out [nseq*L, H*hd].
  * probs: fp32 [nseq, H, L, L] (the attention weights the reference returns; also saved for backward).
  * drop_p/drop_key: attention-probability dropout (attn_drop / attn_pdrop); probs always holds the
  * PRE-dropout probabilities (backward regenerates the mask). */
 int afft_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                        int32_t dtype, int32_t nseq, int32_t L, int32_t H, int32_t hd, float scale, int32_t mask,
-                       float drop_p, uint32_t drop_key, void* out, int64_t ldo, float* probs, void* stream);
+                       int32_t mask_period, float drop_p, uint32_t drop_key, void* out, int64_t ldo, float* probs,
+                       void* stream);
 int afft_attention_bwd(const void* dout, int64_t lddo, const void* q, int64_t ldq, const void* k, int64_t ldk,
                        const void* v, int64_t ldv, int32_t dtype, const float* probs, int32_t nseq, int32_t L,
                        int32_t H, int32_t hd, float scale, float drop_p, uint32_t drop_key, void* dq, int64_t lddq,
@@ -158,6 +162,12 @@ int afft_add_rows_periodic(const float* x, int64_t ldx, const float* table, int6
 /* out[(r % period), :] += sum over r of src[r, :]  (gradient of the above table) */
 int afft_reduce_rows_periodic(const float* src, int64_t lds, int32_t rows, int32_t period, int32_t d,
                               float* out, int64_t ldo, void* stream);
+/* Token means of the fusers without a modality token (models/fusion.py:114-116 CMFuser: mean over the M tokens of a
+ * frame; :207-210 T-SA-Fuser: mean over the M modality tokens of a frame position): x fp32 [G, S, W] contiguous,
+ *   afft_group_sum:   y[g, :]     = scale * sum_s x[g, s, :]
+ *   afft_group_bcast: dx[g, s, :] = scale * dy[g, :]            (its backward) */
+int afft_group_sum(const float* x, int32_t G, int32_t S, int64_t W, float scale, float* y, void* stream);
+int afft_group_bcast(const float* dy, int32_t G, int32_t S, int64_t W, float scale, float* dx, void* stream);
 /* Nesterov-momentum SGD over one flat fp32 parameter buffer (conf/opt/optimizer/sgd.yaml, train.py:262):
  *   g = gscale*g + wd*p ; buf = mom*buf + g ; p -= lr*(g + mom*buf) ; gscale = 1/world after a summing
  *   all-reduce; g may be fp32 or bf16 (bf16 gradient exchange).  p_bf16 (optional, same element offsets as p)

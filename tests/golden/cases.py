@@ -26,6 +26,19 @@ CASES = {
     "t3_m5": dict(fuser="sa", modal_dims={"rgb": 64, "objects": 64, "audio": 64, "poses": 64, "flow": 64},
                   d=64, D=64, depth=2, num_heads=4, fp_layers=2, fp_heads=4, T=8, B=2, num_classes=13,
                   fp_output_len=1),
+    # "next" fusers.  T4: CMFuser = SA-Fuser without modality token (mean over the M tokens), with the
+    # -inf diagonal mask; T5: T-SA-Fuser, M*T = 16 / 20 tokens per clip under the causal mask tiled over the modalities,
+    # with position + modality embeddings; once averaging the modality tokens, once with frame-level modal tokens.
+    "t4_cm": dict(fuser="cm", modal_dims=_MODS4, d=64, D=128, depth=2, num_heads=4, fp_layers=2, fp_heads=2,
+                  T=4, B=3, num_classes=11, fp_output_len=1, cross_attn=True),
+    "t5_tsa": dict(fuser="tsa", modal_dims=_MODS4, d=64, D=128, depth=2, num_heads=4, fp_layers=2, fp_heads=2,
+                   T=4, B=3, num_classes=11, fp_output_len=1, modal_encoding=True),
+    "t5_tsa_tok": dict(fuser="tsa", modal_dims=_MODS4, d=64, D=128, depth=2, num_heads=4, fp_layers=2, fp_heads=2,
+                       T=4, B=3, num_classes=11, fp_output_len=1, modal_encoding=True, frame_level_token=True),
+    # a 40-token T-SA sequence (M = 4, T = 10 as in expts/): exercises the L > 32 attention kernels
+    "t5_tsa_l40": dict(fuser="tsa", modal_dims={"rgb": 64, "objects": 64, "audio": 64, "flow": 64}, d=64, D=64,
+                       depth=1, num_heads=2, fp_layers=1, fp_heads=2, T=10, B=2, num_classes=7, fp_output_len=1,
+                       modal_encoding=True),
 }
 
 GRAD_KEYS_SA = [
@@ -48,7 +61,10 @@ GRAD_KEYS_CA = [
     "future_predictor.future_predictor.gpt_model.h.0.attn.c_proj.weight",
     "future_predictor.classifiers.action.all-fused.1.bias",
 ]
+GRAD_KEYS_CM = [k for k in GRAD_KEYS_SA if "modal_token" not in k] + ["future_predictor.fuser.norm.weight"]
+GRAD_KEYS_TSA = GRAD_KEYS_CM + ["future_predictor.fuser.position_embeddings.weight"]
 OPTIONAL_GRAD_KEYS = [
+    "future_predictor.fuser.modal_token",
     "future_predictor.mapping.objects.mapping.0.weight",
     "future_predictor.dim_encoder.weight",
     "future_predictor.dim_decoder.weight",

@@ -101,6 +101,16 @@ def build_model_cfg(c: dict) -> DictConfig:
                      modalities=_wrap(dict(mods)), modal_encoding=c.get("modal_encoding", False),
                      frame_level_token=c.get("frame_level_token", False),
                      temporal_sequence_length=c["T"] if c.get("frame_level_token") else None)
+    elif c["fuser"] == "cm":
+        fuser = dict(_target_="models.fusion.CMFuser", dim=c["d"], depth=c["depth"], num_heads=c["num_heads"],
+                     embd_drop_rate=0.1, drop_rate=0.1, attn_drop_rate=0.1, drop_path_rate=0.1,
+                     cross_attn=c.get("cross_attn", False))
+    elif c["fuser"] == "tsa":
+        fuser = dict(_target_="models.fusion.TemporalCMFuser", dim=c["d"], depth=c["depth"], num_heads=c["num_heads"],
+                     embd_drop_rate=0.1, drop_rate=0.1, attn_drop_rate=0.1, drop_path_rate=0.1,
+                     modalities=_wrap(dict(mods)), modal_encoding=c.get("modal_encoding", True),
+                     frame_level_token=c.get("frame_level_token", False),
+                     temporal_sequence_length=c["T"] if c.get("frame_level_token") else None)
     else:
         fuser = dict(_target_="models.fusion.TemporalCrossAttentFuser", dim=c["d"], modalities=_wrap(dict(mods)),
                      num_heads=c["num_heads"], embd_drop_rate=0.1, drop_rate=0.1, attn_drop_rate=0.1,
@@ -144,7 +154,7 @@ def surrogate(out: dict):
 
 def run_case(name: str, c: dict):
     import closed_form as cf
-    from cases import GRAD_KEYS_CA, GRAD_KEYS_SA, OPTIONAL_GRAD_KEYS, oracle_cfg
+    from cases import GRAD_KEYS_CA, GRAD_KEYS_CM, GRAD_KEYS_SA, GRAD_KEYS_TSA, OPTIONAL_GRAD_KEYS, oracle_cfg
     from models.base_model import BaseModel
     from common.runner import BasicLossAccuracy, Runner
     from oracle import afft_oracle as O
@@ -232,7 +242,7 @@ def run_case(name: str, c: dict):
     print(f"[{name}] oracle == reference: worst rel-L2 {worst:.2e}; loss {float(total):.6f}")
 
     # ---- store reference outputs
-    keys = (GRAD_KEYS_SA if c["fuser"] == "sa" else GRAD_KEYS_CA) + OPTIONAL_GRAD_KEYS
+    keys = {"sa": GRAD_KEYS_SA, "ca": GRAD_KEYS_CA, "cm": GRAD_KEYS_CM, "tsa": GRAD_KEYS_TSA}[c["fuser"]] + OPTIONAL_GRAD_KEYS
     arrays = {}
     for k, v in ref_flat.items():
         arrays["out:" + k] = v.detach().numpy().astype(np.float32)

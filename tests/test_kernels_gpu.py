@@ -207,7 +207,11 @@ ATTN_CASES = [(7, 5, 4, 16, 0, "f32"), (6, 5, 4, 64, 1, "f32"), (3, 16, 2, 64, 2
               (9, 5, 4, 256, 0, "bf16"), (4, 16, 4, 512, 2, "bf16"), (3, 6, 4, 128, 1, "bf16"), (5, 1, 2, 32, 0, "f32"),
               # bf16 with hd % 64 == 0 takes the MFMA path: packed frames (G=3, ragged last group), G=2, NT=2, T=10
               (7, 5, 4, 512, 0, "bf16"), (64, 5, 4, 64, 1, "bf16"), (3, 8, 2, 64, 0, "bf16"), (2, 32, 2, 64, 2, "bf16"),
-              (5, 10, 4, 64, 2, "bf16"), (3, 17, 2, 128, 2, "bf16"), (4, 16, 2, 16, 2, "bf16")]
+              (5, 10, 4, 64, 2, "bf16"), (3, 17, 2, 128, 2, "bf16"), (4, 16, 2, 16, 2, "bf16"),
+              # T-SA-Fuser sequences: L = M*T > 32 tokens, mask 3 = the causal T x T mask tiled over the modalities
+              # (period T = L / 4 here); plain / causal long sequences too
+              (2, 40, 2, 32, 3, "f32"), (3, 64, 4, 64, 3, "bf16"), (2, 80, 2, 64, 2, "f32"), (1, 128, 2, 32, 0, "bf16"),
+              (2, 20, 2, 64, 3, "bf16"), (1, 96, 1, 16, 3, "f32")]
 
 
 @pytest.mark.parametrize("nseq,L,H,hd,mask,dt", ATTN_CASES)
@@ -225,10 +229,14 @@ def test_attention_fwd_bwd(nseq, L, H, hd, mask, dt):
     out = torch.empty(nseq * L, d, dtype=tdt, device=dev())
     probs = torch.empty(nseq, H, L, L, device=dev())
     scale = hd ** -0.5
-    ops.attention_fwd(q, k, v, nseq, L, H, hd, scale, mask, out, probs)
+    period = L // 4 if mask == 3 else 0
+    ops.attention_fwd(q, k, v, nseq, L, H, hd, scale, mask, out, probs, mask_period=period)
     qr = qkv.clone().double().requires_grad_(True)
     t = qr.view(nseq, L, 3, H, hd).permute(2, 0, 3, 1, 4)
-    m = O.make_mask(["none", "diag", "causal"][mask], L, torch.float64)
+    if mask == 3:
+        m = O.make_mask("causal", period, torch.float64).repeat(4, 4)
+    else:
+        m = O.make_mask(["none", "diag", "causal"][mask], L, torch.float64)
     o_ref, p_ref = O._softmax_attend(t[0], t[1], t[2], scale, m)
     tol = 2e-5 if dt == "f32" else 1e-2
     assert rel_l2(out.float().cpu(), o_ref.reshape(nseq * L, d).float()) < tol
@@ -356,6 +364,15 @@ def test_mse_and_elementwise():
     ops.colsum(src.to(dev()), out, accumulate=False)
     assert rel_l2(out.cpu(), src.sum(0)) < 1e-5
 
+    # token means of the fusers without a modality token, and their backward (a broadcast)
+    xg = rnd(6 * 5, 72, seed=34)
+    yg = torch.empty(6, 72, device=dev())
+    ops.group_sum(xg.to(dev()), 6, 5, 72, 1.0 / 5, yg)
+    assert rel_l2(yg.cpu(), xg.view(6, 5, 72).mean(1)) < 1e-6
+    dxg = torch.empty(6 * 5, 72, device=dev())
+    ops.group_bcast(yg, 6, 5, 72, 0.2, dxg)
+    assert torch.allclose(dxg.cpu().view(6, 5, 72), (yg.cpu() * 0.2)[:, None, :].expand(6, 5, 72))
+
     # periodic tables
     x = rnd(B * T, dd, seed=31)
     tab = rnd(T, dd, seed=32)
@@ -420,6 +437,8 @@ def test_errors_are_reported():
     from afft_amd import ops
     a = torch.zeros(4, 4, device=dev())
     with pytest.raises(RuntimeError, match="sequence length"):
-        ops.attention_fwd(a, a, a, 1, 64, 1, 4, 1.0, 0, a, None)
+        ops.attention_fwd(a, a, a, 1, 129, 1, 4, 1.0, 0, a, None)
+    with pytest.raises(RuntimeError, match="period"):
+        ops.attention_fwd(a, a, a, 1, 4, 1, 4, 1.0, 3, a, None, mask_period=3)
     with pytest.raises(ValueError):
         ops.gemm(a, torch.zeros(5, 4, device=dev()), a)
