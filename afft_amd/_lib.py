@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AFFT_LIB") or os.path.join(_HERE, "lib", "libafft_hip.so")   # AFFT_LIB: kernel-tuning builds
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_DGELU_ERF, ACT_DGELU_TANH = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_DGELU_ERF, ACT_DGELU_TANH, ACT_RELU, ACT_SIGMOID_GATE = 0, 1, 2, 3, 4, 5, 6
 MASK_NONE, MASK_DIAG, MASK_CAUSAL, MASK_BLOCKCAUSAL = 0, 1, 2, 3
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -65,6 +65,11 @@ _SIGS = {
     "afft_sgd_nesterov": ([vp, vp, i32, vp, vp, i64, f32, f32, f32, f32, vp, i32, vp], C.c_int),
     "afft_sumsq": ([vp, i32, i64, f32, vp, vp], C.c_int),
     "afft_group_sum": ([vp, i32, i32, i64, f32, vp, vp], C.c_int),
+    "afft_act_bwd": ([i32, vp, i64, vp, i64, i32, vp, i64, i32, i32, C.POINTER(Dropout), vp, i64, i32, vp, i64, vp], C.c_int),
+    "afft_softmax_small_fwd": ([vp, i64, i32, i32, vp, i64, vp], C.c_int),
+    "afft_softmax_small_bwd": ([vp, i64, vp, i64, i32, i32, vp, i64, vp], C.c_int),
+    "afft_weighted_sum_fwd": ([C.POINTER(vp), i64, vp, i64, i32, i32, i32, vp, i64, vp], C.c_int),
+    "afft_weighted_sum_bwd": ([C.POINTER(vp), i64, vp, i64, vp, i64, i32, i32, i32, C.POINTER(vp), i64, vp, i64, vp], C.c_int),
     "afft_group_bcast": ([vp, i32, i32, i64, f32, vp, vp], C.c_int),
     "afft_clip_coef": ([vp, f32, vp, vp, vp], C.c_int),
 }

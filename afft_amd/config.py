@@ -12,7 +12,10 @@ MODAL_FEATURE_ORDER = ["rgb", "objects", "audio", "poses", "flow"]  # conf/confi
 def make_model_cfg(modal_dims: Dict[str, int], common_dim: int, fp_inter_dim: int = 2048, fuser: str = "sa",
                    depth: int = 6, num_heads: int = 4, fp_layers: int = 6, fp_heads: int = 4, fp_output_len: int = 1,
                    dropout: float = 0.2, drop: float = 0.1, cross_attn: bool = False, modal_encoding: bool = False,
-                   frame_level_token: bool = False, T: Optional[int] = None, fp_output_attentions: bool = False):
+                   frame_level_token: bool = False, T: Optional[int] = None, fp_output_attentions: bool = False,
+                   cmfp: str = "early", mapping: str = "linear", mapping_activation: str = "relu",
+                   mapping_layernorm: Optional[bool] = None, share_predictors: bool = True,
+                   share_classifiers: bool = True):
     """conf/model/{common,fuser/SA-Fuser|CA-Fuser,future_predictor/base_future_predictor,CMFP/cmfp_early,
     mapping/linear}.yaml with expts/01 (SA) / expts/04 (CA) overrides. `drop` sets every transformer dropout
     and DropPath rate (reference value 0.1)."""
@@ -33,22 +36,38 @@ def make_model_cfg(modal_dims: Dict[str, int], common_dim: int, fp_inter_dim: in
                   embd_drop_rate=drop, drop_rate=drop, attn_drop_rate=drop, drop_path_rate=drop,
                   modalities=dict(modal_dims), modal_encoding=modal_encoding, frame_level_token=frame_level_token,
                   temporal_sequence_length=T if frame_level_token else None)
+    elif fuser == "matt":    # conf/model/fuser/MATT.yaml (late score fusion)
+        fz = dict(_target_="models.fusion.MATT", modal_dims=dict(modal_dims), dim=common_dim, drop_rate=0.8)
+    elif fuser == "none":
+        fz = dict(_target_="torch.nn.Identity")
     else:
         raise ValueError(fuser)
+    late = cmfp != "early"
+    mp = {"linear": dict(_target_="models.feature_mapping.Linear",
+                         use_layernorm=bool(mapping_layernorm) if mapping_layernorm is not None else False,
+                         sparse_mapping=True),
+          "nonlinear": dict(_target_="models.feature_mapping.NonLinear",
+                            use_layernorm=bool(mapping_layernorm) if mapping_layernorm is not None else False,
+                            activation=mapping_activation),
+          "gated": dict(_target_="models.feature_mapping.GatedLinear",
+                        use_layernorm=bool(mapping_layernorm) if mapping_layernorm is not None else True)}[mapping]
+    cmfp_target = {"early": "models.future_prediction.CMFPEarly", "score": "models.future_prediction.CMFPScoreFusion",
+                   "individual": "models.future_prediction.IndividualFuturePrediction"}[cmfp]
     cfg = dict(
         modal_dims=dict(modal_dims), modal_feature_order=list(MODAL_FEATURE_ORDER), common_dim=common_dim,
         dropout=dropout,
-        common=dict(in_features=common_dim, share_classifiers=True, share_predictors=True, modality_cls=False,
-                    fusion_cls=True, backbones={m: {"_target_": "torch.nn.Identity"} for m in modal_dims},
+        common=dict(in_features=common_dim, share_classifiers=share_classifiers, share_predictors=share_predictors,
+                    modality_cls=late, fusion_cls=not late,
+                    backbones={m: {"_target_": "torch.nn.Identity"} for m in modal_dims},
                     fp_output_len=fp_output_len, fp_inter_dim=fp_inter_dim, fp_layers=fp_layers, fp_heads=fp_heads,
                     fp_output_attentions=fp_output_attentions, embd_pdrop=drop, resid_pdrop=drop, attn_pdrop=drop),
-        mapping=dict(_target_="models.feature_mapping.Linear", use_layernorm=False, sparse_mapping=True),
+        mapping=mp,
         fuser=fz,
         future_predictor=dict(_target_="models.future_prediction.BaseFuturePredictor", in_features=common_dim,
                               inter_dim=fp_inter_dim, n_layer=fp_layers, n_head=fp_heads,
                               output_attentions=fp_output_attentions, embd_pdrop=drop, resid_pdrop=drop,
                               attn_pdrop=drop),
-        CMFP=dict(_target_="models.future_prediction.CMFPEarly", model_cfg=None),
+        CMFP=dict(_target_=cmfp_target, model_cfg=None),
     )
     return to_attr(cfg)
 

@@ -168,12 +168,17 @@ __device__ __forceinline__ void load4(const void* base, int64_t idx, int dtype, 
   }
 }
 
+__host__ __device__ __forceinline__ bool act_needs_aux(int act) {
+  return act == AFFT_ACT_DGELU_ERF || act == AFFT_ACT_DGELU_TANH || act == AFFT_ACT_SIGMOID_GATE;
+}
 __device__ __forceinline__ float apply_act(int act, float v, float aux) {
   switch (act) {
     case AFFT_ACT_GELU_ERF: return gelu_erf_f(v);
     case AFFT_ACT_GELU_TANH: return gelu_tanh_f(v);
     case AFFT_ACT_DGELU_ERF: return v * dgelu_erf_f(aux);
     case AFFT_ACT_DGELU_TANH: return v * dgelu_tanh_f(aux);
+    case AFFT_ACT_RELU: return v > 0.f ? v : 0.f;
+    case AFFT_ACT_SIGMOID_GATE: return aux / (1.0f + __expf(-v));
     default: return v;
   }
 }
@@ -194,7 +199,7 @@ __device__ __forceinline__ void epilogue4(const EpiParams& e, int m, int n, floa
     if (e.pre) store4(e.pre, (int64_t)m * e.ldpre + n, e.pre_dtype, v);
     if (e.act != AFFT_ACT_NONE) {
       float a[4] = {0.f, 0.f, 0.f, 0.f};
-      if (e.act >= AFFT_ACT_DGELU_ERF) load4(e.aux, (int64_t)m * e.ldaux + n, e.aux_dtype, a);
+      if (act_needs_aux(e.act)) load4(e.aux, (int64_t)m * e.ldaux + n, e.aux_dtype, a);
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = apply_act(e.act, v[r], a[r]);
     }
@@ -225,7 +230,7 @@ __device__ __forceinline__ void epilogue4(const EpiParams& e, int m, int n, floa
       if (e.bias) x += e.bias[nn];
       if (e.pre) st_any(e.pre, (int64_t)m * e.ldpre + nn, e.pre_dtype, x);
       float a = 0.f;
-      if (e.act >= AFFT_ACT_DGELU_ERF) a = ld_any(e.aux, (int64_t)m * e.ldaux + nn, e.aux_dtype);
+      if (act_needs_aux(e.act)) a = ld_any(e.aux, (int64_t)m * e.ldaux + nn, e.aux_dtype);
       x = apply_act(e.act, x, a);
       x *= drop_elem_scale(e.drop, (unsigned)m * (unsigned)e.N + (unsigned)nn);
       x *= rs;
@@ -287,7 +292,7 @@ __device__ __forceinline__ void epilogue8(const EpiParams& e, int m, int n, floa
   if (e.pre) store8(e.pre, (int64_t)m * e.ldpre + n, e.pre_dtype, v);
   if (e.act != AFFT_ACT_NONE) {
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (e.act >= AFFT_ACT_DGELU_ERF) load8(e.aux, (int64_t)m * e.ldaux + n, e.aux_dtype, a);
+    if (act_needs_aux(e.act)) load8(e.aux, (int64_t)m * e.ldaux + n, e.aux_dtype, a);
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = apply_act(e.act, v[r], a[r]);
   }

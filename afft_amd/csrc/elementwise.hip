@@ -269,6 +269,153 @@ extern "C" int afft_reduce_rows_periodic(const float* src, int64_t lds_, int32_t
   return 0;
 }
 
+// backward of y = drop(act(pre)) (see afft_act_bwd in the header)
+__global__ __launch_bounds__(256) void act_bwd_kernel(int act, const float* __restrict__ dy, int64_t lddy,
+                                                      const void* __restrict__ saved, int64_t lds_, int sdt,
+                                                      const float* __restrict__ aux, int64_t ldaux, int rows, int cols,
+                                                      const DropParams drop, void* __restrict__ dpre, int64_t lddp, int pdt,
+                                                      float* __restrict__ daux, int64_t ldda) {
+  const int64_t n = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+    float g = dy[(int64_t)r * lddy + c];
+    if (drop.thresh || drop.path_thresh) g *= drop_row_scale(drop, r) * drop_elem_scale(drop, (unsigned)r * (unsigned)cols + (unsigned)c);
+    const float p = ld_any(saved, (int64_t)r * lds_ + c, sdt);
+    float dp;
+    switch (act) {
+      case AFFT_ACT_GELU_ERF: dp = g * dgelu_erf_f(p); break;
+      case AFFT_ACT_GELU_TANH: dp = g * dgelu_tanh_f(p); break;
+      case AFFT_ACT_RELU: dp = p > 0.f ? g : 0.f; break;
+      case AFFT_ACT_SIGMOID_GATE: {
+        const float sg = 1.0f / (1.0f + __expf(-p));
+        const float a = aux[(int64_t)r * ldaux + c];
+        dp = g * a * sg * (1.0f - sg);
+        if (daux) daux[(int64_t)r * ldda + c] = g * sg;
+        break;
+      }
+      default: dp = g;
+    }
+    st_any(dpre, (int64_t)r * lddp + c, pdt, dp);
+  }
+}
+
+// softmax over n <= 32 columns, one thread per row
+__global__ __launch_bounds__(256) void softmax_small_fwd_kernel(const float* __restrict__ x, int64_t ldx, int rows, int n,
+                                                                float* __restrict__ y, int64_t ldy) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  float v[32];
+  float m = -INFINITY;
+  for (int j = 0; j < n; ++j) { v[j] = x[(int64_t)r * ldx + j]; m = fmaxf(m, v[j]); }
+  float s = 0.f;
+  for (int j = 0; j < n; ++j) { v[j] = expf(v[j] - m); s += v[j]; }
+  const float inv = 1.0f / s;
+  for (int j = 0; j < n; ++j) y[(int64_t)r * ldy + j] = v[j] * inv;
+}
+__global__ __launch_bounds__(256) void softmax_small_bwd_kernel(const float* __restrict__ y, int64_t ldy,
+                                                                const float* __restrict__ dy, int64_t lddy, int rows, int n,
+                                                                float* __restrict__ dx, int64_t lddx) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  float dot = 0.f;
+  for (int j = 0; j < n; ++j) dot += dy[(int64_t)r * lddy + j] * y[(int64_t)r * ldy + j];
+  for (int j = 0; j < n; ++j) dx[(int64_t)r * lddx + j] = y[(int64_t)r * ldy + j] * (dy[(int64_t)r * lddy + j] - dot);
+}
+
+// score fusion: one workgroup per row
+struct WsPtrs { const float* x[8]; float* dx[8]; };
+__global__ __launch_bounds__(256) void weighted_sum_fwd_kernel(WsPtrs p, int64_t ldx, const float* __restrict__ w, int64_t ldw,
+                                                               int n, int cols, float* __restrict__ out, int64_t ldo) {
+  const int r = blockIdx.x;
+  float wr[8];
+  for (int i = 0; i < n; ++i) wr[i] = w[(int64_t)r * ldw + i];
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += wr[i] * p.x[i][(int64_t)r * ldx + c];
+    out[(int64_t)r * ldo + c] = s;
+  }
+}
+__global__ __launch_bounds__(256) void weighted_sum_bwd_kernel(WsPtrs p, int64_t ldx, const float* __restrict__ w, int64_t ldw,
+                                                               const float* __restrict__ dout, int64_t lddo, int n, int cols,
+                                                               int64_t lddx, float* __restrict__ dw, int64_t lddw) {
+  __shared__ float sh[8][4];
+  const int r = blockIdx.x;
+  float wr[8], acc[8];
+  for (int i = 0; i < n; ++i) { wr[i] = w[(int64_t)r * ldw + i]; acc[i] = 0.f; }
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    const float g = dout[(int64_t)r * lddo + c];
+    for (int i = 0; i < n; ++i) {
+      acc[i] += g * p.x[i][(int64_t)r * ldx + c];
+      if (p.dx[i]) p.dx[i][(int64_t)r * lddx + c] = wr[i] * g;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    const float s = wave_sum(acc[i]);
+    if ((threadIdx.x & 63) == 0) sh[i][threadIdx.x >> 6] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < n && dw) dw[(int64_t)r * lddw + threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+
+extern "C" int afft_act_bwd(int32_t act, const float* dy, int64_t lddy, const void* saved, int64_t lds_, int32_t saved_dtype,
+                            const float* aux, int64_t ldaux, int32_t rows, int32_t cols, const afft_dropout_t* drop,
+                            void* dpre, int64_t lddp, int32_t dpre_dtype, float* daux, int64_t ldda, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(dy && dpre, "act_bwd: null pointer");
+  AFFT_CHECK(act == AFFT_ACT_NONE || saved, "act_bwd: the activation needs its saved input");
+  AFFT_CHECK(act != AFFT_ACT_SIGMOID_GATE || aux, "act_bwd: the gate needs aux");
+  AFFT_CHECK(act == AFFT_ACT_NONE || act == AFFT_ACT_GELU_ERF || act == AFFT_ACT_GELU_TANH || act == AFFT_ACT_RELU ||
+             act == AFFT_ACT_SIGMOID_GATE, "act_bwd: bad activation %d", act);
+  if (rows == 0 || cols == 0) return 0;
+  int64_t blocks = ((int64_t)rows * cols + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  const void* sv = saved ? saved : (const void*)dy;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3((int)blocks), dim3(256), 0, stream, act, dy, lddy, sv, saved ? lds_ : lddy,
+                     saved ? saved_dtype : AFFT_F32, aux, ldaux, rows, cols, make_drop(drop), dpre, lddp, dpre_dtype, daux, ldda);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int afft_softmax_small_fwd(const float* x, int64_t ldx, int32_t rows, int32_t n, float* y, int64_t ldy, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(x && y && n >= 1 && n <= 32, "softmax_small_fwd: bad argument (n = %d, at most 32)", n);
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(softmax_small_fwd_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, x, ldx, rows, n, y, ldy);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int afft_softmax_small_bwd(const float* y, int64_t ldy, const float* dy, int64_t lddy, int32_t rows, int32_t n,
+                                      float* dx, int64_t lddx, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(y && dy && dx && n >= 1 && n <= 32, "softmax_small_bwd: bad argument (n = %d, at most 32)", n);
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(softmax_small_bwd_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, y, ldy, dy, lddy, rows, n, dx, lddx);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int afft_weighted_sum_fwd(const float* const* x, int64_t ldx, const float* w, int64_t ldw, int32_t n, int32_t rows,
+                                     int32_t cols, float* out, int64_t ldo, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(x && w && out && n >= 1 && n <= 8, "weighted_sum_fwd: bad argument (n = %d, at most 8)", n);
+  if (rows == 0 || cols == 0) return 0;
+  WsPtrs p;
+  for (int i = 0; i < 8; ++i) { p.x[i] = i < n ? x[i] : nullptr; p.dx[i] = nullptr; }
+  hipLaunchKernelGGL(weighted_sum_fwd_kernel, dim3(rows), dim3(256), 0, stream, p, ldx, w, ldw, n, cols, out, ldo);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int afft_weighted_sum_bwd(const float* const* x, int64_t ldx, const float* w, int64_t ldw, const float* dout,
+                                     int64_t lddo, int32_t n, int32_t rows, int32_t cols, float* const* dx, int64_t lddx,
+                                     float* dw, int64_t lddw, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(x && w && dout && n >= 1 && n <= 8, "weighted_sum_bwd: bad argument (n = %d, at most 8)", n);
+  if (rows == 0 || cols == 0) return 0;
+  WsPtrs p;
+  for (int i = 0; i < 8; ++i) { p.x[i] = i < n ? x[i] : nullptr; p.dx[i] = (i < n && dx) ? dx[i] : nullptr; }
+  hipLaunchKernelGGL(weighted_sum_bwd_kernel, dim3(rows), dim3(256), 0, stream, p, ldx, w, ldw, dout, lddo, n, cols, lddx, dw, lddw);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
 // y[g, :] = scale * sum_s x[g, s, :]  (x fp32 [G, S, W], W % 4 == 0): the token mean of the fusers without a modality
 // token (models/fusion.py:114-116 CMFuser, :207-210 T-SA-Fuser); and its backward, a broadcast
 __global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict__ x, int S, int64_t W, float scale,

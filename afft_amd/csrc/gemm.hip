@@ -343,7 +343,8 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
   AFFT_CHECK(d->dtype == AFFT_F32 || d->dtype == AFFT_BF16, "afft_gemm: bad dtype %d", d->dtype);
   AFFT_CHECK(d->A && d->B && d->out, "afft_gemm: null operand");
   AFFT_CHECK(!d->accumulate || d->out_dtype == AFFT_F32, "afft_gemm: accumulate needs an fp32 output");
-  AFFT_CHECK(d->act < AFFT_ACT_DGELU_ERF || d->aux, "afft_gemm: DGELU needs aux");
+  AFFT_CHECK(d->act >= AFFT_ACT_NONE && d->act <= AFFT_ACT_SIGMOID_GATE, "afft_gemm: bad activation %d", d->act);
+  AFFT_CHECK(!act_needs_aux(d->act) || d->aux, "afft_gemm: this activation needs aux");
   if (d->M == 0 || d->N == 0) return 0;
 
   EpiParams e;

@@ -13,8 +13,8 @@ from typing import NamedTuple, List, Optional, Tuple
 import torch
 
 from . import ops, runtime as rt
-from ._lib import (ACT_DGELU_ERF, ACT_DGELU_TANH, ACT_GELU_ERF, ACT_GELU_TANH, ACT_NONE, MASK_BLOCKCAUSAL, MASK_CAUSAL,
-                   MASK_DIAG, MASK_NONE)
+from ._lib import (ACT_DGELU_ERF, ACT_DGELU_TANH, ACT_GELU_ERF, ACT_GELU_TANH, ACT_NONE, ACT_RELU, ACT_SIGMOID_GATE,
+                   MASK_BLOCKCAUSAL, MASK_CAUSAL, MASK_DIAG, MASK_NONE)
 
 Tensor = torch.Tensor
 
@@ -597,6 +597,109 @@ class Linear(torch.autograd.Function):
         ctx.xa = None
         flush_ready()
         return dx, g_w, g_b, None
+
+
+# --------------------------------------------------------------------------- dense layer with a fused activation
+_ACT_ID = {"none": ACT_NONE, "gelu": ACT_GELU_ERF, "relu": ACT_RELU, "gate": ACT_SIGMOID_GATE}
+
+
+class LinearAct(torch.autograd.Function):
+    """y = drop(act(x W^T + b)), act in none | relu | gelu (exact erf) | gate (y = aux * sigmoid(x W^T + b)), all in the
+    GEMM epilogue: the MATT layers (models/fusion.py:40-46: Linear, ReLU, Dropout 0.8), the NonLinear mapping
+    (models/feature_mapping.py:91-101) and ContextGating = glu(cat(x, fc(x))) of GatedLinear (:22-31, aux = x).
+    Backward: one element-wise kernel turns dy into the GEMM operand d(pre) (and d(aux) for the gate)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act, aux, out_drop):
+        rows, n_out = x.shape[0], W.shape[0]
+        dev = x.device
+        _forget_output()
+        xa = to_act(x)
+        ybuf = torch.empty(rows, rt.pad64(n_out) if n_out % 4 else n_out, dtype=torch.float32, device=dev)
+        y = ybuf[:, :n_out]
+        pre = Act(rows, n_out, dev) if act in ("gelu", "gate") else None
+        if aux is not None:
+            aux = aux.contiguous()
+        _lin_fwd(xa, W, False, y, bias=b, act=_ACT_ID[act], aux=aux, pre=None if pre is None else pre.live, drop=out_drop)
+        ctx.save_for_backward(W, b, aux, y if act == "relu" else None)
+        ctx.acts = (xa, pre)
+        ctx.cfg = (act, out_drop)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        W, b, aux, y = ctx.saved_tensors
+        xa, pre = ctx.acts
+        act, out_drop = ctx.cfg
+        rows, n_out = xa.rows, W.shape[0]
+        dev = dy.device
+        _drop_shadow()
+        dy = dy if dy.stride(-1) == 1 else dy.contiguous()
+        dpre = Act(rows, n_out, dev)
+        daux = torch.empty(rows, n_out, dtype=torch.float32, device=dev) if act == "gate" else None
+        saved = y if act == "relu" else (pre.live if pre is not None else None)
+        ops.act_bwd(_ACT_ID[act], dy, saved, dpre.live, aux, daux, out_drop)
+        with _Side(dev):
+            g_w = _wgrad(dpre, xa, W, False)
+            g_b = _bgrad(dpre.live, b)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(rows, W.shape[1], dtype=torch.float32, device=dev)
+            _lin_dgrad(dpre, W, False, dx)
+        join_side(dev)
+        ctx.acts = None
+        flush_ready()
+        return dx, g_w, g_b, None, daux, None
+
+
+class SoftmaxSmall(torch.autograd.Function):
+    """softmax over the last (<= 32-wide) dimension of an fp32 [rows, n] matrix: MATT's modality weights
+    (models/fusion.py:57)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _forget_output()
+        x = x if x.stride(-1) == 1 else x.contiguous()
+        y = torch.empty(x.shape[0], x.shape[1], dtype=torch.float32, device=x.device)
+        ops.softmax_small_fwd(x, y)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        _drop_shadow()
+        dx = torch.empty_like(y)
+        ops.softmax_small_bwd(y, dy if dy.stride(-1) == 1 else dy.contiguous(), dx)
+        return dx
+
+
+class WeightedSum(torch.autograd.Function):
+    """out[r, :] = sum_i w[r, i] * xs[i][r, :]: the score fusion of CMFPScoreFusion (models/future_prediction.py:343-350);
+    xs are the per-modality logits (fp32 [rows, classes], one common row stride), w the MATT weights [rows, M]."""
+
+    @staticmethod
+    def forward(ctx, w, *xs):
+        _forget_output()
+        w = w.contiguous()
+        ld = xs[0].stride(0)
+        xs = tuple(x if (x.stride(-1) == 1 and x.stride(0) == ld) else x.contiguous() for x in xs)
+        if any(x.stride(0) != xs[0].stride(0) for x in xs):
+            xs = tuple(x.contiguous() for x in xs)
+        out = torch.empty(xs[0].shape[0], xs[0].shape[1], dtype=torch.float32, device=w.device)
+        ops.weighted_sum_fwd(xs, w, out)
+        ctx.save_for_backward(w, *xs)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        w, *xs = ctx.saved_tensors
+        _drop_shadow()
+        dout = dout if dout.stride(-1) == 1 else dout.contiguous()
+        dxs = [torch.empty(x.shape[0], x.shape[1], dtype=torch.float32, device=w.device) for x in xs]
+        dw = torch.empty_like(w)
+        ops.weighted_sum_bwd(xs, w, dout, dxs, dw)
+        return (dw, *dxs)
 
 
 # --------------------------------------------------------------------------- standalone LayerNorm (final norms)

@@ -49,6 +49,32 @@ def _rows(f: Tensor, BT: int, C: int) -> Tensor:
     return f2 if f2.dtype == torch.float32 else f2.float()
 
 
+class MATT(nn.Module):
+    """modality attention module from RULSTM, an MLP with 3 layers (models/fusion.py:35-58): Linear-ReLU-Dropout twice,
+    a Linear to one score per modality, softmax.  The ReLU and the (train-mode) dropout run in the GEMM epilogues."""
+
+    def __init__(self, modal_dims, dim=None, drop_rate=0.8):
+        super().__init__()
+        num_modality = len(modal_dims)
+        in_size = dim * num_modality if dim else sum(modal_dims.values())
+        self.matt = nn.Sequential(nn.Linear(in_size, int(in_size / 4)), nn.ReLU(), nn.Dropout(drop_rate),
+                                  nn.Linear(int(in_size / 4), int(in_size / 8)), nn.ReLU(), nn.Dropout(drop_rate),
+                                  nn.Linear(int(in_size / 8), num_modality))
+
+    def forward(self, modal_feats: Dict[str, Tensor], ordered_feature_list: Callable) -> Tensor:
+        feats = torch.cat(ordered_feature_list(modal_feats), dim=2)
+        B, Tn, C = feats.shape
+        x = feats.reshape(B * Tn, C)
+        x = x if x.dtype == torch.float32 else x.float()
+        for i in (0, 3):
+            lin, drop = self.matt[i], self.matt[i + 2]
+            desc = D_.elementwise(drop.p) if (self.training and drop.p > 0) else None
+            x = F_.LinearAct.apply(x, lin.weight, lin.bias, "relu", None, desc)
+        lin = self.matt[6]
+        x = F_.LinearAct.apply(x, lin.weight, lin.bias, "none", None, None)
+        return F_.SoftmaxSmall.apply(x).view(B, Tn, -1)
+
+
 class ModalTokenCMFuser(nn.Module):
     """Corresponds to SA-Fuser with modality token in the paper"""
 

@@ -247,3 +247,56 @@ def group_bcast(dy: Tensor, G: int, S: int, W: int, scale: float, dx: Tensor):
     assert dy.is_contiguous() and dx.is_contiguous() and dy.dtype == dx.dtype == torch.float32
     L.check(L.lib().afft_group_bcast(_p(dy), G, S, W, scale, _p(dx), _stream()), "group_bcast")
     return dx
+
+
+def act_bwd(act: int, dy: Tensor, saved: Optional[Tensor], dpre: Tensor, aux: Optional[Tensor] = None,
+            daux: Optional[Tensor] = None, drop: Optional["L.Dropout"] = None):
+    """dpre = d/dpre [drop(act(pre))] * dy (see afft_act_bwd)."""
+    rows, cols = dy.shape
+    assert dy.dtype == torch.float32
+    L.check(L.lib().afft_act_bwd(act, _p(dy), _rowmajor(dy, "dy"), _p(saved), _rowmajor(saved, "saved") if saved is not None else 0,
+                                 _dt(saved) if saved is not None else F32, _p(aux),
+                                 _rowmajor(aux, "aux") if aux is not None else 0, rows, cols,
+                                 C.byref(drop) if drop is not None else None, _p(dpre), _rowmajor(dpre, "dpre"), _dt(dpre),
+                                 _p(daux), _rowmajor(daux, "daux") if daux is not None else 0, _stream()), "act_bwd")
+    return dpre
+
+
+def softmax_small_fwd(x: Tensor, y: Tensor):
+    rows, n = x.shape
+    L.check(L.lib().afft_softmax_small_fwd(_p(x), _rowmajor(x, "x"), rows, n, _p(y), _rowmajor(y, "y"), _stream()), "softmax_small_fwd")
+    return y
+
+
+def softmax_small_bwd(y: Tensor, dy: Tensor, dx: Tensor):
+    rows, n = y.shape
+    L.check(L.lib().afft_softmax_small_bwd(_p(y), _rowmajor(y, "y"), _p(dy), _rowmajor(dy, "dy"), rows, n, _p(dx),
+                                           _rowmajor(dx, "dx"), _stream()), "softmax_small_bwd")
+    return dx
+
+
+def _ptr_array(ts):
+    arr = (C.c_void_p * len(ts))()
+    for i, t in enumerate(ts):
+        arr[i] = t.data_ptr() if t is not None else None
+    return arr
+
+
+def weighted_sum_fwd(xs: Sequence[Tensor], w: Tensor, out: Tensor):
+    """out[r, :] = sum_i w[r, i] * xs[i][r, :]; all xs share one row stride."""
+    rows, cols = xs[0].shape
+    ld = _rowmajor(xs[0], "x")
+    assert all(_rowmajor(x, "x") == ld and x.shape == xs[0].shape and x.dtype == torch.float32 for x in xs)
+    L.check(L.lib().afft_weighted_sum_fwd(_ptr_array(xs), ld, _p(w), _rowmajor(w, "w"), len(xs), rows, cols, _p(out),
+                                          _rowmajor(out, "out"), _stream()), "weighted_sum_fwd")
+    return out
+
+
+def weighted_sum_bwd(xs: Sequence[Tensor], w: Tensor, dout: Tensor, dxs: Sequence[Tensor], dw: Tensor):
+    rows, cols = xs[0].shape
+    ld = _rowmajor(xs[0], "x")
+    ldd = _rowmajor(dxs[0], "dx")
+    assert all(_rowmajor(x, "dx") == ldd for x in dxs)
+    L.check(L.lib().afft_weighted_sum_bwd(_ptr_array(xs), ld, _p(w), _rowmajor(w, "w"), _p(dout), _rowmajor(dout, "dout"),
+                                          len(xs), rows, cols, _ptr_array(dxs), ldd, _p(dw), _rowmajor(dw, "dw"),
+                                          _stream()), "weighted_sum_bwd")

@@ -24,7 +24,9 @@ extern "C" {
 enum { AFFT_F32 = 0, AFFT_BF16 = 1 };
 enum { AFFT_ACT_NONE = 0, AFFT_ACT_GELU_ERF = 1, AFFT_ACT_GELU_TANH = 2,
        AFFT_ACT_DGELU_ERF = 3,   /* v *= d/du gelu_erf(aux[m,n])  (backward of nn.GELU)  */
-       AFFT_ACT_DGELU_TANH = 4 };/* v *= d/du gelu_new(aux[m,n])  (backward of HF gelu_new) */
+       AFFT_ACT_DGELU_TANH = 4,  /* v *= d/du gelu_new(aux[m,n])  (backward of HF gelu_new) */
+       AFFT_ACT_RELU = 5,        /* nn.ReLU: MATT (models/fusion.py:40-46), NonLinear mapping (feature_mapping.py:95) */
+       AFFT_ACT_SIGMOID_GATE = 6 };/* v = aux[m,n] * sigmoid(v): ContextGating = glu(cat(x, fc(x))) (feature_mapping.py:22-31) */
 enum { AFFT_MASK_NONE = 0, AFFT_MASK_DIAG = 1, AFFT_MASK_CAUSAL = 2, AFFT_MASK_BLOCKCAUSAL = 3 };
 
 /* Dropout description shared by the kernels that apply or replay a dropout mask.  keep(idx) is a pure
@@ -162,6 +164,27 @@ int afft_add_rows_periodic(const float* x, int64_t ldx, const float* table, int6
 /* out[(r % period), :] += sum over r of src[r, :]  (gradient of the above table) */
 int afft_reduce_rows_periodic(const float* src, int64_t lds, int32_t rows, int32_t period, int32_t d,
                               float* out, int64_t ldo, void* stream);
+/* Backward of a fused output activation (+ output dropout): from the upstream gradient dy (fp32) of
+ *   y = drop(act(pre))   act in { NONE, GELU_ERF, GELU_TANH, RELU, SIGMOID_GATE (y = aux * sigmoid(pre)) }
+ * writes dpre (dtype selectable: the operand of the dgrad / wgrad GEMMs) and, for the gate, daux (fp32) = dy*sigmoid(pre).
+ * saved = pre (any dtype); for RELU `saved` may be the activated output instead (only its sign is used).
+ * drop replays the forward output-dropout mask (NULL = none). */
+int afft_act_bwd(int32_t act, const float* dy, int64_t lddy, const void* saved, int64_t lds, int32_t saved_dtype,
+                 const float* aux, int64_t ldaux, int32_t rows, int32_t cols, const afft_dropout_t* drop,
+                 void* dpre, int64_t lddp, int32_t dpre_dtype, float* daux, int64_t ldda, void* stream);
+/* Softmax over the (few) columns of an fp32 [rows, n] matrix, n <= 32: the modality weights of MATT
+ * (models/fusion.py:57); backward: dx = y * (dy - sum_j dy_j y_j). */
+int afft_softmax_small_fwd(const float* x, int64_t ldx, int32_t rows, int32_t n, float* y, int64_t ldy, void* stream);
+int afft_softmax_small_bwd(const float* y, int64_t ldy, const float* dy, int64_t lddy, int32_t rows, int32_t n,
+                           float* dx, int64_t lddx, void* stream);
+/* Score fusion (models/future_prediction.py:343-350): out[r, :] = sum_i w[r, i] * x_i[r, :] over n <= 8 modalities
+ * (x_i fp32 [rows, cols], row stride ldx, w fp32 [rows, n] row stride ldw); backward: dx_i[r, :] = w[r, i] * dout[r, :],
+ * dw[r, i] = <dout[r, :], x_i[r, :]>. */
+int afft_weighted_sum_fwd(const float* const* x, int64_t ldx, const float* w, int64_t ldw, int32_t n, int32_t rows,
+                          int32_t cols, float* out, int64_t ldo, void* stream);
+int afft_weighted_sum_bwd(const float* const* x, int64_t ldx, const float* w, int64_t ldw, const float* dout, int64_t lddo,
+                          int32_t n, int32_t rows, int32_t cols, float* const* dx, int64_t lddx, float* dw, int64_t lddw,
+                          void* stream);
 /* Token means of the fusers without a modality token (models/fusion.py:114-116 CMFuser: mean over the M tokens of a
  * frame; :207-210 T-SA-Fuser: mean over the M modality tokens of a frame position): x fp32 [G, S, W] contiguous,
  *   afft_group_sum:   y[g, :]     = scale * sum_s x[g, s, :]

@@ -39,6 +39,22 @@ CASES = {
     "t5_tsa_l40": dict(fuser="tsa", modal_dims={"rgb": 64, "objects": 64, "audio": 64, "flow": 64}, d=64, D=64,
                        depth=1, num_heads=2, fp_layers=1, fp_heads=2, T=10, B=2, num_classes=7, fp_output_len=1,
                        modal_encoding=True),
+    # late fusion / per-modality heads and the other mapping layers.  Modality widths differ (24-wide
+    # objects): per-modality dim_encoder / dim_decoder and classifiers; MATT weights mix the class scores.
+    "t6_score": dict(cmfp="score", fuser="matt", modal_dims={"rgb": 64, "objects": 24, "flow": 64}, d=64, D=128,
+                     num_heads=0, fp_layers=2, fp_heads=2, T=4, B=3, num_classes=11, fp_output_len=1,
+                     share_predictors=True, share_classifiers=False),
+    "t6_score_own": dict(cmfp="score", fuser="matt", modal_dims={"rgb": 64, "flow": 64}, d=64, D=64, num_heads=0,
+                         fp_layers=1, fp_heads=2, T=4, B=2, num_classes=7, fp_output_len=1, share_predictors=False,
+                         share_classifiers=False, mapping="nonlinear", mapping_activation="relu"),
+    "t7_indiv": dict(cmfp="individual", fuser="none", modal_dims={"rgb": 64, "objects": 24}, d=64, D=128, num_heads=0,
+                     fp_layers=2, fp_heads=2, T=4, B=3, num_classes=11, fp_output_len=1, share_predictors=True,
+                     share_classifiers=False),
+    "t8_gated": dict(fuser="sa", modal_dims=_MODS4, d=64, D=128, depth=1, num_heads=4, fp_layers=1, fp_heads=2,
+                     T=4, B=3, num_classes=11, fp_output_len=1, mapping="gated", mapping_layernorm=True),
+    "t8_nonlin": dict(fuser="sa", modal_dims=_MODS4, d=64, D=128, depth=1, num_heads=4, fp_layers=1, fp_heads=2,
+                      T=4, B=3, num_classes=11, fp_output_len=1, mapping="nonlinear", mapping_activation="gelu",
+                      mapping_layernorm=True),
 }
 
 GRAD_KEYS_SA = [
@@ -63,7 +79,29 @@ GRAD_KEYS_CA = [
 ]
 GRAD_KEYS_CM = [k for k in GRAD_KEYS_SA if "modal_token" not in k] + ["future_predictor.fuser.norm.weight"]
 GRAD_KEYS_TSA = GRAD_KEYS_CM + ["future_predictor.fuser.position_embeddings.weight"]
+GRAD_KEYS_LATE = [
+    "future_predictor.dim_encoder.objects.weight",
+    "future_predictor.dim_decoder.objects.weight",
+    "future_predictor.dim_encoder.rgb.weight",
+    "future_predictor.future_predictor.gpt_model.h.0.attn.c_attn.weight",
+    "future_predictor.future_predictor.rgb.gpt_model.h.0.mlp.c_fc.weight",
+    "future_predictor.future_predictor.flow.gpt_model.wpe.weight",
+    "future_predictor.classifiers.action.rgb.1.weight",
+    "future_predictor.classifiers.action.objects.1.weight",
+    "future_predictor.classifiers.action.flow.1.bias",
+    "future_predictor.fuser.matt.0.weight",
+    "future_predictor.fuser.matt.3.bias",
+    "future_predictor.fuser.matt.6.weight",
+    "future_predictor.mapping.objects.mapping.0.weight",
+    "future_predictor.mapping.rgb.mapping.0.bias",
+]
 OPTIONAL_GRAD_KEYS = [
+    "future_predictor.mapping.rgb.mapping.0.weight",
+    "future_predictor.mapping.rgb.mapping.0.bias",
+    "future_predictor.mapping.objects.mapping.1.fc.weight",
+    "future_predictor.mapping.objects.mapping.1.fc.bias",
+    "future_predictor.mapping.flow.mapping.2.weight",
+    "future_predictor.mapping.audio.mapping.2.bias",
     "future_predictor.fuser.modal_token",
     "future_predictor.mapping.objects.mapping.0.weight",
     "future_predictor.dim_encoder.weight",
@@ -72,8 +110,16 @@ OPTIONAL_GRAD_KEYS = [
 ]
 
 
+def grad_keys(c: dict):
+    if c.get("cmfp", "early") != "early":
+        return GRAD_KEYS_LATE
+    return {"sa": GRAD_KEYS_SA, "ca": GRAD_KEYS_CA, "cm": GRAD_KEYS_CM, "tsa": GRAD_KEYS_TSA}[c["fuser"]] + OPTIONAL_GRAD_KEYS
+
+
 def oracle_cfg(c: dict) -> dict:
     return dict(fuser=c["fuser"], depth=c.get("depth", 0), num_heads=c["num_heads"], fp_layers=c["fp_layers"],
                 fp_heads=c["fp_heads"], fp_output_len=c.get("fp_output_len", 1),
                 cross_attn=c.get("cross_attn", False), frame_level_token=c.get("frame_level_token", False),
-                num_classes={"action": c["num_classes"]})
+                num_classes={"action": c["num_classes"]}, cmfp=c.get("cmfp", "early"),
+                share_predictors=c.get("share_predictors", True), mapping=c.get("mapping", "linear"),
+                mapping_activation=c.get("mapping_activation", "relu"))

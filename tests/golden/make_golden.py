@@ -111,25 +111,39 @@ def build_model_cfg(c: dict) -> DictConfig:
                      modalities=_wrap(dict(mods)), modal_encoding=c.get("modal_encoding", True),
                      frame_level_token=c.get("frame_level_token", False),
                      temporal_sequence_length=c["T"] if c.get("frame_level_token") else None)
+    elif c["fuser"] == "matt":
+        fuser = dict(_target_="models.fusion.MATT", modal_dims=_wrap(dict(mods)), dim=c["d"], drop_rate=0.8)
+    elif c["fuser"] == "none":
+        fuser = dict(_target_="torch.nn.Identity")
     else:
         fuser = dict(_target_="models.fusion.TemporalCrossAttentFuser", dim=c["d"], modalities=_wrap(dict(mods)),
                      num_heads=c["num_heads"], embd_drop_rate=0.1, drop_rate=0.1, attn_drop_rate=0.1,
                      drop_path_rate=0.1)
+    late = c.get("cmfp", "early") != "early"
+    mapping = {"linear": dict(_target_="models.feature_mapping.Linear", use_layernorm=c.get("mapping_layernorm", False),
+                              sparse_mapping=True),
+               "nonlinear": dict(_target_="models.feature_mapping.NonLinear", use_layernorm=c.get("mapping_layernorm", False),
+                                 activation=c.get("mapping_activation", "relu")),
+               "gated": dict(_target_="models.feature_mapping.GatedLinear",
+                             use_layernorm=c.get("mapping_layernorm", True))}[c.get("mapping", "linear")]
+    cmfp_target = {"early": "models.future_prediction.CMFPEarly", "score": "models.future_prediction.CMFPScoreFusion",
+                   "individual": "models.future_prediction.IndividualFuturePrediction"}[c.get("cmfp", "early")]
     cfg = dict(
         modal_dims=dict(mods),
         modal_feature_order=["rgb", "objects", "audio", "poses", "flow"],
         common_dim=c["d"], dropout=0.2,
-        common=dict(in_features=c["d"], share_classifiers=True, share_predictors=True, modality_cls=False,
-                    fusion_cls=True, backbones={m: {"_target_": "torch.nn.Identity"} for m in mods},
+        common=dict(in_features=c["d"], share_classifiers=c.get("share_classifiers", True),
+                    share_predictors=c.get("share_predictors", True), modality_cls=late,
+                    fusion_cls=not late, backbones={m: {"_target_": "torch.nn.Identity"} for m in mods},
                     fp_output_len=c.get("fp_output_len", 1), fp_inter_dim=c["D"], fp_layers=c["fp_layers"],
                     fp_heads=c["fp_heads"], fp_output_attentions=False, embd_pdrop=0.1, resid_pdrop=0.1,
                     attn_pdrop=0.1),
-        mapping=dict(_target_="models.feature_mapping.Linear", use_layernorm=False, sparse_mapping=True),
+        mapping=mapping,
         fuser=fuser,
         future_predictor=dict(_target_="models.future_prediction.BaseFuturePredictor", in_features=c["d"],
                               inter_dim=c["D"], n_layer=c["fp_layers"], n_head=c["fp_heads"],
                               output_attentions=False, embd_pdrop=0.1, resid_pdrop=0.1, attn_pdrop=0.1),
-        CMFP=dict(_target_="models.future_prediction.CMFPEarly", model_cfg=None),
+        CMFP=dict(_target_=cmfp_target, model_cfg=None),
     )
     return _wrap(cfg)
 
@@ -154,7 +168,7 @@ def surrogate(out: dict):
 
 def run_case(name: str, c: dict):
     import closed_form as cf
-    from cases import GRAD_KEYS_CA, GRAD_KEYS_CM, GRAD_KEYS_SA, GRAD_KEYS_TSA, OPTIONAL_GRAD_KEYS, oracle_cfg
+    from cases import grad_keys, oracle_cfg
     from models.base_model import BaseModel
     from common.runner import BasicLossAccuracy, Runner
     from oracle import afft_oracle as O
@@ -242,7 +256,7 @@ def run_case(name: str, c: dict):
     print(f"[{name}] oracle == reference: worst rel-L2 {worst:.2e}; loss {float(total):.6f}")
 
     # ---- store reference outputs
-    keys = {"sa": GRAD_KEYS_SA, "ca": GRAD_KEYS_CA, "cm": GRAD_KEYS_CM, "tsa": GRAD_KEYS_TSA}[c["fuser"]] + OPTIONAL_GRAD_KEYS
+    keys = grad_keys(c)
     arrays = {}
     for k, v in ref_flat.items():
         arrays["out:" + k] = v.detach().numpy().astype(np.float32)

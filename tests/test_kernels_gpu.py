@@ -433,6 +433,79 @@ def test_mse_and_elementwise():
     assert rel_l2(pg.cpu(), pr.detach()) < 1e-6
 
 
+@pytest.mark.parametrize("act", ["none", "relu", "gelu", "gate"])
+@pytest.mark.parametrize("p_drop", [0.0, 0.4])
+def test_linear_act_forward_backward(act, p_drop):
+    """functional.LinearAct (fused activation + output dropout in the GEMM epilogue, one act_bwd kernel in backward)
+    against torch autograd with the SAME dropout mask (recovered from the output)."""
+    import afft_amd
+    from afft_amd import dropout as D_, functional as F_, runtime as rt
+    afft_amd.set_precision("fp32")
+    rt.set_grad_mode("autograd")
+    try:
+        rows, n_in, n_out = 37, 48, 40
+        x = rnd(rows, n_in, seed=51)
+        W = rnd(n_out, n_in, seed=52) * 0.3
+        b = rnd(n_out, seed=53) * 0.1
+        aux = rnd(rows, n_out, seed=54) if act == "gate" else None
+        xg, Wg, bg = (t.clone().to(dev()).requires_grad_(True) for t in (x, W, b))
+        auxg = aux.clone().to(dev()).requires_grad_(True) if aux is not None else None
+        D_.manual_seed(3)
+        desc = D_.elementwise(p_drop) if p_drop > 0 else None
+        y = F_.LinearAct.apply(xg, Wg, bg, act, auxg, desc)
+        xr, Wr, br = (t.clone().double().requires_grad_(True) for t in (x, W, b))
+        auxr = aux.clone().double().requires_grad_(True) if aux is not None else None
+        pre = xr @ Wr.t() + br
+        a = {"none": lambda t: t, "relu": torch.relu, "gelu": lambda t: torch.nn.functional.gelu(t),
+             "gate": lambda t: auxr * torch.sigmoid(t)}[act](pre)
+        if p_drop > 0:
+            kept = (y.detach().cpu() != 0) | (a.detach().abs() < 1e-12)      # a dropped element is exactly 0
+            frac = 1.0 - float(kept.float().mean())
+            assert abs(frac - p_drop) < 0.08 or act == "relu"                # relu zeros are indistinguishable: only the replay matters
+            ref = a * kept.double() / (1.0 - p_drop)
+        else:
+            ref = a
+        assert rel_l2(y.detach().cpu(), ref.detach().float()) < 2e-5
+        dy = rnd(rows, n_out, seed=55)
+        y.backward(dy.to(dev()))
+        ref.backward(dy.double())
+        assert rel_l2(xg.grad.cpu(), xr.grad.float()) < 3e-5
+        assert rel_l2(Wg.grad.cpu(), Wr.grad.float()) < 3e-5
+        assert rel_l2(bg.grad.cpu(), br.grad.float()) < 3e-5
+        if aux is not None:
+            assert rel_l2(auxg.grad.cpu(), auxr.grad.float()) < 3e-5
+    finally:
+        rt.set_grad_mode("sink")
+        afft_amd.set_precision("bf16")
+
+
+def test_softmax_small_and_weighted_sum():
+    from afft_amd import functional as F_, runtime as rt
+    rt.set_grad_mode("autograd")
+    try:
+        rows, M, C = 29, 5, 130
+        lg = rnd(rows, M, seed=61) * 2
+        xs = [rnd(rows, C, seed=62 + i) for i in range(M)]
+        lgg = lg.clone().to(dev()).requires_grad_(True)
+        xsg = [t.clone().to(dev()).requires_grad_(True) for t in xs]
+        w = F_.SoftmaxSmall.apply(lgg)
+        out = F_.WeightedSum.apply(w, *xsg)
+        lr = lg.clone().double().requires_grad_(True)
+        xr = [t.clone().double().requires_grad_(True) for t in xs]
+        wr = lr.softmax(-1)
+        ref = sum(wr[:, i:i + 1] * xr[i] for i in range(M))
+        assert rel_l2(w.detach().cpu(), wr.detach().float()) < 1e-6
+        assert rel_l2(out.detach().cpu(), ref.detach().float()) < 1e-6
+        dy = rnd(rows, C, seed=70)
+        out.backward(dy.to(dev()))
+        ref.backward(dy.double())
+        assert rel_l2(lgg.grad.cpu(), lr.grad.float()) < 2e-5
+        for a, b in zip(xsg, xr):
+            assert rel_l2(a.grad.cpu(), b.grad.float()) < 1e-6
+    finally:
+        rt.set_grad_mode("sink")
+
+
 def test_errors_are_reported():
     from afft_amd import ops
     a = torch.zeros(4, 4, device=dev())
