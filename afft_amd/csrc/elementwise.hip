@@ -269,6 +269,128 @@ extern "C" int afft_reduce_rows_periodic(const float* src, int64_t lds_, int32_t
   return 0;
 }
 
+// ---- MixUp with an ignore class as a GPU prologue (common/mixup.py:119-182), no host round trip
+// plan: sample b takes part iff none of its T past labels is the ignore class; the participants are mixed with the
+// participants in reverse order (x[sel] * lam + x[sel].flip(0) * (1 - lam)); partner[b] = b when b does not take part
+// or when at most one sample does (:156-158: no mixing then).  One workgroup; B is a batch size (<= 4096).
+__global__ __launch_bounds__(256) void mixup_plan_kernel(const int64_t* __restrict__ sub, int B, int T, int64_t ignore_cls,
+                                                         int* __restrict__ partner, uint8_t* __restrict__ ign) {
+  extern __shared__ int sh[];          // [B] flags, then ranks
+  for (int b = threadIdx.x; b < B; b += 256) {
+    int ok = 1;
+    if (sub)
+      for (int t = 0; t < T; ++t) {
+        const bool ig = sub[(int64_t)b * T + t] == ignore_cls;
+        if (ign) ign[(int64_t)b * T + t] = ig ? 1 : 0;
+        ok &= ig ? 0 : 1;
+      }
+    sh[b] = ok;
+  }
+  __syncthreads();
+  __shared__ int count;
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int b = 0; b < B; ++b) { const int f = sh[b]; sh[b] = f ? c : -1; c += f; }
+    count = c;
+  }
+  __syncthreads();
+  // rank r of the participants pairs with rank count-1-r: find it by a second pass (B is small)
+  for (int b = threadIdx.x; b < B; b += 256) {
+    int pb = b;
+    if (count > 1 && sh[b] >= 0) {
+      const int want = count - 1 - sh[b];
+      for (int j = 0; j < B; ++j)
+        if (sh[j] == want) { pb = j; break; }
+    }
+    partner[b] = pb;
+  }
+}
+__global__ __launch_bounds__(256) void mixup_rows_kernel(const float* __restrict__ x, int64_t W, const int* __restrict__ partner,
+                                                         float lam, float* __restrict__ y) {
+  const int b = blockIdx.y, pb = partner[b];
+  const float* xa = x + (int64_t)b * W;
+  const float* xb = x + (int64_t)pb * W;
+  float* yo = y + (int64_t)b * W;
+  const float oml = 1.0f - lam;
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < W; c += (int64_t)gridDim.x * 256)
+    yo[c] = pb == b ? xa[c] : xa[c] * lam + xb[c] * oml;
+}
+// soft labels of rows r = b * rps + i: lam * onehot(l[r]) + (1 - lam) * onehot(l[partner row]), smoothed one-hot
+// (common/mixup.py:17-47: off value ls / K, on value 1 - ls + ls / K); ignored labels count as class 0 (:150-151)
+__global__ __launch_bounds__(256) void mixup_labels_kernel(const int64_t* __restrict__ labels, int rps, int K, float ls,
+                                                           int64_t ignore_cls, const int* __restrict__ partner, float lam,
+                                                           float* __restrict__ out) {
+  const int r = blockIdx.x, b = r / rps, i = r - b * rps, pb = partner[b];
+  int64_t la = labels[r], lb = labels[(int64_t)pb * rps + i];
+  if (la == ignore_cls) la = 0;
+  if (lb == ignore_cls) lb = 0;
+  const float off = ls / (float)K, on = 1.0f - ls + off, oml = 1.0f - lam;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float a = k == la ? on : off, bb = k == lb ? on : off;
+    out[(int64_t)r * K + k] = pb == b ? a : a * lam + bb * oml;
+  }
+}
+// softmax over wide fp32 rows (one workgroup per row): class probabilities for verb / noun marginalisation
+// (challenge.py:196-203)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int64_t ldx, int C,
+                                                           float* __restrict__ y, int64_t ldy) {
+  __shared__ float sh[4];
+  const float* xr = x + (int64_t)blockIdx.x * ldx;
+  float* yr = y + (int64_t)blockIdx.x * ldy;
+  float m = -INFINITY;
+  for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, xr[c]);
+  for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) s += expf(xr[c] - m);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float inv = 1.0f / ((sh[0] + sh[1]) + (sh[2] + sh[3]));
+  for (int c = threadIdx.x; c < C; c += 256) yr[c] = expf(xr[c] - m) * inv;
+}
+
+extern "C" int afft_mixup_plan(const int64_t* labels_subclips, int32_t B, int32_t T, int64_t ignore_cls, int32_t* partner,
+                               uint8_t* ignore_mask, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(partner && B >= 1 && B <= 4096 && T >= 0, "mixup_plan: bad argument (B = %d, at most 4096)", B);
+  hipLaunchKernelGGL(mixup_plan_kernel, dim3(1), dim3(256), sizeof(int) * B, stream, labels_subclips, B, T, ignore_cls, partner,
+                     ignore_mask);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int afft_mixup_rows(const float* x, int32_t B, int64_t W, const int32_t* partner, float lam, float* y, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(x && y && partner, "mixup_rows: null pointer");
+  if (B == 0 || W == 0) return 0;
+  int64_t gx = (W + 255) / 256;
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(mixup_rows_kernel, dim3((int)gx, B), dim3(256), 0, stream, x, W, partner, lam, y);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int afft_mixup_labels(const int64_t* labels, int32_t B, int32_t rows_per_sample, int32_t K, float label_smooth,
+                                 int64_t ignore_cls, const int32_t* partner, float lam, float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(labels && partner && out && K >= 1 && rows_per_sample >= 1, "mixup_labels: bad argument");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(mixup_labels_kernel, dim3(B * rows_per_sample), dim3(256), 0, stream, labels, rows_per_sample, K, label_smooth,
+                     ignore_cls, partner, lam, out);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int afft_softmax_rows(const float* x, int64_t ldx, int32_t rows, int32_t C, float* y, int64_t ldy, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(x && y && C >= 1, "softmax_rows: bad argument");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, stream, x, ldx, C, y, ldy);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
 // backward of y = drop(act(pre)) (see afft_act_bwd in the header)
 __global__ __launch_bounds__(256) void act_bwd_kernel(int act, const float* __restrict__ dy, int64_t lddy,
                                                       const void* __restrict__ saved, int64_t lds_, int sdt,

@@ -300,3 +300,34 @@ def weighted_sum_bwd(xs: Sequence[Tensor], w: Tensor, dout: Tensor, dxs: Sequenc
     L.check(L.lib().afft_weighted_sum_bwd(_ptr_array(xs), ld, _p(w), _rowmajor(w, "w"), _p(dout), _rowmajor(dout, "dout"),
                                           len(xs), rows, cols, _ptr_array(dxs), ldd, _p(dw), _rowmajor(dw, "dw"),
                                           _stream()), "weighted_sum_bwd")
+
+
+def mixup_plan(labels_subclips: Optional[Tensor], B: int, ignore_cls: int, partner: Tensor, ignore_mask: Optional[Tensor] = None):
+    T = 0
+    if labels_subclips is not None:
+        assert labels_subclips.dtype == torch.int64 and labels_subclips.is_contiguous() and labels_subclips.shape[0] == B
+        T = labels_subclips.numel() // B
+    assert partner.dtype == torch.int32 and partner.numel() == B
+    L.check(L.lib().afft_mixup_plan(_p(labels_subclips), B, T, ignore_cls, _p(partner), _p(ignore_mask), _stream()), "mixup_plan")
+    return partner
+
+
+def mixup_rows(x: Tensor, partner: Tensor, lam: float, y: Tensor):
+    B = x.shape[0]
+    assert x.is_contiguous() and y.is_contiguous() and x.dtype == y.dtype == torch.float32
+    L.check(L.lib().afft_mixup_rows(_p(x), B, x.numel() // B, _p(partner), lam, _p(y), _stream()), "mixup_rows")
+    return y
+
+
+def mixup_labels(labels: Tensor, B: int, K: int, label_smooth: float, ignore_cls: int, partner: Tensor, lam: float, out: Tensor):
+    assert labels.dtype == torch.int64 and labels.is_contiguous() and out.is_contiguous() and out.dtype == torch.float32
+    L.check(L.lib().afft_mixup_labels(_p(labels), B, labels.numel() // B, K, label_smooth, ignore_cls, _p(partner), lam,
+                                      _p(out), _stream()), "mixup_labels")
+    return out
+
+
+def softmax_rows(x: Tensor, y: Tensor):
+    rows, Cc = x.shape
+    assert x.dtype == y.dtype == torch.float32
+    L.check(L.lib().afft_softmax_rows(_p(x), _rowmajor(x, "x"), rows, Cc, _p(y), _rowmajor(y, "y"), _stream()), "softmax_rows")
+    return y

@@ -185,6 +185,20 @@ int afft_weighted_sum_fwd(const float* const* x, int64_t ldx, const float* w, in
 int afft_weighted_sum_bwd(const float* const* x, int64_t ldx, const float* w, int64_t ldw, const float* dout, int64_t lddo,
                           int32_t n, int32_t rows, int32_t cols, float* const* dx, int64_t lddx, float* dw, int64_t lddw,
                           void* stream);
+/* MixUp with an ignore class as a GPU prologue (common/mixup.py:119-182), no host round trip:
+ *   afft_mixup_plan: partner[b] = the sample b is mixed with -- the samples none of whose T past labels is ignore_cls are
+ *     paired in reverse order among themselves (x[sel].flip(0)); partner[b] = b for the others and when at most one
+ *     sample qualifies; labels_subclips NULL = every sample qualifies.  ignore_mask (optional) [B*T] = label == ignore_cls.
+ *   afft_mixup_rows:   y[b, :] = lam * x[b, :] + (1 - lam) * x[partner[b], :]   (x fp32 [B, W]; y = x[b] when partner[b] = b)
+ *   afft_mixup_labels: out[r, :] = lam * onehot(labels[r]) + (1 - lam) * onehot(labels[partner row]) with the smoothed
+ *     one-hot of common/mixup.py:17-47 (ignored labels count as class 0), rows r = b * rows_per_sample + i. */
+int afft_mixup_plan(const int64_t* labels_subclips, int32_t B, int32_t T, int64_t ignore_cls, int32_t* partner,
+                    uint8_t* ignore_mask, void* stream);
+int afft_mixup_rows(const float* x, int32_t B, int64_t W, const int32_t* partner, float lam, float* y, void* stream);
+int afft_mixup_labels(const int64_t* labels, int32_t B, int32_t rows_per_sample, int32_t K, float label_smooth,
+                      int64_t ignore_cls, const int32_t* partner, float lam, float* out, void* stream);
+/* Row softmax of wide fp32 rows: action probabilities for the verb / noun marginalisation (challenge.py:196-203). */
+int afft_softmax_rows(const float* x, int64_t ldx, int32_t rows, int32_t C, float* y, int64_t ldy, void* stream);
 /* Token means of the fusers without a modality token (models/fusion.py:114-116 CMFuser: mean over the M tokens of a
  * frame; :207-210 T-SA-Fuser: mean over the M modality tokens of a frame position): x fp32 [G, S, W] contiguous,
  *   afft_group_sum:   y[g, :]     = scale * sum_s x[g, s, :]

@@ -506,6 +506,51 @@ def test_softmax_small_and_weighted_sum():
         rt.set_grad_mode("sink")
 
 
+@pytest.mark.parametrize("B,T,K,n_ign", [(6, 4, 11, 2), (5, 3, 7, 4), (4, 4, 9, 0), (8, 2, 3806, 3)])
+def test_mixup_prologue_matches_oracle(B, T, K, n_ign):
+    """common.mixup.MixUp on the GPU (plan / rows / labels kernels) against the oracle's restatement of
+    common/mixup.py:119-182 (itself pinned to the reference by the t2_soft golden), incl. the <= 1 participant case."""
+    from afft_amd.common.mixup import MixUp
+    from oracle import afft_oracle as O
+    g = torch.Generator().manual_seed(B * 100 + T)
+    feats = {"rgb": torch.randn(B, T, 24, generator=g), "flow": torch.randn(B, T, 16, generator=g)}
+    tgt = torch.randint(0, K, (B,), generator=g)
+    sub = torch.randint(0, K, (B, T, 1), generator=g)
+    for b in range(n_ign):                       # samples b < n_ign carry an ignored past frame
+        sub[b, (b * 7) % T, 0] = -1
+    lam, ls = 0.3, 0.4
+    mix = MixUp(alpha=0.1, label_smoothing={"action": ls}, num_classes={"action": K})
+
+    class _Fixed:
+        def sample(self_inner):
+            return torch.tensor(lam)
+    mix.mixup_beta_sampler = _Fixed()
+    x_out, t_out, s_out, ign = mix({m: v.to(dev()) for m, v in feats.items()}, {"action": tgt.to(dev())}, {"action": sub.to(dev())})
+    rx, rt_, rs, rign = O.mixup({m: v.clone() for m, v in feats.items()}, tgt, sub, K, ls, lam)
+    for m in feats:
+        assert rel_l2(x_out[m].cpu(), rx[m]) < 1e-6, m
+    assert rel_l2(t_out["action"].cpu(), rt_) < 1e-6
+    assert rel_l2(s_out["action"].cpu(), rs) < 1e-6
+    assert torch.equal(ign["action"].cpu(), rign)
+    if B - n_ign <= 1:                           # no mixing: inputs come back unchanged, labels are plain one-hot
+        for m in feats:
+            assert torch.equal(x_out[m].cpu(), feats[m])
+
+
+def test_marginalize_verb_noun_scores():
+    from afft_amd.challenge import marginalize_scores
+    N, A, V, Nn = 37, 3806, 97, 300
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(N, A, generator=g) * 3
+    mv = (torch.rand(A, V, generator=g) < 0.02).float()
+    mn = (torch.rand(A, Nn, generator=g) < 0.01).float()
+    verb, noun, act = marginalize_scores(logits.to(dev()), {("verb", "action"): mv, ("noun", "action"): mn})
+    p = logits.double().softmax(-1)
+    assert rel_l2(verb.cpu(), (p @ mv.double()).float()) < 2e-5
+    assert rel_l2(noun.cpu(), (p @ mn.double()).float()) < 2e-5
+    assert torch.equal(act.cpu(), logits)
+
+
 def test_errors_are_reported():
     from afft_amd import ops
     a = torch.zeros(4, 4, device=dev())

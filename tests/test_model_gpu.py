@@ -54,13 +54,20 @@ def test_model_matches_reference_golden(name, precision):
     K = c["num_classes"]
     wts = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
     if c.get("soft"):
-        f3 = {m: torch.flatten(d.mean([-1, -2]).permute(0, 1, 3, 2), 1, 2) for m, d in data.items()}
-        f3, t_s, s_s, ign = O.mixup(f3, tgt, sub, K, c["label_smoothing"], c["lam"])   # caller-side MixUp (CPU)
-        out = model.future_predictor({m: v.to(dev) for m, v in f3.items()})
-        out = {k: v for k, v in out.items()}
-        losses, _ = BasicLossAccuracy(compute_metrics=False)(out, {"action": t_s.to(dev)}, {"action": s_s.to(dev)},
+        # the golden was made with the reference's MixUp (Beta sample pinned to lam) inside BaseModel.forward
+        # (mixup_backbone path, base_model.py:55-58): run OUR MixUp, on the GPU, the same way
+        from afft_amd.common.mixup import MixUp
+        mix = MixUp(alpha=0.1, label_smoothing={"action": c["label_smoothing"]}, num_classes={"action": K})
+
+        class _Fixed:
+            def sample(self_inner):
+                return torch.tensor(c["lam"])
+        mix.mixup_beta_sampler = _Fixed()
+        out, out_t = model({m: d.to(dev) for m, d in data.items()}, mixup_fn=mix, target={"action": tgt.to(dev)},
+                           target_subclips={"action": sub.to(dev)}, target_subclips_ignore_index=None)
+        losses, _ = BasicLossAccuracy(compute_metrics=False)(out, out_t["target"], out_t["target_subclips"],
                                                              mixup_enable=True,
-                                                             target_subclips_ignore_index={"action": ign.to(dev)})
+                                                             target_subclips_ignore_index=out_t["target_subclips_ignore_index"])
         total, _ = Runner._reduce_loss(losses, wts, sync=False)
     else:
         out, out_t = model({m: d.to(dev) for m, d in data.items()}, mixup_fn=None, target={"action": tgt.to(dev)},
