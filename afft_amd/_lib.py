@@ -69,6 +69,7 @@ _SIGS = {
     "afft_mixup_rows": ([vp, i32, i64, vp, f32, vp, vp], C.c_int),
     "afft_mixup_labels": ([vp, i32, i32, i32, f32, i64, vp, f32, vp, vp], C.c_int),
     "afft_softmax_rows": ([vp, i64, i32, i32, vp, i64, vp], C.c_int),
+    "afft_zero_mask_frames": ([vp, i32, i32, i64, i32, C.c_uint32, vp], C.c_int),
     "afft_act_bwd": ([i32, vp, i64, vp, i64, i32, vp, i64, i32, i32, C.POINTER(Dropout), vp, i64, i32, vp, i64, vp], C.c_int),
     "afft_softmax_small_fwd": ([vp, i64, i32, i32, vp, i64, vp], C.c_int),
     "afft_softmax_small_bwd": ([vp, i64, vp, i64, i32, i32, vp, i64, vp], C.c_int),

@@ -143,14 +143,44 @@ def get_loss_wts(loss_wts: Dict, key: str) -> float:
     raise ValueError(f'{key} not contained in predefined loss_wts: {loss_wts}')
 
 
-class Runner:
-    """wrapper class of BasicLossAccuracy, runs on each batch, returns all metrics"""
+class PendingScalars:
+    """Loss values on their way to the host: ONE pinned, non-blocking device-to-host copy of all scalars of a step and an
+    event, instead of one blocking .item() per loss term (common/runner.py:211-212 syncs the GPU every step).
+    result() waits for that copy only (and raises the reference's 'The loss is NaN!' then)."""
 
-    def __init__(self, model, device, loss_wts, compute_metrics: bool = True):
+    def __init__(self, named: Dict[str, torch.Tensor]):
+        self.keys = list(named)
+        dev = torch.stack([named[k].detach().float().reshape(()) for k in self.keys])
+        if dev.is_cuda:
+            self.host = torch.empty(len(self.keys), dtype=torch.float32, pin_memory=True)
+            self.host.copy_(dev, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+        else:
+            self.host, self.event = dev.clone(), None
+
+    def ready(self) -> bool:
+        return self.event is None or self.event.query()
+
+    def result(self) -> Dict[str, float]:
+        if self.event is not None:
+            self.event.synchronize()
+        vals = dict(zip(self.keys, self.host.tolist()))
+        if any(v != v for v in vals.values()):
+            raise ValueError('The loss is NaN!')
+        return vals
+
+
+class Runner:
+    """wrapper class of BasicLossAccuracy, runs on each batch, returns all metrics.
+    async_metrics=True: the step never waits for the GPU -- metrics['losses'] is a PendingScalars."""
+
+    def __init__(self, model, device, loss_wts, compute_metrics: bool = True, async_metrics: bool = False):
         self.model = model
         self.device = device
         self.loss_acc_fn = BasicLossAccuracy(compute_metrics)
         self.loss_wts = loss_wts
+        self.async_metrics = async_metrics
 
     @staticmethod
     def _reduce_loss(losses, loss_wts, sync: bool = True):
@@ -188,7 +218,12 @@ class Runner:
         losses, metrics = self.loss_acc_fn(outputs, out_t['target'], out_t['target_subclips'],
                                            mixup_enable=(mixup_fn is not None),
                                            target_subclips_ignore_index=out_t['target_subclips_ignore_index'])
-        loss, losses_metric = self._reduce_loss(losses, self.loss_wts)
-        metrics.update(losses_metric)
+        if self.async_metrics:
+            loss, dev_losses = self._reduce_loss(losses, self.loss_wts, sync=False)
+            dev_losses['total_loss'] = loss.detach()
+            metrics['losses'] = PendingScalars(dev_losses)
+        else:
+            loss, losses_metric = self._reduce_loss(losses, self.loss_wts)
+            metrics.update(losses_metric)
         metrics.update(timings)
         return loss, metrics

@@ -330,6 +330,31 @@ __global__ __launch_bounds__(256) void mixup_labels_kernel(const int64_t* __rest
     out[(int64_t)r * K + k] = pb == b ? a : a * lam + bb * oml;
   }
 }
+// ZeroMaskRULSTMFeats (common/transforms.py:13-26) for a whole batch on the device: in every clip exactly k of the T
+// frames, a uniformly random subset, are set to zero.  Frame t of clip b is masked iff fewer than k frames of the clip
+// have a smaller hash(key, b, t) (ties broken by index): no host RNG, reproducible from the key.
+__global__ __launch_bounds__(256) void zero_mask_frames_kernel(float* __restrict__ x, int T, int64_t C, int k, unsigned key) {
+  const int b = blockIdx.y, t = blockIdx.x;
+  const unsigned mine = mix32(key ^ mix32((unsigned)b * 0x9E3779B1u + (unsigned)t));
+  int smaller = 0;
+  for (int j = 0; j < T; ++j) {
+    const unsigned h = mix32(key ^ mix32((unsigned)b * 0x9E3779B1u + (unsigned)j));
+    smaller += (h < mine || (h == mine && j < t)) ? 1 : 0;
+  }
+  if (smaller >= k) return;
+  float* row = x + ((int64_t)b * T + t) * C;
+  for (int64_t c = threadIdx.x; c < C; c += 256) row[c] = 0.f;
+}
+
+extern "C" int afft_zero_mask_frames(float* x, int32_t B, int32_t T, int64_t C, int32_t k, uint32_t key, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(x && k >= 0 && k <= T, "zero_mask_frames: bad argument (k = %d, T = %d)", k, T);
+  if (B == 0 || T == 0 || C == 0 || k == 0) return 0;
+  hipLaunchKernelGGL(zero_mask_frames_kernel, dim3(T, B), dim3(256), 0, stream, x, T, C, k, key);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
 // softmax over wide fp32 rows (one workgroup per row): class probabilities for verb / noun marginalisation
 // (challenge.py:196-203)
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int64_t ldx, int C,

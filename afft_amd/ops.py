@@ -331,3 +331,11 @@ def softmax_rows(x: Tensor, y: Tensor):
     assert x.dtype == y.dtype == torch.float32
     L.check(L.lib().afft_softmax_rows(_p(x), _rowmajor(x, "x"), rows, Cc, _p(y), _rowmajor(y, "y"), _stream()), "softmax_rows")
     return y
+
+
+def zero_mask_frames(x: Tensor, k: int, key: int):
+    """x fp32 [B, T, ...] contiguous: zero k random frames of every clip in place."""
+    assert x.is_contiguous() and x.dtype == torch.float32 and x.dim() >= 2
+    B, T = x.shape[0], x.shape[1]
+    L.check(L.lib().afft_zero_mask_frames(_p(x), B, T, x.numel() // max(B * T, 1), k, key & 0xFFFFFFFF, _stream()), "zero_mask_frames")
+    return x

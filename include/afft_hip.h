@@ -197,6 +197,9 @@ int afft_mixup_plan(const int64_t* labels_subclips, int32_t B, int32_t T, int64_
 int afft_mixup_rows(const float* x, int32_t B, int64_t W, const int32_t* partner, float lam, float* y, void* stream);
 int afft_mixup_labels(const int64_t* labels, int32_t B, int32_t rows_per_sample, int32_t K, float label_smooth,
                       int64_t ignore_cls, const int32_t* partner, float lam, float* out, void* stream);
+/* ZeroMaskRULSTMFeats (common/transforms.py:13-26) for a batch on the device: in every clip of x fp32 [B, T, C] exactly k
+ * frames -- a uniformly random subset drawn from a counter hash of (key, clip, frame) -- are zeroed in place. */
+int afft_zero_mask_frames(float* x, int32_t B, int32_t T, int64_t C, int32_t k, uint32_t key, void* stream);
 /* Row softmax of wide fp32 rows: action probabilities for the verb / noun marginalisation (challenge.py:196-203). */
 int afft_softmax_rows(const float* x, int64_t ldx, int32_t rows, int32_t C, float* y, int64_t ldy, void* stream);
 /* Token means of the fusers without a modality token (models/fusion.py:114-116 CMFuser: mean over the M tokens of a

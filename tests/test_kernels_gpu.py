@@ -537,6 +537,32 @@ def test_mixup_prologue_matches_oracle(B, T, K, n_ign):
             assert torch.equal(x_out[m].cpu(), feats[m])
 
 
+def test_zero_mask_frames_prologue():
+    """ZeroMaskRULSTMFeats on the device: exactly round(T * rate) zero frames per clip, others untouched, subsets differ
+    between clips and between calls, and every frame gets masked about equally often."""
+    from afft_amd import dropout as D_
+    from afft_amd.common.transforms import ZeroMaskRULSTMFeats
+    D_.manual_seed(9)
+    B, T, C = 64, 16, 40
+    x = torch.randn(B, T, C, 1, 1, 1).abs() + 1.0
+    tr = ZeroMaskRULSTMFeats(mask_rate=0.2)
+    k = round(T * 0.2)
+    counts = torch.zeros(T)
+    prev = None
+    for _ in range(8):
+        y = tr(x.clone().to(dev())).cpu()
+        zero = (y.reshape(B, T, C) == 0).all(-1)
+        assert torch.equal(zero.sum(1), torch.full((B,), k))
+        assert torch.equal(y.reshape(B, T, C)[~zero], x.reshape(B, T, C)[~zero])
+        assert len({tuple(r.tolist()) for r in zero}) > B // 4          # clips draw different subsets
+        if prev is not None:
+            assert not torch.equal(prev, zero)                            # a new key per call
+        prev = zero
+        counts += zero.float().sum(0)
+    assert float(counts.min()) > 0.4 * float(counts.mean()) and float(counts.max()) < 1.8 * float(counts.mean())
+    assert ZeroMaskRULSTMFeats(0)(x) is x
+
+
 def test_marginalize_verb_noun_scores():
     from afft_amd.challenge import marginalize_scores
     N, A, V, Nn = 37, 3806, 97, 300

@@ -292,6 +292,32 @@ def test_trainer_fused_sgd_and_weight_images():
     assert losses[-1] < losses[0], losses
 
 
+def test_runner_async_metrics_equal_synchronous():
+    """Runner(async_metrics=True): the loss scalars reach the host through one pinned non-blocking copy; same values as
+    the reference-style synchronous path."""
+    import afft_amd
+    from afft_amd import runtime as rt
+    from afft_amd.common.runner import PendingScalars, Runner
+    c, state, data, tgt, sub = case_tensors("t0_sa")
+    model = build(c, "fp32")
+    model.load_state_dict(state)
+    model = model.cuda().eval()
+    dev = torch.device("cuda:0")
+    batch = ({"data_dict": data, "target": {"action": tgt}, "target_subclips": {"action": sub}}, {})
+    wts = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
+    rt.SINK.begin_step()
+    loss_s, m_s = Runner(model, dev, wts, compute_metrics=False)(batch)
+    rt.SINK.begin_step()
+    loss_a, m_a = Runner(model, dev, wts, compute_metrics=False, async_metrics=True)(batch)
+    pend = m_a["losses"]
+    assert isinstance(pend, PendingScalars)
+    vals = pend.result()
+    assert pend.ready()
+    assert abs(vals["total_loss"] - float(loss_s)) < 1e-6 * max(1.0, abs(float(loss_s)))
+    for k, v in vals.items():
+        assert abs(v - m_s[k]) < 1e-6 * max(1.0, abs(m_s[k])), k
+
+
 def test_trainer_gradient_clipping_matches_torch():
     """opt.grad_clip (train.py:254-260): global-norm clipping with the coefficient kept on the device equals
     torch.nn.utils.clip_grad_norm_ followed by torch's Nesterov SGD."""
