@@ -21,7 +21,8 @@ def install_as_models():
     _sys.modules["models"] = pkg
     for name in ("base_model", "fusion", "transformerblock", "future_prediction", "feature_mapping"):
         _sys.modules[f"models.{name}"] = importlib.import_module(f"afft_amd.models.{name}")
-    crun = importlib.import_module("afft_amd.common.runner")
     if "common" in _sys.modules:
-        _sys.modules["common.runner"] = crun
-        setattr(_sys.modules["common"], "runner", crun)
+        for name in ("runner", "mixup", "transforms"):
+            mod = importlib.import_module(f"afft_amd.common.{name}")
+            _sys.modules[f"common.{name}"] = mod
+            setattr(_sys.modules["common"], name, mod)
