@@ -176,20 +176,24 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const void* __restrict__ d
   for (int c = threadIdx.x; c < nslab * d; c += 1024) partial[(int64_t)blockIdx.x * nslab * d + c] = slab[c];
 }
 
-// 64 columns x 4 part-lanes per workgroup: coalesced 256-B reads, fixed summation order (deterministic)
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nparts, int d, int nslab,
-                                                            float* __restrict__ dw, float* __restrict__ db, int accumulate,
-                                                            float* __restrict__ dcol, int dcol_accumulate) {
-  __shared__ float sh[4][64];
+// 64 columns x 16 part-lanes per workgroup: coalesced 256-B reads, 16 loads in flight per column, fixed summation order
+// (deterministic)
+constexpr int LNR_PL = 16;
+__global__ __launch_bounds__(64 * LNR_PL) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nparts, int d, int nslab,
+                                                                   float* __restrict__ dw, float* __restrict__ db, int accumulate,
+                                                                   float* __restrict__ dcol, int dcol_accumulate) {
+  __shared__ float sh[LNR_PL][64];
   const int col = threadIdx.x & 63, pl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + col;
   float s = 0.f;
   if (c < nslab * d)
-    for (int p = pl; p < nparts; p += 4) s += partial[(int64_t)p * nslab * d + c];
+    for (int p = pl; p < nparts; p += LNR_PL) s += partial[(int64_t)p * nslab * d + c];
   sh[pl][col] = s;
   __syncthreads();
   if (pl == 0 && c < nslab * d) {
-    s = (sh[0][col] + sh[1][col]) + (sh[2][col] + sh[3][col]);
+    s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LNR_PL; k += 4) s += (sh[k][col] + sh[k + 1][col]) + (sh[k + 2][col] + sh[k + 3][col]);
     const int which = c / d, k = c - which * d;
     float* dst = which == 0 ? dw : which == 1 ? db : dcol;
     const int acc = which == 2 ? dcol_accumulate : accumulate;
@@ -249,7 +253,7 @@ extern "C" int afft_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype
 #undef LN_BWD
   AFFT_LAUNCH_CHECK();
   if (dw || db || dcol) {
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((nslab * d + 63) / 64), dim3(256), 0, stream, partial, grid, d, nslab, dw, db,
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((nslab * d + 63) / 64), dim3(64 * LNR_PL), 0, stream, partial, grid, d, nslab, dw, db,
                        accumulate, dcol, dcol_accumulate);
     AFFT_LAUNCH_CHECK();
   }
