@@ -4,7 +4,8 @@
 using namespace afft_gemm_detail;
 
 #ifndef AFFT_PP_DMA_FIRST
-#define AFFT_PP_DMA_FIRST 0   // experiment: issue the LDS-DMA before the fragment reads of an L segment
+#define AFFT_PP_DMA_FIRST 1   // issue the LDS-DMA before the fragment reads of an L segment: NN +4 %, TN +1-5 %, NT +-1 % with the
+                              // scalar-base staging (with per-lane pointers it had cost the k-strided layouts 30 %)
 #endif
 #ifndef AFFT_PP_PRIO
 #define AFFT_PP_PRIO 1        // experiment: 1 = MFMA segments at raised priority, 0 = no priority change, 2 = L segments raised
