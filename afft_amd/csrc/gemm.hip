@@ -30,7 +30,7 @@ int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipSt
 
 namespace {
 
-template <int WM, int WN, int STAGES, bool A_KS, bool B_KS>
+template <int WM, int WN, int STAGES, bool A_KS, bool B_KS, bool SPLITK>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf16_kernel(const GemmFast g) {
   constexpr int NW = WM * WN;
   constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf1
   }
 
   // Split-K (small grids): see splitk_combine (gemm_tiles.h); the last-arriving slice runs the ordinary epilogue.
-  if (g.splitk > 1) {
+  if constexpr (SPLITK) {   // its own instantiation: the combine code doubles the register footprint of the plain kernel
     __syncthreads();   // every wave is done reading the ring -> smem is free
     if (!splitk_combine<16, 64 * NW>(reinterpret_cast<f32x4(&)[16]>(acc), g.ws, g.counters, blockIdx.x, g.splitk, blockIdx.y, tid, smem))
       return;
@@ -242,14 +242,14 @@ int splitk_workspace(hipStream_t stream, size_t bytes, GemmFast& g) {
 
 int g_variant = 0;  // 0 auto, 1 = 128x128 tile, 2 = 256x128 tile, 3 = 256x256 ping-pong (tuning / tests)
 
-template <int WM, int WN, int STAGES, bool A_KS, bool B_KS>
+template <int WM, int WN, int STAGES, bool A_KS, bool B_KS, bool SPLITK>
 int launch_fast(GemmFast& g, hipStream_t stream) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr size_t ring = (size_t)STAGES * (BM + BN) * BK * 2, epi = (size_t)BM * (BN * 4 + 16);
   constexpr size_t lds = ring > epi ? ring : epi;
   g.tiles_m = (g.e.M + BM - 1) / BM;
   g.tiles_n = (g.e.N + BN - 1) / BN;
-  auto kern = gemm_bf16_kernel<WM, WN, STAGES, A_KS, B_KS>;
+  auto kern = gemm_bf16_kernel<WM, WN, STAGES, A_KS, B_KS, SPLITK>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -303,8 +303,9 @@ int launch_layout(GemmFast& g, hipStream_t stream) {
       g.splitk = s;
     }
   }
-  if (variant == 4) return launch_fast<2, 2, 4, A_KS, B_KS>(g, stream);
-  return launch_fast<2, 2, 2, A_KS, B_KS>(g, stream);
+  if (variant == 4) return launch_fast<2, 2, 4, A_KS, B_KS, false>(g, stream);
+  if (g.splitk > 1) return launch_fast<2, 2, 2, A_KS, B_KS, true>(g, stream);
+  return launch_fast<2, 2, 2, A_KS, B_KS, false>(g, stream);
 }
 
 int choose_variant(int M, int N, int K, bool A_KS, bool B_KS) {

@@ -44,7 +44,7 @@ unsigned long long* g_pp_stamp = nullptr;
 #define STAMP(var) do { } while (0)
 #endif
 
-template <bool A_KS, bool B_KS>
+template <bool A_KS, bool B_KS, bool SPLITK>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
 #ifdef AFFT_PP_STAMP
     , unsigned long long* stamp_out
@@ -215,7 +215,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
   }
 #endif
 
-  if (g.splitk > 1) {   // see splitk_combine (gemm_tiles.h): only the last-arriving slice of a tile goes on
+  // split-K is its own instantiation: the combine code (32 more f32x4 next to the accumulators) makes the register
+  // allocator spill and costs the plain kernel 3-5 % on every shape even when it never runs
+  if constexpr (SPLITK) {   // see splitk_combine (gemm_tiles.h): only the last-arriving slice of a tile goes on
     __syncthreads();    // every wave is done with the ring -> smem is free
     if (!splitk_combine<32, 512>(reinterpret_cast<f32x4(&)[32]>(acc), g.ws, g.counters, blockIdx.x, g.splitk, blockIdx.y, tid, smem))
       return;
@@ -252,12 +254,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
   });
 }
 
-template <bool A_KS, bool B_KS>
+template <bool A_KS, bool B_KS, bool SPLITK>
 int launch_pp(GemmFast& g, hipStream_t stream) {
   constexpr size_t lds = 128 * 1040;          // ring: 2 K-tiles x 4 half-tiles x 16 KiB = 128 KiB; epilogue image: 130 KiB
   g.tiles_m = (g.e.M + 255) / 256;
   g.tiles_n = (g.e.N + 255) / 256;
-  auto kern = gemm_bf16_pp_kernel<A_KS, B_KS>;
+  auto kern = gemm_bf16_pp_kernel<A_KS, B_KS, SPLITK>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -284,10 +286,11 @@ extern "C" void afft_debug_pp_stamp(void* p) { g_pp_stamp = (unsigned long long*
 #endif
 
 int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream) {
-  if (!a_ks && !b_ks) return launch_pp<false, false>(g, stream);
+  const bool sk = g.splitk > 1;
+  if (!a_ks && !b_ks) return sk ? launch_pp<false, false, true>(g, stream) : launch_pp<false, false, false>(g, stream);
 #ifndef AFFT_PP_NT_ONLY   // development switch: build only the NT instantiation (compile time)
-  if (!a_ks && b_ks) return launch_pp<false, true>(g, stream);
-  if (a_ks && b_ks) return launch_pp<true, true>(g, stream);
+  if (!a_ks && b_ks) return sk ? launch_pp<false, true, true>(g, stream) : launch_pp<false, true, false>(g, stream);
+  if (a_ks && b_ks) return sk ? launch_pp<true, true, true>(g, stream) : launch_pp<true, true, false>(g, stream);
 #endif
   afft_set_error("afft_gemm: layout (A k-strided, B k-contiguous) is not built");
   return 1;

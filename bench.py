@@ -93,8 +93,8 @@ class GemmTimer:
             else:
                 var = _lib.lib().afft_gemm_variant_for(M, N, K, int(a_ks), int(b_ks))
                 lay = "%s, %s" % ("true" if a_ks else "false", "true" if b_ks else "false")
-                kind = ("gemm_bf16_pp_kernel<%s>" % lay) if var == 3 else \
-                    ("gemm_bf16_kernel<%s, %s>" % ("2, 2, 2" if var == 1 else "4, 2, 3", lay))
+                kind = ("gemm_bf16_pp_kernel<%s, false>" % lay) if var == 3 else \
+                    ("gemm_bf16_kernel<2, 2, 2, %s>" % lay)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             r = timer.orig(a, b, out, **kw)
@@ -258,7 +258,7 @@ def main():
                 traffic = None
             result["roofline"] = {
                 "kernel": dom + " (bf16 MFMA GEMM, v_mfma_f32_16x16x32_bf16; template <A k-strided, B k-strided>: "
-                          "false,false = NT, false,true = NN, true,true = TN weight gradient)",
+                          "false,false = NT, false,true = NN, true,true = TN weight gradient; third flag = split-K build)",
                 "bound": "mfma", "achieved": round(ach, 1), "peak": dtype_peak, "unit": "TFLOP/s",
                 "frac": round(ach / dtype_peak, 4), "traffic": traffic,
                 "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate --pmc passes of this command "
