@@ -47,6 +47,7 @@ _SIGS = {
     "afft_set_gemm_variant": ([C.c_int], C.c_int),
     "afft_set_gemm_splitk": ([C.c_int], C.c_int),
     "afft_gemm_variant_for": ([C.c_int, C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
+    "afft_gemm_splitk_for": ([C.c_int, C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
     "afft_layernorm_fwd": ([vp, i64, vp, vp, f32, i32, i32, vp, i64, i32, vp, vp, vp], C.c_int),
     "afft_layernorm_bwd_nparts": ([i32], C.c_int),
     "afft_layernorm_bwd": ([vp, i64, i32, vp, i64, vp, vp, vp, i32, i32, vp, vp, i64, vp, C.POINTER(Dropout), vp, vp, i32,

@@ -266,43 +266,47 @@ int launch_fast(GemmFast& g, hipStream_t stream) {
 
 int choose_variant(int M, int N, int K, bool A_KS, bool B_KS);
 
-template <bool A_KS, bool B_KS>
-int launch_layout(GemmFast& g, hipStream_t stream) {
-  const int variant = choose_variant(g.e.M, g.e.N, g.K, A_KS, B_KS);
-  g.splitk = 1;
-  g.ws = nullptr;
-  g.counters = nullptr;
+// K-slices afft_gemm will use for a fast-path problem (1 = no split-K)
+int choose_splitk(int variant, int M, int N, int K) {
+  if (!g_splitk_mode) return 1;
+  const int nk = K / BK;
   if (variant == 3) {
     // 256x256 tiles: a grid that leaves more than a third of the CUs without a tile (160 tiles: every N = 2048 GEMM
     // of the fuser at B = 64) CAN be cut into 3 K-slices -- 480 workgroups = 2 rounds of a third of K each instead of
     // 1 round of all of it.  Measured (5120x2048x8192): 194 -> 240 us, the 256-KiB partial tiles (164 MB written and
     // read back per launch) cost more than the idle CUs; so the automatic mode never picks it (AFFT_PP_SPLIT_MIN_NK
     // lowers the threshold for experiments) and it stays as a tested path for shapes with much longer K.
-    const int64_t t3 = (int64_t)((g.e.M + 255) / 256) * ((g.e.N + 255) / 256);
-    const int nk = g.K / BK;
+    const int64_t t3 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
     int s = 1;
     if (g_splitk_mode == 1) s = (t3 * 3 <= 512 && t3 > 128 && nk >= g_pp_split_min_nk) ? 3 : 1;
     else if (g_splitk_mode > 1 && nk >= 2 * g_splitk_mode) s = g_splitk_mode == 4 ? 3 : 2;
-    if (s > 1 && t3 <= kMaxSplitTiles) {
-      if (int rc = splitk_workspace(stream, (size_t)t3 * s * 256 * 256 * sizeof(float), g)) return rc;
-      g.splitk = s;
-    }
-    return afft_gemm_launch_pp(A_KS, B_KS, g, stream);
+    return (s > 1 && t3 <= kMaxSplitTiles) ? s : 1;
   }
-  if (g_splitk_mode) {
-    // Small grids: <= 128 tiles of 128x128 leave half of the CUs without a workgroup, and what bounds such a launch
-    // is the LDS fill rate of the CUs that have one -- more CUs pulling is the lever.  Cut K in 2 (4 when K is long).
-    const int64_t t1 = (int64_t)((g.e.M + 127) / 128) * ((g.e.N + 127) / 128);
-    const int nk = g.K / BK;
-    int s = 1;
-    if (g_splitk_mode == 1) s = (t1 <= 128 && nk >= 32) ? ((nk >= 96 && t1 * 4 <= 512) ? 4 : 2) : 1;
-    else if (t1 * g_splitk_mode <= kMaxSplitTiles && nk >= 2 * g_splitk_mode) s = g_splitk_mode;
-    while (s > 1 && nk % s != 0) s >>= 1;
-    if (s > 1 && t1 <= kMaxSplitTiles) {
-      if (int rc = splitk_workspace(stream, (size_t)t1 * s * 128 * 128 * sizeof(float), g)) return rc;
-      g.splitk = s;
-    }
+  // 128x128 tiles, small grids: <= 128 tiles leave half of the CUs without a workgroup, and what bounds such a launch
+  // is the LDS fill rate of the CUs that have one -- more CUs pulling is the lever.  Cut K in 2 (4 when K is long).
+  const int64_t t1 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
+  int s = 1;
+  if (g_splitk_mode == 1) s = (t1 <= 128 && nk >= 32) ? ((nk >= 96 && t1 * 4 <= 512) ? 4 : 2) : 1;
+  else if (t1 * g_splitk_mode <= kMaxSplitTiles && nk >= 2 * g_splitk_mode) s = g_splitk_mode;
+  while (s > 1 && nk % s != 0) s >>= 1;
+  return (s > 1 && t1 <= kMaxSplitTiles) ? s : 1;
+}
+
+template <bool A_KS, bool B_KS>
+int launch_layout(GemmFast& g, hipStream_t stream) {
+  const int variant = choose_variant(g.e.M, g.e.N, g.K, A_KS, B_KS);
+  g.splitk = 1;
+  g.ws = nullptr;
+  g.counters = nullptr;
+  const int s = variant == 4 ? 1 : choose_splitk(variant, g.e.M, g.e.N, g.K);
+  if (s > 1) {
+    const int64_t tiles = variant == 3 ? (int64_t)((g.e.M + 255) / 256) * ((g.e.N + 255) / 256)
+                                       : (int64_t)((g.e.M + 127) / 128) * ((g.e.N + 127) / 128);
+    const size_t tile_bytes = (variant == 3 ? 256 * 256 : 128 * 128) * sizeof(float);
+    if (int rc = splitk_workspace(stream, (size_t)tiles * s * tile_bytes, g)) return rc;
+    g.splitk = s;
   }
+  if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream);
   if (variant == 4) return launch_fast<2, 2, 4, A_KS, B_KS, false>(g, stream);
   if (g.splitk > 1) return launch_fast<2, 2, 2, A_KS, B_KS, true>(g, stream);
   return launch_fast<2, 2, 2, A_KS, B_KS, false>(g, stream);
@@ -323,6 +327,11 @@ int choose_variant(int M, int N, int K, bool A_KS, bool B_KS) {
 
 extern "C" int afft_gemm_variant_for(int M, int N, int K, int a_kstrided, int b_kstrided) {
   return choose_variant(M, N, K, a_kstrided != 0, b_kstrided != 0);
+}
+
+extern "C" int afft_gemm_splitk_for(int M, int N, int K, int a_kstrided, int b_kstrided) {
+  const int v = choose_variant(M, N, K, a_kstrided != 0, b_kstrided != 0);
+  return v == 4 ? 1 : choose_splitk(v, M, N, K);
 }
 
 extern "C" int afft_set_gemm_splitk(int mode) {

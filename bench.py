@@ -92,9 +92,10 @@ class GemmTimer:
                 kind = "gemm_f32_kernel"
             else:
                 var = _lib.lib().afft_gemm_variant_for(M, N, K, int(a_ks), int(b_ks))
+                sk = "true" if _lib.lib().afft_gemm_splitk_for(M, N, K, int(a_ks), int(b_ks)) > 1 else "false"
                 lay = "%s, %s" % ("true" if a_ks else "false", "true" if b_ks else "false")
-                kind = ("gemm_bf16_pp_kernel<%s, false>" % lay) if var == 3 else \
-                    ("gemm_bf16_kernel<2, 2, 2, %s>" % lay)
+                kind = ("gemm_bf16_pp_kernel<%s, %s>" % (lay, sk)) if var == 3 else \
+                    ("gemm_bf16_kernel<2, 2, 2, %s, %s>" % (lay, sk))
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             r = timer.orig(a, b, out, **kw)

@@ -81,6 +81,8 @@ int afft_set_gemm_splitk(int mode);
 /* Which bf16 tile shape afft_gemm picks for a fast-path problem (1 / 3 as above); used by bench.py to attribute
  * launches to kernel symbols. */
 int afft_gemm_variant_for(int M, int N, int K, int a_kstrided, int b_kstrided);
+/* K-slices afft_gemm uses for that problem under the current split-K mode (1 = none). */
+int afft_gemm_splitk_for(int M, int N, int K, int a_kstrided, int b_kstrided);
 
 /* ------------------------------------------------------------------ LayerNorm
  * nn.LayerNorm(eps) fwd/bwd: models/fusion.py:281,362 ; transformerblock.py:122,127,150-152 ;
