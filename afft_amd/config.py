@@ -83,6 +83,11 @@ BASELINE_CONFIGS = {
                  fp_inter_dim=2048, fuser="ca", T=16),
     "cfg5": dict(modal_dims={"rgb": 2048, "objects": 2048, "audio": 2048, "poses": 2048, "flow": 2048},
                  common_dim=2048, fp_inter_dim=2048, fuser="sa", T=32),
+    # not BASELINE rows: the other fusers at the cfg2 sizes, for DESIGN.md section 7 (depth 6 like the SA-Fuser)
+    "cfg2_cm": dict(modal_dims={"rgb": 2048, "objects": 2048, "audio": 2048, "flow": 2048}, common_dim=2048,
+                    fp_inter_dim=2048, fuser="cm", T=16),
+    "cfg2_tsa": dict(modal_dims={"rgb": 2048, "objects": 2048, "audio": 2048, "flow": 2048}, common_dim=2048,
+                     fp_inter_dim=2048, fuser="tsa", T=16),
 }
 
 
@@ -96,6 +101,10 @@ def gflop_per_clip(name_or_cfg, fwd_bwd: bool = True) -> float:
     if c.get("fuser", "sa") == "sa":
         S = M + 1
         fl += depth * T * S * 24 * d * d + depth * T * 4 * S * S * d
+    elif c["fuser"] == "cm":       # M tokens per frame
+        fl += depth * T * M * 24 * d * d + depth * T * 4 * M * M * d
+    elif c["fuser"] == "tsa":      # one sequence of M*T tokens per clip
+        fl += depth * T * M * 24 * d * d + depth * 4 * (M * T) * (M * T) * d
     else:
         fl += (M - 1) * T * 32 * d * d + (M - 1) * 8 * T * T * d
     fl += sum(2 * T * C * d for C in md.values() if C != d)

@@ -31,17 +31,34 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, 
   const T* qh = q + row0 * ldq + (int64_t)h * hd;
   const T* kh = k + row0 * ldk + (int64_t)h * hd;
   const T* vh = v + row0 * ldv + (int64_t)h * hd;
-  // scores: one wave per (i, j) pair, lanes stride the head dimension
-  for (int idx = wave; idx < L * L; idx += 4) {
-    const int i = idx / L, j = idx - i * L;
-    float s = 0.f;
-    if (!masked(mask, period, i, j)) {
-      for (int c = lane; c < hd; c += 64) s += Elem<T>::ld(qh + i * ldq + c) * Elem<T>::ld(kh + j * ldk + c);
-      s = wave_sum(s) * scale;
-    } else {
-      s = -INFINITY;
+  // scores: a wave owns query rows i = wave, wave + 4, ...: the row is read once into registers (lanes stride the head
+  // dimension) and dotted with 4 key rows at a time, so 4 x hd/64 independent loads are in flight per reduction
+  // (one (i, j) pair per iteration was a chain of dependent L2 round trips: 1.8 ms per launch at L = 64, hd = 512)
+  constexpr int NQ = 16;                               // hd <= 64 * NQ = 1024
+  for (int i = wave; i < L; i += 4) {
+    float qv[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) qv[t] = (lane + 64 * t) < hd ? Elem<T>::ld(qh + i * ldq + lane + 64 * t) : 0.f;
+    for (int j0 = 0; j0 < L; j0 += 4) {
+      float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u;
+        if (j < L && !masked(mask, period, i, j)) {
+#pragma unroll
+          for (int t = 0; t < NQ; ++t)
+            if ((lane + 64 * t) < hd) acc4[u] += qv[t] * Elem<T>::ld(kh + j * ldk + lane + 64 * t);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u;
+        if (j < L) {
+          const float sv = masked(mask, period, i, j) ? -INFINITY : wave_sum(acc4[u]) * scale;
+          if (lane == 0) sc[i][j] = sv;
+        }
+      }
     }
-    if (lane == 0) sc[i][j] = s;
   }
   __syncthreads();
   if (tid < L) {
@@ -97,13 +114,32 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ dou
   const T* vh = v + row0 * ldv + (int64_t)h * hd;
   const float* pr = probs + ((int64_t)seq * H + h) * L * L;
   for (int idx = tid; idx < L * L; idx += 256) pp[idx / L][idx % L] = pr[idx];
-  // dP[i][j] = sum_c dO[i][c] v[j][c]
-  for (int idx = wave; idx < L * L; idx += 4) {
-    const int i = idx / L, j = idx - i * L;
-    float s = 0.f;
-    for (int c = lane; c < hd; c += 64) s += Elem<T>::ld(doh + i * lddo + c) * Elem<T>::ld(vh + j * ldv + c);
-    s = wave_sum(s);
-    if (lane == 0) ds[i][j] = s;
+  // dP[i][j] = sum_c dO[i][c] v[j][c]: same row-in-registers, 4-keys-at-a-time scheme as the forward scores
+  constexpr int NQ = 16;
+  for (int i = wave; i < L; i += 4) {
+    float dv_[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) dv_[t] = (lane + 64 * t) < hd ? Elem<T>::ld(doh + i * lddo + lane + 64 * t) : 0.f;
+    for (int j0 = 0; j0 < L; j0 += 4) {
+      float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u;
+        if (j < L) {
+#pragma unroll
+          for (int t = 0; t < NQ; ++t)
+            if ((lane + 64 * t) < hd) acc4[u] += dv_[t] * Elem<T>::ld(vh + j * ldv + lane + 64 * t);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u;
+        if (j < L) {
+          const float sv = wave_sum(acc4[u]);
+          if (lane == 0) ds[i][j] = sv;
+        }
+      }
+    }
   }
   __syncthreads();
   if (tid < L) {
@@ -221,9 +257,11 @@ extern "C" int afft_attention_fwd(const void* q, int64_t ldq, const void* k, int
              "attention_fwd: block-causal mask needs a period that divides L (L=%d, period=%d)", L, mask_period);
   AFFT_CHECK(!(mask == AFFT_MASK_DIAG && L == 1), "attention_fwd: diagonal mask with L=1 masks every key");
   AFFT_CHECK(drop_p >= 0.f && drop_p < 1.f, "attention_fwd: dropout p outside [0,1)");
+  AFFT_CHECK(hd >= 1 && hd <= 1024, "attention_fwd: head dimension %d outside 1..1024", hd);
   if (nseq == 0) return 0;
-  if (dtype == AFFT_BF16 && use_mfma_attention() && mask <= AFFT_MASK_CAUSAL) {
-    const int rc = afft_attention_mfma(false, nullptr, 0, q, ldq, k, ldk, v, ldv, probs, nseq, L, H, hd, scale, mask,
+  if (dtype == AFFT_BF16 && use_mfma_attention()) {
+    const int rc = afft_attention_mfma(false, nullptr, 0, q, ldq, k, ldk, v, ldv, probs, nseq, L, H, hd, scale,
+                                       mask | (mask == AFFT_MASK_BLOCKCAUSAL ? mask_period << 8 : 0),
                                        drop_p, drop_key, out, ldo, nullptr, 0, nullptr, 0, nullptr, 0, stream);
     if (rc >= 0) return rc;
   }
@@ -249,6 +287,7 @@ extern "C" int afft_attention_bwd(const void* dout, int64_t lddo, const void* q,
   AFFT_CHECK(dout && q && k && v && probs && dq && dk && dv, "attention_bwd: null pointer");
   AFFT_CHECK(L >= 1 && L <= LMAX, "attention_bwd: sequence length %d outside 1..%d", L, LMAX);
   AFFT_CHECK(drop_p >= 0.f && drop_p < 1.f, "attention_bwd: dropout p outside [0,1)");
+  AFFT_CHECK(hd >= 1 && hd <= 1024, "attention_bwd: head dimension %d outside 1..1024", hd);
   if (nseq == 0) return 0;
   if (dtype == AFFT_BF16 && use_mfma_attention()) {
     const int rc = afft_attention_mfma(true, dout, lddo, q, ldq, k, ldk, v, ldv, const_cast<float*>(probs), nseq, L, H, hd,

@@ -30,19 +30,21 @@ struct AttnArgs {
   int64_t ldo, lddq, lddk, lddv;
   float* probs;        // fwd: written; bwd: read
   int nseq, L, H, hd, G;
+  int hc;              // head-dimension chunk staged in LDS at a time (hd % hc == 0, hc % 64 == 0)
   float scale;
-  int mask;
+  int mask, period;
   unsigned dthresh, dkey;
   float dinv;
 };
 
-__device__ __forceinline__ bool pair_valid(int mask, int L, int rows_valid, int qi, int kj) {
+__device__ __forceinline__ bool pair_valid(int mask, int period, int L, int rows_valid, int qi, int kj) {
   if (qi >= rows_valid || kj >= rows_valid) return false;
   const int sq = qi / L, sk = kj / L;
   if (sq != sk) return false;                    // block-diagonal: tokens of different packed sequences never mix
   const int i = qi - sq * L, j = kj - sk * L;
   if (mask == AFFT_MASK_DIAG && i == j) return false;
   if (mask == AFFT_MASK_CAUSAL && j > i) return false;
+  if (mask == AFFT_MASK_BLOCKCAUSAL && (j % period) > (i % period)) return false;   // T-SA-Fuser: causal T x T tiled
   return true;
 }
 
@@ -55,6 +57,7 @@ __device__ __forceinline__ int tile_off(int row, int chunk16, int row_bytes) {
   return row * row_bytes + ((chunk16 ^ (swz(row, row_bytes) << 1)) << 4);
 }
 
+// stages columns [0, hd) of rows row0.. of src (the caller offsets src to the head and head-dimension chunk)
 __device__ __forceinline__ void load_tile(const bf16_t* __restrict__ src, int64_t ld, int64_t row0, int rows_valid,
                                           int R, int hd, char* lds) {
   const int cpr = hd >> 3;  // 16-byte chunks per row
@@ -92,41 +95,45 @@ template <int NT>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int R = 16 * NT;
-  const int hd = a.hd, L = a.L, H = a.H;
-  const int rb = hd * 2;
+  const int hd = a.hd, hc = a.hc, L = a.L, H = a.H;
+  const int rb = hc * 2;               // bytes per LDS row: one head-dimension chunk
+  const int nch = hd / hc;
   char* Qs = smem;
   char* Ks = Qs + R * rb;
-  char* Vs = Ks + R * rb;
+  char* Vs = nch == 1 ? Ks + R * rb : smem;     // chunked: V chunks reuse the Q/K space after the scores are done
   const int grp = blockIdx.x / H, h = blockIdx.x % H;
   const int seq0 = grp * a.G;
   const int nsq = min(a.G, a.nseq - seq0);
   const int rows_valid = nsq * L;
   const int64_t row0 = (int64_t)seq0 * L;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  load_tile(a.q + (int64_t)h * hd, a.ldq, row0, rows_valid, R, hd, Qs);
-  load_tile(a.k + (int64_t)h * hd, a.ldk, row0, rows_valid, R, hd, Ks);
-  load_tile(a.v + (int64_t)h * hd, a.ldv, row0, rows_valid, R, hd, Vs);
-  __syncthreads();
 
-  // S^T[key][query] : keys on (lane>>4, reg), queries on lane&15
+  // S^T[key][query] : keys on (lane>>4, reg), queries on lane&15; accumulated over the head-dimension chunks
   f32x4 s[NT][NT];
 #pragma unroll
   for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
     for (int qt = 0; qt < NT; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int ks = 0; ks < hd / 32; ++ks) {
-    const int ch = ks * 4 + (lane >> 4);
-    bf16x8 kf[NT], qf[NT];
+  for (int c = 0; c < nch; ++c) {
+    if (c) __syncthreads();            // the previous chunk has been consumed by every wave
+    load_tile(a.q + (int64_t)h * hd + c * hc, a.ldq, row0, rows_valid, R, hc, Qs);
+    load_tile(a.k + (int64_t)h * hd + c * hc, a.ldk, row0, rows_valid, R, hc, Ks);
+    if (nch == 1) load_tile(a.v + (int64_t)h * hd, a.ldv, row0, rows_valid, R, hc, Vs);
+    __syncthreads();
+    for (int ks = 0; ks < hc / 32; ++ks) {
+      const int ch = ks * 4 + (lane >> 4);
+      bf16x8 kf[NT], qf[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      kf[t] = row_frag(Ks, t * 16 + (lane & 15), ch, rb);
-      qf[t] = row_frag(Qs, t * 16 + (lane & 15), ch, rb);
+      for (int t = 0; t < NT; ++t) {
+        kf[t] = row_frag(Ks, t * 16 + (lane & 15), ch, rb);
+        qf[t] = row_frag(Qs, t * 16 + (lane & 15), ch, rb);
+      }
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt)
+          s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], s[kt][qt], 0, 0, 0);
     }
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-      for (int qt = 0; qt < NT; ++qt)
-        s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], s[kt][qt], 0, 0, 0);
   }
   // masked softmax over keys, per query column
   bf16x4 pb[NT][NT];
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int kj = kt * 16 + 4 * (lane >> 4) + r;
-        ok[kt][r] = pair_valid(a.mask, L, rows_valid, qi, kj);
+        ok[kt][r] = pair_valid(a.mask, a.period, L, rows_valid, qi, kj);
         s[kt][qt][r] *= a.scale;
         if (ok[kt][r]) m = fmaxf(m, s[kt][qt][r]);
       }
@@ -189,20 +196,28 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
     }
   }
   // O^T[c][query] = sum_key V^T[c][key] P^T[key][query]; the 4 waves split the head dimension in 16-channel blocks
-  for (int cb = wave; cb < hd / 16; cb += 4) {
-    f32x4 o[NT];
-#pragma unroll
-    for (int qt = 0; qt < NT; ++qt) o[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-      const bf16x4 vt = tr_frag(Vs, kt * 16, cb, lane, rb);
-#pragma unroll
-      for (int qt = 0; qt < NT; ++qt) o[qt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt, pb[kt][qt], o[qt], 0, 0, 0);
+  for (int c = 0; c < nch; ++c) {
+    if (nch > 1) {
+      __syncthreads();                 // scores / previous V chunk done by every wave
+      load_tile(a.v + (int64_t)h * hd + c * hc, a.ldv, row0, rows_valid, R, hc, Vs);
+      __syncthreads();
     }
+    for (int cb = wave; cb < hc / 16; cb += 4) {
+      f32x4 o[NT];
 #pragma unroll
-    for (int qt = 0; qt < NT; ++qt) {
-      const int qi = qt * 16 + (lane & 15);
-      if (qi < rows_valid) store_o4(a.out + (row0 + qi) * a.ldo + (int64_t)h * hd + cb * 16 + 4 * (lane >> 4), o[qt]);
+      for (int qt = 0; qt < NT; ++qt) o[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+        const bf16x4 vt = tr_frag(Vs, kt * 16, cb, lane, rb);
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) o[qt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt, pb[kt][qt], o[qt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int qt = 0; qt < NT; ++qt) {
+        const int qi = qt * 16 + (lane & 15);
+        if (qi < rows_valid)
+          store_o4(a.out + (row0 + qi) * a.ldo + (int64_t)h * hd + c * hc + cb * 16 + 4 * (lane >> 4), o[qt]);
+      }
     }
   }
 }
@@ -211,12 +226,18 @@ template <int NT>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int R = 16 * NT;
-  const int hd = a.hd, L = a.L, H = a.H;
-  const int rb = hd * 2;
-  char* Qs = smem;
-  char* Ks = Qs + R * rb;
-  char* Vs = Ks + R * rb;
-  char* Ds = Vs + R * rb;   // dO
+  const int hd = a.hd, hc = a.hc, L = a.L, H = a.H;
+  const int rb = hc * 2;
+  const int nch = hd / hc;
+  // one chunk: Q, K, V, dO all resident; chunked: phase 1 uses (V, dO), phase 3 re-stages (Q, K, dO) per chunk
+  char* T0 = smem;
+  char* T1 = T0 + R * rb;
+  char* T2 = T1 + R * rb;
+  char* T3 = T2 + R * rb;
+  char* Qs = T0;
+  char* Ks = T1;
+  char* Vs = nch == 1 ? T2 : T0;
+  char* Ds = nch == 1 ? T3 : T1;       // phase 1 (chunked: phase 3 uses T2 for dO)
   const int grp = blockIdx.x / H, h = blockIdx.x % H;
   const int seq0 = grp * a.G;
   const int nsq = min(a.G, a.nseq - seq0);
@@ -224,11 +245,6 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const AttnArgs a) {
   const int64_t row0 = (int64_t)seq0 * L;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c15 = lane & 15;
-  load_tile(a.q + (int64_t)h * hd, a.ldq, row0, rows_valid, R, hd, Qs);
-  load_tile(a.k + (int64_t)h * hd, a.ldk, row0, rows_valid, R, hd, Ks);
-  load_tile(a.v + (int64_t)h * hd, a.ldv, row0, rows_valid, R, hd, Vs);
-  load_tile(a.dout + (int64_t)h * hd, a.lddo, row0, rows_valid, R, hd, Ds);
-  __syncthreads();
 
   // dP in both layouts from the same fragments:  A: dP^T[key][query] (keys on regs) ; B: dP[query][key] (queries on regs)
   f32x4 dpa[NT][NT], dpb[NT][NT];
@@ -236,21 +252,31 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const AttnArgs a) {
   for (int x = 0; x < NT; ++x)
 #pragma unroll
     for (int y = 0; y < NT; ++y) { dpa[x][y] = f32x4{0.f, 0.f, 0.f, 0.f}; dpb[x][y] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  for (int ks = 0; ks < hd / 32; ++ks) {
-    const int ch = ks * 4 + g;
-    bf16x8 vf[NT], df[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      vf[t] = row_frag(Vs, t * 16 + c15, ch, rb);
-      df[t] = row_frag(Ds, t * 16 + c15, ch, rb);
+  for (int c = 0; c < nch; ++c) {
+    if (c) __syncthreads();
+    if (nch == 1) {
+      load_tile(a.q + (int64_t)h * hd, a.ldq, row0, rows_valid, R, hc, Qs);
+      load_tile(a.k + (int64_t)h * hd, a.ldk, row0, rows_valid, R, hc, Ks);
     }
+    load_tile(a.v + (int64_t)h * hd + c * hc, a.ldv, row0, rows_valid, R, hc, Vs);
+    load_tile(a.dout + (int64_t)h * hd + c * hc, a.lddo, row0, rows_valid, R, hc, Ds);
+    __syncthreads();
+    for (int ks = 0; ks < hc / 32; ++ks) {
+      const int ch = ks * 4 + g;
+      bf16x8 vf[NT], df[NT];
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-      for (int qt = 0; qt < NT; ++qt) {
-        dpa[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kt], df[qt], dpa[kt][qt], 0, 0, 0);
-        dpb[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[qt], vf[kt], dpb[qt][kt], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) {
+        vf[t] = row_frag(Vs, t * 16 + c15, ch, rb);
+        df[t] = row_frag(Ds, t * 16 + c15, ch, rb);
       }
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) {
+          dpa[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kt], df[qt], dpa[kt][qt], 0, 0, 0);
+          dpb[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[qt], vf[kt], dpb[qt][kt], 0, 0, 0);
+        }
+    }
   }
   // layout A: query = qt*16 + c15 (lane), key = kt*16 + 4g + r (regs)
   bf16x4 dsa[NT][NT];   // dS^T * scale  (B operand for dQ)
@@ -266,7 +292,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const AttnArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int kj = kt * 16 + 4 * g + r;
         float pv = 0.f, m = 0.f;
-        if (pair_valid(a.mask, L, rows_valid, qi, kj)) {
+        if (pair_valid(a.mask, a.period, L, rows_valid, qi, kj)) {
           const int64_t pidx = ((((int64_t)(seq0 + sq)) * H + h) * L + i) * L + (kj - sq * L);
           pv = a.probs[pidx];
           m = (a.dthresh && !drop_keep(a.dkey, (unsigned)pidx, a.dthresh)) ? 0.f : a.dinv;
@@ -285,75 +311,82 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const AttnArgs a) {
       dsa[kt][qt] = pack4(v4);
     }
   }
-  // layout B: query = qt*16 + 4g + r (regs), key = kt*16 + c15 (lane)
+  // layout B: query = qt*16 + 4g + r (regs), key = kt*16 + c15 (lane); one query tile at a time (registers)
   bf16x4 dsb[NT][NT];   // dS * scale  (B operand for dK)
   bf16x4 ppb[NT][NT];   // dropped-out P (B operand for dV)
-  {
-    float p[NT][NT][4], dp[NT][NT][4], pm[NT][NT][4], dot[NT][4];
 #pragma unroll
-    for (int qt = 0; qt < NT; ++qt)
+  for (int qt = 0; qt < NT; ++qt) {
+    float p[NT][4], dp[NT][4], pm[NT][4], dot[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int qi = qt * 16 + 4 * g + r;
-        const int sq = qi / L, i = qi - sq * L;
-        float d = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-          const int kj = kt * 16 + c15;
-          float pv = 0.f, m = 0.f;
-          if (pair_valid(a.mask, L, rows_valid, qi, kj)) {
-            const int64_t pidx = ((((int64_t)(seq0 + sq)) * H + h) * L + i) * L + (kj - sq * L);
-            pv = a.probs[pidx];
-            m = (a.dthresh && !drop_keep(a.dkey, (unsigned)pidx, a.dthresh)) ? 0.f : a.dinv;
-          }
-          p[qt][kt][r] = pv;
-          pm[qt][kt][r] = pv * m;                 // dropped-out probability P' (for dV)
-          dp[qt][kt][r] = dpb[qt][kt][r] * m;     // dP = dP' * m/(1-p)
-          d += pv * dp[qt][kt][r];
-        }
-        // sum over keys = over the 16 lanes of this lane group
-        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
-        dot[qt][r] = d;
-      }
-#pragma unroll
-    for (int qt = 0; qt < NT; ++qt)
+    for (int r = 0; r < 4; ++r) {
+      const int qi = qt * 16 + 4 * g + r;
+      const int sq = qi / L, i = qi - sq * L;
+      float d = 0.f;
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
-        float v4[4], pd[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v4[r] = p[qt][kt][r] * (dp[qt][kt][r] - dot[qt][r]) * a.scale;
-          pd[r] = pm[qt][kt][r];
+        const int kj = kt * 16 + c15;
+        float pv = 0.f, m = 0.f;
+        if (pair_valid(a.mask, a.period, L, rows_valid, qi, kj)) {
+          const int64_t pidx = ((((int64_t)(seq0 + sq)) * H + h) * L + i) * L + (kj - sq * L);
+          pv = a.probs[pidx];
+          m = (a.dthresh && !drop_keep(a.dkey, (unsigned)pidx, a.dthresh)) ? 0.f : a.dinv;
         }
-        dsb[qt][kt] = pack4(v4);
-        ppb[qt][kt] = pack4(pd);
+        p[kt][r] = pv;
+        pm[kt][r] = pv * m;                   // dropped-out probability P' (for dV)
+        dp[kt][r] = dpb[qt][kt][r] * m;       // dP = dP' * m/(1-p)
+        d += pv * dp[kt][r];
       }
-  }
-  // the three [hd x 16] products, 16 channels per step, waves split the head dimension
-  for (int cb = wave; cb < hd / 16; cb += 4) {
-    f32x4 odq[NT], odk[NT], odv[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) { odq[t] = f32x4{0.f, 0.f, 0.f, 0.f}; odk[t] = odq[t]; odv[t] = odq[t]; }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {          // reduction tile (keys for dQ, queries for dK / dV)
-      const bf16x4 kT = tr_frag(Ks, t * 16, cb, lane, rb);
-      const bf16x4 qT = tr_frag(Qs, t * 16, cb, lane, rb);
-      const bf16x4 dT = tr_frag(Ds, t * 16, cb, lane, rb);
-#pragma unroll
-      for (int u = 0; u < NT; ++u) {        // output tile
-        odq[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kT, dsa[t][u], odq[u], 0, 0, 0);  // dQ^T[c][query u]
-        odk[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qT, dsb[t][u], odk[u], 0, 0, 0);  // dK^T[c][key u]
-        odv[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dT, ppb[t][u], odv[u], 0, 0, 0);  // dV^T[c][key u]
-      }
+      // sum over keys = over the 16 lanes of this lane group
+      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+      dot[r] = d;
     }
 #pragma unroll
-    for (int u = 0; u < NT; ++u) {
-      const int ri = u * 16 + c15;
-      if (ri < rows_valid) {
-        const int64_t col = (int64_t)h * hd + cb * 16 + 4 * g;
-        store_o4(a.dq + (row0 + ri) * a.lddq + col, odq[u]);
-        store_o4(a.dk + (row0 + ri) * a.lddk + col, odk[u]);
-        store_o4(a.dv + (row0 + ri) * a.lddv + col, odv[u]);
+    for (int kt = 0; kt < NT; ++kt) {
+      float v4[4], pd[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v4[r] = p[kt][r] * (dp[kt][r] - dot[r]) * a.scale;
+        pd[r] = pm[kt][r];
+      }
+      dsb[qt][kt] = pack4(v4);
+      ppb[qt][kt] = pack4(pd);
+    }
+  }
+  // the three [hc x 16] products per head-dimension chunk, 16 channels per step, waves split the chunk
+  for (int c = 0; c < nch; ++c) {
+    if (nch > 1) {
+      Ds = T2;
+      __syncthreads();                 // phase 1 / the previous chunk has been consumed by every wave
+      load_tile(a.q + (int64_t)h * hd + c * hc, a.ldq, row0, rows_valid, R, hc, Qs);
+      load_tile(a.k + (int64_t)h * hd + c * hc, a.ldk, row0, rows_valid, R, hc, Ks);
+      load_tile(a.dout + (int64_t)h * hd + c * hc, a.lddo, row0, rows_valid, R, hc, Ds);
+      __syncthreads();
+    }
+    for (int cb = wave; cb < hc / 16; cb += 4) {
+      f32x4 odq[NT], odk[NT], odv[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { odq[t] = f32x4{0.f, 0.f, 0.f, 0.f}; odk[t] = odq[t]; odv[t] = odq[t]; }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {          // reduction tile (keys for dQ, queries for dK / dV)
+        const bf16x4 kT = tr_frag(Ks, t * 16, cb, lane, rb);
+        const bf16x4 qT = tr_frag(Qs, t * 16, cb, lane, rb);
+        const bf16x4 dT = tr_frag(Ds, t * 16, cb, lane, rb);
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {        // output tile
+          odq[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kT, dsa[t][u], odq[u], 0, 0, 0);  // dQ^T[c][query u]
+          odk[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qT, dsb[t][u], odk[u], 0, 0, 0);  // dK^T[c][key u]
+          odv[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dT, ppb[t][u], odv[u], 0, 0, 0);  // dV^T[c][key u]
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const int ri = u * 16 + c15;
+        if (ri < rows_valid) {
+          const int64_t col = (int64_t)h * hd + c * hc + cb * 16 + 4 * g;
+          store_o4(a.dq + (row0 + ri) * a.lddq + col, odq[u]);
+          store_o4(a.dk + (row0 + ri) * a.lddk + col, odk[u]);
+          store_o4(a.dv + (row0 + ri) * a.lddv + col, odv[u]);
+        }
       }
     }
   }
@@ -368,22 +401,31 @@ int afft_attention_mfma(bool backward, const void* dout, int64_t lddo, const voi
                         int64_t ldk, const void* v, int64_t ldv, float* probs, int nseq, int L, int H, int hd,
                         float scale, int mask, float drop_p, unsigned drop_key, void* out, int64_t ldo, void* dq,
                         int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, hipStream_t stream) {
-  if (L > 32 || hd % 64 != 0 || hd > 1024) return -1;
+  if (L > 64 || hd % 64 != 0 || hd > 1024) return -1;
   if (ldq % 8 || ldk % 8 || ldv % 8 || !al16(q) || !al16(k) || !al16(v)) return -1;
   if (!backward && (ldo % 4 || (((uintptr_t)out) & 7))) return -1;
   if (backward && (lddo % 8 || !al16(dout) || lddq % 4 || lddk % 4 || lddv % 4 || (((uintptr_t)dq) & 7) ||
                    (((uintptr_t)dk) & 7) || (((uintptr_t)dv) & 7) || !probs)) return -1;
-  const int NT = L > 16 ? 2 : 1;
-  const size_t lds = (size_t)(backward ? 4 : 3) * 16 * NT * hd * 2;
-  if (lds > 160 * 1024) return -1;
+  const int NT = L > 32 ? 4 : L > 16 ? 2 : 1;
+  // the whole head dimension in LDS when it fits (3 tiles forward, 4 backward); else chunks of the head dimension,
+  // the scores / dP accumulate over the chunks and the operand tiles are re-staged (2 tiles forward, 3 backward)
+  int hc = hd;
+  size_t lds = (size_t)(backward ? 4 : 3) * 16 * NT * hd * 2;
+  if (lds > 160 * 1024) {
+    hc = 0;
+    for (int cand = hd / 2; cand >= 64; cand /= 2)
+      if (hd % cand == 0 && cand % 64 == 0 && (size_t)(backward ? 3 : 2) * 16 * NT * cand * 2 <= 160 * 1024) { hc = cand; break; }
+    if (!hc) return -1;
+    lds = (size_t)(backward ? 3 : 2) * 16 * NT * hc * 2;
+  }
   AttnArgs a;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.dout = (const bf16_t*)dout;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo;
   a.out = (bf16_t*)out; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
   a.ldo = ldo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.probs = probs;
-  a.nseq = nseq; a.L = L; a.H = H; a.hd = hd; a.G = (16 * NT) / L;
-  a.scale = scale; a.mask = mask;
+  a.nseq = nseq; a.L = L; a.H = H; a.hd = hd; a.G = (16 * NT) / L; a.hc = hc;
+  a.scale = scale; a.mask = mask & 0xff; a.period = mask >> 8;   // block-causal period rides in the upper bits
   afft_dropout_t dd = {drop_p, drop_key, 0.f, 0u, 1};
   const DropParams dp = make_drop(&dd);
   a.dthresh = dp.thresh; a.dkey = dp.key; a.dinv = dp.inv_keep;
@@ -399,8 +441,15 @@ int afft_attention_mfma(bool backward, const void* dout, int64_t lddo, const voi
     }                                                                                                       \
     hipLaunchKernelGGL(KERN, grid, block, lds, stream, a);                                                  \
   } while (0)
-  if (!backward) { if (NT == 1) AFFT_ATTN_LAUNCH(attn_fwd_mfma_kernel<1>); else AFFT_ATTN_LAUNCH(attn_fwd_mfma_kernel<2>); }
-  else { if (NT == 1) AFFT_ATTN_LAUNCH(attn_bwd_mfma_kernel<1>); else AFFT_ATTN_LAUNCH(attn_bwd_mfma_kernel<2>); }
+  if (!backward) {
+    if (NT == 1) AFFT_ATTN_LAUNCH(attn_fwd_mfma_kernel<1>);
+    else if (NT == 2) AFFT_ATTN_LAUNCH(attn_fwd_mfma_kernel<2>);
+    else AFFT_ATTN_LAUNCH(attn_fwd_mfma_kernel<4>);
+  } else {
+    if (NT == 1) AFFT_ATTN_LAUNCH(attn_bwd_mfma_kernel<1>);
+    else if (NT == 2) AFFT_ATTN_LAUNCH(attn_bwd_mfma_kernel<2>);
+    else AFFT_ATTN_LAUNCH(attn_bwd_mfma_kernel<4>);
+  }
 #undef AFFT_ATTN_LAUNCH
   AFFT_LAUNCH_CHECK();
   return 0;

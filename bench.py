@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="cfg2", help="cfg2 (default) | ek100 | cfg1 | cfg4 | cfg5")
+    ap.add_argument("--config", default="cfg2", help="cfg2 (default) | ek100 | cfg1 | cfg4 | cfg5 | cfg2_cm | cfg2_tsa")
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--comm-dtype", default="bf16", choices=["bf16", "fp32"], help="gradient all-reduce payload")
@@ -62,7 +62,8 @@ def build_model(name, device, drop=0.1):
     from afft_amd.models.base_model import BaseModel
     c = BASELINE_CONFIGS[name]
     torch.manual_seed(42)   # conf/config.yaml:4
-    cfg = make_model_cfg(c["modal_dims"], c["common_dim"], c["fp_inter_dim"], fuser=c["fuser"], T=c["T"], drop=drop)
+    cfg = make_model_cfg(c["modal_dims"], c["common_dim"], c["fp_inter_dim"], fuser=c["fuser"], T=c["T"], drop=drop,
+                         modal_encoding=(c["fuser"] == "tsa"))
     model = BaseModel(cfg, num_classes={"action": 3806}, class_mappings={})
     return model.to(device), c
 

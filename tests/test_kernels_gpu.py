@@ -211,7 +211,11 @@ ATTN_CASES = [(7, 5, 4, 16, 0, "f32"), (6, 5, 4, 64, 1, "f32"), (3, 16, 2, 64, 2
               # T-SA-Fuser sequences: L = M*T > 32 tokens, mask 3 = the causal T x T mask tiled over the modalities
               # (period T = L / 4 here); plain / causal long sequences too
               (2, 40, 2, 32, 3, "f32"), (3, 64, 4, 64, 3, "bf16"), (2, 80, 2, 64, 2, "f32"), (1, 128, 2, 32, 0, "bf16"),
-              (2, 20, 2, 64, 3, "bf16"), (1, 96, 1, 16, 3, "f32")]
+              (2, 20, 2, 64, 3, "bf16"), (1, 96, 1, 16, 3, "f32"),
+              # MFMA path with 4 row tiles (L <= 64) and the head dimension staged in chunks (hd = 512: 2 x 256 forward and
+              # backward; hd = 1024: 4 x 256), block-causal and causal; L = 40 (ragged last tile)
+              (3, 64, 2, 512, 3, "bf16"), (2, 64, 1, 1024, 2, "bf16"), (5, 40, 2, 256, 3, "bf16"), (2, 48, 4, 128, 0, "bf16"),
+              (3, 32, 2, 1024, 2, "bf16")]
 
 
 @pytest.mark.parametrize("nseq,L,H,hd,mask,dt", ATTN_CASES)
