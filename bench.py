@@ -221,7 +221,15 @@ def main():
         "final_loss": round(loss_val, 4),
     }
 
-    if rank == 0 and world == 1:
+    # the instrumented step for the roofline object runs on EVERY rank (its gradient all-reduce is a collective);
+    # only rank 0 keeps the timings
+    summ = None
+    if not args.no_roofline:
+        with GemmTimer() as gt:
+            trainer.step(feats, tgt, sub, optimize=False)
+        summ = gt.summary()
+
+    if rank == 0:
         # forward latency, eval mode (BASELINE.json: "fwd p50 ms")
         model.eval()
         lat = []
@@ -238,10 +246,7 @@ def main():
         result["fwd_p50_ms"] = round(lat[len(lat) // 2], 3)
         model.train(not args.eval_drop)
 
-        if not args.no_roofline:
-            with GemmTimer() as gt:
-                trainer.step(feats, tgt, sub, optimize=False)
-            summ = gt.summary()
+        if summ is not None:
             # dominant kernel symbol = largest total duration in this instrumented step; the rocprofv3 --stats summary
             # of the same command (profiles/) ranks the symbols the same way.  Weight-gradient (TN) and nn.Linear
             # dgrad (NN) launches share the chip with each other (two streams), so their per-launch durations are
@@ -271,7 +276,7 @@ def main():
                                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else None}
                               for k, v in summ.items()},
             }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             try:
                 result["cpu_baseline"] = cpu_baseline(args.config, args.cpu_batch)
             except Exception as ex:  # noqa: BLE001
