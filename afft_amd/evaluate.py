@@ -1,0 +1,100 @@
+"""Inference / evaluation side of the path: the forward-only loops of the reference's ``test.py``
+(``evaluate`` :66-102, ``save_logits`` :33-63) without its per-batch host round trips.
+
+The reference copies every batch of logits to the host (``.detach().cpu().numpy()``, a device sync per batch),
+concatenates there and marginalises verbs / nouns in numpy.  Here the logits of the branch the reference keeps (the only
+modality, or 'all-fused') stay on the device, are concatenated once, marginalised by ``afft_amd.challenge.
+marginalize_scores`` (row softmax + two fp32 MFMA GEMMs) and leave the device in ONE copy per result.  The accuracy
+bookkeeping over the dataset's annotations (``challenge.compute_accuracies_epic``) stays with the caller.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from typing import Dict, Iterable, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .challenge import marginalize_scores
+
+LOGITS_KEY = 'logits/action'
+
+
+def _eval_kwargs():
+    return dict(mixup_fn=None, target=None, target_subclips=None, target_subclips_ignore_index=None)
+
+
+def _branch(outputs) -> Tuple[str, torch.Tensor]:
+    """the entry test.py keeps: the single modality / early-fusion branch, else 'all-fused' (test.py:48-58)"""
+    heads = outputs[LOGITS_KEY]
+    if len(heads) == 1:
+        modk = next(iter(heads.keys()))
+    else:
+        modk = 'all-fused'
+        logging.info('This model consists of multiple branches. Saving fusion branch "%s" only ...', modk)
+    return f'{LOGITS_KEY}_{modk}', heads[modk][:, 0, :]
+
+
+@torch.no_grad()
+def collect_logits(model, data_loader: Iterable, device) -> Tuple[str, torch.Tensor]:
+    """(key, fp32 [N, classes] ON THE DEVICE) over the whole loader; batches are ``(data, timings)`` pairs with
+    ``data['data_dict']`` as the reference's loader yields them."""
+    model.eval()
+    key, parts = None, []
+    for data in data_loader:
+        data, _ = data
+        feats = {mod: t.to(device, non_blocking=True) for mod, t in data["data_dict"].items()}
+        outputs, _ = model(feats, **_eval_kwargs())
+        key, lg = _branch(outputs)
+        parts.append(lg.detach())
+    assert parts, "empty data loader"
+    return key, torch.cat(parts, dim=0)
+
+
+@torch.no_grad()
+def evaluate_scores(model, class_mappings, data_loader: Iterable, device, to_prob: bool = True) -> Dict[str, np.ndarray]:
+    """verb / noun / action score matrices of test.py:evaluate -> challenge.marginalize_verb_noun (:196-210), computed on
+    the device; returns numpy arrays (one device-to-host copy each)."""
+    _, logits = collect_logits(model, data_loader, device)
+    verb, noun, action = marginalize_scores(logits, class_mappings, to_prob=to_prob)
+    return {"verb": verb.cpu().numpy(), "noun": noun.cpu().numpy(), "action": action.cpu().numpy()}
+
+
+def store_append(endpoints: Dict[str, np.ndarray], output_dir: str, save_file_name: str) -> str:
+    """test.py:20-31 (append-able, gzip-9, chunked h5 datasets keyed like 'logits/action_<modk>') when h5py is available;
+    otherwise the same keys in an .npz that is re-written with the rows appended."""
+    os.makedirs(output_dir, exist_ok=True)
+    path = os.path.join(output_dir, save_file_name)
+    try:
+        import h5py  # noqa: PLC0415
+    except ImportError:
+        h5py = None
+    if h5py is not None:
+        with h5py.File(path, 'a') as fout:
+            for key, val in endpoints.items():
+                if key not in fout:
+                    fout.create_dataset(key, data=val, compression='gzip', compression_opts=9, chunks=True,
+                                        maxshape=(None,) + val.shape[1:])
+                else:
+                    fout[key].resize((fout[key].shape[0] + val.shape[0],) + val.shape[1:])
+                    fout[key][-val.shape[0]:, ...] = val
+        return path
+    path = path if path.endswith(".npz") else path + ".npz"
+    old = dict(np.load(path)) if os.path.exists(path) else {}
+    for key, val in endpoints.items():
+        k = key.replace('/', '__')          # npz member names cannot hold '/'
+        old[k] = np.concatenate([old[k], val], axis=0) if k in old else val
+    np.savez_compressed(path, **old)
+    return path
+
+
+@torch.no_grad()
+def save_logits(model, data_loader: Iterable, device, logger=None, save_dir: Optional[str] = None,
+                save_file_name: Optional[str] = None) -> str:
+    """test.py:33-63: logits of the kept branch for ensembling / analysis; one host copy for the whole loader."""
+    key, logits = collect_logits(model, data_loader, device)
+    path = store_append({key: logits.cpu().numpy()}, save_dir, save_file_name)
+    if logger is not None:
+        logger.info(f'Saved logits {[key]} as {save_file_name} to {save_dir}.')
+    return path

@@ -318,6 +318,43 @@ def test_runner_async_metrics_equal_synchronous():
         assert abs(v - m_s[k]) < 1e-6 * max(1.0, abs(m_s[k])), k
 
 
+def test_evaluate_loop_scores_and_logit_store(tmp_path):
+    """test.py's evaluate / save_logits without per-batch host copies: the collected logits equal the per-batch model
+    outputs, the verb / noun scores equal softmax @ mapping, the stored file appends across calls."""
+    import numpy as np
+    from afft_amd import evaluate as E
+    c, state, data, tgt, sub = case_tensors("t0_sa")
+    model = build(c, "fp32")
+    model.load_state_dict(state)
+    model = model.cuda().eval()
+    dev = torch.device("cuda:0")
+    K = c["num_classes"]
+    loader = [({"data_dict": {m: d[i:i + 2] for m, d in data.items()}}, {}) for i in range(0, c["B"], 2)]   # ragged last batch
+    key, logits = E.collect_logits(model, loader, dev)
+    assert key == "logits/action_all-fused" and logits.shape == (c["B"], K) and logits.is_cuda
+    with torch.no_grad():
+        ref, _ = model({m: d.to(dev) for m, d in data.items()}, mixup_fn=None, target=None, target_subclips=None,
+                       target_subclips_ignore_index=None)
+    assert rel_l2(logits, ref["logits/action"]["all-fused"][:, 0, :]) < 1e-5
+    g = torch.Generator().manual_seed(3)
+    maps = {("verb", "action"): (torch.rand(K, 4, generator=g) < 0.3).float(),
+            ("noun", "action"): (torch.rand(K, 5, generator=g) < 0.3).float()}
+    sc = E.evaluate_scores(model, maps, loader, dev)
+    p = logits.double().softmax(-1).cpu()
+    assert rel_l2(torch.from_numpy(sc["verb"]), (p @ maps[("verb", "action")].double()).float()) < 2e-5
+    assert rel_l2(torch.from_numpy(sc["noun"]), (p @ maps[("noun", "action")].double()).float()) < 2e-5
+    assert np.array_equal(sc["action"], logits.cpu().numpy())
+    path = E.save_logits(model, loader, dev, save_dir=str(tmp_path), save_file_name="run1")
+    path = E.save_logits(model, loader, dev, save_dir=str(tmp_path), save_file_name="run1")    # appends
+    if path.endswith(".npz"):
+        z = np.load(path)
+        arr = z["logits__action_all-fused"]
+    else:
+        import h5py
+        arr = h5py.File(path, "r")["logits/action_all-fused"][...]
+    assert arr.shape == (2 * c["B"], K) and np.allclose(arr[:c["B"]], arr[c["B"]:])
+
+
 def test_trainer_gradient_clipping_matches_torch():
     """opt.grad_clip (train.py:254-260): global-norm clipping with the coefficient kept on the device equals
     torch.nn.utils.clip_grad_norm_ followed by torch's Nesterov SGD."""
