@@ -17,7 +17,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 constexpr int BK = 64;
-constexpr int GROUP_M = 8;
+#ifndef AFFT_GROUP_M
+#define AFFT_GROUP_M 8
+#endif
+constexpr int GROUP_M = AFFT_GROUP_M;
 
 struct GemmFast {
   const bf16_t* A; int64_t lda;  // k-contiguous: A[M][K] ; k-strided: A[K][M]
