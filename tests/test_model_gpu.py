@@ -318,6 +318,65 @@ def test_runner_async_metrics_equal_synchronous():
         assert abs(v - m_s[k]) < 1e-6 * max(1.0, abs(m_s[k])), k
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_full_width_cfg2_matches_oracle(precision):
+    """Parity at BASELINE cfg2's full widths (4 modalities x T=16 x d=D=2048, head dim 512, 6+6 layers, 3806 classes, 614 M
+    parameters; B=2 clips so that the CPU oracle finishes in seconds): outputs, the three losses and gradients of weights in
+    the first fuser block, a middle GPT-2 block and the classifier against the oracle on the same random weights."""
+    import afft_amd
+    from afft_amd import runtime as rt
+    from afft_amd.common.runner import BasicLossAccuracy, Runner
+    from afft_amd.config import BASELINE_CONFIGS, make_model_cfg
+    from afft_amd.models.base_model import BaseModel
+    from oracle import afft_oracle as O
+    c = BASELINE_CONFIGS["cfg2"]
+    B, T, K = 2, c["T"], 3806
+    afft_amd.set_precision(precision)
+    rt.set_grad_mode("sink")
+    torch.manual_seed(1)
+    cfg = make_model_cfg(c["modal_dims"], c["common_dim"], c["fp_inter_dim"], fuser="sa", T=T, drop=0.0)
+    model = BaseModel(cfg, {"action": K}, {}).eval()
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(2)
+    data = {m: torch.randn(B, T, C, 1, 1, 1, generator=g) for m, C in c["modal_dims"].items()}
+    tgt = torch.randint(0, K, (B,), generator=g)
+    sub = torch.randint(0, K, (B, T, 1), generator=g)
+    sub[0, :5] = -1
+    dev = torch.device("cuda:0")
+    model = model.to(dev)
+    rt.SINK.begin_step()
+    out, out_t = model({m: d.to(dev) for m, d in data.items()}, mixup_fn=None, target={"action": tgt.to(dev)},
+                       target_subclips={"action": sub.to(dev)}, target_subclips_ignore_index=None)
+    losses, _ = BasicLossAccuracy(False)(out, out_t["target"], out_t["target_subclips"])
+    total, _ = Runner._reduce_loss(losses, {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}, sync=False)
+    total.backward()
+    rt.SINK.finish_step(list(model.parameters()))
+    torch.cuda.synchronize()
+    gkeys = ["future_predictor.fuser.blocks.0.attn.qkv.weight", "future_predictor.fuser.blocks.5.mlp.mlp.2.weight",
+             "future_predictor.future_predictor.gpt_model.h.3.mlp.c_fc.weight",
+             "future_predictor.classifiers.action.all-fused.1.weight", "future_predictor.fuser.modal_token"]
+    P = {k: (v.clone().requires_grad_(True) if k in gkeys else v) for k, v in state.items()}
+    ocfg = dict(fuser="sa", depth=6, num_heads=4, fp_layers=6, fp_heads=4, fp_output_len=1, num_classes={"action": K})
+    oout = O.base_model_forward(P, data, ocfg)
+    ototal, olosses = O.loss(oout, tgt, sub)
+    ototal.backward()
+    tol = TOL[precision]
+    for key in ("logits/action", "past_logits/action", "past_futures", "orig_past", "future"):
+        e = rel_l2(out[key]["all-fused"].float().cpu(), oout[key]["all-fused"])
+        assert e < tol, (key, e)
+    assert abs(float(total) - float(ototal)) < tol * max(1.0, abs(float(ototal)))
+    for k, v in olosses.items():
+        assert abs(float(losses[k].mean()) - float(v)) < tol * max(1.0, abs(float(v))), k
+    params = dict(model.named_parameters())
+    gtol = tol if precision == "fp32" else 8e-2
+    for k in gkeys:
+        e = rel_l2(params[k].grad.cpu(), P[k].grad)
+        assert e < gtol, (k, e)
+    del model, P, state
+    torch.cuda.empty_cache()
+    afft_amd.set_precision("bf16")
+
+
 def test_evaluate_loop_scores_and_logit_store(tmp_path):
     """test.py's evaluate / save_logits without per-batch host copies: the collected logits equal the per-batch model
     outputs, the verb / noun scores equal softmax @ mapping, the stored file appends across calls."""
