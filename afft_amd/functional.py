@@ -91,11 +91,14 @@ def _lin_dgrad(dy: Act, W: Tensor, conv1d: bool, out: Tensor, **ep) -> Tensor:
     return ops.gemm(dy.live, W, out, b_t=conv1d, **ep)
 
 
+_SIDE_STREAM = None      # the auxiliary stream while a `with _Side(dev):` block is open (set / cleared by _Side)
+
+
 def _on_side(t: Tensor) -> Tensor:
     """The tensor is about to be read by a kernel on the auxiliary stream: tell the caching allocator, so that its
     memory is not handed out again (to main-stream allocations) before that kernel has run."""
-    if t.is_cuda and rt.overlap_wgrad() and torch.cuda.current_stream() != torch.cuda.default_stream():
-        t.record_stream(torch.cuda.current_stream())
+    if _SIDE_STREAM is not None and t.is_cuda:
+        t.record_stream(_SIDE_STREAM)
     return t
 
 
@@ -149,10 +152,14 @@ class _Side:
             st.wait_event(ev)
             self.ctx = torch.cuda.stream(st)
             self.ctx.__enter__()
+            global _SIDE_STREAM
+            _SIDE_STREAM = st
         return self
 
     def __exit__(self, *exc):
         if self.on:
+            global _SIDE_STREAM
+            _SIDE_STREAM = None
             self.ctx.__exit__(*exc)
         return False
 
