@@ -17,10 +17,14 @@ for _ in range(3):
     tr.step(feats, tgt, sub)
 torch.cuda.synchronize()
 pr = cProfile.Profile()
-pr.enable()
-for _ in range(5):
-    tr.step(feats, tgt, sub)
-pr.disable()
+with torch.autograd.set_multithreading_enabled(False):     # backward in this thread, so that the profiler sees it
+    for _ in range(2):
+        tr.step(feats, tgt, sub)
+    torch.cuda.synchronize()
+    pr.enable()
+    for _ in range(5):
+        tr.step(feats, tgt, sub)
+    pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(22)
+st.sort_stats("tottime").print_stats(32)
