@@ -66,6 +66,8 @@ _SIGS = {
     "afft_sgd_nesterov": ([vp, vp, i32, vp, vp, i64, f32, f32, f32, f32, vp, i32, vp], C.c_int),
     "afft_sumsq": ([vp, i32, i64, f32, vp, vp], C.c_int),
     "afft_group_sum": ([vp, i32, i32, i64, f32, vp, vp], C.c_int),
+    "afft_set_dropout_salt": ([vp], C.c_int),
+    "afft_dropout_salt_step": ([vp, vp], C.c_int),
     "afft_mixup_plan": ([vp, i32, i32, i64, vp, vp, vp], C.c_int),
     "afft_mixup_rows": ([vp, i32, i64, vp, f32, vp, vp], C.c_int),
     "afft_mixup_labels": ([vp, i32, i32, i32, f32, i64, vp, f32, vp, vp], C.c_int),

@@ -21,8 +21,9 @@ template <typename T, int LM>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, int64_t ldq, const T* __restrict__ k,
                                                        int64_t ldk, const T* __restrict__ v, int64_t ldv, int L, int H,
                                                        int hd, float scale, int mask, int period, unsigned dthresh,
-                                                       unsigned dkey, float dinv, T* __restrict__ out, int64_t ldo,
-                                                       float* __restrict__ probs) {
+                                                       unsigned dkey, float dinv, const unsigned* __restrict__ salt,
+                                                       T* __restrict__ out, int64_t ldo, float* __restrict__ probs) {
+  if (salt) dkey ^= *salt;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float (*sc)[LM + 1] = reinterpret_cast<float (*)[LM + 1]>(smem_raw);
   const int seq = blockIdx.x / H, h = blockIdx.x % H;
@@ -100,8 +101,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ dou
                                                        const T* __restrict__ v, int64_t ldv,
                                                        const float* __restrict__ probs, int L, int H, int hd, float scale,
                                                        unsigned dthresh, unsigned dkey, float dinv,
+                                                       const unsigned* __restrict__ salt,
                                                        T* __restrict__ dq, int64_t lddq, T* __restrict__ dk, int64_t lddk,
                                                        T* __restrict__ dv, int64_t lddv) {
+  if (salt) dkey ^= *salt;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float (*pp)[LM + 1] = reinterpret_cast<float (*)[LM + 1]>(smem_raw);                  // probabilities (pre-dropout), later the dropped-out P' used by dV
   float (*ds)[LM + 1] = reinterpret_cast<float (*)[LM + 1]>(smem_raw) + LM;             // dP, then dS*scale
@@ -209,7 +212,7 @@ int launch_fwd(dim3 grid, hipStream_t stream, const void* q, int64_t ldq, const 
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv, L, H, hd, scale,
-                     mask, period, dp.thresh, dp.key, dp.inv_keep, (T*)out, ldo, probs);
+                     mask, period, dp.thresh, dp.key, dp.inv_keep, dp.salt, (T*)out, ldo, probs);
   return 0;
 }
 template <typename T, int LM>
@@ -228,7 +231,7 @@ int launch_bwd(dim3 grid, hipStream_t stream, const void* dout, int64_t lddo, co
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)dout, lddo, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
-                     probs, L, H, hd, scale, dp.thresh, dp.key, dp.inv_keep, (T*)dq, lddq, (T*)dk, lddk, (T*)dv, lddv);
+                     probs, L, H, hd, scale, dp.thresh, dp.key, dp.inv_keep, dp.salt, (T*)dq, lddq, (T*)dk, lddk, (T*)dv, lddv);
   return 0;
 }
 

@@ -35,6 +35,7 @@ struct AttnArgs {
   int mask, period;
   unsigned dthresh, dkey;
   float dinv;
+  const unsigned* salt;   // device word XOR-ed into dkey (afft_set_dropout_salt) or NULL
 };
 
 __device__ __forceinline__ bool pair_valid(int mask, int period, int L, int rows_valid, int qi, int kj) {
@@ -94,6 +95,7 @@ __device__ __forceinline__ void store_o4(bf16_t* dst, const f32x4& a) {
 template <int NT>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned dkey = a.dkey ^ (a.salt ? *a.salt : 0u);
   constexpr int R = 16 * NT;
   const int hd = a.hd, hc = a.hc, L = a.L, H = a.H;
   const int rb = hc * 2;               // bytes per LDS row: one head-dimension chunk
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
           const int j = kj - sq * L;
           const int64_t pidx = ((((int64_t)(seq0 + sq)) * H + h) * L + i) * L + j;
           if (wave == 0 && a.probs) a.probs[pidx] = p;
-          if (a.dthresh) pv[r] = drop_keep(a.dkey, (unsigned)pidx, a.dthresh) ? p * a.dinv : 0.f;
+          if (a.dthresh) pv[r] = drop_keep(dkey, (unsigned)pidx, a.dthresh) ? p * a.dinv : 0.f;
         }
       }
       pb[kt][qt] = pack4(pv);
@@ -225,6 +227,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
 template <int NT>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned dkey = a.dkey ^ (a.salt ? *a.salt : 0u);
   constexpr int R = 16 * NT;
   const int hd = a.hd, hc = a.hc, L = a.L, H = a.H;
   const int rb = hc * 2;
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const AttnArgs a) {
         if (pair_valid(a.mask, a.period, L, rows_valid, qi, kj)) {
           const int64_t pidx = ((((int64_t)(seq0 + sq)) * H + h) * L + i) * L + (kj - sq * L);
           pv = a.probs[pidx];
-          m = (a.dthresh && !drop_keep(a.dkey, (unsigned)pidx, a.dthresh)) ? 0.f : a.dinv;
+          m = (a.dthresh && !drop_keep(dkey, (unsigned)pidx, a.dthresh)) ? 0.f : a.dinv;
         }
         p[kt][r] = pv;
         dp[kt][r] = dpa[kt][qt][r] * m;
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const AttnArgs a) {
         if (pair_valid(a.mask, a.period, L, rows_valid, qi, kj)) {
           const int64_t pidx = ((((int64_t)(seq0 + sq)) * H + h) * L + i) * L + (kj - sq * L);
           pv = a.probs[pidx];
-          m = (a.dthresh && !drop_keep(a.dkey, (unsigned)pidx, a.dthresh)) ? 0.f : a.dinv;
+          m = (a.dthresh && !drop_keep(dkey, (unsigned)pidx, a.dthresh)) ? 0.f : a.dinv;
         }
         p[kt][r] = pv;
         pm[kt][r] = pv * m;                   // dropped-out probability P' (for dV)
@@ -428,7 +431,7 @@ int afft_attention_mfma(bool backward, const void* dout, int64_t lddo, const voi
   a.scale = scale; a.mask = mask & 0xff; a.period = mask >> 8;   // block-causal period rides in the upper bits
   afft_dropout_t dd = {drop_p, drop_key, 0.f, 0u, 1};
   const DropParams dp = make_drop(&dd);
-  a.dthresh = dp.thresh; a.dkey = dp.key; a.dinv = dp.inv_keep;
+  a.dthresh = dp.thresh; a.dkey = dp.key; a.dinv = dp.inv_keep; a.salt = dp.salt;
   const int groups = (nseq + a.G - 1) / a.G;
   const dim3 grid(groups * H), block(256);
 #define AFFT_ATTN_LAUNCH(KERN)                                                                              \

@@ -85,10 +85,15 @@ struct DropParams {
   unsigned path_key;
   float path_inv_keep;
   int path_group;       // rows per sample (frame / clip)
+  const unsigned* salt; // device word XOR-ed into the keys at kernel start (afft_set_dropout_salt), or NULL
 };
+// Process-wide device pointer to a 32-bit "salt" (afft_set_dropout_salt): a captured hipGraph replays the same kernel
+// arguments every step, so what changes the masks from step to step has to live in device memory.
+extern const unsigned* g_afft_drop_salt;
 inline DropParams make_drop(const afft_dropout_t* d) {
-  DropParams o = {0u, 0u, 1.0f, 0u, 0u, 1.0f, 1};
+  DropParams o = {0u, 0u, 1.0f, 0u, 0u, 1.0f, 1, nullptr};
   if (!d) return o;
+  if (d->p > 0.f || d->path_p > 0.f) o.salt = g_afft_drop_salt;
   if (d->p > 0.f) {
     double t = (double)d->p * 4294967296.0;
     o.thresh = t >= 4294967295.0 ? 0xffffffffu : (unsigned)t;
@@ -103,6 +108,15 @@ inline DropParams make_drop(const afft_dropout_t* d) {
     o.path_group = d->path_group > 0 ? d->path_group : 1;
   }
   return o;
+}
+// call once at kernel start: folds the device salt into the keys
+__device__ __forceinline__ DropParams with_salt(DropParams d) {
+  if (d.salt) {
+    const unsigned s = *d.salt;
+    d.key ^= s;
+    d.path_key ^= mix32(s ^ 0x5bd1e995u);
+  }
+  return d;
 }
 __device__ __forceinline__ float drop_row_scale(const DropParams& d, int m) {
   if (!d.path_thresh) return 1.0f;
@@ -184,11 +198,12 @@ __device__ __forceinline__ float apply_act(int act, float v, float aux) {
 }
 
 // v[0..3] = accumulators for C[m, n..n+3]
-__device__ __forceinline__ void epilogue4(const EpiParams& e, int m, int n, float (&v)[4]) {
+// dp = with_salt(e.drop), computed once per thread by the caller
+__device__ __forceinline__ void epilogue4(const EpiParams& e, const DropParams& dp, int m, int n, float (&v)[4]) {
   if (m >= e.M || n >= e.N) return;
   const bool full = e.vec4 && (n + 3 < e.N);
-  const float rs = (e.rowscale ? e.rowscale[m] : 1.0f) * drop_row_scale(e.drop, m);
-  const bool scaled = e.rowscale || e.drop.path_thresh;
+  const float rs = (e.rowscale ? e.rowscale[m] : 1.0f) * drop_row_scale(dp, m);
+  const bool scaled = e.rowscale || dp.path_thresh;
   if (full) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] *= e.alpha;
@@ -203,9 +218,9 @@ __device__ __forceinline__ void epilogue4(const EpiParams& e, int m, int n, floa
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = apply_act(e.act, v[r], a[r]);
     }
-    if (e.drop.thresh) {
+    if (dp.thresh) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] *= drop_elem_scale(e.drop, (unsigned)m * (unsigned)e.N + (unsigned)(n + r));
+      for (int r = 0; r < 4; ++r) v[r] *= drop_elem_scale(dp, (unsigned)m * (unsigned)e.N + (unsigned)(n + r));
     }
     if (scaled) {
 #pragma unroll
@@ -232,7 +247,7 @@ __device__ __forceinline__ void epilogue4(const EpiParams& e, int m, int n, floa
       float a = 0.f;
       if (act_needs_aux(e.act)) a = ld_any(e.aux, (int64_t)m * e.ldaux + nn, e.aux_dtype);
       x = apply_act(e.act, x, a);
-      x *= drop_elem_scale(e.drop, (unsigned)m * (unsigned)e.N + (unsigned)nn);
+      x *= drop_elem_scale(dp, (unsigned)m * (unsigned)e.N + (unsigned)nn);
       x *= rs;
       if (e.residual) x += e.residual[(int64_t)m * e.ldres + nn];
       if (e.accumulate) x += ((const float*)e.out)[(int64_t)m * e.ldo + nn];
@@ -271,16 +286,16 @@ __device__ __forceinline__ void load8(const void* base, int64_t idx, int dtype, 
 }
 
 // v[0..7] = accumulators for C[m, n..n+7], n % 8 == 0
-__device__ __forceinline__ void epilogue8(const EpiParams& e, int m, int n, float (&v)[8]) {
+__device__ __forceinline__ void epilogue8(const EpiParams& e, const DropParams& dp, int m, int n, float (&v)[8]) {
   if (m >= e.M || n >= e.N) return;
   if (!(e.vec8 && n + 7 < e.N)) {
     float lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
-    epilogue4(e, m, n, lo);
-    epilogue4(e, m, n + 4, hi);
+    epilogue4(e, dp, m, n, lo);
+    epilogue4(e, dp, m, n + 4, hi);
     return;
   }
-  const float rs = (e.rowscale ? e.rowscale[m] : 1.0f) * drop_row_scale(e.drop, m);
-  const bool scaled = e.rowscale || e.drop.path_thresh;
+  const float rs = (e.rowscale ? e.rowscale[m] : 1.0f) * drop_row_scale(dp, m);
+  const bool scaled = e.rowscale || dp.path_thresh;
 #pragma unroll
   for (int r = 0; r < 8; ++r) v[r] *= e.alpha;
   if (e.bias) {
@@ -296,9 +311,9 @@ __device__ __forceinline__ void epilogue8(const EpiParams& e, int m, int n, floa
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = apply_act(e.act, v[r], a[r]);
   }
-  if (e.drop.thresh) {
+  if (dp.thresh) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] *= drop_elem_scale(e.drop, (unsigned)m * (unsigned)e.N + (unsigned)(n + r));
+    for (int r = 0; r < 8; ++r) v[r] *= drop_elem_scale(dp, (unsigned)m * (unsigned)e.N + (unsigned)(n + r));
   }
   if (scaled) {
 #pragma unroll

@@ -21,7 +21,8 @@ namespace {
 __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, int64_t lds_, int rows, int cols,
                                                    void* __restrict__ dst, int64_t ldd, int dst_dtype,
                                                    void* __restrict__ dst_t, int64_t ldt, int pad_cols,
-                                                   const DropParams drop) {
+                                                   const DropParams drop_) {
+  const DropParams drop = with_salt(drop_);
   __shared__ float tile[64][65];
   const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -47,7 +48,8 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
 // dst-only copy/cast, 4 elements per thread (cols % 4 == 0, aligned rows), optional dropout replay
 __global__ __launch_bounds__(256) void cast_rows4_kernel(const float* __restrict__ src, int64_t lds_, int rows, int cols,
                                                          void* __restrict__ dst, int64_t ldd, int dst_dtype,
-                                                         const DropParams drop) {
+                                                         const DropParams drop_) {
+  const DropParams drop = with_salt(drop_);
   const int nq = cols >> 2;
   const int64_t total = (int64_t)rows * nq;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -269,6 +271,9 @@ extern "C" int afft_reduce_rows_periodic(const float* src, int64_t lds_, int32_t
   return 0;
 }
 
+// ---- dropout salt (see common.h): set once, advanced by a one-thread kernel at the start of every step
+__global__ void salt_step_kernel(unsigned* salt) { *salt = mix32(*salt + 0x9E3779B9u); }
+
 // ---- MixUp with an ignore class as a GPU prologue (common/mixup.py:119-182), no host round trip
 // plan: sample b takes part iff none of its T past labels is the ignore class; the participants are mixed with the
 // participants in reverse order (x[sel] * lam + x[sel].flip(0) * (1 - lam)); partner[b] = b when b does not take part
@@ -378,6 +383,20 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   for (int c = threadIdx.x; c < C; c += 256) yr[c] = expf(xr[c] - m) * inv;
 }
 
+const unsigned* g_afft_drop_salt = nullptr;
+
+extern "C" int afft_set_dropout_salt(const uint32_t* salt_dev) {
+  g_afft_drop_salt = salt_dev;
+  return 0;
+}
+extern "C" int afft_dropout_salt_step(uint32_t* salt_dev, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(salt_dev, "dropout_salt_step: null pointer");
+  hipLaunchKernelGGL(salt_step_kernel, dim3(1), dim3(1), 0, stream, salt_dev);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int afft_mixup_plan(const int64_t* labels_subclips, int32_t B, int32_t T, int64_t ignore_cls, int32_t* partner,
                                uint8_t* ignore_mask, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -420,8 +439,9 @@ extern "C" int afft_softmax_rows(const float* x, int64_t ldx, int32_t rows, int3
 __global__ __launch_bounds__(256) void act_bwd_kernel(int act, const float* __restrict__ dy, int64_t lddy,
                                                       const void* __restrict__ saved, int64_t lds_, int sdt,
                                                       const float* __restrict__ aux, int64_t ldaux, int rows, int cols,
-                                                      const DropParams drop, void* __restrict__ dpre, int64_t lddp, int pdt,
+                                                      const DropParams drop_, void* __restrict__ dpre, int64_t lddp, int pdt,
                                                       float* __restrict__ daux, int64_t ldda) {
+  const DropParams drop = with_salt(drop_);
   const int64_t n = (int64_t)rows * cols;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);

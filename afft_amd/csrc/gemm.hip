@@ -133,6 +133,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf1
   });
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  const DropParams dp = with_salt(g.e.drop);
   constexpr int LPR = BN / 8;            // lanes per row (8 columns each: 16-byte bf16 stores)
   constexpr int RPI = 64 / LPR;          // rows per wave-iteration
   for (int it = 0; it < BM / NW / RPI; ++it) {
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf1
     const f32x4 t0 = *(const f32x4*)(smem + row * ESTRIDE + c8 * 32);
     const f32x4 t1 = *(const f32x4*)(smem + row * ESTRIDE + c8 * 32 + 16);
     float o[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-    epilogue8(g.e, m0 + row, n0 + 8 * c8, o);
+    epilogue8(g.e, dp, m0 + row, n0 + 8 * c8, o);
   }
 }
 
@@ -195,11 +196,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32 g) {
     __syncthreads();
   }
   const int m = m0 + wr * 32 + (lane & 31);
+  const DropParams dp = with_salt(g.e.drop);
   static_for<0, 4>([&](auto idx) {
     constexpr int gq = decltype(idx)::value;
     const int n = n0 + wc * 32 + 8 * gq + 4 * (lane >> 5);
     float v[4] = {acc[4 * gq + 0], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]};
-    epilogue4(g.e, m, n, v);
+    epilogue4(g.e, dp, m, n, v);
   });
 }
 

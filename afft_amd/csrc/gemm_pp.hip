@@ -229,6 +229,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
   // coalesced global accesses (bias, residual, pre-activation, outputs) in a runtime loop -- no 32-fold unrolled
   // epilogue, no 32-byte store segments.
   constexpr int ESTRIDE = 1040;
+  const DropParams dp = with_salt(g.e.drop);
   if (AFFT_PP_DIAG & 16) return;
   static_for<0, 2>([&](auto ihc) {
     constexpr int ih = decltype(ihc)::value;
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
       const f32x4 t0 = *(const f32x4*)(smem + row * ESTRIDE + c8 * 32);
       const f32x4 t1 = *(const f32x4*)(smem + row * ESTRIDE + c8 * 32 + 16);
       float o[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-      if (!(AFFT_PP_DIAG & 8)) epilogue8(g.e, m0 + ih * 128 + row, n0 + 8 * c8, o);
+      if (!(AFFT_PP_DIAG & 8)) epilogue8(g.e, dp, m0 + ih * 128 + row, n0 + 8 * c8, o);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   });

@@ -72,7 +72,8 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const void* __restrict__ d
                                                       const float* __restrict__ rstd, int rows, int d,
                                                       const float* __restrict__ dx_in, float* __restrict__ dx_out,
                                                       int64_t lddx, bf16_t* __restrict__ dx_bf16,
-                                                      const DropParams drop, int nslab, float* __restrict__ partial) {
+                                                      const DropParams drop_, int nslab, float* __restrict__ partial) {
+  const DropParams drop = with_salt(drop_);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* slab = (float*)smem;                      // [nslab][d]: dw, db (, column sums of the masked copy)
   float* cell = slab + nslab * d;                  // [2 buffers][LNB_RG][LNB_CS][2]

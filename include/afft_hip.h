@@ -187,6 +187,11 @@ int afft_weighted_sum_fwd(const float* const* x, int64_t ldx, const float* w, in
 int afft_weighted_sum_bwd(const float* const* x, int64_t ldx, const float* w, int64_t ldw, const float* dout, int64_t lddo,
                           int32_t n, int32_t rows, int32_t cols, float* const* dx, int64_t lddx, float* dw, int64_t lddw,
                           void* stream);
+/* Dropout salt: a device word that every kernel XORs into its dropout / DropPath keys at kernel start.  A captured
+ * hipGraph replays identical kernel arguments every step; with the salt advanced by afft_dropout_salt_step inside the
+ * graph the masks still differ from step to step.  afft_set_dropout_salt(NULL) (the default) turns it off. */
+int afft_set_dropout_salt(const uint32_t* salt_dev);
+int afft_dropout_salt_step(uint32_t* salt_dev, void* stream);
 /* MixUp with an ignore class as a GPU prologue (common/mixup.py:119-182), no host round trip:
  *   afft_mixup_plan: partner[b] = the sample b is mixed with -- the samples none of whose T past labels is ignore_cls are
  *     paired in reverse order among themselves (x[sel].flip(0)); partner[b] = b for the others and when at most one
