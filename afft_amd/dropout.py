@@ -24,6 +24,37 @@ def manual_seed(seed: int):
     _counter = itertools.count(1)
 
 
+_salt = None     # device word (torch.int32[1]) every kernel XORs into its keys once enabled
+
+
+def enable_device_salt(device) -> "torch.Tensor":
+    """Move the step-to-step variation of the dropout masks into device memory (afft_set_dropout_salt): needed by a
+    captured hipGraph of the training step, whose kernel arguments -- including the host-drawn keys -- are frozen."""
+    global _salt
+    import torch
+    from . import _lib
+    if _salt is None or _salt.device != torch.device(device):
+        _salt = torch.zeros(1, dtype=torch.int32, device=device)
+        _lib.check(_lib.lib().afft_set_dropout_salt(_salt.data_ptr()), "set_dropout_salt")
+    return _salt
+
+
+def disable_device_salt():
+    global _salt
+    from . import _lib
+    _lib.check(_lib.lib().afft_set_dropout_salt(None), "set_dropout_salt")
+    _salt = None
+
+
+def salt_step():
+    """advance the device salt (one tiny kernel on the current stream); no-op while the salt is off"""
+    if _salt is not None:
+        import torch
+        from . import _lib
+        _lib.check(_lib.lib().afft_dropout_salt_step(_salt.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                   "dropout_salt_step")
+
+
 def next_key() -> int:
     c = next(_counter)
     x = (_seed * 0x9E3779B1 + c * 0x85EBCA77) & 0xFFFFFFFF

@@ -98,7 +98,10 @@ def _on_side(t: Tensor) -> Tensor:
     """The tensor is about to be read by a kernel on the auxiliary stream: tell the caching allocator, so that its
     memory is not handed out again (to main-stream allocations) before that kernel has run."""
     if _SIDE_STREAM is not None and t.is_cuda:
-        t.record_stream(_SIDE_STREAM)
+        if rt.CAPTURING:
+            rt.KEEPALIVE.append(t)
+        else:
+            t.record_stream(_SIDE_STREAM)
     return t
 
 

@@ -256,7 +256,53 @@ class Trainer:
             self.opt.end_step()
         return loss.detach(), parts
 
+    # ---- captured step (hipGraph): for configurations whose step is bound by the host's enqueue rate
+    def capture(self, feats, target, target_subclips, warmup: int = 3):
+        """Capture one whole training step (forward, loss, backward with its three streams, fused SGD) on THESE input
+        tensors into a hipGraph; step() then replays it whenever it is called with the same tensors (new batches are
+        copied into them).  Single GPU only (the RCCL all-reduce is not captured).  The dropout masks still change every
+        step: the keys drawn on the host are frozen in the graph, the salt they are XOR-ed with lives in device memory
+        and is advanced by the first node of the graph."""
+        from . import dropout as D_
+        assert self.flat.flat_p.is_cuda and not self.reducer.comm, "capture(): single-GPU training only"
+        assert self.overlap_optimizer, "capture(): needs the optimizer inside the backward pass (no gradient clipping)"
+        D_.enable_device_salt(self.flat.flat_p.device)
+        self._graph = None
+        # warm up ON the capture stream: the library keeps its split-K workspace per stream and would otherwise
+        # allocate it (hipMalloc) inside the capture; also learns the bucket counts and sets the kernel attributes
+        cap = torch.cuda.Stream(device=self.flat.flat_p.device)
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            for _ in range(max(warmup, 2)):
+                self._eager_step(feats, target, target_subclips)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        rt.CAPTURING = True
+        try:
+            with torch.cuda.graph(graph, stream=cap):
+                loss, parts = self._eager_step(feats, target, target_subclips)
+        finally:
+            rt.CAPTURING = False
+            rt.KEEPALIVE.clear()
+        self._graph = graph
+        self._graph_io = (tuple(id(t) for t in feats.values()), loss, parts)
+        return self
+
+    def release_graph(self):
+        """back to eager steps (the device salt stays on: eager kernels read it too)"""
+        self._graph = None
+        self._graph_io = None
+
+    def _eager_step(self, feats, target, target_subclips):
+        from . import dropout as D_
+        D_.salt_step()
+        return self.forward_backward(feats, target, target_subclips, optimize_in_backward=True)
+
     def step(self, feats, target, target_subclips, optimize: bool = True):
+        g = getattr(self, "_graph", None)
+        if g is not None and optimize and tuple(id(t) for t in feats.values()) == self._graph_io[0]:
+            g.replay()
+            return self._graph_io[1], self._graph_io[2]
         fused = optimize and self.overlap_optimizer
         loss, parts = self.forward_backward(feats, target, target_subclips, optimize_in_backward=fused)
         if optimize and not fused:

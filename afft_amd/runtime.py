@@ -184,6 +184,11 @@ def set_overlap_wgrad(on: bool):
     _OVERLAP_WGRAD = bool(on)
 
 
+CAPTURING = False          # a hipGraph capture of the step is under way (afft_amd.parallel.Trainer.capture)
+KEEPALIVE: list = []       # tensors read on the auxiliary stream during a capture: kept until the capture ends, because
+                           # inside a capture the allocator would hand their memory to a later main-stream allocation
+
+
 _HANDOVER = os.environ.get("AFFT_HANDOVER", "1") != "0"
 
 

@@ -26,6 +26,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+GRAPH_AUTO: tuple = ()      # configurations replayed as a captured hipGraph under --graph auto (filled from measurements)
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
@@ -41,6 +42,9 @@ def parse():
     ap.add_argument("--comm-dtype", default="bf16", choices=["bf16", "fp32"], help="gradient all-reduce payload")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+loss+bwd(+all-reduce) only")
     ap.add_argument("--eval-drop", action="store_true", help="disable dropout (eval-mode layers) in the timed steps")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the step as one captured hipGraph (Trainer.capture); single GPU with the optimizer only; "
+                         "auto = on for the configurations whose eager step is bound by the host's enqueue rate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
@@ -187,6 +191,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    captured = False
+    if world == 1 and not args.no_optimizer and args.graph != "off":
+        if args.graph == "on" or args.config in GRAPH_AUTO:
+            trainer.capture(feats, tgt, sub, warmup=2)
+            captured = True
     for _ in range(args.warmup):
         trainer.step(feats, tgt, sub, optimize=not args.no_optimizer)
     sync_all()
@@ -200,6 +209,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     loss_val = float(loss)
+    if captured:
+        trainer.release_graph()
     ms_per_step = elapsed / args.steps * 1e3
     clips_s = world * B * args.steps / elapsed
     gf = gflop_per_clip(args.config, fwd_bwd=True)
@@ -214,7 +225,8 @@ def main():
                                f"(dropout {'off' if args.eval_drop else 'on'}), step = fwd+loss+bwd"
                                f"{'+allreduce' if world > 1 else ''}{'' if args.no_optimizer else '+nesterov-sgd'}",
                    "per_gpu_batch": B, "global_batch": B * world, "seq_len": T,
-                   "parallelism": f"dp{world}", "grad_comm_dtype": args.comm_dtype if world > 1 else None},
+                   "parallelism": f"dp{world}", "grad_comm_dtype": args.comm_dtype if world > 1 else None,
+                   "step_launch": "hipGraph replay" if captured else "eager, 3 streams"},
         "algorithmic_gflop_per_clip": round(gf, 2),
         "model_tflops": round(clips_s * gf / 1e3, 1),
         "mfma_frac_whole_step": round(clips_s * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4),

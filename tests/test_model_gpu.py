@@ -451,6 +451,59 @@ def test_trainer_gradient_clipping_matches_torch():
     assert abs(float(tr.opt.last_grad_norm) - float(grad.norm())) < 1e-4 * float(grad.norm())
 
 
+def test_captured_step_graph_equals_eager_and_masks_change():
+    """Trainer.capture(): the replayed hipGraph of a whole step (3 streams, fused SGD) gives the same parameters as eager steps
+    (dropout off: exact same kernels), and with dropout on the device salt changes the masks from replay to replay."""
+    import afft_amd
+    from afft_amd import dropout as D_, runtime as rt
+    from afft_amd.config import make_model_cfg
+    from afft_amd.models.base_model import BaseModel
+    from afft_amd.parallel import Trainer
+    afft_amd.set_precision("bf16")
+    rt.set_grad_mode("sink")
+    dev = torch.device("cuda:0")
+    mods = {"rgb": 256, "objects": 96, "audio": 256, "flow": 256}
+    B, T = 16, 16
+    g = torch.Generator().manual_seed(13)
+    feats = {m: torch.randn(B, T, C, 1, 1, 1, generator=g).to(dev) for m, C in mods.items()}
+    tgt = {"action": torch.randint(0, 97, (B,), generator=g).to(dev)}
+    sub = {"action": torch.randint(0, 97, (B, T, 1), generator=g).to(dev)}
+    wts = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
+    try:
+        res = {}
+        for mode in ("eager", "graph"):
+            torch.manual_seed(5)
+            cfg = make_model_cfg(mods, 256, 512, depth=2, fp_layers=2, fp_heads=4, drop=0.0)
+            model = BaseModel(cfg, {"action": 97}, {}).to(dev).eval()
+            tr = Trainer(model, wts, lr=0.01, bucket_elems=1 << 18)
+            if mode == "graph":
+                tr.capture(feats, tgt, sub, warmup=3)
+                for _ in range(4):
+                    loss, _ = tr.step(feats, tgt, sub)          # replays
+            else:
+                for _ in range(7):
+                    loss, _ = tr.step(feats, tgt, sub)
+            torch.cuda.synchronize()
+            res[mode] = (tr.flat.flat_p.clone(), float(loss))
+        d = rel_l2(res["graph"][0], res["eager"][0])
+        assert d < 5e-5, d                     # same kernels; only the float atomics of the bias column sums differ
+        assert abs(res["graph"][1] - res["eager"][1]) < 1e-3 * max(1.0, abs(res["eager"][1]))
+        # dropout on, learning rate 0: the parameters never move, yet every replay sees other masks
+        torch.manual_seed(5)
+        cfg = make_model_cfg(mods, 256, 512, depth=2, fp_layers=2, fp_heads=4, drop=0.1)
+        model = BaseModel(cfg, {"action": 97}, {}).to(dev).train()
+        tr = Trainer(model, wts, lr=0.0, momentum=0.0, weight_decay=0.0, bucket_elems=1 << 18)
+        tr.capture(feats, tgt, sub, warmup=2)
+        losses = []
+        for _ in range(4):
+            loss, _ = tr.step(feats, tgt, sub)
+            losses.append(float(loss))
+        assert all(l == l for l in losses) and len({round(l, 6) for l in losses}) == 4, losses
+        assert max(losses) - min(losses) < 0.2 * abs(losses[0])      # ... masks, not garbage
+    finally:
+        D_.disable_device_salt()
+
+
 def test_overlapped_optimizer_and_wgrad_streams_equal_serial():
     """Per-bucket SGD on the side stream (under backward) and weight-gradient GEMMs on the auxiliary stream must give
     the same parameters as the fully serial schedule (same kernels, same order of accumulation)."""
