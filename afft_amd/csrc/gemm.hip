@@ -27,6 +27,7 @@
 using namespace afft_gemm_detail;
 
 int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream);
+int afft_gemm_launch_w4(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream);
 
 namespace {
 
@@ -300,7 +301,7 @@ int launch_layout(GemmFast& g, hipStream_t stream) {
   g.splitk = 1;
   g.ws = nullptr;
   g.counters = nullptr;
-  const int s = variant == 4 ? 1 : choose_splitk(variant, g.e.M, g.e.N, g.K);
+  const int s = variant >= 4 ? 1 : choose_splitk(variant, g.e.M, g.e.N, g.K);
   if (s > 1) {
     const int64_t tiles = variant == 3 ? (int64_t)((g.e.M + 255) / 256) * ((g.e.N + 255) / 256)
                                        : (int64_t)((g.e.M + 127) / 128) * ((g.e.N + 127) / 128);
@@ -310,6 +311,7 @@ int launch_layout(GemmFast& g, hipStream_t stream) {
   }
   if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream);
   if (variant == 4) return launch_fast<2, 2, 4, A_KS, B_KS, false>(g, stream);
+  if (variant == 5) return afft_gemm_launch_w4(A_KS, B_KS, g, stream);
   if (g.splitk > 1) return launch_fast<2, 2, 2, A_KS, B_KS, true>(g, stream);
   return launch_fast<2, 2, 2, A_KS, B_KS, false>(g, stream);
 }
@@ -333,7 +335,7 @@ extern "C" int afft_gemm_variant_for(int M, int N, int K, int a_kstrided, int b_
 
 extern "C" int afft_gemm_splitk_for(int M, int N, int K, int a_kstrided, int b_kstrided) {
   const int v = choose_variant(M, N, K, a_kstrided != 0, b_kstrided != 0);
-  return v == 4 ? 1 : choose_splitk(v, M, N, K);
+  return v >= 4 ? 1 : choose_splitk(v, M, N, K);
 }
 
 extern "C" int afft_set_gemm_splitk(int mode) {
@@ -343,7 +345,7 @@ extern "C" int afft_set_gemm_splitk(int mode) {
 }
 
 extern "C" int afft_set_gemm_variant(int v) {
-  if (v != 0 && v != 1 && v != 3 && v != 4) { afft_set_error("afft_set_gemm_variant: %d is not 0 (auto), 1 (128x128) or 3 (256x256 ping-pong)", v); return 1; }
+  if (v != 0 && v != 1 && v != 3 && v != 4 && v != 5) { afft_set_error("afft_set_gemm_variant: %d is not 0 (auto), 1 (128x128) or 3 (256x256 ping-pong)", v); return 1; }
   g_variant = v;
   return 0;
 }

@@ -80,33 +80,39 @@ __device__ __forceinline__ void glds16(const char* sbase, unsigned voff, unsigne
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(AFFT_LDS const char*)p; }
 
 // rows row0.. of a k-contiguous operand G[nrows][ld], K offset k0 -> PIECES pieces of this wave at LDS address dst
+template <int NW>
+__device__ __forceinline__ void stage_kc_piece(const bf16_t* __restrict__ G, int64_t ld, unsigned ld2, unsigned voff_full,
+                                               const LaneOffsets& lo, int row0, int nrows, int k0, unsigned dst, int wave, int jj) {
+  const int j = wave + jj * NW;
+  const int pb = min(row0 + j * 8, nrows - 1);          // tail pieces re-read valid rows; the epilogue drops them
+  const int lim = nrows - 1 - pb;
+  const char* sbase = (const char*)(G + (int64_t)pb * ld + k0);
+  unsigned voff = voff_full;
+  if (lim < 7) voff = min(lo.kc_row, (unsigned)lim) * ld2 + lo.kc_chunk16;
+  glds16(sbase, voff, dst + j * 1024);
+}
 template <int NW, int PIECES>
 __device__ __forceinline__ void stage_kc(const bf16_t* __restrict__ G, int64_t ld, unsigned ld2, unsigned voff_full,
                                          const LaneOffsets& lo, int row0, int nrows, int k0, unsigned dst, int wave) {
 #pragma unroll
-  for (int jj = 0; jj < PIECES; ++jj) {
-    const int j = wave + jj * NW;
-    const int pb = min(row0 + j * 8, nrows - 1);          // tail pieces re-read valid rows; the epilogue drops them
-    const int lim = nrows - 1 - pb;
-    const char* sbase = (const char*)(G + (int64_t)pb * ld + k0);
-    unsigned voff = voff_full;
-    if (lim < 7) voff = min(lo.kc_row, (unsigned)lim) * ld2 + lo.kc_chunk16;
-    glds16(sbase, voff, dst + j * 1024);
-  }
+  for (int jj = 0; jj < PIECES; ++jj) stage_kc_piece<NW>(G, ld, ld2, voff_full, lo, row0, nrows, k0, dst, wave, jj);
 }
 // columns col0..col0+127 of a k-strided operand G[K][ld], K rows k0..k0+63
+template <int NW>
+__device__ __forceinline__ void stage_ks_piece(const bf16_t* __restrict__ G, int64_t ld, unsigned ld2, unsigned voff_full,
+                                               const LaneOffsets& lo, int col0, int k0, unsigned dst, int wave, int jj) {
+  const int limc = ((int)ld - 8 - col0) * 2;              // last 16-byte chunk that stays inside the row
+  const int j = wave + jj * NW;
+  const char* sbase = (const char*)(G + (int64_t)(k0 + j * 4) * ld + col0);
+  unsigned voff = voff_full;
+  if (limc < 240) voff = lo.ks_row * ld2 + min(lo.ks_c16, (unsigned)max(limc, 0));
+  glds16(sbase, voff, dst + j * 1024);
+}
 template <int NW, int PIECES>
 __device__ __forceinline__ void stage_ks(const bf16_t* __restrict__ G, int64_t ld, unsigned ld2, unsigned voff_full,
                                          const LaneOffsets& lo, int col0, int k0, unsigned dst, int wave) {
-  const int limc = ((int)ld - 8 - col0) * 2;              // last 16-byte chunk that stays inside the row
 #pragma unroll
-  for (int jj = 0; jj < PIECES; ++jj) {
-    const int j = wave + jj * NW;
-    const char* sbase = (const char*)(G + (int64_t)(k0 + j * 4) * ld + col0);
-    unsigned voff = voff_full;
-    if (limc < 240) voff = lo.ks_row * ld2 + min(lo.ks_c16, (unsigned)max(limc, 0));
-    glds16(sbase, voff, dst + j * 1024);
-  }
+  for (int jj = 0; jj < PIECES; ++jj) stage_ks_piece<NW>(G, ld, ld2, voff_full, lo, col0, k0, dst, wave, jj);
 }
 __device__ __forceinline__ bf16x8 frag_kc(const char* lds_tile, int row, int chunk) {
   return *(const bf16x8*)(lds_tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
