@@ -12,7 +12,8 @@ using namespace afft_gemm_detail;
 #define AFFT_W4_LEAD 7        // half-tiles of look-ahead of the LDS-DMA stream (3..9)
 #endif
 #ifndef AFFT_W4_DIAG
-#define AFFT_W4_DIAG 0        // diagnostic builds only (wrong results): 1 = no fragment reads, 2 = no LDS-DMA in the loop, 4 = no MFMA
+#define AFFT_W4_DIAG 0        // diagnostic builds only (wrong results): 1 = no fragment reads, 2 = no LDS-DMA in the loop, 4 = no MFMA,
+                              // 8 = no barrier, 16 = vmcnt(0) instead of the counted wait chain
 #endif
 
 namespace {
@@ -149,16 +150,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmFast g) {
   };
   // end of phase n: this wave's pieces of every half-tile <= n + 3 have landed; then everybody's
   auto end_phase = [&](int n) {
-    const int last = min(n + LEAD, NH - 1);
-    const int out = last - (n + 3);           // half-tiles allowed to stay in flight (4 instructions each)
-    if (out >= 6) wait_vmcnt_only<24>();
-    else if (out == 5) wait_vmcnt_only<20>();
-    else if (out == 4) wait_vmcnt_only<16>();
-    else if (out == 3) wait_vmcnt_only<12>();
-    else if (out == 2) wait_vmcnt_only<8>();
-    else if (out == 1) wait_vmcnt_only<4>();
-    else wait_vmcnt_only<0>();
-    __builtin_amdgcn_s_barrier();
+    if (AFFT_W4_DIAG & 16) {
+      wait_vmcnt_only<0>();
+    } else {
+      const int last = min(n + LEAD, NH - 1);
+      const int out = last - (n + 3);           // half-tiles allowed to stay in flight (4 instructions each)
+      if (out >= 6) wait_vmcnt_only<24>();
+      else if (out == 5) wait_vmcnt_only<20>();
+      else if (out == 4) wait_vmcnt_only<16>();
+      else if (out == 3) wait_vmcnt_only<12>();
+      else if (out == 2) wait_vmcnt_only<8>();
+      else if (out == 1) wait_vmcnt_only<4>();
+      else wait_vmcnt_only<0>();
+    }
+    if (!(AFFT_W4_DIAG & 8)) __builtin_amdgcn_s_barrier();
     AFFT_CLOBBER_AGPRS();
   };
   // One phase = 8 groups of { the k-th fragment read of the NEXT phase's new half ; 4 MFMAs }
