@@ -27,7 +27,7 @@
 using namespace afft_gemm_detail;
 
 int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream);
-int afft_gemm_launch_w4(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream);
+int afft_gemm_launch_w4(int a_ks, int b_ks, int reg_staged, afft_gemm_detail::GemmFast& g, hipStream_t stream);
 
 namespace {
 
@@ -311,7 +311,7 @@ int launch_layout(GemmFast& g, hipStream_t stream) {
   }
   if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream);
   if (variant == 4) return launch_fast<2, 2, 4, A_KS, B_KS, false>(g, stream);
-  if (variant == 5) return afft_gemm_launch_w4(A_KS, B_KS, g, stream);
+  if (variant == 5 || variant == 6) return afft_gemm_launch_w4(A_KS, B_KS, variant == 6, g, stream);
   if (g.splitk > 1) return launch_fast<2, 2, 2, A_KS, B_KS, true>(g, stream);
   return launch_fast<2, 2, 2, A_KS, B_KS, false>(g, stream);
 }
@@ -345,7 +345,7 @@ extern "C" int afft_set_gemm_splitk(int mode) {
 }
 
 extern "C" int afft_set_gemm_variant(int v) {
-  if (v != 0 && v != 1 && v != 3 && v != 4 && v != 5) { afft_set_error("afft_set_gemm_variant: %d is not 0 (auto), 1 (128x128) or 3 (256x256 ping-pong)", v); return 1; }
+  if (v != 0 && v != 1 && v != 3 && v != 4 && v != 5 && v != 6) { afft_set_error("afft_set_gemm_variant: %d is not 0 (auto), 1 (128x128) or 3 (256x256 ping-pong)", v); return 1; }
   g_variant = v;
   return 0;
 }

@@ -79,17 +79,35 @@ __device__ __forceinline__ void glds16(const char* sbase, unsigned voff, unsigne
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(AFFT_LDS const char*)p; }
 
+// source of piece jj of this wave: wave-uniform base pointer + per-lane byte offset
+template <int NW>
+__device__ __forceinline__ void src_kc_piece(const bf16_t* __restrict__ G, int64_t ld, unsigned ld2, unsigned voff_full,
+                                             const LaneOffsets& lo, int row0, int nrows, int k0, int wave, int jj,
+                                             const char*& sbase, unsigned& voff) {
+  const int j = wave + jj * NW;
+  const int pb = min(row0 + j * 8, nrows - 1);          // tail pieces re-read valid rows; the epilogue drops them
+  const int lim = nrows - 1 - pb;
+  sbase = (const char*)(G + (int64_t)pb * ld + k0);
+  voff = voff_full;
+  if (lim < 7) voff = min(lo.kc_row, (unsigned)lim) * ld2 + lo.kc_chunk16;
+}
+template <int NW>
+__device__ __forceinline__ void src_ks_piece(const bf16_t* __restrict__ G, int64_t ld, unsigned ld2, unsigned voff_full,
+                                             const LaneOffsets& lo, int col0, int k0, int wave, int jj,
+                                             const char*& sbase, unsigned& voff) {
+  const int limc = ((int)ld - 8 - col0) * 2;              // last 16-byte chunk that stays inside the row
+  const int j = wave + jj * NW;
+  sbase = (const char*)(G + (int64_t)(k0 + j * 4) * ld + col0);
+  voff = voff_full;
+  if (limc < 240) voff = lo.ks_row * ld2 + min(lo.ks_c16, (unsigned)max(limc, 0));
+}
 // rows row0.. of a k-contiguous operand G[nrows][ld], K offset k0 -> PIECES pieces of this wave at LDS address dst
 template <int NW>
 __device__ __forceinline__ void stage_kc_piece(const bf16_t* __restrict__ G, int64_t ld, unsigned ld2, unsigned voff_full,
                                                const LaneOffsets& lo, int row0, int nrows, int k0, unsigned dst, int wave, int jj) {
-  const int j = wave + jj * NW;
-  const int pb = min(row0 + j * 8, nrows - 1);          // tail pieces re-read valid rows; the epilogue drops them
-  const int lim = nrows - 1 - pb;
-  const char* sbase = (const char*)(G + (int64_t)pb * ld + k0);
-  unsigned voff = voff_full;
-  if (lim < 7) voff = min(lo.kc_row, (unsigned)lim) * ld2 + lo.kc_chunk16;
-  glds16(sbase, voff, dst + j * 1024);
+  const char* sbase; unsigned voff;
+  src_kc_piece<NW>(G, ld, ld2, voff_full, lo, row0, nrows, k0, wave, jj, sbase, voff);
+  glds16(sbase, voff, dst + (wave + jj * NW) * 1024);
 }
 template <int NW, int PIECES>
 __device__ __forceinline__ void stage_kc(const bf16_t* __restrict__ G, int64_t ld, unsigned ld2, unsigned voff_full,
@@ -101,12 +119,9 @@ __device__ __forceinline__ void stage_kc(const bf16_t* __restrict__ G, int64_t l
 template <int NW>
 __device__ __forceinline__ void stage_ks_piece(const bf16_t* __restrict__ G, int64_t ld, unsigned ld2, unsigned voff_full,
                                                const LaneOffsets& lo, int col0, int k0, unsigned dst, int wave, int jj) {
-  const int limc = ((int)ld - 8 - col0) * 2;              // last 16-byte chunk that stays inside the row
-  const int j = wave + jj * NW;
-  const char* sbase = (const char*)(G + (int64_t)(k0 + j * 4) * ld + col0);
-  unsigned voff = voff_full;
-  if (limc < 240) voff = lo.ks_row * ld2 + min(lo.ks_c16, (unsigned)max(limc, 0));
-  glds16(sbase, voff, dst + j * 1024);
+  const char* sbase; unsigned voff;
+  src_ks_piece<NW>(G, ld, ld2, voff_full, lo, col0, k0, wave, jj, sbase, voff);
+  glds16(sbase, voff, dst + (wave + jj * NW) * 1024);
 }
 template <int NW, int PIECES>
 __device__ __forceinline__ void stage_ks(const bf16_t* __restrict__ G, int64_t ld, unsigned ld2, unsigned voff_full,

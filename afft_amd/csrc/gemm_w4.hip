@@ -1,9 +1,10 @@
 // 256x256x64 bf16 MFMA GEMM, four waves of 128x128 each ("w4"): see the comment above the kernel.
-// EXPERIMENTAL (afft_set_gemm_variant(5); never picked automatically).  Correct on every layout (tests/test_kernels_gpu.py,
+// EXPERIMENTAL (afft_set_gemm_variant(5) = LDS-DMA staging, 6 = register staging; never picked automatically).  Correct on every layout (tests/test_kernels_gpu.py,
 // *_w4 cases), but slower than the 8-wave ping-pong kernel: 8192^3 1.09 ms vs 0.89 ms, 5120x6144x2048 175 vs 129 us
 // (profiles/r01_experiments_late.txt).  With one wave per SIMD nothing hides what a wave's own LDS-DMA instructions cost
 // at issue (60+ cycles each under back-pressure from the L2->LDS fill path, 4 per 512-cycle phase) nor the barrier at the end
-// of every phase: MFMA + barriers alone 0.77 ms, + fragment reads 0.82, + LDS-DMA 0.96 / 1.09 with both.
+// of every phase: MFMA + barriers alone 0.77 ms, + fragment reads 0.82, + LDS-DMA 0.96 / 1.09 with both.  The register-staged
+// variant (second kernel below) reaches 0.98 ms: its ds_writes cost what the LDS-DMA issue stalls did.
 #include "gemm_tiles.h"
 
 using namespace afft_gemm_detail;
@@ -13,7 +14,7 @@ using namespace afft_gemm_detail;
 #endif
 #ifndef AFFT_W4_DIAG
 #define AFFT_W4_DIAG 0        // diagnostic builds only (wrong results): 1 = no fragment reads, 2 = no LDS-DMA in the loop, 4 = no MFMA,
-                              // 8 = no barrier, 16 = vmcnt(0) instead of the counted wait chain
+                              // 8 = no barrier, 16 = vmcnt(0) instead of the counted wait chain, 32 = no ds_write of staged operands (w4r)
 #endif
 
 namespace {
@@ -266,12 +267,178 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmFast g) {
   });
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Register-staged variant ("w4r", afft_set_gemm_variant(6)): same wave layout, phases, LDS images and epilogue, but the
+// operands go global -> VGPR -> ds_write_b128 instead of LDS-DMA (what the vendor library's 256x256 kernels do): a
+// global_load_dwordx4 issues in a few cycles where an LDS-DMA instruction holds its wave -- and, at one wave per SIMD, the
+// matrix pipe -- for the 60+ cycles the fill path takes to accept it.  All memory operations are compiler-visible, so
+// the s_waitcnt vmcnt before each ds_write is the compiler's (exact, in order), and there is no run-time wait selection.
+//   half-tile h: loaded (4 x 16 B per lane, register set h & 3) in phase h - 6, written to LDS slot h & 7 in phase h - 3,
+//   visible after the barrier that ends phase h - 3, read into fragments in phase h - 2, consumed from phase h - 1 on.
+//   Loads past the end of K re-read the last K-tile (never consumed): the loop body has no guards, no tail copy.
 template <bool A_KS, bool B_KS>
+__global__ __launch_bounds__(256) void gemm_bf16_w4r_kernel(const GemmFast g) {
+  constexpr int HB = 128 * BK * 2;   // half-tile bytes (16 KiB)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  int tm, tn;
+  tile_coords(g.tiles_m, g.tiles_n, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int M = g.e.M, N = g.e.N;
+  const int nk = g.K / BK;
+
+  static_for<0, 64>([&](auto tc) { zero_tile<decltype(tc)::value>(); });
+  AFFT_CLOBBER_AGPRS();
+  bf16x8 aF[2][4][2], bF[2][4][2];   // [slot][16-row block][k half]
+  bf16x8 st[4][4];                   // staging registers [set = half-tile & 3][piece]
+  bool in_loop = false; (void)in_loop;
+
+  const unsigned lda2 = (unsigned)(g.lda * 2), ldb2 = (unsigned)(g.ldb * 2);
+  const LaneOffsets lo = lane_offsets(wave, lane);
+  const unsigned voffA = A_KS ? lo.ks_row * lda2 + lo.ks_c16 : lo.kc_row * lda2 + lo.kc_chunk16;
+  const unsigned voffB = B_KS ? lo.ks_row * ldb2 + lo.ks_c16 : lo.kc_row * ldb2 + lo.kc_chunk16;
+  // piece jj (0..3) of this wave's share of half-tile m -> staging set; q = m & 3 and the set are compile-time
+  auto gload = [&](int m, auto qc, auto setc, auto jjc) {
+    constexpr int q = decltype(qc)::value, set = decltype(setc)::value, jj = decltype(jjc)::value;
+    const int kt = min(m >> 2, nk - 1);
+    const char* sbase; unsigned voff;
+    if constexpr (q == 0 || q == 3) {
+      const int r0 = m0 + (q == 3 ? 128 : 0);
+      if constexpr (A_KS) src_ks_piece<4>(g.A, g.lda, lda2, voffA, lo, r0, kt * BK, wave, jj, sbase, voff);
+      else src_kc_piece<4>(g.A, g.lda, lda2, voffA, lo, r0, M, kt * BK, wave, jj, sbase, voff);
+    } else {
+      const int c0 = n0 + (q == 2 ? 128 : 0);
+      if constexpr (B_KS) src_ks_piece<4>(g.B, g.ldb, ldb2, voffB, lo, c0, kt * BK, wave, jj, sbase, voff);
+      else src_kc_piece<4>(g.B, g.ldb, ldb2, voffB, lo, c0, N, kt * BK, wave, jj, sbase, voff);
+    }
+    if ((AFFT_W4_DIAG & 2) && in_loop) return;
+    st[set][jj] = *(const bf16x8*)(sbase + voff);
+  };
+  auto lwrite = [&](int m, auto qc, auto setc, auto jjc) {   // staging set -> LDS slot of half-tile m (lane-linear 1-KiB piece)
+    constexpr int q = decltype(qc)::value, set = decltype(setc)::value, jj = decltype(jjc)::value;
+    if ((AFFT_W4_DIAG & 32) && in_loop) return;
+    char* dst = smem + (((m >> 2) & 1) * 4 + q) * HB + (wave + jj * 4) * 1024 + lane * 16;
+    *(bf16x8*)dst = st[set][jj];
+  };
+  auto mfma4 = [&](auto ihc, auto jhc, auto sac, auto sbc, auto kc) {
+    constexpr int ih = decltype(ihc)::value, jh = decltype(jhc)::value, sa = decltype(sac)::value, sb = decltype(sbc)::value;
+    constexpr int k = decltype(kc)::value, s = k >> 2, i = k & 3;
+    static_for<0, 4>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      mfma_tile<((ih * 2 + jh) * 4 + i) * 4 + j>(bF[sb][j][s], aF[sa][i][s]);
+    });
+  };
+  auto read_a = [&](const char* base, auto slotc, auto kc) {   // fragment k = (s, i) of an A half
+    constexpr int slot = decltype(slotc)::value, k = decltype(kc)::value, s = k >> 2, i = k & 3;
+    if constexpr (A_KS) aF[slot][i][s] = frag_ks<128>(base, 32 * s, wr * 4 + i, lane);
+    else aF[slot][i][s] = frag_kc(base, wr * 64 + i * 16 + (lane & 15), s * 4 + (lane >> 4));
+  };
+  auto read_b = [&](const char* base, auto slotc, auto kc) {
+    constexpr int slot = decltype(slotc)::value, k = decltype(kc)::value, s = k >> 2, j = k & 3;
+    if constexpr (B_KS) bF[slot][j][s] = frag_ks<128>(base, 32 * s, wc * 4 + j, lane);
+    else bF[slot][j][s] = frag_kc(base, wc * 64 + j * 16 + (lane & 15), s * 4 + (lane >> 4));
+  };
+  // phase p (0..3) of K-tile kt, n = 4kt + p: 32 MFMAs on (A slot sa, B slot sb) in 8 groups of 4; beside them
+  //   groups 0-3: two fragment reads of half-tile n + 2 (-> slot ns) and the ds_write of one piece of half-tile n + 3,
+  //   groups 4-7: the global load of one piece of half-tile n + 6;  then lgkmcnt(0) (the writes have landed) + barrier.
+  auto phase = [&](auto pc, auto ihc, auto jhc, auto sac, auto sbc, auto nqc, auto nsc, int next_kt, int kt) {
+    constexpr int p = decltype(pc)::value, nq = decltype(nqc)::value;
+    const int n = 4 * kt + p;
+    const char* base = smem + ((next_kt & 1) * 4 + nq) * HB;
+    static_for<0, 8>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+#ifndef AFFT_W4R_ORDER
+#define AFFT_W4R_ORDER 0      // 0 = ds_writes in groups 0-3, global loads in 4-7;  1 = loads in groups 0-3, ds_writes in 4-7
+#endif
+      if constexpr (k < 4) {
+        if (!(AFFT_W4_DIAG & 1))
+        static_for<0, 2>([&](auto rc) {
+          using FK = std::integral_constant<int, 2 * k + decltype(rc)::value>;
+          if constexpr (nq == 0 || nq == 3) read_a(base, nsc, FK{}); else read_b(base, nsc, FK{});
+        });
+      }
+      if constexpr ((k < 4) == (AFFT_W4R_ORDER == 0)) {
+        lwrite(n + 3, std::integral_constant<int, (p + 3) & 3>{}, std::integral_constant<int, (p + 3) & 3>{},
+               std::integral_constant<int, (k & 3)>{});
+      } else {
+        gload(n + 6, std::integral_constant<int, (p + 6) & 3>{}, std::integral_constant<int, (p + 6) & 3>{},
+              std::integral_constant<int, (k & 3)>{});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma4(ihc, jhc, sac, sbc, kc);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!(AFFT_W4_DIAG & 8)) __builtin_amdgcn_s_barrier();
+    AFFT_CLOBBER_AGPRS();
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+
+  // prologue: half-tiles 0..2 in LDS, 3..5 in flight, K-tile 0's first fragments in registers
+  static_for<0, 3>([&](auto hc) { static_for<0, 4>([&](auto jc) { gload(decltype(hc)::value, hc, hc, jc); }); });
+  static_for<0, 3>([&](auto hc) { static_for<0, 4>([&](auto jc) { lwrite(decltype(hc)::value, hc, hc, jc); }); });
+  static_for<3, 6>([&](auto hc) {
+    constexpr int h = decltype(hc)::value;
+    static_for<0, 4>([&](auto jc) { gload(h, std::integral_constant<int, h & 3>{}, std::integral_constant<int, h & 3>{}, jc); });
+  });
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  static_for<0, 8>([&](auto kc) { read_a(smem + 0 * HB, I0{}, kc); });
+  static_for<0, 8>([&](auto kc) { read_b(smem + 1 * HB, I0{}, kc); });
+
+  in_loop = true;
+  auto ktile = [&](auto Pc, int kt) {
+    using SP = std::integral_constant<int, decltype(Pc)::value>;        // slot of B half 0 in this K-tile
+    using SQ = std::integral_constant<int, 1 - decltype(Pc)::value>;    // slot of B half 1
+    phase(I0{}, I0{}, I0{}, I0{}, SP{}, I2{}, SQ{}, kt, kt);
+    phase(I1{}, I0{}, I1{}, I0{}, SQ{}, I3{}, I1{}, kt, kt);
+    phase(I2{}, I1{}, I1{}, I1{}, SQ{}, I0{}, I0{}, kt + 1, kt);
+    phase(I3{}, I1{}, I0{}, I1{}, SP{}, I1{}, SQ{}, kt + 1, kt);
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    ktile(I0{}, kt);
+    if (kt + 1 < nk) ktile(I1{}, kt + 1);
+  }
+
+  constexpr int ESTRIDE = 1040;
+  const DropParams dp = with_salt(g.e.drop);
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");   // last MFMAs retired; the overshoot loads are back
+  static_for<0, 2>([&](auto ihc) {
+    constexpr int ih = decltype(ihc)::value;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    static_for<0, 32>([&](auto idx) {
+      constexpr int v = decltype(idx)::value;
+      constexpr int jh = v >> 4, i = (v >> 2) & 3, j = v & 3;
+      const int row = wr * 64 + i * 16 + (lane & 15);
+      const int col = jh * 128 + wc * 64 + j * 16 + 4 * (lane >> 4);
+      *(f32x4*)(smem + row * ESTRIDE + col * 4) = read_tile<((ih * 2 + jh) * 4 + i) * 4 + j>();
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int rr = 0; rr < 16; ++rr) {
+      const int row = wave * 32 + rr * 2 + (lane >> 5);
+      const int c8 = lane & 31;
+      const f32x4 t0 = *(const f32x4*)(smem + row * ESTRIDE + c8 * 32);
+      const f32x4 t1 = *(const f32x4*)(smem + row * ESTRIDE + c8 * 32 + 16);
+      float o[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+      epilogue8(g.e, dp, m0 + ih * 128 + row, n0 + 8 * c8, o);
+    }
+  });
+}
+
+template <bool A_KS, bool B_KS, bool RS>
 int launch_w4(GemmFast& g, hipStream_t stream) {
   constexpr size_t lds = 128 * 1040;          // ring: 8 half-tiles x 16 KiB = 128 KiB; epilogue image: 130 KiB
   g.tiles_m = (g.e.M + 255) / 256;
   g.tiles_n = (g.e.N + 255) / 256;
-  auto kern = gemm_bf16_w4_kernel<A_KS, B_KS>;
+  auto kern = RS ? gemm_bf16_w4r_kernel<A_KS, B_KS> : gemm_bf16_w4_kernel<A_KS, B_KS>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -288,12 +455,20 @@ int launch_w4(GemmFast& g, hipStream_t stream) {
 
 }  // namespace
 
-int afft_gemm_launch_w4(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream) {
-  if (!a_ks && !b_ks) return launch_w4<false, false>(g, stream);
-#ifndef AFFT_W4_NT_ONLY   // development switch: build only the NT instantiation (compile time)
-  if (!a_ks && b_ks) return launch_w4<false, true>(g, stream);
-  if (a_ks && b_ks) return launch_w4<true, true>(g, stream);
+int afft_gemm_launch_w4(int a_ks, int b_ks, int reg_staged, afft_gemm_detail::GemmFast& g, hipStream_t stream) {
+  if (reg_staged) {
+    if (!a_ks && !b_ks) return launch_w4<false, false, true>(g, stream);
+#ifndef AFFT_W4_NT_ONLY
+    if (!a_ks && b_ks) return launch_w4<false, true, true>(g, stream);
+    if (a_ks && b_ks) return launch_w4<true, true, true>(g, stream);
 #endif
+  } else {
+    if (!a_ks && !b_ks) return launch_w4<false, false, false>(g, stream);
+#ifndef AFFT_W4_NT_ONLY   // development switch: build only the NT instantiation (compile time)
+    if (!a_ks && b_ks) return launch_w4<false, true, false>(g, stream);
+    if (a_ks && b_ks) return launch_w4<true, true, false>(g, stream);
+#endif
+  }
   afft_set_error("afft_gemm: layout (A k-strided, B k-contiguous) is not built");
   return 1;
 }

@@ -69,6 +69,12 @@ GEMM_CASES = [
     ("nn_bf16_w4", 300, 512, 640, "bf16", "nn", dict(bias=True, residual=True, out_f32=True)),
     ("tn_bf16_w4", 512, 264, 704, "bf16", "tn", dict(out_f32=True)),
     ("tn_bf16_w4_acc", 1000, 520, 64, "bf16", "tn", dict(out_f32=True, accumulate=True, lda_pad=1024, ldb_pad=528)),
+    # the same kernel with register-staged operands (global -> VGPR -> ds_write)
+    ("nt_bf16_w4r", 300, 520, 192, "bf16", "nt", dict(bias=True, act=2, out2=True)),
+    ("nt_bf16_w4r_long", 512, 768, 1024, "bf16", "nt", dict(bias=True, act=1, pre=True)),
+    ("nn_bf16_w4r", 300, 512, 640, "bf16", "nn", dict(bias=True, residual=True, out_f32=True)),
+    ("tn_bf16_w4r", 512, 264, 704, "bf16", "tn", dict(out_f32=True)),
+    ("tn_bf16_w4r_acc", 1000, 520, 64, "bf16", "tn", dict(out_f32=True, accumulate=True, lda_pad=1024, ldb_pad=528)),
     ("nt_f32", 150, 130, 100, "f32", "nt", dict(bias=True, act=1, pre=True)),
     ("nn_f32", 96, 200, 77, "f32", "nn", dict(bias=True, residual=True, out_f32=True)),
     ("tn_f32", 66, 70, 130, "f32", "tn", dict(accumulate=True, out_f32=True)),
@@ -83,7 +89,7 @@ def test_gemm(case):
     name, M, N, K, dt, layout, ep = case
     from afft_amd import _lib
     _lib.check(_lib.lib().afft_set_gemm_splitk(0 if "nosplit" in name else 4 if "pp_splitk3" in name else 1))   # 1 = auto (default)
-    _lib.check(_lib.lib().afft_set_gemm_variant(3 if "_pp" in name else 5 if "_w4" in name else 0))
+    _lib.check(_lib.lib().afft_set_gemm_variant(3 if "_pp" in name else 6 if "_w4r" in name else 5 if "_w4" in name else 0))
     tdt = torch.bfloat16 if dt == "bf16" else torch.float32
     a_t, b_t = layout[0] == "t", layout[1] == "t"
     lda_pad, ldb_pad = ep.get("lda_pad"), ep.get("ldb_pad")

@@ -10,7 +10,7 @@ with tempfile.TemporaryDirectory() as d:
                            src, "-o", out] + sys.argv[1:])
     text = open(out).read()
 bad = 0
-for m in re.finditer(r"^(_ZN\S*gemm_bf16_w4_kernel\S*):[^\n]*\n(.*?)\.Lfunc_end\d+:", text, re.S | re.M):
+for m in re.finditer(r"^(_ZN\S*gemm_bf16_w4r?_kernel\S*):[^\n]*\n(.*?)\.Lfunc_end\d+:", text, re.S | re.M):
     name, body = m.group(1), m.group(2)
     in_asm = False
     n_out = 0
