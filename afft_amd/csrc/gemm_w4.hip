@@ -351,8 +351,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4r_kernel(const GemmFast g) {
     static_for<0, 8>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
 #ifndef AFFT_W4R_ORDER
-#define AFFT_W4R_ORDER 0      // 0 = ds_writes in groups 0-3, global loads in 4-7;  1 = loads in groups 0-3, ds_writes in 4-7
+#define AFFT_W4R_ORDER 1      // 0 = ds_writes in groups 0-3, global loads in 4-7;  1 = loads in groups 0-3, ds_writes in 4-7 (-2 %);  2 = alternating (no gain)
 #endif
+      if constexpr (AFFT_W4R_ORDER == 2) {   // one fragment read per group; ds_writes in the even groups, global loads in the odd ones
+        if (!(AFFT_W4_DIAG & 1)) { if constexpr (nq == 0 || nq == 3) read_a(base, nsc, kc); else read_b(base, nsc, kc); }
+        if constexpr ((k & 1) == 0)
+          lwrite(n + 3, std::integral_constant<int, (p + 3) & 3>{}, std::integral_constant<int, (p + 3) & 3>{},
+                 std::integral_constant<int, (k >> 1)>{});
+        else
+          gload(n + 6, std::integral_constant<int, (p + 6) & 3>{}, std::integral_constant<int, (p + 6) & 3>{},
+                std::integral_constant<int, (k >> 1)>{});
+      } else {
       if constexpr (k < 4) {
         if (!(AFFT_W4_DIAG & 1))
         static_for<0, 2>([&](auto rc) {
@@ -366,6 +375,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4r_kernel(const GemmFast g) {
       } else {
         gload(n + 6, std::integral_constant<int, (p + 6) & 3>{}, std::integral_constant<int, (p + 6) & 3>{},
               std::integral_constant<int, (k & 3)>{});
+      }
       }
       __builtin_amdgcn_sched_barrier(0);
       mfma4(ihc, jhc, sac, sbc, kc);
