@@ -2,6 +2,7 @@
 // assembly, bias-gradient column sums, periodic (position / token) row tables, Nesterov SGD.
 #include <stdarg.h>
 
+#include <cstdlib>
 #include "common.h"
 
 // ---- error plumbing shared by every translation unit
@@ -685,7 +686,15 @@ extern "C" int afft_sgd_nesterov(float* p, const void* g, int32_t g_dtype, float
   AFFT_CHECK(g_dtype == AFFT_F32 || g_dtype == AFFT_BF16, "sgd: bad gradient dtype");
   if (n == 0) return 0;
   int64_t blocks = (n + 1023) / 1024;
-  if (blocks > 4096) blocks = 4096;
+  // Grid cap: one 256-thread block per CU.  The update runs beside the backward GEMMs, whose workgroups need a CU's whole
+  // register file, so every CU an update wave sits on is a CU without a GEMM tile (4096 blocks: 17.4 ms/step, 256: 16.9,
+  // 128: 17.1; tools/sgd_blocks.sh).  AFFT_SGD_BLOCKS overrides.
+  static const int64_t max_blocks = [] {
+    const char* e = getenv("AFFT_SGD_BLOCKS");
+    const long v = e ? atol(e) : 0;
+    return (int64_t)(v > 0 ? v : 256);
+  }();
+  if (blocks > max_blocks) blocks = max_blocks;
   hipLaunchKernelGGL(sgd_kernel, dim3((int)blocks), dim3(256), 0, stream, p, g, g_dtype, buf, (bf16_t*)p_bf16, n, lr, mom, wd,
                      gscale, gscale_dev, first_step);
   AFFT_LAUNCH_CHECK();
