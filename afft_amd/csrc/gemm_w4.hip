@@ -1,7 +1,9 @@
 // 256x256x64 bf16 MFMA GEMM, four waves of 128x128 each ("w4"): see the comment above the kernel.
 // EXPERIMENTAL (afft_set_gemm_variant(5) = LDS-DMA staging, 6 = register staging; never picked automatically).  Correct on every layout (tests/test_kernels_gpu.py,
-// *_w4 cases), but slower than the 8-wave ping-pong kernel: 8192^3 1.09 ms vs 0.89 ms, 5120x6144x2048 175 vs 129 us
-// (profiles/r01_experiments_late.txt).  With one wave per SIMD nothing hides what a wave's own LDS-DMA instructions cost
+// *_w4 cases).  First build: slower than the 8-wave ping-pong kernel (8192^3 1.09 ms vs 0.89 ms, 5120x6144x2048 175 vs 129 us;
+// profiles/r01_experiments_late.txt); with the branch-free K-loop (the LDS-DMA stream re-reads the last K-tile past the end of
+// K, so there is no issue guard and ONE constant counted wait) it equals it: 8192^3 0.88-0.90 ms, TN shapes 4-7 % faster, NN
+// +-3 %, NT 6-13 % slower; inside the training step TN on this kernel changes nothing (3784 vs 3783 clips/s).  With one wave per SIMD nothing hides what a wave's own LDS-DMA instructions cost
 // at issue (60+ cycles each under back-pressure from the L2->LDS fill path, 4 per 512-cycle phase) nor the barrier at the end
 // of every phase: MFMA + barriers alone 0.77 ms, + fragment reads 0.82, + LDS-DMA 0.96 / 1.09 with both.  The register-staged
 // variant (second kernel below) reaches 0.98 ms: its ds_writes cost what the LDS-DMA issue stalls did.
@@ -71,7 +73,8 @@ __device__ __forceinline__ f32x4 read_tile() {
 //   phase n = 4kt + 2: MFMA(A1, B1)   reads A0(kt+1)   -> A slot 0
 //   phase n = 4kt + 3: MFMA(A1, B0)   reads B0(kt+1)   -> the slot of B1(kt)   (the two B slots swap roles per K-tile)
 // In every phase the half-tile read is m = n + 2.  Rules (one s_waitcnt vmcnt + s_barrier at the end of every phase):
-//   RAW: at the end of phase n every wave waits until ITS pieces of half-tile n + 3 have landed, then the barrier;
+//   RAW: at the end of phase n every wave waits until ITS pieces of half-tile n + 3 have landed (LEAD - 3 half-tiles stay in
+//        flight), then the barrier;
 //   WAR: phase n issues half-tile n + LEAD into the slot of n + LEAD - 8 <= n + 1, which every wave finished reading
 //        (into registers) before the barrier that ended phase n - 1.
 template <bool A_KS, bool B_KS>
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmFast g) {
   tile_coords(g.tiles_m, g.tiles_n, tm, tn);
   const int m0 = tm * 256, n0 = tn * 256;
   const int M = g.e.M, N = g.e.N;
-  const int nk = g.K / BK, NH = 4 * nk;
+  const int nk = g.K / BK;
 
   // accumulator tile (ih, jh, i, j) = a[4*T : 4*T+3], T = ((ih*2 + jh)*4 + i)*4 + j
   static_for<0, 64>([&](auto tc) { zero_tile<decltype(tc)::value>(); });
@@ -107,10 +110,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmFast g) {
   bool in_loop = false; (void)in_loop;
   // piece jj (0..3) of this wave's share of half-tile m; q = m & 3 is compile-time at every call site
   auto issue_piece = [&](int m, int q, int jj) {
-    if (m >= NH) return;
     if ((AFFT_W4_DIAG & 2) && in_loop) return;
-    const int kt = m >> 2;
-    const unsigned dst = lds0 + ((kt & 1) * 4 + q) * HB;
+    // past the end of K the stream re-reads the last K-tile into the (dead) ring slot: no guard, and the number of
+    // LDS-DMA instructions in flight is the same in every phase -> one constant counted wait, no scalar branch chain
+    const int kt = min(m >> 2, nk - 1);
+    const unsigned dst = lds0 + (((m >> 2) & 1) * 4 + q) * HB;
     if (q == 0 || q == 3) {
       const int r0 = m0 + (q == 3 ? 128 : 0);
       if constexpr (A_KS) stage_ks_piece<4>(g.A, g.lda, lda2, voffA, lo, r0, kt * BK, dst, wave, jj);
@@ -150,20 +154,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmFast g) {
       }
   };
   // end of phase n: this wave's pieces of every half-tile <= n + 3 have landed; then everybody's
-  auto end_phase = [&](int n) {
-    if (AFFT_W4_DIAG & 16) {
-      wait_vmcnt_only<0>();
-    } else {
-      const int last = min(n + LEAD, NH - 1);
-      const int out = last - (n + 3);           // half-tiles allowed to stay in flight (4 instructions each)
-      if (out >= 6) wait_vmcnt_only<24>();
-      else if (out == 5) wait_vmcnt_only<20>();
-      else if (out == 4) wait_vmcnt_only<16>();
-      else if (out == 3) wait_vmcnt_only<12>();
-      else if (out == 2) wait_vmcnt_only<8>();
-      else if (out == 1) wait_vmcnt_only<4>();
-      else wait_vmcnt_only<0>();
-    }
+  auto end_phase = [&](int) {
+    wait_vmcnt_only<4 * (LEAD - 3)>();
     if (!(AFFT_W4_DIAG & 8)) __builtin_amdgcn_s_barrier();
     AFFT_CLOBBER_AGPRS();
   };
@@ -242,7 +234,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmFast g) {
   // every wave walks whole rows -- 16-byte LDS reads, fully coalesced global accesses (gemm_pp.hip's epilogue).
   constexpr int ESTRIDE = 1040;
   const DropParams dp = with_salt(g.e.drop);
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the MFMAs are opaque to the hazard recognizer: let the last ones retire
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");   // the MFMAs are opaque to the hazard recognizer: let the
+                                                                              // last ones retire; the overshoot LDS-DMA has landed
   static_for<0, 2>([&](auto ihc) {
     constexpr int ih = decltype(ihc)::value;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
