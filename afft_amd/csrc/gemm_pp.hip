@@ -10,6 +10,9 @@ using namespace afft_gemm_detail;
 #ifndef AFFT_PP_PRIO
 #define AFFT_PP_PRIO 1        // experiment: 1 = MFMA segments at raised priority, 0 = no priority change, 2 = L segments raised
 #endif
+#ifndef AFFT_PP_CLAMP
+#define AFFT_PP_CLAMP 2       // 2 = branch-free wait: 256-byte dummy LDS-DMA past the end of K (see issue()); 1 = re-read the last K-tile; 0 = guarded issue + run-time wait selection
+#endif
 #ifndef AFFT_PP_DIAG
 #define AFFT_PP_DIAG 0    // diagnostic builds only (wrong results): 1 = no fragment reads, 2 = no LDS-DMA in the loop, 4 = no MFMA,
                           // 8 = no global accesses in the epilogue, 16 = no epilogue at all
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
   // split-K (grids that leave > 1/3 of the CUs without a tile): slice blockIdx.y owns K-tiles [kt_lo, kt_lo + nk)
   const int nk_all = g.K / BK;
   const int kt_lo = (int)(((int64_t)blockIdx.y * nk_all) / g.splitk);
-  const int nk = (int)(((int64_t)(blockIdx.y + 1) * nk_all) / g.splitk) - kt_lo, NH = 4 * nk;
+  const int nk = (int)(((int64_t)(blockIdx.y + 1) * nk_all) / g.splitk) - kt_lo, NH = 4 * nk; (void)NH;
 
   f32x4 acc[2][2][4][2];
 #pragma unroll
@@ -96,10 +99,27 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
   const unsigned voffB = B_KS ? lo.ks_row * ldb2 + lo.ks_c16 : lo.kc_row * ldb2 + lo.kc_chunk16;
   bool in_loop = false; (void)in_loop;
   auto issue = [&](int m, int q) {   // q = m & 3 (compile-time at every call site)
-    if (m >= NH) return;
-    if ((AFFT_PP_DIAG & 2) && in_loop) return;
+#if AFFT_PP_CLAMP == 2
+    // past the end of K every wave still issues its two vmcnt-counted operations per half-tile, but as 256-byte dummies
+    // (first bytes of A into the dead ring slot): the number of LDS-DMA instructions in flight is the same in every phase
+    // -> one constant counted wait instead of a run-time selection, at 1/4 of the overshoot traffic of re-reading a K-tile
+    if (m >= NH) {
+      const unsigned dd = lds0 + (((m >> 2) & 1) * 4 + q) * HB + wave * 1024;
+      glds4((const char*)g.A, (unsigned)lane * 4, dd);
+      glds4((const char*)g.A, (unsigned)lane * 4, dd + 256);
+      return;
+    }
     const int kt = m >> 2;
-    const unsigned dst = lds0 + ((kt & 1) * 4 + q) * HB;
+#elif AFFT_PP_CLAMP
+    // past the end of K the stream re-reads the last K-tile into the (dead) ring slot: no guard, and the same number of
+    // LDS-DMA instructions in flight in every phase -> one constant counted wait instead of a scalar branch chain
+    const int kt = min(m >> 2, nk - 1);
+#else
+    if (m >= NH) return;
+    const int kt = m >> 2;
+#endif
+    if ((AFFT_PP_DIAG & 2) && in_loop) return;
+    const unsigned dst = lds0 + (((m >> 2) & 1) * 4 + q) * HB;
     if (q == 0 || q == 3) {
       const int r0 = m0l + (q == 3 ? 128 : 0);
       if constexpr (A_KS) stage_ks<8, 2>(g.A, g.lda, lda2, voffA, lo, r0, (kt_lo + kt) * BK, dst, wave);
@@ -138,8 +158,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
   (void)sL; (void)sW; (void)sB1; (void)sC; (void)sB2; (void)t0; (void)t1; (void)t2; (void)t3; (void)t4; (void)t5;
   auto wait_then_barrier = [&](int n) {
     STAMP(t1);
+#if AFFT_PP_CLAMP
+    const int out = LEAD - 3; (void)n;
+#else
     const int last = min(n + LEAD, NH - 1);
     const int out = last - (n + 3);           // half-tiles allowed to stay in flight
+#endif
     // no lgkmcnt here: the LDS reads of this segment only have to be back before this wave's own MFMAs (the
     // compiler's wait after the barrier), so their latency overlaps the barrier; the ring slot they read is not
     // refilled until >= 3 barriers later, each of which this wave passes with lgkmcnt already drained.
@@ -208,6 +232,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
     if (kt + 1 < nk) ktile(I1{}, kt + 1);
   }
   if (gp == 0) __builtin_amdgcn_s_barrier();
+#if AFFT_PP_CLAMP
+  wait_vmcnt_only<0>();            // the overshoot LDS-DMA has landed before the ring is reused (split-K combine / epilogue image)
+#endif
 #ifdef AFFT_PP_STAMP
   if (stamp_out && blockIdx.x == 0 && lane == 0) {
     unsigned long long* o = stamp_out + wave * 8;

@@ -77,6 +77,10 @@ __device__ __forceinline__ LaneOffsets lane_offsets(int wave, int lane) {   // N
 __device__ __forceinline__ void glds16(const char* sbase, unsigned voff, unsigned lds_dst) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_dst) : "memory");
 }
+// 4 bytes per lane (256 B per wave-instruction): the cheapest operation that still counts in vmcnt (K-loop overshoot)
+__device__ __forceinline__ void glds4(const char* sbase, unsigned voff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_dst) : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(AFFT_LDS const char*)p; }
 
 // source of piece jj of this wave: wave-uniform base pointer + per-lane byte offset
