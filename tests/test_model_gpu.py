@@ -377,6 +377,63 @@ def test_full_width_cfg2_matches_oracle(precision):
     afft_amd.set_precision("bf16")
 
 
+def test_full_size_batch_split_invariants():
+    """Size-independent properties at the bench's full size (cfg2: 4 modalities x T=16 x d=D=2048, 6+6 layers, 64 clips, bf16
+    operands, dropout off), no oracle involved.  Clips are independent, so (1) a clip's logits do not depend on which batch it
+    sits in -- the batch of 64 runs on the 256x256 GEMM kernels, batches of 32 / 8 on other tile paths and split-K -- and (2) the
+    data-parallel identity holds: the gradient of the mean loss over 64 clips is the average of the gradients over its two halves
+    (what an all-reduce over two ranks computes)."""
+    import afft_amd
+    from afft_amd import runtime as rt
+    from afft_amd.common.runner import BasicLossAccuracy, Runner
+    from afft_amd.config import BASELINE_CONFIGS, make_model_cfg
+    from afft_amd.models.base_model import BaseModel
+    c = BASELINE_CONFIGS["cfg2"]
+    B, T, K = 64, c["T"], 3806
+    afft_amd.set_precision("bf16")
+    rt.set_grad_mode("sink")
+    torch.manual_seed(3)
+    dev = torch.device("cuda:0")
+    cfg = make_model_cfg(c["modal_dims"], c["common_dim"], c["fp_inter_dim"], fuser="sa", T=T, drop=0.0)
+    model = BaseModel(cfg, {"action": K}, {}).to(dev).eval()
+    g = torch.Generator().manual_seed(4)
+    data = {m: torch.randn(B, T, C, 1, 1, 1, generator=g).to(dev) for m, C in c["modal_dims"].items()}
+    tgt = torch.randint(0, K, (B,), generator=g).to(dev)
+    sub = torch.randint(0, K, (B, T, 1), generator=g).to(dev)       # no ignored rows: every half has the same number of terms
+    wts = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def run(lo, hi):
+        rt.SINK.begin_step()
+        out, out_t = model({m: d[lo:hi] for m, d in data.items()}, mixup_fn=None, target={"action": tgt[lo:hi]},
+                           target_subclips={"action": sub[lo:hi]}, target_subclips_ignore_index=None)
+        losses, _ = BasicLossAccuracy(False)(out, out_t["target"], out_t["target_subclips"])
+        total, _ = Runner._reduce_loss(losses, wts, sync=False)
+        total.backward()
+        rt.SINK.finish_step(params)
+        torch.cuda.synchronize()
+        return (out["logits/action"]["all-fused"].float().clone(), out["past_logits/action"]["all-fused"].float().clone(),
+                float(total.detach()), [p.grad.clone() for p in params])
+
+    lg, plg, loss, grads = run(0, B)
+    lg_a, plg_a, loss_a, grads_a = run(0, B // 2)
+    lg_b, plg_b, loss_b, grads_b = run(B // 2, B)
+    lg_s, plg_s, _, _ = run(40, 48)
+    # (1) batch independence (different GEMM kernels / tile paths; bf16 operand rounding is the only difference)
+    assert rel_l2(torch.cat([lg_a, lg_b]), lg) < 2e-2
+    assert rel_l2(torch.cat([plg_a, plg_b]), plg) < 2e-2
+    assert rel_l2(lg_s, lg[40:48]) < 2e-2 and rel_l2(plg_s, plg[40:48]) < 2e-2
+    # (2) data-parallel identity: loss and gradient of the whole batch = mean over the halves
+    assert abs(loss - 0.5 * (loss_a + loss_b)) < 2e-3 * max(1.0, abs(loss))
+    num = sum(float(((ga + gb) * 0.5 - gf).double().pow(2).sum()) for gf, ga, gb in zip(grads, grads_a, grads_b))
+    den = sum(float(gf.double().pow(2).sum()) for gf in grads)
+    assert (num / den) ** 0.5 < 3e-2, (num / den) ** 0.5
+    big = max(range(len(params)), key=lambda i: params[i].numel())
+    assert rel_l2((grads_a[big] + grads_b[big]) * 0.5, grads[big]) < 5e-2
+    del model, grads, grads_a, grads_b
+    torch.cuda.empty_cache()
+
+
 def test_evaluate_loop_scores_and_logit_store(tmp_path):
     """test.py's evaluate / save_logits without per-batch host copies: the collected logits equal the per-batch model
     outputs, the verb / noun scores equal softmax @ mapping, the stored file appends across calls."""
