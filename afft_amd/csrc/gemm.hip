@@ -345,7 +345,7 @@ extern "C" int afft_set_gemm_splitk(int mode) {
 }
 
 extern "C" int afft_set_gemm_variant(int v) {
-  if (v != 0 && v != 1 && v != 3 && v != 4 && v != 5 && v != 6) { afft_set_error("afft_set_gemm_variant: %d is not 0 (auto), 1 (128x128) or 3 (256x256 ping-pong)", v); return 1; }
+  if (v != 0 && v != 1 && v != 3 && v != 4 && v != 5 && v != 6) { afft_set_error("afft_set_gemm_variant: %d is not 0 (auto), 1 (128x128), 3 (256x256 ping-pong), 4 (128x128, 4 stages), 5 or 6 (256x256 four-wave)", v); return 1; }
   g_variant = v;
   return 0;
 }

@@ -72,7 +72,8 @@ typedef struct {
   afft_dropout_t drop;               /* dropout / DropPath on the output (train mode), p = 0 -> off */
 } afft_gemm_t;
 int afft_gemm(const afft_gemm_t* g, void* stream);
-/* Tuning / test hook: force the bf16 tile shape (0 = auto, 1 = 128x128x64 2-stage, 3 = 256x256x64 ping-pong). */
+/* Tuning / test hook: force the bf16 kernel (0 = auto, 1 = 128x128x64 2-stage, 3 = 256x256x64 ping-pong, 4 = 128x128x64 4-stage,
+ * 5 / 6 = experimental 256x256x64 four-wave kernels with LDS-DMA / register-staged operands). */
 int afft_set_gemm_variant(int variant);
 /* Split-K for small grids of the 128x128 kernel (<= 128 tiles, K >= 2048): K is cut into 2 or 4 slices, every slice
  * parks its fp32 partial tile in a per-stream workspace and the slice that arrives last adds them up in slice order
