@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step as one captured hipGraph (Trainer.capture); single GPU with the optimizer only; "
                          "auto = on for the configurations whose eager step is bound by the host's enqueue rate")
+    ap.add_argument("--bucket-melems", type=int, default=32, help="gradient bucket size (Mi elements) of the all-reduce / SGD pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
@@ -183,7 +184,7 @@ def main():
     B, T = args.batch, c["T"]
     feats, tgt, sub = make_inputs(c, B, T, rank, device)
     wts = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
-    trainer = Trainer(model, wts, comm_dtype=args.comm_dtype)
+    trainer = Trainer(model, wts, comm_dtype=args.comm_dtype, bucket_elems=args.bucket_melems * 1024 * 1024)
     model.train(not args.eval_drop)
 
     def sync_all():
