@@ -30,13 +30,16 @@ namespace {
 // apart: while one group issues its 16 MFMAs of a phase, the other reads the next phase's fragments from LDS and
 // issues LDS-DMA.  Per K-tile (64 deep) a wave runs 4 phases = the 4 quadrants of its 128x64 output, and its rows /
 // columns are interleaved over the two 128-row halves of the A and B tiles, so a K-tile is consumed half-tile by
-// half-tile (A0,B0 | B1 | A1 | -) and staged half-tile by half-tile, LEAD = 6 half-tiles (12 LDS-DMA instructions
-// per wave) ahead, behind a counted s_waitcnt vmcnt(8).
+// half-tile (A0,B0 | B1 | A1 | B0 of the next K-tile) and staged half-tile by half-tile, LEAD = 7 half-tiles (14 LDS-DMA
+// instructions per wave) ahead, behind a counted s_waitcnt vmcnt(8) that is the same in every phase: past the end of K
+// the stream goes on with 256-byte dummy transfers (AFFT_PP_CLAMP), so no phase needs a run-time choice of the wait.
+// What bounds it: the chip-wide L2->LDS fill rate with MFMAs running (~7.5 TB/s = 1 PFLOP/s at this
+// tile's 128 FLOP per filled byte) and the power-limited clock (1.85 GHz inside the loop).
 //
 //   stream of half-tiles (16 KiB each): index m = 4*kt + q, q: 0 = A rows 0-127, 1 = B rows 0-127,
 //   2 = B rows 128-255, 3 = A rows 128-255; ring slot = ((kt & 1) * 4 + q).
-//   phase n = 4*kt + p:  L(n): read the fragments phase n needs, issue half-tile n + LEAD, wait until half-tile
-//   n + 2 has landed (this wave's pieces), s_barrier;  C(n): 16 MFMAs, s_barrier.
+//   phase n = 4*kt + p:  L(n): issue half-tile n + LEAD, read the fragments phase n needs, wait until half-tile
+//   n + 3 has landed (this wave's pieces), s_barrier;  C(n): 16 MFMAs, s_barrier.
 //   slot 2n:   group 0 runs L(n),  group 1 runs C(n-1)      slot 2n+1: group 0 runs C(n),  group 1 runs L(n)
 //   RAW: half-tile m is first read in L(m - (m&3 ? 1 : 0) ...) >= two slots after every wave's wait for it;
 //   WAR: half-tile m overwrites m - 8, whose last reader (group 1) finished >= 3 slots earlier (LEAD <= 7).
