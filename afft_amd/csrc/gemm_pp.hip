@@ -33,8 +33,9 @@ namespace {
 // half-tile (A0,B0 | B1 | A1 | B0 of the next K-tile) and staged half-tile by half-tile, LEAD = 7 half-tiles (14 LDS-DMA
 // instructions per wave) ahead, behind a counted s_waitcnt vmcnt(8) that is the same in every phase: past the end of K
 // the stream goes on with 256-byte dummy transfers (AFFT_PP_CLAMP), so no phase needs a run-time choice of the wait.
-// What bounds it: the chip-wide L2->LDS fill rate with MFMAs running (~7.5 TB/s = 1 PFLOP/s at this
-// tile's 128 FLOP per filled byte) and the power-limited clock (1.85 GHz inside the loop).
+// What bounds it (tools/fill_bench.hip): not the fill -- LDS-DMA sustains 15 TB/s beside 1.9 PFLOP/s of
+// register-operand MFMAs -- but the LDS -> register leg (the MFMAs wait for their ds_read fragments; a bare loop with the
+// same reads reaches 1.4 PFLOP/s) and the power-limited clock (1.85 GHz inside the loop).
 //
 //   stream of half-tiles (16 KiB each): index m = 4*kt + q, q: 0 = A rows 0-127, 1 = B rows 0-127,
 //   2 = B rows 128-255, 3 = A rows 128-255; ring slot = ((kt & 1) * 4 + q).
