@@ -21,8 +21,15 @@ def install_as_models():
     _sys.modules["models"] = pkg
     for name in ("base_model", "fusion", "transformerblock", "future_prediction", "feature_mapping"):
         _sys.modules[f"models.{name}"] = importlib.import_module(f"afft_amd.models.{name}")
-    if "common" in _sys.modules:
-        for name in ("runner", "mixup", "transforms"):
-            mod = importlib.import_module(f"afft_amd.common.{name}")
-            _sys.modules[f"common.{name}"] = mod
-            setattr(_sys.modules["common"], name, mod)
+    # common.{runner,mixup,transforms}: registered unconditionally.  When the reference's own `common` package is (or will be)
+    # importable its other modules (utils, scheduler, sampler, ...) must keep resolving, so only the three mirrored
+    # sub-modules are overridden; without it, this package's `afft_amd.common` stands in as `common`.
+    try:
+        common = importlib.import_module("common")
+    except ImportError:
+        common = importlib.import_module("afft_amd.common")
+        _sys.modules["common"] = common
+    for name in ("runner", "mixup", "transforms"):
+        mod = importlib.import_module(f"afft_amd.common.{name}")
+        _sys.modules[f"common.{name}"] = mod
+        setattr(common, name, mod)

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AFFT_LIB") or os.path.join(_HERE, "lib", "libafft_hip.so")   # AFFT_LIB: kernel-tuning builds
 
 F32, BF16 = 0, 1
+GEMM_WS_HEADER = 4096
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_DGELU_ERF, ACT_DGELU_TANH, ACT_RELU, ACT_SIGMOID_GATE = 0, 1, 2, 3, 4, 5, 6
 MASK_NONE, MASK_DIAG, MASK_CAUSAL, MASK_BLOCKCAUSAL = 0, 1, 2, 3
 
@@ -38,6 +39,9 @@ class GemmDesc(C.Structure):
         ("out", vp), ("ldo", i64), ("out_dtype", i32),
         ("out2", vp), ("ldo2", i64), ("out2_dtype", i32),
         ("drop", Dropout),
+        ("workspace", vp), ("workspace_bytes", i64),
+        ("max_workgroups", i32),
+        ("split3", i32), ("a_lo", i64), ("b_lo", i64),
     ]
 
 
@@ -48,6 +52,8 @@ _SIGS = {
     "afft_set_gemm_splitk": ([C.c_int], C.c_int),
     "afft_gemm_variant_for": ([C.c_int, C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
     "afft_gemm_splitk_for": ([C.c_int, C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
+    "afft_gemm_workspace_bytes": ([C.c_int, C.c_int, C.c_int, C.c_int, C.c_int], i64),
+    "afft_split_bf16": ([vp, i64, i32, i32, vp, i64, i32, i64, vp], C.c_int),
     "afft_layernorm_fwd": ([vp, i64, vp, vp, f32, i32, i32, vp, i64, i32, vp, vp, vp], C.c_int),
     "afft_layernorm_bwd_nparts": ([i32], C.c_int),
     "afft_layernorm_bwd": ([vp, i64, i32, vp, i64, vp, vp, vp, i32, i32, vp, vp, i64, vp, C.POINTER(Dropout), vp, vp, i32,

@@ -202,15 +202,9 @@ int launch_fwd(dim3 grid, hipStream_t stream, const void* q, int64_t ldq, const 
                float* probs) {
   constexpr size_t lds = sizeof(float) * LM * (LM + 1);
   auto kern = attn_fwd_kernel<T, LM>;
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      afft_set_error("attention_fwd: cannot reserve %zu bytes of LDS", lds);
-      (void)hipGetLastError();
-      return 2;
-    }
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (lds > 48 * 1024)
+    if (int rc = afft_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, &attr_done)) return rc;
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv, L, H, hd, scale,
                      mask, period, dp.thresh, dp.key, dp.inv_keep, dp.salt, (T*)out, ldo, probs);
   return 0;
@@ -221,15 +215,9 @@ int launch_bwd(dim3 grid, hipStream_t stream, const void* dout, int64_t lddo, co
                const DropParams& dp, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv) {
   constexpr size_t lds = sizeof(float) * 2 * LM * (LM + 1);
   auto kern = attn_bwd_kernel<T, LM>;
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      afft_set_error("attention_bwd: cannot reserve %zu bytes of LDS", lds);
-      (void)hipGetLastError();
-      return 2;
-    }
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (lds > 48 * 1024)
+    if (int rc = afft_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, &attr_done)) return rc;
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)dout, lddo, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
                      probs, L, H, hd, scale, dp.thresh, dp.key, dp.inv_keep, dp.salt, (T*)dq, lddq, (T*)dk, lddk, (T*)dv, lddv);
   return 0;

@@ -436,12 +436,8 @@ int afft_attention_mfma(bool backward, const void* dout, int64_t lddo, const voi
   const dim3 grid(groups * H), block(256);
 #define AFFT_ATTN_LAUNCH(KERN)                                                                              \
   do {                                                                                                      \
-    static bool attr = false;                                                                               \
-    if (!attr) {                                                                                            \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              160 * 1024) != hipSuccess) { (void)hipGetLastError(); return -1; }             \
-      attr = true;                                                                                          \
-    }                                                                                                       \
+    static std::atomic<uint64_t> attr_done{0};                                                              \
+    if (afft_ensure_dynamic_lds(reinterpret_cast<const void*>(KERN), 160 * 1024, &attr_done)) return -1;    \
     hipLaunchKernelGGL(KERN, grid, block, lds, stream, a);                                                  \
   } while (0)
   if (!backward) {

@@ -25,6 +25,11 @@ void afft_set_error(const char* fmt, ...);
     }                                    \
   } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device), from any host thread.  `done` is the
+// call site's own bit set (one bit per device ordinal); the attribute is a property of the function on a device.
+#include <atomic>
+int afft_ensure_dynamic_lds(const void* kern, size_t bytes, std::atomic<uint64_t>* done);
+
 #define AFFT_LAUNCH_CHECK()                                                     \
   do {                                                                          \
     hipError_t e_ = hipGetLastError();                                          \

@@ -14,6 +14,23 @@ void afft_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* afft_last_error(void) { return g_err; }
+
+#include <mutex>
+int afft_ensure_dynamic_lds(const void* kern, size_t bytes, std::atomic<uint64_t>* done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+  const uint64_t bit = dev < 64 ? (1ull << dev) : 0;     // devices >= 64: set the attribute on every launch
+  if (bit && (done->load(std::memory_order_acquire) & bit)) return 0;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+    afft_set_error("afft: cannot reserve %zu bytes of dynamic LDS on device %d", bytes, dev);
+    (void)hipGetLastError();
+    return 2;
+  }
+  done->fetch_or(bit, std::memory_order_release);
+  return 0;
+}
 extern "C" int afft_version(void) { return 1; }
 
 namespace {
@@ -63,6 +80,31 @@ __global__ __launch_bounds__(256) void cast_rows4_kernel(const float* __restrict
       for (int k = 0; k < 4; ++k) v[k] *= rs * drop_elem_scale(drop, (unsigned)r * (unsigned)cols + (unsigned)(c + k));
     }
     store4(dst, (int64_t)r * ldd + c, dst_dtype, v);
+  }
+}
+
+// two-plane bf16 split x = hi + lo of an fp32 matrix (bf16x3 GEMM operands), zero-filled out to [rows_pad, ldd];
+// 8 columns per thread: two 16-byte loads when the source allows, one 16-byte store per plane
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ src, int64_t lds_, int rows, int cols,
+                                                         bf16_t* __restrict__ hi, int64_t ldd, int rows_pad,
+                                                         int64_t plane_stride, int src_vec) {
+  const int nq = (int)(ldd >> 3);
+  const int64_t total = (int64_t)rows_pad * nq;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / nq), c = (int)(i - (int64_t)r * nq) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r < rows) {
+      const float* p = src + (int64_t)r * lds_ + c;
+      if (src_vec && c + 7 < cols) load8(p, 0, AFFT_F32, v);
+      else
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (c + k < cols) v[k] = p[k];
+    }
+    float h[8], l[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { h[k] = bf2f(f2bf(v[k])); l[k] = v[k] - h[k]; }
+    store8(hi, (int64_t)r * ldd + c, AFFT_BF16, h);
+    store8(hi + plane_stride, (int64_t)r * ldd + c, AFFT_BF16, l);
   }
 }
 
@@ -206,6 +248,23 @@ extern "C" int afft_cast(const float* src, int64_t lds_, int32_t rows, int32_t c
   dim3 grid((pad_cols + 63) / 64, (rows + 63) / 64);
   hipLaunchKernelGGL(cast_kernel, grid, dim3(256), 0, stream, src, lds_, rows, cols, dst, ldd, dst_dtype, dst_t, ldt,
                      pad_cols, make_drop(drop));
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int afft_split_bf16(const float* src, int64_t lds_, int32_t rows, int32_t cols, void* hi, int64_t ldd,
+                               int32_t rows_pad, int64_t plane_stride, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(src && hi, "split_bf16: null pointer");
+  AFFT_CHECK(rows >= 0 && cols >= 0 && rows_pad >= rows && ldd >= cols, "split_bf16: bad sizes");
+  AFFT_CHECK(ldd % 8 == 0 && plane_stride % 8 == 0 && (((uintptr_t)hi) & 15) == 0, "split_bf16: planes must be 16-byte aligned with ldd %% 8 == 0");
+  AFFT_CHECK(plane_stride >= (int64_t)rows_pad * ldd, "split_bf16: planes overlap");
+  if (rows_pad == 0 || ldd == 0) return 0;
+  const int src_vec = lds_ % 4 == 0 && (((uintptr_t)src) & 15) == 0;
+  int64_t blocks = ((int64_t)rows_pad * (ldd / 8) + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(split_bf16_kernel, dim3((int)blocks), dim3(256), 0, stream, src, lds_, rows, cols, (bf16_t*)hi, ldd,
+                     rows_pad, plane_stride, src_vec);
   AFFT_LAUNCH_CHECK();
   return 0;
 }

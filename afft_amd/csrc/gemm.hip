@@ -26,12 +26,12 @@
 
 using namespace afft_gemm_detail;
 
-int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream);
+int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream, int x3, int max_wg);
 int afft_gemm_launch_w4(int a_ks, int b_ks, int reg_staged, afft_gemm_detail::GemmFast& g, hipStream_t stream);
 
 namespace {
 
-template <int WM, int WN, int STAGES, bool A_KS, bool B_KS, bool SPLITK>
+template <int WM, int WN, int STAGES, bool A_KS, bool B_KS, bool SPLITK, bool X3 = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf16_kernel(const GemmFast g) {
   constexpr int NW = WM * WN;
   constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf1
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WN, wc = wave % WN;
   int tm, tn;
-  tile_coords(g.tiles_m, g.tiles_n, tm, tn);
+  tile_coords(g.tiles_m, g.tiles_n, blockIdx.x, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int M = g.e.M, N = g.e.N;
 
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf1
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = g.K / BK / g.splitk;          // K-steps of this slice
-  const int kbase = blockIdx.y * nk * BK;      // split-K: slice z = blockIdx.y
+  const int ktbase = blockIdx.y * nk;          // split-K: slice z = blockIdx.y
   static_assert(BM == 128 && BN == 128, "staging helpers assume 128-row / 128-column operand tiles");
   const unsigned lds0 = lds_addr(smem);
   const unsigned lda2 = (unsigned)(g.lda * 2), ldb2 = (unsigned)(g.ldb * 2);
@@ -64,10 +64,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf1
   auto stage = [&](int kt) {
     const unsigned a = lds0 + (kt % STAGES) * STAGE_BYTES;
     const unsigned b = a + A_BYTES;
-    if constexpr (A_KS) stage_ks<NW, 16 / NW>(g.A, g.lda, lda2, voffA, lo, m0, kbase + kt * BK, a, wave);
-    else stage_kc<NW, 16 / NW>(g.A, g.lda, lda2, voffA, lo, m0, M, kbase + kt * BK, a, wave);
-    if constexpr (B_KS) stage_ks<NW, 16 / NW>(g.B, g.ldb, ldb2, voffB, lo, n0, kbase + kt * BK, b, wave);
-    else stage_kc<NW, 16 / NW>(g.B, g.ldb, ldb2, voffB, lo, n0, N, kbase + kt * BK, b, wave);
+    int k0; const bf16_t *Ap, *Bp;
+    seg_operands<X3>(g, ktbase + kt, k0, Ap, Bp);
+    if constexpr (A_KS) stage_ks<NW, 16 / NW>(Ap, g.lda, lda2, voffA, lo, m0, k0, a, wave);
+    else stage_kc<NW, 16 / NW>(Ap, g.lda, lda2, voffA, lo, m0, M, k0, a, wave);
+    if constexpr (B_KS) stage_ks<NW, 16 / NW>(Bp, g.ldb, ldb2, voffB, lo, n0, k0, b, wave);
+    else stage_kc<NW, 16 / NW>(Bp, g.ldb, ldb2, voffB, lo, n0, N, k0, b, wave);
   };
   // wait until all but the `ahead` most recently issued tiles of this wave have landed, then rendezvous
   auto wait_tiles_then_barrier = [&](int ahead) {
@@ -211,57 +213,22 @@ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 int g_splitk_mode = 1;   // 0 off, 1 auto, 2 / 4: force that many slices wherever the shape allows (tests, tuning)
 int g_pp_split_min_nk = [] { const char* e = getenv("AFFT_PP_SPLIT_MIN_NK"); return e ? atoi(e) : (1 << 30); }();
 
-// Split-K workspace: per stream (two streams may run small GEMMs at the same time), grown on demand, never freed.
-struct SplitWs { float* ws = nullptr; size_t bytes = 0; int* counters = nullptr; };
-constexpr int kMaxSplitTiles = 1024;
-std::mutex g_ws_mu;
-std::unordered_map<hipStream_t, SplitWs> g_ws;
-
-int splitk_workspace(hipStream_t stream, size_t bytes, GemmFast& g) {
-  std::lock_guard<std::mutex> lk(g_ws_mu);
-  SplitWs& w = g_ws[stream];
-  if (!w.counters) {
-    if (hipMalloc((void**)&w.counters, kMaxSplitTiles * sizeof(int)) != hipSuccess ||
-        hipMemset(w.counters, 0, kMaxSplitTiles * sizeof(int)) != hipSuccess) {
-      afft_set_error("afft_gemm: split-K counter allocation failed");
-      (void)hipGetLastError();
-      return 2;
-    }
-  }
-  if (w.bytes < bytes) {
-    // a launch still using the old buffer may be in flight on this stream: drain it before the buffer goes away
-    if (w.ws) { (void)hipStreamSynchronize(stream); (void)hipFree(w.ws); w.ws = nullptr; w.bytes = 0; }
-    if (hipMalloc((void**)&w.ws, bytes) != hipSuccess) {
-      afft_set_error("afft_gemm: split-K workspace allocation (%zu bytes) failed", bytes);
-      (void)hipGetLastError();
-      return 2;
-    }
-    w.bytes = bytes;
-  }
-  g.ws = w.ws;
-  g.counters = w.counters;
-  return 0;
-}
+// Split-K workspace: provided by the caller per launch (afft_gemm_t.workspace, private to the stream): AFFT_GEMM_WS_HEADER
+// bytes of arrival counters (zero between launches) followed by the fp32 partial tiles.  Nothing is allocated here.
+constexpr int kMaxSplitTiles = AFFT_GEMM_WS_HEADER / (int)sizeof(int);
 
 int g_variant = 0;  // 0 auto, 1 = 128x128 tile, 2 = 256x128 tile, 3 = 256x256 ping-pong (tuning / tests)
 
-template <int WM, int WN, int STAGES, bool A_KS, bool B_KS, bool SPLITK>
+template <int WM, int WN, int STAGES, bool A_KS, bool B_KS, bool SPLITK, bool X3 = false>
 int launch_fast(GemmFast& g, hipStream_t stream) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr size_t ring = (size_t)STAGES * (BM + BN) * BK * 2, epi = (size_t)BM * (BN * 4 + 16);
   constexpr size_t lds = ring > epi ? ring : epi;
   g.tiles_m = (g.e.M + BM - 1) / BM;
   g.tiles_n = (g.e.N + BN - 1) / BN;
-  auto kern = gemm_bf16_kernel<WM, WN, STAGES, A_KS, B_KS, SPLITK>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      afft_set_error("afft_gemm: cannot reserve %zu bytes of LDS", lds);
-      (void)hipGetLastError();
-      return 2;
-    }
-    attr_set = true;
-  }
+  auto kern = gemm_bf16_kernel<WM, WN, STAGES, A_KS, B_KS, SPLITK, X3>;
+  static std::atomic<uint64_t> attr_done{0};
+  if (int rc = afft_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, &attr_done)) return rc;
   hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.splitk), dim3(64 * WM * WN), lds, stream, g);
   AFFT_LAUNCH_CHECK();
   return 0;
@@ -295,21 +262,33 @@ int choose_splitk(int variant, int M, int N, int K) {
   return (s > 1 && t1 <= kMaxSplitTiles) ? s : 1;
 }
 
+// bytes of partial tiles (without the counter header) split-K needs for this problem; 0 = it does not split
+int64_t splitk_bytes(int variant, int M, int N, int K, int* slices) {
+  const int s = variant >= 4 ? 1 : choose_splitk(variant, M, N, K);
+  if (slices) *slices = s;
+  if (s <= 1) return 0;
+  const int64_t tiles = variant == 3 ? (int64_t)((M + 255) / 256) * ((N + 255) / 256) : (int64_t)((M + 127) / 128) * ((N + 127) / 128);
+  return tiles * s * (variant == 3 ? 256 * 256 : 128 * 128) * (int64_t)sizeof(float);
+}
+
 template <bool A_KS, bool B_KS>
-int launch_layout(GemmFast& g, hipStream_t stream) {
+int launch_layout(GemmFast& g, hipStream_t stream, const afft_gemm_t* d) {
   const int variant = choose_variant(g.e.M, g.e.N, g.K, A_KS, B_KS);
   g.splitk = 1;
   g.ws = nullptr;
   g.counters = nullptr;
-  const int s = variant >= 4 ? 1 : choose_splitk(variant, g.e.M, g.e.N, g.K);
-  if (s > 1) {
-    const int64_t tiles = variant == 3 ? (int64_t)((g.e.M + 255) / 256) * ((g.e.N + 255) / 256)
-                                       : (int64_t)((g.e.M + 127) / 128) * ((g.e.N + 127) / 128);
-    const size_t tile_bytes = (variant == 3 ? 256 * 256 : 128 * 128) * sizeof(float);
-    if (int rc = splitk_workspace(stream, (size_t)tiles * s * tile_bytes, g)) return rc;
+  if (d->split3) {     // bf16x3: 256x256 tiles once the grid fills the chip, else 128x128; no split-K
+    if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream, 1, 0);
+    return launch_fast<2, 2, 2, A_KS, B_KS, false, true>(g, stream);
+  }
+  int s = 1;
+  const int64_t need = splitk_bytes(variant, g.e.M, g.e.N, g.K, &s);
+  if (s > 1 && d->workspace && d->workspace_bytes >= need + AFFT_GEMM_WS_HEADER) {   // else: run unsplit
+    g.counters = (int*)d->workspace;
+    g.ws = (float*)((char*)d->workspace + AFFT_GEMM_WS_HEADER);
     g.splitk = s;
   }
-  if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream);
+  if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream, 0, d->max_workgroups);
   if (variant == 4) return launch_fast<2, 2, 4, A_KS, B_KS, false>(g, stream);
   if (variant == 5 || variant == 6) return afft_gemm_launch_w4(A_KS, B_KS, variant == 6, g, stream);
   if (g.splitk > 1) return launch_fast<2, 2, 2, A_KS, B_KS, true>(g, stream);
@@ -331,6 +310,12 @@ int choose_variant(int M, int N, int K, bool A_KS, bool B_KS) {
 
 extern "C" int afft_gemm_variant_for(int M, int N, int K, int a_kstrided, int b_kstrided) {
   return choose_variant(M, N, K, a_kstrided != 0, b_kstrided != 0);
+}
+
+extern "C" int64_t afft_gemm_workspace_bytes(int M, int N, int K, int a_kstrided, int b_kstrided) {
+  const int v = choose_variant(M, N, K, a_kstrided != 0, b_kstrided != 0);
+  const int64_t b = splitk_bytes(v, M, N, K, nullptr);
+  return b ? b + AFFT_GEMM_WS_HEADER : 0;
 }
 
 extern "C" int afft_gemm_splitk_for(int M, int N, int K, int a_kstrided, int b_kstrided) {
@@ -391,16 +376,19 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
   fast = fast && (a_kc || a_ks) && (b_kc || b_ks) && lda % 8 == 0 && ldb % 8 == 0 && lda >= 8 && ldb >= 8;
   fast = fast && !(a_ks && !a_kc && b_kc && !b_ks);   // (A k-strided, B k-contiguous) does not occur on the path
 
+  AFFT_CHECK(!d->split3 || fast, "afft_gemm: split3 needs bf16 planes in a fast-path layout (K %% 64 == 0, 16-byte aligned rows)");
   if (fast) {
     GemmFast g;
     g.A = (const bf16_t*)d->A; g.B = (const bf16_t*)d->B;
     g.lda = lda; g.ldb = ldb;
-    g.K = d->K;
+    g.K = d->split3 ? 3 * d->K : d->K;
+    g.nk_seg = d->K / BK;
+    g.a_lo = d->a_lo; g.b_lo = d->b_lo;
     g.e = e;
     const bool A_KS = !a_kc, B_KS = !b_kc;
-    if (!A_KS && !B_KS) return launch_layout<false, false>(g, stream);
-    if (!A_KS && B_KS) return launch_layout<false, true>(g, stream);
-    return launch_layout<true, true>(g, stream);
+    if (!A_KS && !B_KS) return launch_layout<false, false>(g, stream, d);
+    if (!A_KS && B_KS) return launch_layout<false, true>(g, stream, d);
+    return launch_layout<true, true>(g, stream, d);
   }
   GemmF32 g;
   g.A = d->A; g.a_rs = d->a_rs; g.a_cs = d->a_cs;

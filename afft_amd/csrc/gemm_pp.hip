@@ -51,7 +51,10 @@ unsigned long long* g_pp_stamp = nullptr;
 #define STAMP(var) do { } while (0)
 #endif
 
-template <bool A_KS, bool B_KS, bool SPLITK>
+// X3: bf16x3 operand planes (gemm_tiles.h: seg_operands).  PERSIST: the grid is capped (a multiple of 8 workgroups, one per
+// CU) and every workgroup walks the tiles bid, bid + gridDim.x, ... -- the launch then holds that many CUs and no more,
+// which is how the weight-gradient GEMMs leave the rest of the chip to the data-gradient chain of the other stream.
+template <bool A_KS, bool B_KS, bool SPLITK, bool X3 = false, bool PERSIST = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
 #ifdef AFFT_PP_STAMP
     , unsigned long long* stamp_out
@@ -63,11 +66,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
 #endif
   constexpr int LEAD = AFFT_PP_LEAD;             // half-tiles of look-ahead of the LDS-DMA stream (<= 7)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int gp = wave >> 2, wc = wave & 3;
+  static_assert(!(PERSIST && SPLITK), "a capped grid does not split K");
+  int vb = blockIdx.x;
+  do {    // one pass unless PERSIST
+  int lane_ = lane0;
+  if constexpr (PERSIST) asm volatile("" : "+v"(lane_));   // keep the per-tile address arithmetic from being hoisted out of
+  const int lane = lane_;                                   // the tile loop: its live ranges would span the epilogue (spills)
   int tm, tn;
-  tile_coords(g.tiles_m, g.tiles_n, tm, tn);
+  tile_coords(g.tiles_m, g.tiles_n, vb, tm, tn);
   const int m0 = tm * 256, n0 = tn * 256;
 #ifdef AFFT_PP_SAMETILE   // diagnostic build only: every workgroup stages tile (0,0) -> all L2 hits (results are wrong)
   const int m0l = 0, n0l = 0;
@@ -124,14 +133,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
 #endif
     if ((AFFT_PP_DIAG & 2) && in_loop) return;
     const unsigned dst = lds0 + (((m >> 2) & 1) * 4 + q) * HB;
+    int k0; const bf16_t *Ap, *Bp;
+    seg_operands<X3>(g, kt_lo + kt, k0, Ap, Bp);
     if (q == 0 || q == 3) {
       const int r0 = m0l + (q == 3 ? 128 : 0);
-      if constexpr (A_KS) stage_ks<8, 2>(g.A, g.lda, lda2, voffA, lo, r0, (kt_lo + kt) * BK, dst, wave);
-      else stage_kc<8, 2>(g.A, g.lda, lda2, voffA, lo, r0, M, (kt_lo + kt) * BK, dst, wave);
+      if constexpr (A_KS) stage_ks<8, 2>(Ap, g.lda, lda2, voffA, lo, r0, k0, dst, wave);
+      else stage_kc<8, 2>(Ap, g.lda, lda2, voffA, lo, r0, M, k0, dst, wave);
     } else {
       const int c0 = n0l + (q == 2 ? 128 : 0);
-      if constexpr (B_KS) stage_ks<8, 2>(g.B, g.ldb, ldb2, voffB, lo, c0, (kt_lo + kt) * BK, dst, wave);
-      else stage_kc<8, 2>(g.B, g.ldb, ldb2, voffB, lo, c0, N, (kt_lo + kt) * BK, dst, wave);
+      if constexpr (B_KS) stage_ks<8, 2>(Bp, g.ldb, ldb2, voffB, lo, c0, k0, dst, wave);
+      else stage_kc<8, 2>(Bp, g.ldb, ldb2, voffB, lo, c0, N, k0, dst, wave);
     }
   };
   auto load_a = [&](int kt, int ih) {
@@ -284,27 +295,26 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   });
+  if constexpr (!PERSIST) break;
+  vb += gridDim.x;
+  __builtin_amdgcn_s_barrier();   // the epilogue image has been read back everywhere before the next tile's LDS-DMA lands
+  } while (vb < g.tiles_m * g.tiles_n);
 }
 
-template <bool A_KS, bool B_KS, bool SPLITK>
-int launch_pp(GemmFast& g, hipStream_t stream) {
+template <bool A_KS, bool B_KS, bool SPLITK, bool X3 = false, bool PERSIST = false>
+int launch_pp(GemmFast& g, hipStream_t stream, int grid_cap = 0) {
   constexpr size_t lds = 128 * 1040;          // ring: 2 K-tiles x 4 half-tiles x 16 KiB = 128 KiB; epilogue image: 130 KiB
   g.tiles_m = (g.e.M + 255) / 256;
   g.tiles_n = (g.e.N + 255) / 256;
-  auto kern = gemm_bf16_pp_kernel<A_KS, B_KS, SPLITK>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      afft_set_error("afft_gemm: cannot reserve %zu bytes of LDS", lds);
-      (void)hipGetLastError();
-      return 2;
-    }
-    attr_set = true;
-  }
+  auto kern = gemm_bf16_pp_kernel<A_KS, B_KS, SPLITK, X3, PERSIST>;
+  static std::atomic<uint64_t> attr_done{0};
+  if (int rc = afft_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, &attr_done)) return rc;
+  int grid = g.tiles_m * g.tiles_n;
+  if (PERSIST) grid = grid_cap;     // a multiple of 8, < tiles (afft_gemm_launch_pp)
 #ifdef AFFT_PP_STAMP
-  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.splitk), dim3(512), lds, stream, g, g_pp_stamp);
+  hipLaunchKernelGGL(kern, dim3(grid, g.splitk), dim3(512), lds, stream, g, g_pp_stamp);
 #else
-  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.splitk), dim3(512), lds, stream, g);
+  hipLaunchKernelGGL(kern, dim3(grid, g.splitk), dim3(512), lds, stream, g);
 #endif
   AFFT_LAUNCH_CHECK();
   return 0;
@@ -317,10 +327,21 @@ int launch_pp(GemmFast& g, hipStream_t stream) {
 extern "C" void afft_debug_pp_stamp(void* p) { g_pp_stamp = (unsigned long long*)p; }
 #endif
 
-int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream) {
+int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream, int x3, int max_wg) {
   const bool sk = g.splitk > 1;
+#ifndef AFFT_PP_NT_ONLY   // development switch: build only the plain NT instantiation (compile time)
+  if (x3) {    // bf16x3 operand planes; never combined with split-K or a capped grid
+    if (sk) { afft_set_error("afft_gemm: split3 with split-K"); return 1; }
+    if (!a_ks && !b_ks) return launch_pp<false, false, false, true>(g, stream);
+    if (!a_ks && b_ks) return launch_pp<false, true, false, true>(g, stream);
+    if (a_ks && b_ks) return launch_pp<true, true, false, true>(g, stream);
+  }
+  // capped grid: built for the weight-gradient layout only (the GEMMs that run beside another stream's chain)
+  const int cap = max_wg & ~7, tiles = ((g.e.M + 255) / 256) * ((g.e.N + 255) / 256);
+  if (!x3 && !sk && a_ks && b_ks && cap >= 8 && cap < tiles) return launch_pp<true, true, false, false, true>(g, stream, cap);
+#endif
   if (!a_ks && !b_ks) return sk ? launch_pp<false, false, true>(g, stream) : launch_pp<false, false, false>(g, stream);
-#ifndef AFFT_PP_NT_ONLY   // development switch: build only the NT instantiation (compile time)
+#ifndef AFFT_PP_NT_ONLY
   if (!a_ks && b_ks) return sk ? launch_pp<false, true, true>(g, stream) : launch_pp<false, true, false>(g, stream);
   if (a_ks && b_ks) return sk ? launch_pp<true, true, true>(g, stream) : launch_pp<true, true, false>(g, stream);
 #endif

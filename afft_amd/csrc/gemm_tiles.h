@@ -30,15 +30,33 @@ struct GemmFast {
   int splitk;   // K is cut into `splitk` slices along gridDim.y; 1 = off
   float* ws;    // split-K: fp32 partial tiles [tile][slice][128*128]
   int* counters;  // split-K: arrivals per tile (zero between launches)
+  // bf16x3 (X3 instantiations): K counts the K-tiles of all three segments, nk_seg of them per segment; segment 0 reads
+  // (A hi, B hi), 1 (A lo, B hi), 2 (A hi, B lo); the lo planes sit a_lo / b_lo elements behind A / B
+  int nk_seg;
+  int64_t a_lo, b_lo;
   EpiParams e;
 };
 
-__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int& tm, int& tn) {
+// global K-tile index -> K offset inside the segment and the operand planes of that segment (wave-uniform SALU work)
+template <bool X3>
+__device__ __forceinline__ void seg_operands(const GemmFast& g, int kt, int& k0, const bf16_t*& A, const bf16_t*& B) {
+  A = g.A; B = g.B;
+  if constexpr (X3) {
+    const int s1 = kt >= g.nk_seg, s2 = kt >= 2 * g.nk_seg;
+    kt -= (s1 + s2) * g.nk_seg;
+    if (s1 && !s2) A += g.a_lo;
+    if (s2) B += g.b_lo;
+  }
+  k0 = kt * BK;
+}
+
+// bid: the workgroup's (virtual) index -- blockIdx.x, or blockIdx.x + i * gridDim.x for the i-th tile of a workgroup of a
+// capped grid whose size is a multiple of 8 (the XCD of bid is then the XCD the workgroup really runs on)
+__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int bid, int& tm, int& tn) {
   // XCD-aware remap: workgroups b and b+8 share an XCD (and its L2); give each XCD a contiguous
   // chunk of the tile list, then walk that chunk in GROUP_M-tall column groups so that co-resident
   // tiles share A row-panels and B column-panels in that XCD's L2.
   const int nwg = tiles_m * tiles_n;
-  const int bid = blockIdx.x;
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   const int width = GROUP_M * tiles_n;

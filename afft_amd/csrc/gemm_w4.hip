@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmFast g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   int tm, tn;
-  tile_coords(g.tiles_m, g.tiles_n, tm, tn);
+  tile_coords(g.tiles_m, g.tiles_n, blockIdx.x, tm, tn);
   const int m0 = tm * 256, n0 = tn * 256;
   const int M = g.e.M, N = g.e.N;
   const int nk = g.K / BK;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4r_kernel(const GemmFast g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   int tm, tn;
-  tile_coords(g.tiles_m, g.tiles_n, tm, tn);
+  tile_coords(g.tiles_m, g.tiles_n, blockIdx.x, tm, tn);
   const int m0 = tm * 256, n0 = tn * 256;
   const int M = g.e.M, N = g.e.N;
   const int nk = g.K / BK;
@@ -442,15 +442,8 @@ int launch_w4(GemmFast& g, hipStream_t stream) {
   g.tiles_m = (g.e.M + 255) / 256;
   g.tiles_n = (g.e.N + 255) / 256;
   auto kern = RS ? gemm_bf16_w4r_kernel<A_KS, B_KS> : gemm_bf16_w4_kernel<A_KS, B_KS>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      afft_set_error("afft_gemm: cannot reserve %zu bytes of LDS", lds);
-      (void)hipGetLastError();
-      return 2;
-    }
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (int rc = afft_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, &attr_done)) return rc;
   hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), lds, stream, g);
   AFFT_LAUNCH_CHECK();
   return 0;

@@ -28,7 +28,10 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
   const float* x = logits + (int64_t)row * ldl;
   bool kept = true;
   int64_t lab = -1;
-  if (labels) { lab = labels[row]; kept = lab >= 0; }
+  if (labels) { lab = labels[row]; kept = lab != -1; }
+  // a label outside [-1, C) (torch raises a device-side assert there): nothing out of bounds is read, and the row's loss
+  // and gradient come out NaN so that the total cannot look healthy
+  const bool bad = labels && (lab >= C || lab < -1);
   if (keep) kept = kept && keep[row] != 0;
   if (!kept) {  // uniform per block
     if (dlogits) for (int c = tid; c < ldd; c += 256) st_any(dlogits, (int64_t)row * ldd + c, d_dtype, 0.f);
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
     loss = lse * tsum - tx;
   } else {
     tsum = 1.f;
-    loss = lse - x[lab];
+    loss = bad ? NAN : lse - x[lab];
   }
   if (tid == 0) {
     if (row_loss) row_loss[row] = loss;
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
       if (c < C) {
         const float p = expf(x[c] - m) * inv;
         const float tc = t ? t[c] : (c == lab ? 1.f : 0.f);
-        g = gscale * (p * tsum - tc);
+        g = bad ? NAN : gscale * (p * tsum - tc);
       }
       st_any(dlogits, (int64_t)row * ldd + c, d_dtype, g);
     }

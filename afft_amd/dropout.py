@@ -104,11 +104,10 @@ def elementwise(p: float) -> Optional[Dropout]:
 
 
 def drop_path_standalone(x, p: float):
-    """DropPath applied outside a fused sub-layer: x is (N, ...), one decision per dim-0 sample."""
-    import torch
-    from . import ops
+    """DropPath applied outside a fused sub-layer (the public DropPath module, models/transformerblock.py:96-115): x is
+    (N, ...), one decision per dim-0 sample.  Differentiable: the backward pass replays the same per-sample mask."""
+    from . import functional as F_
     n = x.shape[0]
     x2 = x.reshape(n, -1).float().contiguous()
-    y = torch.empty_like(x2)
-    ops.cast(x2, y, drop=Dropout(0.0, 0, float(p), next_key(), 1))
+    y = F_.ElementDropout.apply(x2, Dropout(0.0, 0, float(p), next_key(), 1))
     return y.view_as(x)

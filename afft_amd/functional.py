@@ -8,6 +8,7 @@ probabilities, losses, master weights and gradients are fp32; GEMM operands are 
 """
 from __future__ import annotations
 
+import threading
 from typing import NamedTuple, List, Optional, Tuple
 
 import torch
@@ -24,11 +25,12 @@ class Act:
     """A GEMM operand/result buffer [rows, width] in the activation dtype. In bf16 mode it is allocated
     [pad64(rows), pad64(width)] with zero tails so it can be the k-contiguous operand of the next GEMM
     (K = pad64(width)) and the k-strided operand of a wgrad GEMM (K = pad64(rows))."""
-    __slots__ = ("buf", "rows", "width")
+    __slots__ = ("buf", "rows", "width", "_split")
 
     def __init__(self, rows: int, width: int, device, dtype=None, like: Optional[Tensor] = None):
         dtype = dtype or rt.act_dtype()
         self.rows, self.width = rows, width
+        self._split = None
         if dtype == torch.bfloat16:
             pr, pw = rt.pad64(rows), rt.pad64(width)
             self.buf = (torch.empty if (pr == rows and pw == width) else torch.zeros)(pr, pw, dtype=dtype, device=device)
@@ -50,16 +52,24 @@ class Act:
     def cols(self, c0: int, c1: int) -> Tensor:
         return self.buf[:self.rows, c0:c1]
 
+    def split(self) -> "ops.Split":
+        """bf16x3 mode: the two-plane bf16 split of this (fp32) buffer, made once and used by every GEMM that reads it
+        (forward / dgrad as the k-contiguous operand, wgrad as the k-strided one)."""
+        if self._split is None:
+            self._split = ops.Split(self.live)
+        return self._split
+
 
 def to_act(x: Tensor, drop=None) -> Act:
     """fp32 [rows, width] (any row stride) -> Act in the activation dtype (a cast kernel in bf16 mode;
     in fp32 mode the tensor is used in place when dense).  drop: optional _lib.Dropout replayed/applied
     element-wise during the copy (backward of an epilogue dropout, or forward dropout of a GEMM input)."""
     rows, width = x.shape
-    if rt.precision() == "fp32" and drop is None:
+    if rt.fp32_acts() and drop is None:
         a = Act.__new__(Act)
         a.rows, a.width = rows, width
         a.buf = x if x.stride(1) == 1 else x.contiguous()
+        a._split = None
         return a
     a = Act(rows, width, x.device)
     ops.cast(x, a.live, drop=drop)
@@ -76,6 +86,8 @@ def _lin_fwd(x: Act, W: Tensor, conv1d: bool, out: Tensor, **ep) -> Tensor:
         if wt16 is not None:                 # W^T [out, in]: "NT"
             return ops.gemm(x.k, wt16[:W.shape[1]], out, b_t=True, **ep)
         return ops.gemm(x.k, w16[:, :W.shape[1]], out, **ep)             # W [in, out] = [K, N]: "NN"
+    if rt.precision() == "bf16x3":
+        return ops.gemm(x.split(), rt.weight_split(W), out, b_t=not conv1d, **ep)
     return ops.gemm(x.live, W, out, b_t=not conv1d, **ep)
 
 
@@ -88,35 +100,78 @@ def _lin_dgrad(dy: Act, W: Tensor, conv1d: bool, out: Tensor, **ep) -> Tensor:
         if wt16 is not None:                 # dx = dy W, W^T [in, out] is B stored [N, K]: "NT"
             return ops.gemm(dy.k, wt16[:W.shape[1]], out, b_t=True, **ep)
         return ops.gemm(dy.k, w16[:, :W.shape[1]], out, **ep)            # W [out, in] = [K, N]: "NN"
+    if rt.precision() == "bf16x3":
+        return ops.gemm(dy.split(), rt.weight_split(W), out, b_t=conv1d, **ep)
     return ops.gemm(dy.live, W, out, b_t=conv1d, **ep)
 
 
-_SIDE_STREAM = None      # the auxiliary stream while a `with _Side(dev):` block is open (set / cleared by _Side)
+class _ThreadState(threading.local):
+    """Everything this module remembers between two calls lives here, per THREAD: a forward pass runs on one thread per
+    device (the main thread; nn.DataParallel's replica threads, test.py:130 of the reference) and a backward pass on the
+    autograd engine's one worker thread per device, and every hand-off below (noting a sub-layer's output and looking it
+    up, emitting a shadow and picking it up, queueing readiness notifications and flushing them, opening and closing a
+    side-stream block) is between two calls made by the same thread for the same device."""
+
+    def __init__(self):
+        self.side_stream = None      # the auxiliary stream while a `with _Side(dev):` block is open
+        self.main_stream = None      # ... and the stream the block was entered from
+        self.join_queued = False     # a join of the auxiliary stream is queued for the end of the running backward
+        self.pending_ready = []      # parameters whose gradient was enqueued by the running Function.backward
+        self.last_out = None         # _Up of the sub-layer that ran last in this thread's forward
+        self.shadow = None           # the hand-over emitted by the LayerNorm backward that ran last in this thread
+        with _ALL_LOCK:     # nn.DataParallel starts fresh replica threads every forward: drop the finished ones
+            _ALL_STATES[:] = [(t, d) for t, d in _ALL_STATES if t.is_alive()]
+            _ALL_STATES.append((threading.current_thread(), self.__dict__))
+
+
+_ALL_LOCK = threading.Lock()
+_ALL_STATES: list = []     # (thread, its state dictionary): flush_ready(all_threads=True) walks them
+_TS = _ThreadState()
 
 
 def _on_side(t: Tensor) -> Tensor:
     """The tensor is about to be read by a kernel on the auxiliary stream: tell the caching allocator, so that its
     memory is not handed out again (to main-stream allocations) before that kernel has run."""
-    if _SIDE_STREAM is not None and t.is_cuda:
+    if _TS.side_stream is not None and t.is_cuda:
         if rt.CAPTURING:
             rt.KEEPALIVE.append(t)
         else:
-            t.record_stream(_SIDE_STREAM)
+            t.record_stream(_TS.side_stream)
     return t
+
+
+def _split_for_side(act: Act):
+    """bf16x3: the operand split of `act` for a GEMM on the auxiliary stream.  A split is cached on the Act and later read
+    by main-stream GEMMs too (the dgrad that follows the side block), so it is always MADE on the main stream; the
+    auxiliary stream then waits for it."""
+    if act._split is None and _TS.side_stream is not None:
+        with torch.cuda.stream(_TS.main_stream):
+            act.split()
+            ev = torch.cuda.Event()
+            ev.record()
+        _TS.side_stream.wait_event(ev)
+    return act.split()
 
 
 def _wgrad(dy: Act, x: Act, W: Tensor, conv1d: bool) -> Optional[Tensor]:
     """dW = dy^T x (nn.Linear) or x^T dy (Conv1D); accumulated into W.grad (sink mode) or returned."""
     a, b = (x, dy) if conv1d else (dy, x)
-    _on_side(a.buf)
-    _on_side(b.buf)
+    if rt.precision() == "bf16x3":
+        at, bt = _split_for_side(a), _split_for_side(b)
+        _on_side(at.planes)
+        _on_side(bt.planes)
+    else:
+        at, bt = a.tn, b.tn
+        _on_side(a.buf)
+        _on_side(b.buf)
+    cap = rt.wgrad_workgroups() if _TS.side_stream is not None else 0
     if rt.grad_mode() == "sink":
         g, acc = rt.SINK.grad_buffer(W)
-        ops.gemm(a.tn, b.tn, g, a_t=True, accumulate=acc)
+        ops.gemm(at, bt, g, a_t=True, accumulate=acc, max_workgroups=cap)
         _ready(W)
         return None
     g = torch.empty_like(W)
-    ops.gemm(a.tn, b.tn, g, a_t=True)
+    ops.gemm(at, bt, g, a_t=True, max_workgroups=cap)
     return g
 
 
@@ -153,21 +208,17 @@ class _Side:
             ev.record()
             st = rt.aux_stream(self.device)
             st.wait_event(ev)
+            _TS.main_stream = torch.cuda.current_stream()
             self.ctx = torch.cuda.stream(st)
             self.ctx.__enter__()
-            global _SIDE_STREAM
-            _SIDE_STREAM = st
+            _TS.side_stream = st
         return self
 
     def __exit__(self, *exc):
         if self.on:
-            global _SIDE_STREAM
-            _SIDE_STREAM = None
+            _TS.side_stream = None
             self.ctx.__exit__(*exc)
         return False
-
-
-_JOIN_QUEUED = False
 
 
 def join_side(device):
@@ -175,19 +226,19 @@ def join_side(device):
     (an autograd-engine callback) -- a per-sub-layer join would stall the dgrad chain behind every weight gradient
     and costs a cross-stream bubble each time.  Autograd mode: right away (the gradients returned to autograd are
     consumed on the current stream)."""
-    global _JOIN_QUEUED
     if not (rt.overlap_wgrad() and device.type == "cuda"):
         return
     main, aux = torch.cuda.current_stream(), rt.aux_stream(device)
     if rt.grad_mode() == "sink":
-        if not _JOIN_QUEUED:
-            def _final(main=main, aux=aux):
-                global _JOIN_QUEUED
-                _JOIN_QUEUED = False
+        if not _TS.join_queued:
+            ts = _TS.__dict__
+
+            def _final(main=main, aux=aux, ts=ts):      # runs on whichever thread ends the backward pass
+                ts["join_queued"] = False
                 main.wait_stream(aux)
             try:
                 torch.autograd.Variable._execution_engine.queue_callback(_final)
-                _JOIN_QUEUED = True
+                _TS.join_queued = True
                 return
             except RuntimeError:      # not inside a backward pass (a Function.backward called by hand)
                 pass
@@ -196,24 +247,29 @@ def join_side(device):
     main.wait_stream(aux)
 
 
-_PENDING_READY: list = []
-
-
 def _ready(p: Tensor):
     """The gradient of p has been enqueued.  Notification is deferred to the end of the running backward
     (flush_ready) so that a consumer -- bucket all-reduce, per-bucket SGD on a side stream -- is ordered after
     every kernel of this backward that still READS the parameter (e.g. the dgrad GEMM reads the weight image the
     optimizer is about to overwrite)."""
     if rt.SINK.on_grad_ready is not None:
-        _PENDING_READY.append(p)
+        _TS.pending_ready.append(p)
 
 
-def flush_ready():
+def flush_ready(all_threads: bool = False):
+    """Deliver the queued notifications of this thread (all_threads: of every thread -- GradReducer.finish_step, after
+    backward() has returned, so no worker is appending any more)."""
     cb = rt.SINK.on_grad_ready
-    if cb is not None:
-        for p in _PENDING_READY:
-            cb(p)
-    _PENDING_READY.clear()
+    if all_threads:
+        with _ALL_LOCK:
+            lists = [d["pending_ready"] for _, d in _ALL_STATES]
+    else:
+        lists = [_TS.pending_ready]
+    for pending in lists:
+        if cb is not None:
+            for p in pending:
+                cb(p)
+        pending.clear()
 
 
 # --------------------------------------------------------------------------- gradient hand-over between sub-layers
@@ -222,7 +278,7 @@ def flush_ready():
 # for my output bias".  The LayerNorm-backward kernel that writes dx can emit both on the way (it has the row in
 # registers), which saves a read of dy, a cast kernel and a column-sum kernel per sub-layer.  Who that upstream
 # sub-layer is, is noted in the forward pass (_note_output / _upstream_of, matched on the tensor the two share); the
-# emitted pieces travel in a single-slot hand-over (_SHADOW) that the upstream backward accepts only for the very
+# emitted pieces travel in a single-slot hand-over (the thread's `shadow`) that the upstream backward accepts only for the very
 # tensor (storage, shape, version counter) it was made from -- anything else (summed gradients, hooks, a different
 # graph) falls back to the separate kernels.
 class _Up(NamedTuple):
@@ -239,11 +295,9 @@ class _Shadow(NamedTuple):
     od: object
     bias: object
     act: Act
-    gbias: object       # autograd mode: the bias gradient tensor; sink mode: None (already accumulated)
-
-
-_LAST_OUT: Optional[_Up] = None
-_SHADOW: Optional[_Shadow] = None
+    gbias: object       # autograd mode: the bias gradient tensor (returned to autograd on acceptance)
+    sink_direct: bool   # sink mode: the kernel wrote the column sums straight into bias.grad as the FIRST touch of the step
+    sink_tmp: object    # sink mode, bias already touched this step: the column sums wait here and are added on acceptance
 
 
 def _same_drop(a, b) -> bool:
@@ -253,57 +307,85 @@ def _same_drop(a, b) -> bool:
 
 
 def _note_output(y: Tensor, od, bias):
-    global _LAST_OUT
-    _LAST_OUT = _Up(y.data_ptr(), tuple(y.shape), od, bias) if rt.precision() == "bf16" else None
+    _TS.last_out = _Up(y.data_ptr(), tuple(y.shape), od, bias) if rt.precision() == "bf16" else None
 
 
 def _upstream_of(x: Tensor) -> Optional[_Up]:
-    u = _LAST_OUT
+    u = _TS.last_out
     if u is not None and u.ptr == x.data_ptr() and u.shape == tuple(x.shape) and rt.handover():
         return u
     return None
 
 
+def _discard(sh: Optional[_Shadow]):
+    """A hand-over nobody accepted: the bias gradient it carries must not count.  Written straight into bias.grad as the
+    first touch of the step -> forget the touch, so that whoever produces the real gradient overwrites it (and
+    GradSink.finish_step zeroes it if nobody does); parked in a scratch vector -> just dropped.  Readiness is only ever
+    notified on acceptance (_accept_bias), so the bucket counts do not depend on which way a hand-over went."""
+    if sh is not None and sh.sink_direct and sh.bias is not None:
+        rt.SINK.touched[id(sh.bias)] = False
+
+
 def _take_shadow(dy: Tensor, od, bias) -> Optional[_Shadow]:
-    global _SHADOW
-    sh, _SHADOW = _SHADOW, None
+    sh, _TS.shadow = _TS.shadow, None
     if (sh is not None and sh.ptr == dy.data_ptr() and sh.shape == tuple(dy.shape) and sh.version == dy._version
             and sh.bias is bias and _same_drop(sh.od, od)):
         return sh
+    _discard(sh)
+    return None
+
+
+def _accept_bias(sh: _Shadow):
+    """The accepted hand-over's output-bias gradient: autograd mode returns the tensor; sink mode commits it now."""
+    if sh.bias is None:
+        return None
+    if rt.grad_mode() != "sink":
+        return sh.gbias
+    if sh.sink_tmp is not None:
+        g, acc = rt.SINK.grad_buffer(sh.bias)
+        _on_side(sh.sink_tmp)
+        if acc:
+            g.add_(sh.sink_tmp)
+        else:
+            g.copy_(sh.sink_tmp)
+    _ready(sh.bias)
     return None
 
 
 def _drop_shadow():
-    global _SHADOW
-    _SHADOW = None
+    sh, _TS.shadow = _TS.shadow, None
+    _discard(sh)
 
 
 def _forget_output():
     """Called by the forward of every op that is not a sub-layer: the next sub-layer has no sub-layer upstream."""
-    global _LAST_OUT
-    _LAST_OUT = None
+    _TS.last_out = None
 
 
 def _ln_bwd(dy: Tensor, x: Tensor, w: Optional[Tensor], b: Optional[Tensor], mean, rstd, dx_in: Optional[Tensor],
             dx_out: Optional[Tensor] = None, up: Optional[_Up] = None):
     """returns (dx, dw, db) with dw/db None in sink mode (accumulated in place).  `up`: the sub-layer that consumes dx
-    (see above); its bf16 operand and bias gradient are emitted by the same kernel and left in _SHADOW."""
-    global _SHADOW
+    (see above); its bf16 operand and bias gradient are emitted by the same kernel and left in this thread's shadow slot."""
     rows, d = x.shape
     if dx_out is None:
         dx_out = torch.empty(rows, d, dtype=torch.float32, device=x.device)
     sink = rt.grad_mode() == "sink"
     extra = {}
     dxa = gbu = None
+    direct, tmp = False, None
     if up is not None and d % 64 == 0 and dx_out.stride(0) == d:
+        _drop_shadow()      # an earlier hand-over that was never picked up
         dxa = Act(rows, d, x.device)
         extra = dict(dx_bf16=dxa.live, copy_drop=up.od)
         if up.bias is not None:
-            if sink:
-                gbu, accu = rt.SINK.grad_buffer(up.bias)
+            # the upstream sub-layer may still turn the hand-over down (autograd summed other gradients into dy, hooks,
+            # another graph): nothing is committed here that _discard cannot take back
+            if sink and up.bias.grad is not None and not rt.SINK.touched.get(id(up.bias), False):
+                gbu, direct = up.bias.grad, True
+                rt.SINK.touched[id(up.bias)] = True
             else:
-                gbu, accu = torch.empty_like(up.bias), False
-            extra.update(dcol=gbu, dcol_accumulate=accu)
+                gbu = tmp = torch.empty_like(up.bias)
+            extra.update(dcol=gbu, dcol_accumulate=False)
     if sink:
         gw = gb = None
         acc_w = acc_b = True
@@ -320,16 +402,14 @@ def _ln_bwd(dy: Tensor, x: Tensor, w: Optional[Tensor], b: Optional[Tensor], mea
             _ready(w)
         if b is not None:
             _ready(b)
-        if gbu is not None:
-            _ready(up.bias)
         gw = gb = None
     else:
         gw = torch.empty_like(w) if w is not None else None
         gb = torch.empty_like(b) if b is not None else None
         ops.layernorm_bwd(dy, x, w, mean, rstd, dx_out, dx_in=dx_in, dw=gw, db=gb, accumulate=False, **extra)
     if dxa is not None:
-        _SHADOW = _Shadow(dx_out.data_ptr(), tuple(dx_out.shape), dx_out._version, up.od, up.bias, dxa,
-                          None if sink else gbu)
+        _TS.shadow = _Shadow(dx_out.data_ptr(), tuple(dx_out.shape), dx_out._version, up.od, up.bias, dxa,
+                          None if sink else gbu, direct, tmp if sink else None)
     return dx_out, gw, gb
 
 
@@ -406,7 +486,7 @@ class AttnSublayer(torch.autograd.Function):
         dya = sh.act if sh is not None else to_act(dy, od)
         with _Side(dev):
             g_wp = _wgrad(dya, ao, w_proj, conv1d)
-            g_bp = sh.gbias if sh is not None else _bgrad(dy if od is None else dya.live, b_proj)
+            g_bp = _accept_bias(sh) if sh is not None else _bgrad(dy if od is None else dya.live, b_proj)
         dao = Act(R, d, dev)
         _lin_dgrad(dya, w_proj, conv1d, dao.live)
         dqkv = Act(R, 3 * d, dev)
@@ -469,7 +549,7 @@ class MLPSublayer(torch.autograd.Function):
         dya = sh.act if sh is not None else to_act(dy, od)
         with _Side(dev):
             g_w2 = _wgrad(dya, h, w2, conv1d)
-            g_b2 = sh.gbias if sh is not None else _bgrad(dy if od is None else dya.live, b2)
+            g_b2 = _accept_bias(sh) if sh is not None else _bgrad(dy if od is None else dya.live, b2)
         du = Act(R, hidden, dev)
         _lin_dgrad(dya, w2, conv1d, du.live, act=_GELU[gelu][1], aux=u.live)
         with _Side(dev):
@@ -541,7 +621,7 @@ class CrossAttnSublayer(torch.autograd.Function):
         dya = sh.act if sh is not None else to_act(dy, od)
         with _Side(dev):
             g_wp = _wgrad(dya, ao, w_proj, False)
-            g_bp = sh.gbias if sh is not None else _bgrad(dy if od is None else dya.live, b_proj)
+            g_bp = _accept_bias(sh) if sh is not None else _bgrad(dy if od is None else dya.live, b_proj)
         dao = Act(R, d, dev)
         _lin_dgrad(dya, w_proj, False, dao.live)
         dq, dk, dv = Act(R, d, dev), Act(R, d, dev), Act(R, d, dev)
@@ -596,7 +676,7 @@ class Linear(torch.autograd.Function):
         dya = to_act(dy)
         with _Side(dy.device):
             g_w = _wgrad(dya, xa, W, False)
-            g_b = _bgrad(dya.live if rt.precision() == "fp32" else dy if dy.stride(1) == 1 else dy.contiguous(), b)
+            g_b = _bgrad(dya.live if rt.fp32_acts() else dy if dy.stride(1) == 1 else dy.contiguous(), b)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(xa.rows, W.shape[1], dtype=torch.float32, device=dy.device)
@@ -827,6 +907,7 @@ class AddRowTable(torch.autograd.Function):
                 g.zero_()
             ops.reduce_rows_periodic(dy, period, g[offset:offset + period])
             _ready(table)
+            flush_ready()
             return dy, None, None, None
         g = torch.zeros_like(table)
         ops.reduce_rows_periodic(dy, period, g[offset:offset + period])

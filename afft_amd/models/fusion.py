@@ -1,12 +1,14 @@
-"""MI355X mirror of the reference's ``models/fusion.py`` for the hot path:
+"""MI355X mirror of the reference's ``models/fusion.py``:
 
   ModalTokenCMFuser         (SA-Fuser with modality token)   <- models/fusion.py:273-365
   TemporalCrossAttentFuser  (CA-Fuser)                       <- models/fusion.py:218-270
+  CMFuser                   (SA-Fuser without the token)     <- models/fusion.py:61-118
+  TemporalCMFuser           (T-SA-Fuser)                     <- models/fusion.py:121-215
+  MATT                      (RULSTM modality attention)      <- models/fusion.py:35-58
 
 Same constructor keywords (the Hydra surface of conf/model/fuser/{SA,CA}-Fuser.yaml), same parameter
 names (checkpoints load unchanged), same return values.  Token assembly, the transformer blocks and the
 final LayerNorm (on token 0 only: the reference normalises all S tokens and keeps one) run in HIP kernels.
-CMFuser / TemporalCMFuser / MATT are "next" rows of SURVEY.md 8(f) and are not provided here.
 """
 from __future__ import annotations
 

@@ -1,8 +1,10 @@
-"""MI355X mirror of the reference's ``models/future_prediction.py`` for the hot path:
+"""MI355X mirror of the reference's ``models/future_prediction.py``:
 
   CrossModalFusionPrediction (helpers)  <- models/future_prediction.py:19-186
+  IndividualFuturePrediction            <- models/future_prediction.py:189-225
   CMFPEarly                             <- models/future_prediction.py:228-291
-  BaseFuturePredictor                   <- models/future_prediction.py:354-415
+  CMFPScoreFusion                       <- models/future_prediction.py:294-351
+  BaseFuturePredictor                   <- models/future_prediction.py:354-415  (incl. the fp_output_len > 1 roll-out)
 
 The reference's temporal predictor is HuggingFace ``transformers.GPT2Model`` (pinned 4.18.0,
 environment.yml:166).  Here the same network is built natively (no ``transformers`` import) with HF's
@@ -10,7 +12,6 @@ parameter names and layouts -- ``gpt_model.wpe.weight``, ``gpt_model.h.{i}.{ln_1
 ``.attn.c_attn/.attn.c_proj/.mlp.c_fc/.mlp.c_proj`` as Conv1D ``[in, out]`` weights, ``gpt_model.ln_f`` --
 so reference checkpoints load by name.  GPT-2 semantics restated from HF modeling_gpt2.py: pre-LN blocks,
 eps 1e-5, c_attn bias, causal softmax scaled by head_dim^-0.5, gelu_new, learned absolute positions.
-IndividualFuturePrediction / CMFPScoreFusion are outside BASELINE's configs.
 """
 from __future__ import annotations
 

@@ -47,25 +47,79 @@ def _rowmajor(t: Tensor, what: str):
     return t.stride(0)
 
 
-def gemm(a: Tensor, b: Tensor, out: Tensor, *, a_t: bool = False, b_t: bool = False, bias: Optional[Tensor] = None,
+_WS: dict = {}      # (device index, raw stream) -> split-K scratch of that stream (afft_gemm_t.workspace), never shared
+_WS_BYTES = 48 << 20   # covers every split-K problem the automatic mode picks (<= 128 tiles x 4 slices x 64 KiB + header)
+
+
+def set_workspace_bytes(n: int):
+    """Size of the per-stream split-K scratch (tests that force split-K on the 256x256 kernel need 3 x 256 KiB per tile).
+    A launch whose problem needs more than it is given simply runs unsplit."""
+    global _WS_BYTES
+    if n != _WS_BYTES:
+        _WS_BYTES = int(n)
+        _WS.clear()
+
+
+def gemm_workspace(device) -> Tensor:
+    """The split-K scratch of the CURRENT stream on `device`: allocated once per stream (counters zeroed once; every
+    launch leaves them zero), owned here so that the library itself never allocates (include/afft_hip.h)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+    ws = _WS.get(key)
+    if ws is None:
+        ws = torch.zeros(_WS_BYTES, dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+class Split(object):
+    """fp32 matrix [rows, cols] as two bf16 planes hi + lo (afft_split_bf16), each [pad64(rows), pad64(cols)] with zero
+    tails: the operand of a bf16x3 GEMM in either role (k-contiguous rows or k-strided columns)."""
+    __slots__ = ("planes", "rows", "cols")
+
+    def __init__(self, x: Tensor):
+        assert x.dtype == torch.float32 and x.dim() == 2
+        rows, cols = x.shape
+        pr, pc = (rows + 63) // 64 * 64, (cols + 63) // 64 * 64
+        self.rows, self.cols = rows, cols
+        self.planes = torch.empty(2, pr, pc, dtype=torch.bfloat16, device=x.device)
+        L.check(L.lib().afft_split_bf16(_p(x), _rowmajor(x, "x"), rows, cols, _p(self.planes), pc, pr, pr * pc, _stream()),
+                "split_bf16")
+
+
+def gemm(a, b, out: Tensor, *, a_t: bool = False, b_t: bool = False, bias: Optional[Tensor] = None,
          act: int = ACT_NONE, aux: Optional[Tensor] = None, pre: Optional[Tensor] = None,
          rowscale: Optional[Tensor] = None, residual: Optional[Tensor] = None, accumulate: bool = False,
-         out2: Optional[Tensor] = None, alpha: float = 1.0, drop: Optional["L.Dropout"] = None) -> Tensor:
-    """out = epilogue(alpha * A @ B).  A = a (or a.T if a_t), B = b (or b.T if b_t); a, b 2-D views."""
-    M, K = (a.shape[1], a.shape[0]) if a_t else (a.shape[0], a.shape[1])
-    Kb, N = (b.shape[1], b.shape[0]) if b_t else (b.shape[0], b.shape[1])
+         out2: Optional[Tensor] = None, alpha: float = 1.0, drop: Optional["L.Dropout"] = None,
+         max_workgroups: int = 0) -> Tensor:
+    """out = epilogue(alpha * A @ B).  A = a (or a.T if a_t), B = b (or b.T if b_t); a, b 2-D views -- or both `Split`
+    (two-plane bf16 splits of fp32 matrices): the bf16x3 GEMM, fp32-accurate products on the bf16 MFMA path."""
+    d = L.GemmDesc()
+    if isinstance(a, Split):
+        if not isinstance(b, Split):
+            raise TypeError("afft_amd.gemm: both operands must be Split for a bf16x3 GEMM")
+        sa, sb = a, b
+        a, b = sa.planes[0], sb.planes[0]
+        M, K = (sa.cols, a.shape[0]) if a_t else (sa.rows, a.shape[1])
+        Kb, N = (b.shape[1], sb.rows) if b_t else (b.shape[0], sb.cols)
+        d.split3, d.a_lo, d.b_lo = 1, a.numel(), b.numel()
+    else:
+        M, K = (a.shape[1], a.shape[0]) if a_t else (a.shape[0], a.shape[1])
+        Kb, N = (b.shape[1], b.shape[0]) if b_t else (b.shape[0], b.shape[1])
     if K != Kb:
         raise ValueError(f"afft_amd.gemm: inner sizes differ ({K} vs {Kb})")
     if a.dtype != b.dtype:
         raise TypeError("afft_amd.gemm: operand dtypes differ")
     if out.shape[0] != M or out.shape[1] != N:
         raise ValueError(f"afft_amd.gemm: out is {tuple(out.shape)}, expected ({M},{N})")
-    d = L.GemmDesc()
     d.M, d.N, d.K, d.dtype = M, N, K, _dt(a)
     d.A = _p(a)
     d.a_rs, d.a_cs = (a.stride(1), a.stride(0)) if a_t else (a.stride(0), a.stride(1))
     d.B = _p(b)
     d.b_rs, d.b_cs = (b.stride(1), b.stride(0)) if b_t else (b.stride(0), b.stride(1))
+    if a.dtype == torch.bfloat16 and not d.split3:
+        ws = gemm_workspace(a.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    d.max_workgroups = max_workgroups
     d.alpha = alpha
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()

@@ -73,6 +73,16 @@ class FlatParams:
                         rt.adopt_weight_image(p, self.flat_p16[o:o + p.numel()].view(p.shape), vt)
         rt.invalidate_weight_images()
 
+    def refresh_images(self):
+        """Re-derive every bf16 image from the fp32 masters (after the masters were written from outside: a parameter
+        broadcast, a checkpoint load into the flat buffer)."""
+        if self.flat_p16 is not None:
+            n = self.total
+            with torch.no_grad():
+                ops.cast(self.flat_p.view(n // 64, 64), self.flat_p16.view(n // 64, 64))
+            self.refresh_transposed(0, n)
+        rt.invalidate_weight_images()
+
     def refresh_transposed(self, s: int, e: int):
         """Re-cast the transposed bf16 images of the weights that live in flat range [s, e)."""
         for o, p, vt in self.transposed:
@@ -165,6 +175,8 @@ class GradReducer:
 
     def finish_step(self):
         """Call after backward: zero untouched grads, hand over whatever is still pending, join the side stream."""
+        from . import functional as F_
+        F_.flush_ready(all_threads=True)       # a notification whose Function did not flush must not leak into the next step's counts
         rt.SINK.on_grad_ready = None
         rt.SINK.finish_step(self.flat.params)
         if not self.comm and self.on_bucket is None:
@@ -237,11 +249,27 @@ class Trainer:
         self.reducer = GradReducer(self.flat, group=group, bucket_elems=bucket_elems, comm_dtype=comm_dtype,
                                    force_comm=force_comm)
         self.opt = FusedSGD(self.flat, lr, momentum, weight_decay)
+        if self.reducer.world > 1:
+            self.sync_parameters(group)
         self.loss_fn = BasicLossAccuracy(compute_metrics=False)
         self._reduce = Runner._reduce_loss
         self.loss_wts = loss_wts
         self.grad_clip = grad_clip     # opt.grad_clip of the reference's config; needs the whole gradient first
         self.overlap_optimizer = overlap_optimizer and self.flat.flat_p.is_cuda and grad_clip is None
+
+    def sync_parameters(self, group=None, src: int = 0):
+        """Every replica starts from rank `src`'s parameters and momentum (what torch DDP does at construction,
+        train.py:364-368): only gradients are exchanged afterwards, so replicas that differ here never meet again --
+        a checkpoint loaded on one rank, an unseeded init.  Refreshes the bf16 weight images from the received values."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        root = dist.get_global_rank(group, src) if group is not None else src
+        dist.broadcast(self.flat.flat_p, src=root, group=group)
+        dist.broadcast(self.opt.buf, src=root, group=group)
+        steps = torch.tensor([self.opt.steps], dtype=torch.int64, device=self.flat.flat_p.device)
+        dist.broadcast(steps, src=root, group=group)
+        self.opt.steps = int(steps)
+        self.flat.refresh_images()
 
     def forward_backward(self, feats: Dict[str, Tensor], target, target_subclips, optimize_in_backward: bool = False):
         self.reducer.on_bucket = self.opt.step_range if optimize_in_backward else None
@@ -285,24 +313,50 @@ class Trainer:
             rt.CAPTURING = False
             rt.KEEPALIVE.clear()
         self._graph = graph
-        self._graph_io = (tuple(id(t) for t in feats.values()), loss, parts)
+        # strong references to every tensor the captured kernels read: the replay reads THESE addresses, so a new batch
+        # (features and labels alike) is copied into them, and they cannot be freed or recycled while the graph lives
+        self._graph_in = (dict(feats), dict(target), dict(target_subclips) if target_subclips is not None else None)
+        self._graph_io = (loss, parts)
         return self
 
     def release_graph(self):
         """back to eager steps (the device salt stays on: eager kernels read it too)"""
         self._graph = None
         self._graph_io = None
+        self._graph_in = None
 
     def _eager_step(self, feats, target, target_subclips):
         from . import dropout as D_
         D_.salt_step()
         return self.forward_backward(feats, target, target_subclips, optimize_in_backward=True)
 
+    def _feed_graph(self, feats, target, target_subclips) -> bool:
+        """Copy a batch into the tensors the captured graph reads (no-op for the captured tensors themselves).  False when
+        the batch does not have the captured structure (keys, shapes, dtypes): the caller then runs an eager step."""
+        cf, ct, cs = self._graph_in
+        pairs = []
+        for cap, new in ((cf, feats), (ct, target), (cs, target_subclips)):
+            if (cap is None) != (new is None):
+                return False
+            if cap is None:
+                continue
+            if cap.keys() != new.keys():
+                return False
+            for k, t in cap.items():
+                n = new[k]
+                if n.shape != t.shape or n.dtype != t.dtype:
+                    return False
+                pairs.append((t, n))
+        for t, n in pairs:
+            if n is not t:
+                t.copy_(n, non_blocking=True)
+        return True
+
     def step(self, feats, target, target_subclips, optimize: bool = True):
         g = getattr(self, "_graph", None)
-        if g is not None and optimize and tuple(id(t) for t in feats.values()) == self._graph_io[0]:
+        if g is not None and optimize and self._feed_graph(feats, target, target_subclips):
             g.replay()
-            return self._graph_io[1], self._graph_io[2]
+            return self._graph_io
         fused = optimize and self.overlap_optimizer
         loss, parts = self.forward_backward(feats, target, target_subclips, optimize_in_backward=fused)
         if optimize and not fused:

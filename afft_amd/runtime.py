@@ -8,6 +8,10 @@ Precision modes
     softmax / losses / master weights / gradients.
   * ``fp32`` (parity mode): every GEMM on the exact-fp32 MFMA path, all activations fp32; this is
     the mode whose logits are checked to 1e-3 against the reference's fp32 CPU path.
+  * ``bf16x3`` (fast parity mode, SURVEY.md 7 hard part 1): activations, residual stream and every non-GEMM kernel
+    as in ``fp32``; each GEMM splits its fp32 operands into two bf16 planes (x = hi + lo) and accumulates
+    hi*hi + lo*hi + hi*lo in ONE launch of the bf16 MFMA kernels (afft_gemm_t.split3): products exact to
+    ~2^-17, logits within the 1e-3 tolerance at roughly a third of the bf16 mode's GEMM rate instead of 1/16.
 """
 from __future__ import annotations
 
@@ -27,8 +31,8 @@ _GRAD_MODE = os.environ.get("AFFT_GRAD_MODE", "sink")  # 'sink' | 'autograd'
 
 def set_precision(p: str):
     global _PRECISION
-    if p not in ("bf16", "fp32"):
-        raise ValueError("precision must be 'bf16' or 'fp32'")
+    if p not in ("bf16", "fp32", "bf16x3"):
+        raise ValueError("precision must be 'bf16', 'fp32' or 'bf16x3'")
     _PRECISION = p
 
 
@@ -38,6 +42,11 @@ def precision() -> str:
 
 def act_dtype() -> torch.dtype:
     return torch.bfloat16 if _PRECISION == "bf16" else torch.float32
+
+
+def fp32_acts() -> bool:
+    """activations are kept in fp32 (the parity modes 'fp32' and 'bf16x3')"""
+    return _PRECISION != "bf16"
 
 
 def set_grad_mode(m: str):
@@ -93,6 +102,21 @@ def weight_images(p: Tensor):
     return img.w, img.wt
 
 
+def weight_split(p: Tensor):
+    """bf16x3 mode: the two-plane bf16 split (ops.Split) of a 2-D fp32 parameter, cached until the parameter changes
+    (version counter / storage) or invalidate_weight_images() is called (the fused SGD kernel writes through raw
+    pointers, so the Trainer invalidates after every step)."""
+    ent = getattr(p, "_afft_split", None)
+    if ent is None or ent[0] != p._version or ent[1] != p.data_ptr():
+        with torch.no_grad():
+            sp = ops.Split(p.detach())
+        if ent is None:
+            _wlist.append(weakref.ref(p))
+        ent = (p._version, p.data_ptr(), sp)
+        p._afft_split = ent
+    return ent[2]
+
+
 _TRANSPOSED_IMAGES = os.environ.get("AFFT_WT_IMAGES", "0") != "0"
 
 
@@ -120,9 +144,14 @@ def invalidate_weight_images(include_external: bool = False):
     alive = []
     for r in _wlist:
         p = r()
-        if p is not None and getattr(p, "_afft_img", None) is not None:
-            if include_external or not p._afft_img.external:
-                p._afft_img.version = -1
+        if p is None:
+            continue
+        img = getattr(p, "_afft_img", None)
+        if img is not None and (include_external or not img.external):
+            img.version = -1
+        if getattr(p, "_afft_split", None) is not None:
+            p._afft_split = None
+        if img is not None or hasattr(p, "_afft_split"):
             alive.append(r)
     _wlist[:] = alive
 
@@ -182,6 +211,21 @@ def overlap_wgrad() -> bool:
 def set_overlap_wgrad(on: bool):
     global _OVERLAP_WGRAD
     _OVERLAP_WGRAD = bool(on)
+
+
+_WGRAD_WGS = int(os.environ.get("AFFT_WGRAD_WGS", "0"))
+
+
+def wgrad_workgroups() -> int:
+    """Cap on the workgroups (= CUs) of a weight-gradient GEMM that runs on the auxiliary stream beside the data-gradient
+    chain (afft_gemm_t.max_workgroups): the chain's 160-tile GEMMs and its HBM-bound kernels then always find free CUs
+    instead of queueing behind 130-us weight-gradient tiles.  0 = no cap (one workgroup per tile)."""
+    return _WGRAD_WGS
+
+
+def set_wgrad_workgroups(n: int):
+    global _WGRAD_WGS
+    _WGRAD_WGS = max(0, int(n))
 
 
 CAPTURING = False          # a hipGraph capture of the step is under way (afft_amd.parallel.Trainer.capture)

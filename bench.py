@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2", help="cfg2 (default) | ek100 | cfg1 | cfg4 | cfg5 | cfg2_cm | cfg2_tsa")
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--comm-dtype", default="bf16", choices=["bf16", "fp32"], help="gradient all-reduce payload")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+loss+bwd(+all-reduce) only")
     ap.add_argument("--eval-drop", action="store_true", help="disable dropout (eval-mode layers) in the timed steps")
@@ -48,7 +48,9 @@ def parse():
     ap.add_argument("--bucket-melems", type=int, default=32, help="gradient bucket size (Mi elements) of the all-reduce / SGD pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-batch", type=int, default=16, help="clips per CPU-baseline step on the bench workload (SURVEY.md 8d: 16)")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the bf16x3 (1e-3-accurate) throughput / error side measurements")
+    ap.add_argument("--wgrad-wgs", type=int, default=None, help="CU cap of the weight-gradient GEMMs on the auxiliary stream (default: runtime's)")
     return ap.parse_args()
 
 
@@ -90,18 +92,30 @@ class GemmTimer:
 
         def timed(a, b, out, **kw):
             a_t, b_t = kw.get("a_t", False), kw.get("b_t", False)
-            M, K = (a.shape[1], a.shape[0]) if a_t else (a.shape[0], a.shape[1])
-            N = b.shape[0] if b_t else b.shape[1]
-            fast = a.dtype == torch.bfloat16 and K % 64 == 0
+            x3 = not torch.is_tensor(a)      # ops.Split operands: the bf16x3 GEMM (algorithmic FLOPs stay 2*M*N*K)
+            if x3:
+                M, K = (a.cols, a.planes.shape[1]) if a_t else (a.rows, a.planes.shape[2])
+                N = b.rows if b_t else b.cols
+            else:
+                M, K = (a.shape[1], a.shape[0]) if a_t else (a.shape[0], a.shape[1])
+                N = b.shape[0] if b_t else b.shape[1]
+            fast = x3 or (a.dtype == torch.bfloat16 and K % 64 == 0)
             a_ks, b_ks = bool(a_t), not bool(b_t)
             if not fast or (a_ks and not b_ks):
                 kind = "gemm_f32_kernel"
+            elif x3:
+                var = _lib.lib().afft_gemm_variant_for(M, N, 3 * K, int(a_ks), int(b_ks))
+                lay = "%s, %s" % ("true" if a_ks else "false", "true" if b_ks else "false")
+                kind = ("gemm_bf16_pp_kernel<%s, false, true, false>" % lay) if var == 3 else \
+                    ("gemm_bf16_kernel<2, 2, 2, %s, false, true>" % lay)
             else:
                 var = _lib.lib().afft_gemm_variant_for(M, N, K, int(a_ks), int(b_ks))
                 sk = "true" if _lib.lib().afft_gemm_splitk_for(M, N, K, int(a_ks), int(b_ks)) > 1 else "false"
                 lay = "%s, %s" % ("true" if a_ks else "false", "true" if b_ks else "false")
-                kind = ("gemm_bf16_pp_kernel<%s, %s>" % (lay, sk)) if var == 3 else \
-                    ("gemm_bf16_kernel<2, 2, 2, %s, %s>" % (lay, sk))
+                capped = var == 3 and a_ks and b_ks and sk == "false" and 8 <= (kw.get("max_workgroups", 0) & ~7) < \
+                    ((M + 255) // 256) * ((N + 255) // 256)
+                kind = ("gemm_bf16_pp_kernel<%s, %s, false, %s>" % (lay, sk, "true" if capped else "false")) if var == 3 else \
+                    ("gemm_bf16_kernel<2, 2, 2, %s, %s, false>" % (lay, sk))
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             r = timer.orig(a, b, out, **kw)
@@ -130,9 +144,8 @@ class GemmTimer:
         return out
 
 
-def cpu_baseline(name, B, steps=2):
-    """The oracle (CPU restatement, proven equal to the reference: tests/test_oracle_golden.py) timed on this
-    host's cores on a bounded sample of the same workload: fwd + loss + bwd, eval-mode math."""
+def _cpu_steps(name, B, steps):
+    """seconds per fwd + loss + bwd step of the oracle on cfg `name` at batch B: 1 warm-up + `steps` timed, median"""
     from oracle import afft_oracle as O
     from afft_amd.config import BASELINE_CONFIGS
     c = BASELINE_CONFIGS[name]
@@ -152,10 +165,69 @@ def cpu_baseline(name, B, steps=2):
         total.backward()
         times.append(time.perf_counter() - t0)
     times = sorted(times[1:])
-    t = times[len(times) // 2]
-    return {"value": round(B / t, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{name} B={B}: 1 warm-up + {steps} timed fwd+loss+bwd steps of oracle/afft_oracle.py (torch fp32 "
-                      f"CPU, {torch.get_num_threads()} threads of {os.cpu_count()} logical cores), median"}
+    return times[len(times) // 2]
+
+
+def cpu_baseline(name, B, steps=3):
+    """The oracle (CPU restatement, proven equal to the reference: tests/test_oracle_golden.py) timed on this host's cores
+    on a bounded sample of the same workload: fwd + loss + bwd, eval-mode math, cfg1 (B = 4) and the bench
+    configuration (B = 16), 1 warm-up + >= 3 timed steps, at the best intra-op thread count of a short sweep on cfg1."""
+    ncpu = os.cpu_count() or 1
+    cands = sorted({t for t in (16, 32, 64, 128, ncpu // 2, ncpu) if 1 <= t <= ncpu}) or [1]
+    sweep = {}
+    for t in cands:
+        torch.set_num_threads(t)
+        sweep[t] = round(4 / _cpu_steps("cfg1", 4, 2), 2)
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    cfg1 = 4 / _cpu_steps("cfg1", 4, steps)
+    t = _cpu_steps(name, B, steps)
+    return {"value": round(B / t, 3), "unit": "clips/s", "cores": best, "kind": "port",
+            "sample": f"{name} B={B}: 1 warm-up + {steps} timed fwd+loss+bwd steps of oracle/afft_oracle.py (torch fp32 CPU, "
+                      f"{best} intra-op threads of {ncpu} logical cores, the best of the sweep), median",
+            "cfg1_B4_clips_s": round(cfg1, 3), "thread_sweep_cfg1_clips_s": {str(k): v for k, v in sweep.items()}}
+
+
+def parity_side_measurements(args, device, feats, tgt, sub, c):
+    """What the precision of the headline number costs, on the record: throughput of the 1e-3-accurate mode
+    (bf16x3: fp32-grade GEMMs from three bf16 MFMA passes) on the same workload and step definition, and the relative L2
+    error of each mode's logits against the exact-fp32 mode (itself within 1e-6 of the oracle: tests/test_model_gpu.py) on
+    8 clips of the same synthetic input, eval mode."""
+    import afft_amd
+    from afft_amd.parallel import Trainer
+    wts = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
+    out = {}
+    small = {m: f[:8].contiguous() for m, f in feats.items()}
+    ts, ss = {"action": tgt["action"][:8].contiguous()}, {"action": sub["action"][:8].contiguous()}
+    logits = {}
+    for mode in ("fp32", "bf16x3", "bf16"):
+        afft_amd.set_precision(mode)
+        model, _ = build_model(args.config, device)
+        model.eval()
+        with torch.no_grad():
+            o, _ = model(small, mixup_fn=None, target=ts, target_subclips=ss, target_subclips_ignore_index=None)
+        logits[mode] = o["logits/action"]["all-fused"].double()
+        if mode == "bf16x3":
+            model.train(not args.eval_drop)
+            tr = Trainer(model, wts, bucket_elems=args.bucket_melems * 1024 * 1024)
+            for _ in range(2):
+                tr.step(feats, tgt, sub)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 5
+            for _ in range(n):
+                tr.step(feats, tgt, sub)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            out["parity_mode"] = {"precision": "bf16x3", "clips_per_s": round(args.batch / dt, 1), "ms_per_step": round(dt * 1e3, 2),
+                                  "steps": n}
+            del tr
+        del model
+        torch.cuda.empty_cache()
+    ref = logits["fp32"]
+    out["logits_rel_l2_vs_exact_fp32_mode"] = {m: float(((logits[m] - ref).norm() / ref.norm()).cpu()) for m in ("bf16", "bf16x3")}
+    afft_amd.set_precision(args.precision)
+    return out
 
 
 def main():
@@ -178,6 +250,8 @@ def main():
     from afft_amd.parallel import Trainer
     afft_amd.set_precision(args.precision)
     afft_amd.set_grad_mode("sink")
+    if args.wgrad_wgs is not None:
+        afft_amd.runtime.set_wgrad_workgroups(args.wgrad_wgs)
     D_.manual_seed(42 + rank)
 
     model, c = build_model(args.config, device)
@@ -227,7 +301,8 @@ def main():
                                f"{'+allreduce' if world > 1 else ''}{'' if args.no_optimizer else '+nesterov-sgd'}",
                    "per_gpu_batch": B, "global_batch": B * world, "seq_len": T,
                    "parallelism": f"dp{world}", "grad_comm_dtype": args.comm_dtype if world > 1 else None,
-                   "step_launch": "hipGraph replay" if captured else "eager, 3 streams"},
+                   "step_launch": "hipGraph replay" if captured else "eager, 3 streams",
+                   "wgrad_cu_cap": afft_amd.runtime.wgrad_workgroups() or None},
         "algorithmic_gflop_per_clip": round(gf, 2),
         "model_tflops": round(clips_s * gf / 1e3, 1),
         "mfma_frac_whole_step": round(clips_s * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
@@ -247,16 +322,17 @@ def main():
         model.eval()
         lat = []
         with torch.no_grad():
-            for i in range(25):
+            for i in range(110):
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 model(feats, mixup_fn=None, target=tgt, target_subclips=sub, target_subclips_ignore_index=None)
                 e.record()
                 torch.cuda.synchronize()
-                if i >= 5:
+                if i >= 10:
                     lat.append(s.elapsed_time(e))
         lat.sort()
         result["fwd_p50_ms"] = round(lat[len(lat) // 2], 3)
+        result["fwd_p50_samples"] = len(lat)
         model.train(not args.eval_drop)
 
         if summ is not None:
@@ -289,6 +365,11 @@ def main():
                                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else None}
                               for k, v in summ.items()},
             }
+        if not args.no_parity_mode and world == 1 and args.precision == "bf16":
+            try:
+                result.update(parity_side_measurements(args, device, feats, tgt, sub, c))
+            except Exception as ex:  # noqa: BLE001
+                result["parity_mode"] = {"error": repr(ex)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 result["cpu_baseline"] = cpu_baseline(args.config, args.cpu_batch)

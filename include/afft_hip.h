@@ -7,8 +7,12 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocator); the library
- *     never allocates, frees or retains them; `stream` is a hipStream_t passed as void*;
+ *     never allocates, frees or retains device memory (scratch space is passed in: afft_gemm_t.workspace,
+ *     the `partial` argument of afft_layernorm_bwd, the workspaces of the composite entry points);
+ *     `stream` is a hipStream_t passed as void*;
  *   - no entry point synchronises the host; all work is enqueued on `stream`;
+ *   - entry points may be called from several host threads and for several devices at once (the device is
+ *     the calling thread's current HIP device); a workspace must not be shared by two streams;
  *   - return value 0 = success; non-zero = error, text via afft_last_error() (thread-local);
  *   - matrices are row-major with explicit element strides; dtype codes below.
  */
@@ -70,7 +74,23 @@ typedef struct {
   void* out; int64_t ldo; int32_t out_dtype;
   void* out2; int64_t ldo2; int32_t out2_dtype;        /* optional second copy */
   afft_dropout_t drop;               /* dropout / DropPath on the output (train mode), p = 0 -> off */
+  /* Split-K scratch, owned by the caller, private to `stream`: AFFT_GEMM_WS_HEADER bytes of counters (zeroed ONCE by the
+   * caller before the first use; every launch leaves them zero) followed by fp32 partial tiles.  NULL or smaller than
+   * afft_gemm_workspace_bytes() for the problem: the launch simply runs without split-K. */
+  void* workspace; int64_t workspace_bytes;
+  /* > 0: at most this many workgroups (rounded down to a multiple of 8, one per CU) walk the tiles of a 256x256-tile
+   * launch, i.e. the launch occupies at most that many CUs and leaves the others to kernels of other streams
+   * (the weight-gradient GEMMs beside the data-gradient chain, afft_amd/functional.py).  0 = one workgroup per tile. */
+  int32_t max_workgroups;
+  /* "bf16x3": fp32-accurate products from bf16 MFMAs.  A and B each point at the HI plane of a two-plane split
+   * x = hi + lo (afft_split_bf16: hi = bf16(x), lo = bf16(x - hi)); the lo plane sits a_lo / b_lo ELEMENTS behind it.
+   * The kernel accumulates A_hi*B_hi + A_lo*B_hi + A_hi*B_lo in one pass over a 3x longer K (fp32 accumulate):
+   * products exact to ~2^-17 relative, the precision mode whose logits meet the 1e-3 tolerance at MFMA speed. */
+  int32_t split3; int64_t a_lo, b_lo;
 } afft_gemm_t;
+enum { AFFT_GEMM_WS_HEADER = 4096 };
+/* bytes of afft_gemm_t.workspace that let this problem use split-K under the current mode (0 = it would not split) */
+int64_t afft_gemm_workspace_bytes(int M, int N, int K, int a_kstrided, int b_kstrided);
 int afft_gemm(const afft_gemm_t* g, void* stream);
 /* Tuning / test hook: force the bf16 kernel (0 = auto, 1 = 128x128x64 2-stage, 3 = 256x256x64 ping-pong, 4 = 128x128x64 4-stage,
  * 5 / 6 = experimental 256x256x64 four-wave kernels with LDS-DMA / register-staged operands). */
@@ -130,7 +150,9 @@ int afft_attention_bwd(const void* dout, int64_t lddo, const void* q, int64_t ld
 
 /* ------------------------------------------------------------------ losses (common/runner.py:13-37,112-168)
  * Softmax cross-entropy over C classes, fwd + bwd in one pass.
- *   hard: labels int64[rows], label -1 = ignored row (loss 0, grad 0);   soft: targets fp32 [rows, C] and
+ *   hard: labels int64[rows], label -1 = ignored row (loss 0, grad 0); any other label outside [0, C) makes the row's
+ *   loss and gradient NaN (torch raises a device-side assert there; nothing out of bounds is read);
+ *   soft: targets fp32 [rows, C] and
  *   optional keep uint8[rows] (0 = row removed).  loss_sum += sum of row losses (fp32 atomic);
  *   dlogits[r,:] = gscale * row_g[r] * (softmax*sum(target) - target) for kept rows, 0 otherwise (row_g NULL = 1:
  *   the per-row upstream gradient of a reduction='none' loss); columns C..ldd-1 are zeroed. */
@@ -152,6 +174,11 @@ int afft_mse(const float* a, int64_t lda, const float* b, int64_t ldb, int32_t r
  * dropout of a GEMM input (classifier Dropout(0.2), future_prediction.py:108). */
 int afft_cast(const float* src, int64_t lds, int32_t rows, int32_t cols, void* dst, int64_t ldd, int32_t dst_dtype,
               void* dst_t, int64_t ldt, int32_t zero_pad, const afft_dropout_t* drop, void* stream);
+/* Two-plane bf16 split of an fp32 matrix for afft_gemm_t.split3: hi[r, c] = bf16(src[r, c]), lo[r, c] = bf16(src[r, c] - hi[r, c]),
+ * both planes [rows_pad, ldd] bf16 with everything outside [rows, cols] zero-filled (K padding of either GEMM operand role);
+ * lo = hi + plane_stride elements. */
+int afft_split_bf16(const float* src, int64_t lds, int32_t rows, int32_t cols, void* hi, int64_t ldd, int32_t rows_pad,
+                    int64_t plane_stride, void* stream);
 /* ModalTokenCMFuser token assembly (models/fusion.py:338-352): X[(b*T+t), s, :] for s=0 the modal token
  * (token + (t)*tok_stride_t; stride 0 = one universal token), s>=1 modality s-1 at feats[s-1] + (b*T+t)*ldf[s-1];
  * + modality_embedding[s,:] if given.  feats / ldf are HOST arrays of n_mod (<= 8) device pointers / strides. */

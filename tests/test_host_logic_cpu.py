@@ -1,0 +1,199 @@
+"""Build-container tests of the HOST logic (no GPU, no kernels): the mirrored reference modules, the autograd wiring of
+afft_amd.functional (gradient sink, gradient hand-over) and the Trainer run on CPU tensors with tests/cpu_ops.py standing in
+for the C-ABI wrappers, against the goldens produced by the reference.  What the kernels compute is tested on the GPU only."""
+import pytest
+import torch
+
+import cpu_ops
+from cases import CASES
+from helpers import case_tensors, flatten_outputs, load_golden, rel_l2
+
+
+def _build(c, precision):
+    import afft_amd
+    from afft_amd import runtime as rt
+    from afft_amd.config import make_model_cfg
+    from afft_amd.models.base_model import BaseModel
+    afft_amd.set_precision(precision)
+    rt.set_grad_mode("sink")
+    cfg = make_model_cfg(c["modal_dims"], c["d"], c["D"], fuser=c["fuser"], depth=c.get("depth", 1),
+                         num_heads=c["num_heads"], fp_layers=c["fp_layers"], fp_heads=c["fp_heads"],
+                         fp_output_len=c.get("fp_output_len", 1), cross_attn=c.get("cross_attn", False),
+                         modal_encoding=c.get("modal_encoding", False),
+                         frame_level_token=c.get("frame_level_token", False), T=c["T"], cmfp=c.get("cmfp", "early"),
+                         mapping=c.get("mapping", "linear"), mapping_activation=c.get("mapping_activation", "relu"),
+                         mapping_layernorm=c.get("mapping_layernorm"), share_predictors=c.get("share_predictors", True),
+                         share_classifiers=c.get("share_classifiers", True))
+    return BaseModel(cfg, num_classes={"action": c["num_classes"]}, class_mappings={})
+
+
+def _step(model, data, tgt, sub):
+    from afft_amd import runtime as rt
+    from afft_amd.common.runner import BasicLossAccuracy, Runner
+    rt.SINK.begin_step()
+    for p in model.parameters():
+        p.grad = None
+    out, out_t = model(data, mixup_fn=None, target={"action": tgt}, target_subclips={"action": sub},
+                       target_subclips_ignore_index=None)
+    losses, _ = BasicLossAccuracy(compute_metrics=False)(out, out_t["target"], out_t["target_subclips"])
+    total, _ = Runner._reduce_loss(losses, {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}, sync=False)
+    total.backward()
+    rt.SINK.finish_step(list(model.parameters()))
+    return out, total
+
+
+HOST_CASES = ["t0_sa", "t1_ca", "t2_flt", "t3_m5", "t4_cm", "t5_tsa", "t6_score", "t7_indiv", "t8_gated"]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
+@pytest.mark.parametrize("name", HOST_CASES)
+def test_host_wiring_reproduces_reference_golden(name, precision):
+    import afft_amd
+    z, _ = load_golden(name)
+    c, state, data, tgt, sub = case_tensors(name)
+    tol = 6e-2 if precision == "bf16" else 2e-4
+    with cpu_ops.installed():
+        model = _build(c, precision)
+        model.load_state_dict(state, strict=True)
+        model.eval()
+        out, total = _step(model, data, tgt, sub)
+    afft_amd.set_precision("bf16")
+    flat = flatten_outputs(out)
+    for k in z.files:
+        if k.startswith("out:") and not k.endswith("modality_attns"):
+            assert rel_l2(flat[k[4:]].float(), torch.from_numpy(z[k])) < tol, k
+    assert abs(float(total) - float(z["loss:total"])) < tol * max(1.0, abs(float(z["loss:total"])))
+    params = dict(model.named_parameters())
+    n = 0
+    for k in z.files:
+        if k.startswith("grad:"):
+            assert rel_l2(params[k[5:]].grad, torch.from_numpy(z[k])) < (0.2 if precision == "bf16" else tol), k
+            n += 1
+    assert n >= 5
+
+
+def _grads(model):
+    return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+
+def test_gradient_handover_accepted_and_off_agree():
+    """bf16 mode: the LayerNorm-backward hand-over (operand + output-bias gradient of the upstream sub-layer) gives the same
+    gradients as the separate cast / column-sum kernels."""
+    import afft_amd
+    from afft_amd import runtime as rt
+    c, state, data, tgt, sub = case_tensors("t0_sa")
+    res = {}
+    with cpu_ops.installed():
+        for on in (True, False):
+            rt.set_handover(on)
+            model = _build(c, "bf16")
+            model.load_state_dict(state)
+            model.eval()
+            _step(model, data, tgt, sub)
+            res[on] = _grads(model)
+    rt.set_handover(True)
+    afft_amd.set_precision("bf16")
+    assert res[True].keys() == res[False].keys()
+    for k in res[True]:
+        assert rel_l2(res[True][k], res[False][k]) < 2e-2, k     # bf16 rounding of the summed copy vs the fp32 tensor
+
+
+def test_gradient_handover_rejected_does_not_double_count():
+    """A sub-layer output with TWO consumers: autograd sums their gradients into a new tensor, so the upstream sub-layer must
+    turn the hand-over down -- and its output-bias gradient must then be the column sum of the REAL dy, once (the hand-over
+    used to commit colsum(dx) to the sink at emission time and the fall-back added colsum(dy) on top)."""
+    import afft_amd
+    from afft_amd import functional as F_
+    from afft_amd import runtime as rt
+    torch.manual_seed(0)
+    R, d, L_, H = 12, 64, 4, 2
+    mk = lambda *s: torch.nn.Parameter(torch.randn(*s) * 0.1)   # noqa: E731
+    P = dict(l1w=mk(d), l1b=mk(d), wq=mk(3 * d, d), wp=mk(d, d), bp=mk(d), l2w=mk(d), l2b=mk(d), w1=mk(4 * d, d), b1=mk(4 * d),
+             w2=mk(d, 4 * d), b2=mk(d))
+    x = torch.randn(R, d)
+    out = {}
+    with cpu_ops.installed():
+        afft_amd.set_precision("bf16")
+        rt.set_grad_mode("sink")
+        for on in (True, False):
+            rt.set_handover(on)
+            rt.SINK.begin_step()
+            for p in P.values():
+                p.grad = torch.full_like(p, 7.0)    # stale values: first touch must overwrite
+            xin = x.clone().requires_grad_(True)
+            y, _ = F_.AttnSublayer.apply(xin, P["l1w"], P["l1b"], P["wq"], None, P["wp"], P["bp"], L_, H, "none", 1e-6, False)
+            z = F_.MLPSublayer.apply(y, P["l2w"], P["l2b"], P["w1"], P["b1"], P["w2"], P["b2"], 1e-6, "erf", False)
+            (z.sum() + (y * y).sum()).backward()       # second consumer of y
+            out[on] = {k: p.grad.clone() for k, p in P.items()}
+    rt.set_handover(True)
+    for k in out[True]:
+        assert rel_l2(out[True][k], out[False][k]) < 2e-2, k
+    assert float(out[True]["bp"].abs().max()) < 1e3
+
+
+def test_trainer_on_cpu_matches_torch_sgd():
+    """Trainer (flat buffers + sink + per-bucket fused SGD inside backward) against torch.optim.SGD on autograd-mode
+    gradients of the same model, two steps."""
+    import afft_amd
+    from afft_amd import runtime as rt
+    from afft_amd.parallel import Trainer
+    c, state, data, tgt, sub = case_tensors("t0_sa")
+    wts = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
+    with cpu_ops.installed():
+        m1 = _build(c, "fp32")
+        m1.load_state_dict(state)
+        m1.eval()
+        tr = Trainer(m1, wts, lr=1e-2, momentum=0.9, weight_decay=1e-4, bucket_elems=4096, overlap_optimizer=True)
+        for _ in range(2):
+            tr.step(data, {"action": tgt}, {"action": sub})
+        m2 = _build(c, "fp32")
+        m2.load_state_dict(state)
+        m2.eval()
+        rt.set_grad_mode("autograd")
+        opt = torch.optim.SGD(m2.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-4, nesterov=True)
+        from afft_amd.common.runner import BasicLossAccuracy, Runner
+        for _ in range(2):
+            opt.zero_grad()
+            o, ot = m2(data, mixup_fn=None, target={"action": tgt}, target_subclips={"action": sub},
+                       target_subclips_ignore_index=None)
+            ls, _ = BasicLossAccuracy(False)(o, ot["target"], ot["target_subclips"])
+            tot, _ = Runner._reduce_loss(ls, wts, sync=False)
+            tot.backward()
+            opt.step()
+        rt.set_grad_mode("sink")
+    afft_amd.set_precision("bf16")
+    p2 = dict(m2.named_parameters())
+    for k, p in m1.named_parameters():
+        assert rel_l2(p, p2[k]) < 1e-5, k
+
+
+def test_multi_crop_7d_input_averages_crops():
+    """BaseModel.forward with 7-D (B, #clips, #crops, C, 1, 1, 1) inputs (models/base_model.py:68-119): a single crop equals
+    the 6-D call; with 3 crops every output is the mean of the per-crop outputs, the attention maps are the first crop's, a
+    modality delivered with one crop is shared by all crops, and the targets are handed through."""
+    import afft_amd
+    c, state, data, tgt, sub = case_tensors("t0_sa")
+    g = torch.Generator().manual_seed(5)
+    kw = dict(mixup_fn=None, target={"action": tgt}, target_subclips={"action": sub}, target_subclips_ignore_index=None)
+    with cpu_ops.installed(), torch.no_grad():
+        model = _build(c, "fp32")
+        model.load_state_dict(state)
+        model.eval()
+        base, t0 = model(data, **kw)
+        one, _ = model({m: d.unsqueeze(2) for m, d in data.items()}, **kw)
+        crops = {m: torch.stack([d, d + 0.1 * torch.randn(d.shape, generator=g), d * 0.5], dim=2) for m, d in data.items()}
+        crops["flow"] = data["flow"].unsqueeze(2)          # one crop only: cycled
+        multi, t3 = model(crops, **kw)
+        per = [model({m: (x[:, :, i] if x.shape[2] > 1 else x[:, :, 0]) for m, x in crops.items()}, **kw)[0] for i in range(3)]
+    afft_amd.set_precision("bf16")
+    assert t3["target"]["action"] is tgt and t0["target_subclips"]["action"] is sub
+    for key, by_mod in base.items():
+        for m, v in by_mod.items():
+            if key == "attentions":
+                assert torch.equal(multi[key][m]["modality_attns"], per[0][key][m]["modality_attns"])
+                continue
+            assert torch.equal(one[key][m], v), key
+            want = torch.stack([p[key][m] for p in per]).mean(0)
+            assert torch.allclose(multi[key][m], want, atol=1e-6), key
+    with pytest.raises(NotImplementedError):
+        model({m: d[:, :, :, 0] for m, d in data.items()}, **kw)

@@ -166,6 +166,98 @@ def test_gemm(case):
     _lib.check(_lib.lib().afft_set_gemm_variant(0))
 
 
+def test_split_bf16_planes():
+    """afft_split_bf16: x = hi + lo to ~2^-17 relative, zero tails out to the padded plane."""
+    from afft_amd import ops
+    x = rnd(70, 100, seed=11) * 3.0
+    sp = ops.Split(x.to(dev()))
+    torch.cuda.synchronize()
+    assert sp.planes.shape == (2, 128, 128)
+    hi, lo = sp.planes[0].float().cpu(), sp.planes[1].float().cpu()
+    assert torch.equal(hi[:70, :100], bfr(x))
+    assert float((hi + lo)[:70, :100].sub(x).abs().max()) <= float(x.abs().max()) * 2.0 ** -16
+    assert float(hi[70:].abs().max()) == 0 and float(hi[:, 100:].abs().max()) == 0
+    assert float(lo[70:].abs().max()) == 0 and float(lo[:, 100:].abs().max()) == 0
+    # a strided (non-16-byte-aligned rows) source takes the scalar path
+    y = rnd(33, 67, seed=12).to(dev())
+    sp2 = ops.Split(y[:, 1:66])
+    torch.cuda.synchronize()
+    assert torch.equal(sp2.planes[0].float().cpu()[:33, :65], bfr(y[:, 1:66].cpu()))
+
+
+X3_CASES = [
+    # name, M, N, K, layout, variant (0 = auto: 128x128 kernel at these sizes, 3 = 256x256 ping-pong forced), epilogue
+    ("nt_x3", 300, 520, 200, "nt", 0, dict(bias=True, act=1, pre=True)),
+    ("nn_x3", 130, 256, 320, "nn", 0, dict(bias=True, residual=True)),
+    ("tn_x3", 256, 130, 500, "tn", 0, dict(accumulate=True)),
+    ("nt_x3_pp", 300, 520, 200, "nt", 3, dict(bias=True, act=2)),
+    ("nn_x3_pp", 512, 300, 320, "nn", 3, dict(residual=True)),
+    ("tn_x3_pp", 512, 264, 704, "tn", 3, dict(accumulate=True)),
+    ("nt_x3_big", 1100, 3806, 2048, "nt", 0, dict(bias=True)),      # auto-selected ping-pong kernel, classifier-shaped tails
+]
+
+
+@pytest.mark.parametrize("case", X3_CASES, ids=[c[0] for c in X3_CASES])
+def test_gemm_bf16x3(case):
+    """bf16x3: A_hi B_hi + A_lo B_hi + A_hi B_lo in one launch over two-plane splits of fp32 operands -- fp32-grade results
+    (the lo x lo term, 2^-18 relative, is the only thing dropped) from the bf16 MFMA kernels, every layout and both tiles."""
+    from afft_amd import _lib, ops
+    name, M, N, K, layout, variant, ep = case
+    _lib.check(_lib.lib().afft_set_gemm_variant(variant))
+    A, Bm = rnd(M, K, seed=21), rnd(K, N, seed=22)
+    a_t, b_t = layout[0] == "t", layout[1] == "t"
+    sa = ops.Split((A.t().contiguous() if a_t else A).to(dev()))
+    sb = ops.Split((Bm.t().contiguous() if b_t else Bm).to(dev()))
+    bias = rnd(N, seed=3) if ep.get("bias") else None
+    act = ep.get("act", 0)
+    res = rnd(M, N, seed=5) if ep.get("residual") else None
+    out = torch.zeros(M, N, device=dev())
+    init = None
+    if ep.get("accumulate"):
+        init = rnd(M, N, seed=7)
+        out.copy_(init.to(dev()))
+    pre = torch.zeros(M, N, device=dev()) if ep.get("pre") else None
+    ops.gemm(sa, sb, out, a_t=a_t, b_t=b_t, bias=None if bias is None else bias.to(dev()), act=act, pre=pre,
+             residual=None if res is None else res.to(dev()), accumulate=bool(ep.get("accumulate")))
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().afft_set_gemm_variant(0))
+    ref = (A.double() @ Bm.double()).float()
+    if bias is not None:
+        ref = ref + bias
+    pre_ref = ref.clone()
+    ref = _act(act, ref, None)
+    if res is not None:
+        ref = ref + res
+    if init is not None:
+        ref = ref + init
+    assert rel_l2(out.cpu(), ref) < 1e-5, (name, rel_l2(out.cpu(), ref))
+    if pre is not None:
+        assert rel_l2(pre.cpu(), pre_ref) < 1e-5
+
+
+@pytest.mark.parametrize("cap", [8, 24, 1000])
+def test_gemm_weight_gradient_capped_grid(cap):
+    """max_workgroups: the 256x256 weight-gradient kernel with a capped grid (every workgroup walks several tiles) gives
+    bitwise the results of the one-workgroup-per-tile launch; a cap above the tile count is ignored."""
+    from afft_amd import _lib, ops
+    _lib.check(_lib.lib().afft_set_gemm_variant(3))
+    K, M, N = 640, 2048, 1100           # 8 x 5 = 40 tiles, column tail
+    a = bfr(rnd(K, M, seed=31)).to(torch.bfloat16).to(dev())
+    b_buf = torch.zeros(K, 1104, dtype=torch.bfloat16, device=dev())
+    b_buf[:, :N] = bfr(rnd(K, N, seed=32)).to(torch.bfloat16).to(dev())
+    b = b_buf[:, :N]
+    ref = torch.zeros(M, N, device=dev())
+    ops.gemm(a, b, ref, a_t=True)
+    for acc in (False, True):
+        out = torch.full((M, N), 0.5, device=dev())
+        want = ref + 0.5 if acc else ref
+        ops.gemm(a, b, out, a_t=True, accumulate=acc, max_workgroups=cap)
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), (cap, acc)
+    _lib.check(_lib.lib().afft_set_gemm_variant(0))
+    assert rel_l2(ref.cpu(), (a.float().t() @ b.float()).cpu()) < 2e-3
+
+
 @pytest.mark.parametrize("rows,d,dt", [(37, 64, "f32"), (300, 1024, "bf16"), (130, 2048, "f32"), (5, 128, "bf16")])
 def test_layernorm_fwd_bwd(rows, d, dt):
     from afft_amd import ops
@@ -334,6 +426,24 @@ def test_softmax_ce(rows, C, soft):
     assert abs(float(loss_sum) - float(ref.sum())) < 1e-4 * max(1.0, float(ref.sum()))
     assert rel_l2(dl[:, :C].float().cpu(), lr.grad.float()) < 5e-3
     assert float(dl[:, C:].float().abs().max()) == 0.0
+
+
+def test_softmax_ce_out_of_range_label_poisons_the_row():
+    """a label >= C (torch: device-side assert) reads nothing out of bounds; that row's loss and gradient are NaN, the other
+    rows are untouched"""
+    from afft_amd import ops
+    rows, C = 6, 11
+    logits = rnd(rows, C, seed=1).to(dev())
+    labels = torch.tensor([1, C, 3, -1, 10, C + 100]).to(dev())
+    row_loss = torch.empty(rows, device=dev())
+    dl = torch.zeros(rows, C, device=dev())
+    ops.softmax_ce(logits, C, labels=labels, dlogits=dl, row_loss=row_loss)
+    torch.cuda.synchronize()
+    rl, g = row_loss.cpu(), dl.cpu()
+    assert torch.isnan(rl[[1, 5]]).all() and torch.isnan(g[[1, 5]]).all()
+    assert torch.isfinite(rl[[0, 2, 3, 4]]).all() and torch.isfinite(g[[0, 2, 3, 4]]).all() and float(rl[3]) == 0.0
+    ref = torch.nn.functional.cross_entropy(logits.cpu()[[0, 2, 4]], labels.cpu()[[0, 2, 4]], reduction="none")
+    assert rel_l2(rl[[0, 2, 4]], ref) < 1e-5
 
 
 def test_mse_and_elementwise():
