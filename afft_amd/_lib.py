@@ -45,6 +45,71 @@ class GemmDesc(C.Structure):
     ]
 
 
+u32, fp = C.c_uint32, C.POINTER(C.c_float)
+DropP = C.POINTER(Dropout)
+_WS = [("gemm_ws", vp), ("gemm_ws_bytes", i64), ("gemm_ws_aux", vp), ("gemm_ws_aux_bytes", i64), ("wgrad_workgroups", i32)]
+_HAND = [("dx_bf16", vp), ("up_drop", DropP), ("up_dcol", vp)]
+
+
+class AttnSublayer(C.Structure):      # afft_attn_sublayer_t
+    _fields_ = [
+        ("rows", i32), ("d", i32), ("L", i32), ("H", i32),
+        ("conv1d", i32), ("mask", i32), ("mask_period", i32),
+        ("eps", f32), ("scale", f32),
+        ("x", vp), ("ln_w", vp), ("ln_b", vp),
+        ("w_qkv", vp), ("ldw_qkv", i64), ("b_qkv", vp),
+        ("w_proj", vp), ("ldw_proj", i64), ("b_proj", vp),
+        ("p_attn", f32), ("k_attn", u32),
+        ("out_drop", Dropout),
+        ("xn", vp), ("qkv", vp), ("ao", vp),
+        ("mean", vp), ("rstd", vp), ("probs", vp), ("y", vp),
+        ("dy", vp), ("dya", vp), ("dya_ready", i32),
+        ("dao", vp), ("dqkv", vp), ("dxn", vp),
+        ("g_w_qkv", vp), ("acc_w_qkv", i32), ("g_b_qkv", vp), ("acc_b_qkv", i32),
+        ("g_w_proj", vp), ("acc_w_proj", i32), ("g_b_proj", vp), ("acc_b_proj", i32),
+        ("g_ln_w", vp), ("g_ln_b", vp), ("acc_ln", i32),
+        ("dx", vp)] + _HAND + [("ln_partial", vp)] + _WS
+
+
+class MLPSublayer(C.Structure):       # afft_mlp_sublayer_t
+    _fields_ = [
+        ("rows", i32), ("d", i32), ("hidden", i32), ("conv1d", i32),
+        ("gelu", i32), ("eps", f32),
+        ("x", vp), ("ln_w", vp), ("ln_b", vp),
+        ("w1", vp), ("ldw1", i64), ("b1", vp),
+        ("w2", vp), ("ldw2", i64), ("b2", vp),
+        ("out_drop", Dropout),
+        ("xn", vp), ("u", vp), ("h", vp),
+        ("mean", vp), ("rstd", vp), ("y", vp),
+        ("dy", vp), ("dya", vp), ("dya_ready", i32),
+        ("du", vp), ("dxn", vp),
+        ("g_w1", vp), ("acc_w1", i32), ("g_b1", vp), ("acc_b1", i32),
+        ("g_w2", vp), ("acc_w2", i32), ("g_b2", vp), ("acc_b2", i32),
+        ("g_ln_w", vp), ("g_ln_b", vp), ("acc_ln", i32),
+        ("dx", vp)] + _HAND + [("ln_partial", vp)] + _WS
+
+
+class CrossAttnSublayer(C.Structure):  # afft_cross_attn_sublayer_t
+    _fields_ = [
+        ("rows", i32), ("d", i32), ("L", i32), ("H", i32), ("mask", i32), ("mask_period", i32),
+        ("eps", f32), ("scale", f32),
+        ("x", vp), ("mem", vp),
+        ("nq_w", vp), ("nq_b", vp), ("nkv_w", vp), ("nkv_b", vp),
+        ("w_q", vp), ("w_k", vp), ("w_v", vp), ("w_proj", vp), ("ldw", i64),
+        ("b_proj", vp),
+        ("p_attn", f32), ("k_attn", u32), ("out_drop", Dropout),
+        ("xq", vp), ("mkv", vp), ("q", vp), ("k", vp), ("v", vp), ("ao", vp),
+        ("mean_q", vp), ("rstd_q", vp), ("mean_kv", vp), ("rstd_kv", vp), ("probs", vp),
+        ("y", vp),
+        ("dy", vp), ("dya", vp), ("dya_ready", i32),
+        ("dao", vp), ("dq", vp), ("dk", vp), ("dv", vp), ("dxq", vp),
+        ("dmkv", vp),
+        ("g_w_q", vp), ("acc_w_q", i32), ("g_w_k", vp), ("acc_w_k", i32), ("g_w_v", vp), ("acc_w_v", i32),
+        ("g_w_proj", vp), ("acc_w_proj", i32), ("g_b_proj", vp), ("acc_b_proj", i32),
+        ("g_nq_w", vp), ("g_nq_b", vp), ("acc_nq", i32), ("g_nkv_w", vp), ("g_nkv_b", vp), ("acc_nkv", i32),
+        ("dx", vp), ("dmem", vp)] + _HAND + [("ln_partial", vp), ("ln_partial2", vp)] + _WS
+
+
 _SIGS = {
     "afft_version": ([], C.c_int),
     "afft_gemm": ([C.POINTER(GemmDesc), vp], C.c_int),
@@ -86,6 +151,12 @@ _SIGS = {
     "afft_weighted_sum_bwd": ([C.POINTER(vp), i64, vp, i64, vp, i64, i32, i32, i32, C.POINTER(vp), i64, vp, i64, vp], C.c_int),
     "afft_group_bcast": ([vp, i32, i32, i64, f32, vp, vp], C.c_int),
     "afft_clip_coef": ([vp, f32, vp, vp, vp], C.c_int),
+    "afft_attn_sublayer_fwd": ([C.POINTER(AttnSublayer), vp], C.c_int),
+    "afft_attn_sublayer_bwd": ([C.POINTER(AttnSublayer), vp, vp], C.c_int),
+    "afft_mlp_sublayer_fwd": ([C.POINTER(MLPSublayer), vp], C.c_int),
+    "afft_mlp_sublayer_bwd": ([C.POINTER(MLPSublayer), vp, vp], C.c_int),
+    "afft_cross_attn_sublayer_fwd": ([C.POINTER(CrossAttnSublayer), vp], C.c_int),
+    "afft_cross_attn_sublayer_bwd": ([C.POINTER(CrossAttnSublayer), vp, vp], C.c_int),
 }
 
 EXPORTS = sorted(list(_SIGS) + ["afft_last_error"])

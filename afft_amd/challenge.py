@@ -1,11 +1,14 @@
 """GPU side of the reference's ``challenge.marginalize_verb_noun`` (challenge.py:196-210): action logits -> softmax ->
 verb and noun scores by the class-mapping matrices, as one row-softmax kernel and two exact-fp32 MFMA GEMMs on tensors
-that are already on the device (the reference does this in numpy on host copies).  The accuracy bookkeeping
-(top-k / mean-top-5-recall over the dataset annotations) stays with the caller."""
+that are already on the device (the reference does this in numpy on host copies), followed by the reference's accuracy
+bookkeeping (top-1 / top-5 / mean top-5 recall per verb, noun and action: challenge.py:94-106,161-193, common/utils.py:19-56)
+on ONE host copy of the three score matrices.  Pinned by tests/golden/m0_marginalize.npz, produced by the reference's own
+``marginalize_verb_noun`` on a stub dataset object."""
 from __future__ import annotations
 
 from typing import Dict, Tuple
 
+import numpy as np
 import torch
 
 from . import ops
@@ -29,3 +32,61 @@ def marginalize_scores(res_action: torch.Tensor, class_mappings: Dict[Tuple[str,
         ops.gemm(probs, m, y)      # fp32 operands -> exact v_mfma_f32_32x32x2_f32 path
         out.append(y)
     return [out[0], out[1], res_action]
+
+
+def topk_accuracy(scores: np.ndarray, labels: np.ndarray, ks, selected_class=None):
+    """common/utils.py:19-42: share of rows whose label is among the k best scores (argpartition instead of a full sort)"""
+    if selected_class is not None:
+        keep = labels == selected_class
+        scores, labels = scores[keep], labels[keep]
+    kmax = int(max(ks))
+    order = np.argsort(-scores, axis=1, kind="stable")[:, :kmax] if scores.shape[1] <= 4 * kmax else None
+    if order is None:
+        part = np.argpartition(-scores, kmax - 1, axis=1)[:, :kmax]
+        order = np.take_along_axis(part, np.argsort(-np.take_along_axis(scores, part, 1), axis=1, kind="stable"), 1)
+    hit = order == labels.reshape(-1, 1)
+    return [hit[:, :k].any(axis=1).mean() for k in ks]
+
+
+def topk_recall(scores: np.ndarray, labels: np.ndarray, k: int = 5, classes=None):
+    """common/utils.py:45-56: mean over the classes present in `labels` of their top-k accuracy"""
+    present = np.unique(labels)
+    classes = present if classes is None else np.intersect1d(classes, present)
+    return sum(topk_accuracy(scores, labels, ks=(k,), selected_class=c)[0] for c in classes) / len(classes)
+
+
+def compute_accuracy(predictions: np.ndarray, labels: np.ndarray, classes=None):
+    """challenge.py:94-106: (top-1, top-5, mean top-5 recall) in percent; classes: optional {name: class id} subset"""
+    if classes is not None:
+        classes = list(classes.values())
+    top1, top5 = topk_accuracy(predictions, labels, ks=(1, 5))
+    return top1 * 100, top5 * 100, topk_recall(predictions, labels, k=5, classes=classes) * 100
+
+
+def compute_accuracies_epic(probs, dataset, compute_manyshot_unseen_tail: bool = False) -> Dict[str, float]:
+    """challenge.py:161-193: probs = [verb, noun, action] score matrices; dataset.df carries verb_class / noun_class /
+    action_class, dataset.classes_manyshot the many-shot subsets.  (The EPIC-100 unseen / tail split of :109-158 needs the
+    dataset's participant tables and is not mirrored.)"""
+    assert len(probs) == 3, 'Probs should contain probs for verb, noun and action'
+    many = dataset.classes_manyshot
+    res = {}
+    for short, key, p in (("v", "verb", probs[0]), ("n", "noun", probs[1]), ("a", "action", probs[2])):
+        labels = getattr(dataset.df, f"{key}_class").values
+        p = np.asarray(p)
+        res[f"{short}top1"], res[f"{short}top5"], res[f"{short}mt5r"] = compute_accuracy(p, labels)
+        res[f"{short}mt5r_ms"] = float("nan")
+        if key in many and compute_manyshot_unseen_tail:
+            res[f"{short}mt5r_ms"] = compute_accuracy(p, labels, classes=many[key])[2]
+    return res
+
+
+def marginalize_verb_noun(res_action, dataset, to_prob: bool = True, compute_manyshot_unseen_tail: bool = False):
+    """challenge.py:196-210 with the same signature and return value: (accuracies, [verb, noun, action] as numpy arrays).
+    res_action: action logits, a device tensor (kept on the device for the softmax and the two mapping GEMMs) or anything
+    torch.as_tensor accepts (moved to cuda:0)."""
+    x = torch.as_tensor(res_action)
+    if not x.is_cuda:
+        x = x.cuda()
+    verb, noun, action = marginalize_scores(x.float(), dataset.class_mappings, to_prob=to_prob)
+    scores = [t.detach().cpu().numpy() for t in (verb, noun, action.reshape(-1, action.shape[-1]))]
+    return compute_accuracies_epic(scores, dataset, compute_manyshot_unseen_tail), scores

@@ -40,10 +40,10 @@ class MixUp(torch.nn.Module):
         self.mixup_beta_sampler = torch.distributions.beta.Beta(alpha, alpha)   # sampled on the host: no GPU sync
         self.label_smoothing = label_smoothing
         self.num_classes = num_classes
+        # kept for the constructor contract: the reference stores the flag (common/mixup.py:116) and its forward never
+        # reads it (labels always arrive as class indices and go through convert_to_one_hot, :133-150)
         self.one_hot = one_hot
         self.ignore_cls = ignore_cls
-        if one_hot:
-            raise NotImplementedError("afft_amd: MixUp(one_hot=True) (labels already one-hot) is not built")
 
     def forward(self, x_video: Dict, labels: Dict, labels_subclips: Union[Dict, None]) -> Sequence[Union[Dict, None]]:
         first = next(iter(x_video.values()))

@@ -8,12 +8,14 @@ probabilities, losses, master weights and gradients are fp32; GEMM operands are 
 """
 from __future__ import annotations
 
+import contextlib
+import ctypes as C
 import threading
 from typing import NamedTuple, List, Optional, Tuple
 
 import torch
 
-from . import ops, runtime as rt
+from . import _lib as L_, ops, runtime as rt
 from ._lib import (ACT_DGELU_ERF, ACT_DGELU_TANH, ACT_GELU_ERF, ACT_GELU_TANH, ACT_NONE, ACT_RELU, ACT_SIGMOID_GATE,
                    MASK_BLOCKCAUSAL, MASK_CAUSAL, MASK_DIAG, MASK_NONE)
 
@@ -36,6 +38,15 @@ class Act:
             self.buf = (torch.empty if (pr == rows and pw == width) else torch.zeros)(pr, pw, dtype=dtype, device=device)
         else:
             self.buf = torch.empty(rows, width, dtype=dtype, device=device)
+
+    @classmethod
+    def carve(cls, flat: Tensor, offset: int, rows: int, width: int) -> "Act":
+        """bf16 Act over flat[offset : offset + pad64(rows) * width] (width % 64 == 0); the row tail is zeroed by whoever
+        fills it (the composite entry points do)."""
+        a = cls.__new__(cls)
+        a.rows, a.width, a._split = rows, width, None
+        a.buf = flat[offset:offset + rt.pad64(rows) * width].view(rt.pad64(rows), width)
+        return a
 
     @property
     def live(self) -> Tensor:            # [rows, width]
@@ -343,11 +354,24 @@ def _accept_bias(sh: _Shadow):
         return sh.gbias
     if sh.sink_tmp is not None:
         g, acc = rt.SINK.grad_buffer(sh.bias)
-        _on_side(sh.sink_tmp)
-        if acc:
-            g.add_(sh.sink_tmp)
-        else:
-            g.copy_(sh.sink_tmp)
+        # the buffer was already touched this step, possibly by a kernel still pending on the auxiliary stream (a shared
+        # sub-layer used twice): commit there, behind it and behind the LayerNorm backward that wrote the scratch vector
+        side = _TS.side_stream
+        own = side is None and g.is_cuda and rt.overlap_wgrad()
+        if own:
+            side = rt.aux_stream(g.device)
+            side.wait_stream(torch.cuda.current_stream())
+        ctx = torch.cuda.stream(side) if own else contextlib.nullcontext()
+        with ctx:
+            if acc:
+                g.add_(sh.sink_tmp)
+            else:
+                g.copy_(sh.sink_tmp)
+        if side is not None and g.is_cuda:
+            if rt.CAPTURING:
+                rt.KEEPALIVE.append(sh.sink_tmp)
+            else:
+                sh.sink_tmp.record_stream(side)
     _ready(sh.bias)
     return None
 
@@ -436,6 +460,418 @@ def _mask_args(mask):
     return _MASK[mask[0]], int(mask[1])
 
 
+# --------------------------------------------------------------------------- composite path: one C-ABI call per sub-layer
+# afft_{attn,mlp,cross_attn}_sublayer_{fwd,bwd} (include/afft_hip.h, csrc/sublayer.hip) enqueue exactly the kernel sequences
+# written out call by call in the three Functions below.  What stays here is bookkeeping: buffers (one allocation for the
+# saved activations, one for the backward scratch), gradient-sink state, the hand-over, readiness notifications.
+def _composite_ok(x: Tensor, pre_ln: bool, *widths: int) -> bool:
+    return (rt.composite() and pre_ln and rt.precision() == "bf16" and x.is_cuda and x.stride(0) == x.shape[1]
+            and all(w % 64 == 0 for w in widths))
+
+
+def _img(W: Tensor):
+    """(pointer, leading dimension) of the bf16 image of a 2-D weight"""
+    w16, _ = rt.weight_images(W)
+    return w16.data_ptr(), w16.stride(0)
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _grad_slot(p: Optional[Tensor], fresh: list):
+    """(gradient tensor or None, accumulate flag) for parameter p: the sink's buffer, or a fresh tensor (autograd mode)"""
+    if p is None:
+        return None, 0
+    if rt.grad_mode() == "sink":
+        g, acc = rt.SINK.grad_buffer(p)
+        return g, int(acc)
+    g = torch.empty_like(p)
+    fresh.append(g)
+    return g, 0
+
+
+def _ln_grad_slots(w: Optional[Tensor], b: Optional[Tensor], fresh: list):
+    """LayerNorm weight / bias gradient buffers with ONE accumulate flag (see _ln_bwd for the mixed first-touch case)"""
+    gw, aw = _grad_slot(w, fresh)
+    gb, ab = _grad_slot(b, fresh)
+    if w is not None and b is not None and aw != ab:
+        (gw if not aw else gb).zero_()
+        aw = ab = 1
+    return gw, gb, (aw if w is not None else ab)
+
+
+class _HandOut(NamedTuple):
+    dxa: Optional[Act]
+    gbu: Optional[Tensor]
+    direct: bool
+    tmp: Optional[Tensor]
+
+
+def _plan_handover(up: Optional[_Up], rows: int, d: int, dev) -> _HandOut:
+    """What the LayerNorm backward at the end of a composite backward emits for the sub-layer upstream (cf. _ln_bwd)"""
+    if up is None or d % 64 != 0:
+        return _HandOut(None, None, False, None)
+    _drop_shadow()
+    dxa = Act(rows, d, dev)
+    gbu, direct, tmp = None, False, None
+    if up.bias is not None:
+        if rt.grad_mode() == "sink" and up.bias.grad is not None and not rt.SINK.touched.get(id(up.bias), False):
+            gbu, direct = up.bias.grad, True
+            rt.SINK.touched[id(up.bias)] = True
+        else:
+            gbu = tmp = torch.empty_like(up.bias)
+    return _HandOut(dxa, gbu, direct, tmp)
+
+
+def _publish_handover(ho: _HandOut, up: Optional[_Up], dx: Tensor):
+    if ho.dxa is not None:
+        sink = rt.grad_mode() == "sink"
+        _TS.shadow = _Shadow(dx.data_ptr(), tuple(dx.shape), dx._version, up.od, up.bias, ho.dxa,
+                             None if sink else ho.gbu, ho.direct, ho.tmp if sink else None)
+
+
+def _streams(dev):
+    """(raw main stream, raw auxiliary stream or None, torch auxiliary stream or None)"""
+    main = ops._stream()
+    if rt.overlap_wgrad():
+        aux = rt.aux_stream(dev)
+        return main, aux.cuda_stream, aux
+    return main, None, None
+
+
+def _fill_ws(s, dev, main_raw, aux_raw):
+    ws = ops.gemm_workspace(dev, main_raw)
+    s.gemm_ws, s.gemm_ws_bytes = ws.data_ptr(), ws.numel()
+    if aux_raw is not None:
+        wa = ops.gemm_workspace(dev, aux_raw)
+        s.gemm_ws_aux, s.gemm_ws_aux_bytes = wa.data_ptr(), wa.numel()
+    s.wgrad_workgroups = rt.wgrad_workgroups() if aux_raw is not None else 0
+
+
+def _keep_for_aux(aux, *tensors):
+    """tensors a kernel on the auxiliary stream reads or writes: keep their memory from the allocator until it has run"""
+    if aux is None:
+        return
+    for t in tensors:
+        if t is not None and t.is_cuda:
+            if rt.CAPTURING:
+                rt.KEEPALIVE.append(t)
+            else:
+                t.record_stream(aux)
+
+
+def _ln_partial(rows: int, d: int, dev) -> Tensor:
+    return torch.empty(L_.lib().afft_layernorm_bwd_nparts(rows) * 3 * d, dtype=torch.float32, device=dev)
+
+
+def _attn_fwd_c(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, eps, conv1d, scale, drop):
+    R, d = x.shape
+    dev = x.device
+    nseq, pr = R // L, rt.pad64(R)
+    ctx.up = _upstream_of(x)
+    saved = torch.empty(pr * 5 * d, dtype=torch.bfloat16, device=dev)
+    xn, qkv, ao = Act.carve(saved, 0, R, d), Act.carve(saved, pr * d, R, 3 * d), Act.carve(saved, pr * 4 * d, R, d)
+    stats = torch.empty(2, R, dtype=torch.float32, device=dev)
+    probs = torch.empty(nseq, H, L, L, dtype=torch.float32, device=dev)
+    y = torch.empty(R, d, dtype=torch.float32, device=dev)
+    scale = float(scale) if scale else float(d // H) ** -0.5
+    mk, per = _mask_args(mask)
+    s = L_.AttnSublayer()
+    s.rows, s.d, s.L, s.H, s.conv1d, s.mask, s.mask_period, s.eps, s.scale = R, d, L, H, int(conv1d), mk, per, eps, scale
+    s.x, s.ln_w, s.ln_b = x.data_ptr(), _ptr(ln_w), _ptr(ln_b)
+    s.w_qkv, s.ldw_qkv = _img(w_qkv)
+    s.w_proj, s.ldw_proj = _img(w_proj)
+    s.b_qkv, s.b_proj = _ptr(b_qkv), _ptr(b_proj)
+    s.p_attn, s.k_attn = _attn_drop(drop)
+    od = _out_drop(drop)
+    if od is not None:
+        s.out_drop = od
+    s.xn, s.qkv, s.ao = xn.buf.data_ptr(), qkv.buf.data_ptr(), ao.buf.data_ptr()
+    s.mean, s.rstd, s.probs, s.y = stats[0].data_ptr(), stats[1].data_ptr(), probs.data_ptr(), y.data_ptr()
+    main_raw = ops._stream()
+    _fill_ws(s, dev, main_raw, None)
+    L_.check(L_.lib().afft_attn_sublayer_fwd(C.byref(s), main_raw), "attn_sublayer_fwd")
+    ctx.save_for_backward(x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, stats[0], stats[1], probs)
+    ctx.acts = (xn, qkv, ao, saved)
+    ctx.cfg = (L, H, scale, conv1d, True, drop)
+    ctx.mask = (mk, per)
+    ctx.composite = True
+    ctx.mark_non_differentiable(probs)
+    _note_output(y, od, b_proj)
+    return y, probs
+
+
+def _attn_bwd_c(ctx, dy):
+    x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, mean, rstd, probs = ctx.saved_tensors
+    xn, qkv, ao, saved = ctx.acts
+    L, H, scale, conv1d, _, drop = ctx.cfg
+    R, d = x.shape
+    dev = x.device
+    pr = rt.pad64(R)
+    dy = dy.contiguous()
+    od = _out_drop(drop)
+    sh = _take_shadow(dy, od, b_proj)
+    main_raw, aux_raw, aux = _streams(dev)
+    fresh: list = []
+    scratch = torch.empty(pr * 6 * d, dtype=torch.bfloat16, device=dev)      # dya | dao | dqkv | dxn
+    s = L_.AttnSublayer()
+    s.rows, s.d, s.L, s.H, s.conv1d, s.eps, s.scale = R, d, L, H, int(conv1d), 0.0, scale
+    s.mask, s.mask_period = ctx.mask
+    s.x, s.ln_w = x.data_ptr(), _ptr(ln_w)
+    s.w_qkv, s.ldw_qkv = _img(w_qkv)
+    s.w_proj, s.ldw_proj = _img(w_proj)
+    s.p_attn, s.k_attn = _attn_drop(drop)
+    if od is not None:
+        s.out_drop = od
+    s.xn, s.qkv, s.ao = xn.buf.data_ptr(), qkv.buf.data_ptr(), ao.buf.data_ptr()
+    s.mean, s.rstd, s.probs = mean.data_ptr(), rstd.data_ptr(), probs.data_ptr()
+    s.dy = dy.data_ptr()
+    base = scratch.data_ptr()
+    if sh is not None:
+        s.dya, s.dya_ready = sh.act.buf.data_ptr(), 1
+        g_bp = _accept_bias(sh)
+    else:
+        s.dya, s.dya_ready = base, 0
+        gb, acc = _grad_slot(b_proj, fresh)
+        s.g_b_proj, s.acc_b_proj = _ptr(gb), acc
+        g_bp = gb if rt.grad_mode() != "sink" else None
+    s.dao, s.dqkv, s.dxn = base + pr * d * 2, base + pr * 2 * d * 2, base + pr * 5 * d * 2
+    g_wq, s.acc_w_qkv = _grad_slot(w_qkv, fresh)
+    g_bq, s.acc_b_qkv = _grad_slot(b_qkv, fresh)
+    g_wp, s.acc_w_proj = _grad_slot(w_proj, fresh)
+    g_lw, g_lb, s.acc_ln = _ln_grad_slots(ln_w, ln_b, fresh)
+    s.g_w_qkv, s.g_b_qkv, s.g_w_proj, s.g_ln_w, s.g_ln_b = _ptr(g_wq), _ptr(g_bq), _ptr(g_wp), _ptr(g_lw), _ptr(g_lb)
+    dx = torch.empty(R, d, dtype=torch.float32, device=dev)
+    s.dx = dx.data_ptr()
+    ho = _plan_handover(ctx.up, R, d, dev)
+    if ho.dxa is not None:
+        s.dx_bf16 = ho.dxa.buf.data_ptr()
+        if ctx.up.od is not None:
+            s.up_drop = C.pointer(ctx.up.od)
+        s.up_dcol = _ptr(ho.gbu)
+    partial = _ln_partial(R, d, dev)
+    s.ln_partial = partial.data_ptr()
+    _fill_ws(s, dev, main_raw, aux_raw)
+    L_.check(L_.lib().afft_attn_sublayer_bwd(C.byref(s), main_raw, aux_raw), "attn_sublayer_bwd")
+    _keep_for_aux(aux, saved, scratch, dy, sh.act.buf if sh is not None else None, *fresh)
+    _publish_handover(ho, ctx.up, dx)
+    if rt.grad_mode() == "sink":
+        for p in (w_proj, None if sh is not None else b_proj, w_qkv, b_qkv, ln_w, ln_b):
+            if p is not None:
+                _ready(p)
+        g_wq = g_bq = g_wp = g_bp = g_lw = g_lb = None
+    join_side(dev)
+    ctx.acts = None
+    flush_ready()
+    return dx, g_lw, g_lb, g_wq, g_bq, g_wp, g_bp, None, None, None, None, None, None, None, None
+
+
+def _mlp_fwd_c(ctx, x, ln_w, ln_b, w1, b1, w2, b2, eps, gelu, conv1d, hidden, drop):
+    R, d = x.shape
+    dev = x.device
+    pr = rt.pad64(R)
+    ctx.up = _upstream_of(x)
+    saved = torch.empty(pr * (d + 2 * hidden), dtype=torch.bfloat16, device=dev)
+    xn, u, h = Act.carve(saved, 0, R, d), Act.carve(saved, pr * d, R, hidden), Act.carve(saved, pr * (d + hidden), R, hidden)
+    stats = torch.empty(2, R, dtype=torch.float32, device=dev)
+    y = torch.empty(R, d, dtype=torch.float32, device=dev)
+    s = L_.MLPSublayer()
+    s.rows, s.d, s.hidden, s.conv1d, s.gelu, s.eps = R, d, hidden, int(conv1d), _GELU[gelu][0], eps
+    s.x, s.ln_w, s.ln_b = x.data_ptr(), _ptr(ln_w), _ptr(ln_b)
+    s.w1, s.ldw1 = _img(w1)
+    s.w2, s.ldw2 = _img(w2)
+    s.b1, s.b2 = _ptr(b1), _ptr(b2)
+    od = _out_drop(drop)
+    if od is not None:
+        s.out_drop = od
+    s.xn, s.u, s.h = xn.buf.data_ptr(), u.buf.data_ptr(), h.buf.data_ptr()
+    s.mean, s.rstd, s.y = stats[0].data_ptr(), stats[1].data_ptr(), y.data_ptr()
+    main_raw = ops._stream()
+    _fill_ws(s, dev, main_raw, None)
+    L_.check(L_.lib().afft_mlp_sublayer_fwd(C.byref(s), main_raw), "mlp_sublayer_fwd")
+    ctx.save_for_backward(x, ln_w, ln_b, w1, b1, w2, b2, stats[0], stats[1])
+    ctx.acts = (xn, u, h, saved)
+    ctx.cfg = (gelu, conv1d, hidden, True, drop)
+    ctx.composite = True
+    _note_output(y, od, b2)
+    return y
+
+
+def _mlp_bwd_c(ctx, dy):
+    x, ln_w, ln_b, w1, b1, w2, b2, mean, rstd = ctx.saved_tensors
+    xn, u, h, saved = ctx.acts
+    gelu, conv1d, hidden, _, drop = ctx.cfg
+    R, d = x.shape
+    dev = x.device
+    pr = rt.pad64(R)
+    dy = dy.contiguous()
+    od = _out_drop(drop)
+    sh = _take_shadow(dy, od, b2)
+    main_raw, aux_raw, aux = _streams(dev)
+    fresh: list = []
+    scratch = torch.empty(pr * (2 * d + hidden), dtype=torch.bfloat16, device=dev)    # dya | dxn | du
+    s = L_.MLPSublayer()
+    s.rows, s.d, s.hidden, s.conv1d, s.gelu = R, d, hidden, int(conv1d), _GELU[gelu][0]
+    s.x, s.ln_w = x.data_ptr(), _ptr(ln_w)
+    s.w1, s.ldw1 = _img(w1)
+    s.w2, s.ldw2 = _img(w2)
+    if od is not None:
+        s.out_drop = od
+    s.xn, s.u, s.h = xn.buf.data_ptr(), u.buf.data_ptr(), h.buf.data_ptr()
+    s.mean, s.rstd = mean.data_ptr(), rstd.data_ptr()
+    s.dy = dy.data_ptr()
+    base = scratch.data_ptr()
+    if sh is not None:
+        s.dya, s.dya_ready = sh.act.buf.data_ptr(), 1
+        g_b2 = _accept_bias(sh)
+    else:
+        s.dya, s.dya_ready = base, 0
+        gb, acc = _grad_slot(b2, fresh)
+        s.g_b2, s.acc_b2 = _ptr(gb), acc
+        g_b2 = gb if rt.grad_mode() != "sink" else None
+    s.dxn, s.du = base + pr * d * 2, base + pr * 2 * d * 2
+    g_w1, s.acc_w1 = _grad_slot(w1, fresh)
+    g_b1, s.acc_b1 = _grad_slot(b1, fresh)
+    g_w2, s.acc_w2 = _grad_slot(w2, fresh)
+    g_lw, g_lb, s.acc_ln = _ln_grad_slots(ln_w, ln_b, fresh)
+    s.g_w1, s.g_b1, s.g_w2, s.g_ln_w, s.g_ln_b = _ptr(g_w1), _ptr(g_b1), _ptr(g_w2), _ptr(g_lw), _ptr(g_lb)
+    dx = torch.empty(R, d, dtype=torch.float32, device=dev)
+    s.dx = dx.data_ptr()
+    ho = _plan_handover(ctx.up, R, d, dev)
+    if ho.dxa is not None:
+        s.dx_bf16 = ho.dxa.buf.data_ptr()
+        if ctx.up.od is not None:
+            s.up_drop = C.pointer(ctx.up.od)
+        s.up_dcol = _ptr(ho.gbu)
+    partial = _ln_partial(R, d, dev)
+    s.ln_partial = partial.data_ptr()
+    _fill_ws(s, dev, main_raw, aux_raw)
+    L_.check(L_.lib().afft_mlp_sublayer_bwd(C.byref(s), main_raw, aux_raw), "mlp_sublayer_bwd")
+    _keep_for_aux(aux, saved, scratch, dy, sh.act.buf if sh is not None else None, *fresh)
+    _publish_handover(ho, ctx.up, dx)
+    if rt.grad_mode() == "sink":
+        for p in (w2, None if sh is not None else b2, w1, b1, ln_w, ln_b):
+            if p is not None:
+                _ready(p)
+        g_w1 = g_b1 = g_w2 = g_b2 = g_lw = g_lb = None
+    join_side(dev)
+    ctx.acts = None
+    flush_ready()
+    return dx, g_lw, g_lb, g_w1, g_b1, g_w2, g_b2, None, None, None, None, None
+
+
+def _cross_fwd_c(ctx, x, mem, nq_w, nq_b, nkv_w, nkv_b, w_q, w_k, w_v, w_proj, b_proj, L, H, mask, eps, scale, drop):
+    R, d = x.shape
+    dev = x.device
+    nseq, pr = R // L, rt.pad64(R)
+    ctx.up = _upstream_of(x)
+    saved = torch.empty(pr * 6 * d, dtype=torch.bfloat16, device=dev)
+    xq, mkv, q, k, v, ao = (Act.carve(saved, i * pr * d, R, d) for i in range(6))
+    stats = torch.empty(4, R, dtype=torch.float32, device=dev)
+    probs = torch.empty(nseq, H, L, L, dtype=torch.float32, device=dev)
+    y = torch.empty(R, d, dtype=torch.float32, device=dev)
+    scale = float(scale) if scale else float(d // H) ** -0.5
+    mk, per = _mask_args(mask)
+    s = L_.CrossAttnSublayer()
+    s.rows, s.d, s.L, s.H, s.mask, s.mask_period, s.eps, s.scale = R, d, L, H, mk, per, eps, scale
+    s.x, s.mem = x.data_ptr(), mem.data_ptr()
+    s.nq_w, s.nq_b, s.nkv_w, s.nkv_b = _ptr(nq_w), _ptr(nq_b), _ptr(nkv_w), _ptr(nkv_b)
+    imgs = [_img(w) for w in (w_q, w_k, w_v, w_proj)]
+    assert len({ld for _, ld in imgs}) == 1
+    (s.w_q, s.ldw), (s.w_k, _), (s.w_v, _), (s.w_proj, _) = imgs
+    s.b_proj = _ptr(b_proj)
+    s.p_attn, s.k_attn = _attn_drop(drop)
+    od = _out_drop(drop)
+    if od is not None:
+        s.out_drop = od
+    s.xq, s.mkv, s.q, s.k, s.v, s.ao = (a.buf.data_ptr() for a in (xq, mkv, q, k, v, ao))
+    s.mean_q, s.rstd_q, s.mean_kv, s.rstd_kv = (stats[i].data_ptr() for i in range(4))
+    s.probs, s.y = probs.data_ptr(), y.data_ptr()
+    main_raw = ops._stream()
+    _fill_ws(s, dev, main_raw, None)
+    L_.check(L_.lib().afft_cross_attn_sublayer_fwd(C.byref(s), main_raw), "cross_attn_sublayer_fwd")
+    ctx.save_for_backward(x, mem, nq_w, nq_b, nkv_w, nkv_b, w_q, w_k, w_v, w_proj, b_proj, stats[0], stats[1], stats[2], stats[3],
+                          probs)
+    ctx.acts = (xq, mkv, q, k, v, ao, saved)
+    ctx.cfg = (L, H, scale, True, drop)
+    ctx.mask = (mk, per)
+    ctx.composite = True
+    _note_output(y, od, b_proj)
+    return y
+
+
+def _cross_bwd_c(ctx, dy):
+    (x, mem, nq_w, nq_b, nkv_w, nkv_b, w_q, w_k, w_v, w_proj, b_proj, mq, rq, mkm, rk, probs) = ctx.saved_tensors
+    xq, mkv, q, k, v, ao, saved = ctx.acts
+    L, H, scale, _, drop = ctx.cfg
+    R, d = x.shape
+    dev = x.device
+    pr = rt.pad64(R)
+    dy = dy.contiguous()
+    od = _out_drop(drop)
+    sh = _take_shadow(dy, od, b_proj)
+    main_raw, aux_raw, aux = _streams(dev)
+    fresh: list = []
+    scratch = torch.empty(pr * 6 * d, dtype=torch.bfloat16, device=dev)       # dya | dao | dq | dk | dv | dxq
+    dmkv = torch.empty(R, d, dtype=torch.float32, device=dev)
+    s = L_.CrossAttnSublayer()
+    s.rows, s.d, s.L, s.H, s.scale = R, d, L, H, scale
+    s.mask, s.mask_period = ctx.mask
+    s.x, s.mem, s.nq_w, s.nkv_w = x.data_ptr(), mem.data_ptr(), _ptr(nq_w), _ptr(nkv_w)
+    (s.w_q, s.ldw), (s.w_k, _), (s.w_v, _), (s.w_proj, _) = [_img(w) for w in (w_q, w_k, w_v, w_proj)]
+    s.p_attn, s.k_attn = _attn_drop(drop)
+    if od is not None:
+        s.out_drop = od
+    s.xq, s.mkv, s.q, s.k, s.v, s.ao = (a.buf.data_ptr() for a in (xq, mkv, q, k, v, ao))
+    s.mean_q, s.rstd_q, s.mean_kv, s.rstd_kv, s.probs = mq.data_ptr(), rq.data_ptr(), mkm.data_ptr(), rk.data_ptr(), probs.data_ptr()
+    s.dy = dy.data_ptr()
+    base = scratch.data_ptr()
+    if sh is not None:
+        s.dya, s.dya_ready = sh.act.buf.data_ptr(), 1
+        g_bp = _accept_bias(sh)
+    else:
+        s.dya, s.dya_ready = base, 0
+        gb, acc = _grad_slot(b_proj, fresh)
+        s.g_b_proj, s.acc_b_proj = _ptr(gb), acc
+        g_bp = gb if rt.grad_mode() != "sink" else None
+    s.dao, s.dq, s.dk, s.dv, s.dxq = (base + i * pr * d * 2 for i in range(1, 6))
+    s.dmkv = dmkv.data_ptr()
+    g_q, s.acc_w_q = _grad_slot(w_q, fresh)
+    g_k, s.acc_w_k = _grad_slot(w_k, fresh)
+    g_v, s.acc_w_v = _grad_slot(w_v, fresh)
+    g_wp, s.acc_w_proj = _grad_slot(w_proj, fresh)
+    g_qw, g_qb, s.acc_nq = _ln_grad_slots(nq_w, nq_b, fresh)
+    g_kw, g_kb, s.acc_nkv = _ln_grad_slots(nkv_w, nkv_b, fresh)
+    s.g_w_q, s.g_w_k, s.g_w_v, s.g_w_proj = _ptr(g_q), _ptr(g_k), _ptr(g_v), _ptr(g_wp)
+    s.g_nq_w, s.g_nq_b, s.g_nkv_w, s.g_nkv_b = _ptr(g_qw), _ptr(g_qb), _ptr(g_kw), _ptr(g_kb)
+    dx = torch.empty(R, d, dtype=torch.float32, device=dev)
+    dmem = torch.empty(R, d, dtype=torch.float32, device=dev)
+    s.dx, s.dmem = dx.data_ptr(), dmem.data_ptr()
+    ho = _plan_handover(ctx.up, R, d, dev)
+    if ho.dxa is not None:
+        s.dx_bf16 = ho.dxa.buf.data_ptr()
+        if ctx.up.od is not None:
+            s.up_drop = C.pointer(ctx.up.od)
+        s.up_dcol = _ptr(ho.gbu)
+    partial = _ln_partial(R, 2 * d, dev)
+    s.ln_partial, s.ln_partial2 = partial.data_ptr(), partial.data_ptr() + partial.numel() * 2
+    _fill_ws(s, dev, main_raw, aux_raw)
+    L_.check(L_.lib().afft_cross_attn_sublayer_bwd(C.byref(s), main_raw, aux_raw), "cross_attn_sublayer_bwd")
+    _keep_for_aux(aux, saved, scratch, dy, sh.act.buf if sh is not None else None, *fresh)
+    _publish_handover(ho, ctx.up, dx)
+    if rt.grad_mode() == "sink":
+        for p in (w_proj, None if sh is not None else b_proj, w_q, w_k, w_v, nkv_w, nkv_b, nq_w, nq_b):
+            if p is not None:
+                _ready(p)
+        g_q = g_k = g_v = g_wp = g_bp = g_qw = g_qb = g_kw = g_kb = None
+    join_side(dev)
+    ctx.acts = None
+    flush_ready()
+    return dx, dmem, g_qw, g_qb, g_kw, g_kb, g_q, g_k, g_v, g_wp, g_bp, None, None, None, None, None, None, None
+
+
+
 # --------------------------------------------------------------------------- pre-LN self-attention sub-layer
 class AttnSublayer(torch.autograd.Function):
     """y = x + proj(attn(split(qkv(LN(x)))))   -- Block / DecoderBlock self-attention half
@@ -448,6 +884,9 @@ class AttnSublayer(torch.autograd.Function):
         R, d = x.shape
         nseq, hd = R // L, d // H
         dev = x.device
+        ctx.composite = False
+        if _composite_ok(x, pre_ln, d):
+            return _attn_fwd_c(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, eps, conv1d, scale, drop)
         ctx.up = _upstream_of(x) if pre_ln else None
         mean, rstd = _stats(R if pre_ln else 0, dev)
         if pre_ln:
@@ -474,6 +913,8 @@ class AttnSublayer(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dprobs):
+        if ctx.composite:
+            return _attn_bwd_c(ctx, dy)
         x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, mean, rstd, probs = ctx.saved_tensors
         xn, qkv, ao = ctx.acts
         L, H, scale, conv1d, pre_ln, drop = ctx.cfg
@@ -519,6 +960,9 @@ class MLPSublayer(torch.autograd.Function):
         dev = x.device
         hidden = w1.shape[1] if conv1d else w1.shape[0]
         d_out = w2.shape[1] if conv1d else w2.shape[0]
+        ctx.composite = False
+        if d_out == d and _composite_ok(x, pre_ln, d, hidden):
+            return _mlp_fwd_c(ctx, x, ln_w, ln_b, w1, b1, w2, b2, eps, gelu, conv1d, hidden, drop)
         ctx.up = _upstream_of(x) if pre_ln else None
         mean, rstd = _stats(R if pre_ln else 0, dev)
         if pre_ln:
@@ -538,6 +982,8 @@ class MLPSublayer(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.composite:
+            return _mlp_bwd_c(ctx, dy)
         x, ln_w, ln_b, w1, b1, w2, b2, mean, rstd = ctx.saved_tensors
         xn, u, h = ctx.acts
         gelu, conv1d, hidden, pre_ln, drop = ctx.cfg
@@ -580,6 +1026,10 @@ class CrossAttnSublayer(torch.autograd.Function):
         R, d = x.shape
         nseq, hd = R // L, d // H
         dev = x.device
+        ctx.composite = False
+        if _composite_ok(x, pre_ln, d) and mem.stride(0) == d:
+            return _cross_fwd_c(ctx, x, mem, nq_w, nq_b, nkv_w, nkv_b, w_q, w_k, w_v, w_proj, b_proj, L, H, mask, eps, scale,
+                                drop)
         ctx.up = _upstream_of(x) if pre_ln else None
         mq, rq = _stats(R if pre_ln else 0, dev)
         mk, rk = _stats(R if pre_ln else 0, dev)
@@ -609,6 +1059,8 @@ class CrossAttnSublayer(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.composite:
+            return _cross_bwd_c(ctx, dy)
         (x, mem, nq_w, nq_b, nkv_w, nkv_b, w_q, w_k, w_v, w_proj, b_proj, mq, rq, mk, rk, probs) = ctx.saved_tensors
         xq, mkv, q, k, v, ao = ctx.acts
         L, H, scale, pre_ln, drop = ctx.cfg

@@ -60,10 +60,11 @@ def set_workspace_bytes(n: int):
         _WS.clear()
 
 
-def gemm_workspace(device) -> Tensor:
-    """The split-K scratch of the CURRENT stream on `device`: allocated once per stream (counters zeroed once; every
-    launch leaves them zero), owned here so that the library itself never allocates (include/afft_hip.h)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+def gemm_workspace(device, raw_stream: Optional[int] = None) -> Tensor:
+    """The split-K scratch of the CURRENT stream (or of `raw_stream`) on `device`: allocated once per stream (counters
+    zeroed once; every launch leaves them zero), owned here so that the library itself never allocates (include/afft_hip.h)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           _stream() if raw_stream is None else raw_stream)
     ws = _WS.get(key)
     if ws is None:
         ws = torch.zeros(_WS_BYTES, dtype=torch.uint8, device=device)

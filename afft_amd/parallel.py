@@ -98,7 +98,13 @@ class GradReducer:
     called on the side stream right after a bucket's gradient is final (reduced): the per-bucket optimizer hook."""
 
     def __init__(self, flat: FlatParams, group=None, bucket_elems: int = 32 * 1024 * 1024, comm_dtype: str = "fp32",
-                 force_comm: bool = False):
+                 force_comm: bool = False, comm_algo: str = "allreduce"):
+        """comm_algo: 'allreduce' (one all-reduce per bucket) or 'rs_ag' (reduce-scatter + all-gather of the same bucket: the
+        same bytes per link as a ring all-reduce, in two collectives the library schedules independently -- the fallback
+        for a fabric on which the all-reduce picks a slow algorithm; xGMI is point-to-point)."""
+        if comm_algo not in ("allreduce", "rs_ag"):
+            raise ValueError("comm_algo must be 'allreduce' or 'rs_ag'")
+        self.comm_algo = comm_algo
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -156,7 +162,10 @@ class GradReducer:
         s, e = self.buckets[b]
         if not self._use_cuda:
             if self.comm:
-                self._handles.append(dist.all_reduce(self.flat.flat_g[s:e], group=self.group, async_op=True))
+                if self.comm_algo == "rs_ag":
+                    self._reduce(self.flat.flat_g[s:e])
+                else:
+                    self._handles.append(dist.all_reduce(self.flat.flat_g[s:e], group=self.group, async_op=True))
             return
         ev = torch.cuda.Event()
         ev.record()
@@ -169,9 +178,20 @@ class GradReducer:
                     n = e - s
                     ops.cast(self.flat.flat_g[s:e].view(n // 64, 64), self.flat_g16[s:e].view(n // 64, 64))
                 # RCCL enqueues behind the work already on this stream; later work on this stream follows it
-                dist.all_reduce(self._grad_slice(s, e), group=self.group)
+                self._reduce(self._grad_slice(s, e))
             if self.on_bucket is not None:
                 self.on_bucket(s, e, self._grad_slice(s, e), 1.0 / self.world)
+
+    def _reduce(self, g: Tensor):
+        """sum `g` (a contiguous bucket of the flat gradient buffer) over the ranks, in place"""
+        if self.comm_algo == "allreduce" or g.numel() % self.world != 0:
+            dist.all_reduce(g, group=self.group)
+            return
+        n = g.numel() // self.world
+        r = dist.get_rank(self.group)
+        shard = g[r * n:(r + 1) * n]        # reduce-scatter into this rank's own slice of the bucket, all-gather in place
+        dist.reduce_scatter_tensor(shard, g, group=self.group)
+        dist.all_gather_into_tensor(g, shard, group=self.group)
 
     def finish_step(self):
         """Call after backward: zero untouched grads, hand over whatever is still pending, join the side stream."""
@@ -242,12 +262,13 @@ class Trainer:
 
     def __init__(self, model, loss_wts: Dict[str, float], lr=1e-3, momentum=0.9, weight_decay=1e-6,
                  comm_dtype: str = "fp32", bucket_elems: int = 32 * 1024 * 1024, group=None,
-                 overlap_optimizer: bool = True, force_comm: bool = False, grad_clip: Optional[float] = None):
+                 overlap_optimizer: bool = True, force_comm: bool = False, grad_clip: Optional[float] = None,
+                 comm_algo: str = "allreduce"):
         from .common.runner import BasicLossAccuracy, Runner
         self.model = model
         self.flat = FlatParams(model)
         self.reducer = GradReducer(self.flat, group=group, bucket_elems=bucket_elems, comm_dtype=comm_dtype,
-                                   force_comm=force_comm)
+                                   force_comm=force_comm, comm_algo=comm_algo)
         self.opt = FusedSGD(self.flat, lr, momentum, weight_decay)
         if self.reducer.world > 1:
             self.sync_parameters(group)
@@ -285,15 +306,19 @@ class Trainer:
         return loss.detach(), parts
 
     # ---- captured step (hipGraph): for configurations whose step is bound by the host's enqueue rate
-    def capture(self, feats, target, target_subclips, warmup: int = 3):
+    def capture(self, feats, target, target_subclips, warmup: int = 3, single_stream: bool = False):
         """Capture one whole training step (forward, loss, backward with its three streams, fused SGD) on THESE input
         tensors into a hipGraph; step() then replays it whenever it is called with the same tensors (new batches are
         copied into them).  Single GPU only (the RCCL all-reduce is not captured).  The dropout masks still change every
         step: the keys drawn on the host are frozen in the graph, the salt they are XOR-ed with lives in device memory
-        and is advanced by the first node of the graph."""
+        and is advanced by the first node of the graph.
+        single_stream: capture the step as ONE linear chain (weight gradients on the main stream, the optimizer after the
+        backward pass): no cross-stream edges in the graph, for the configurations whose eager step is bound by the host's
+        enqueue rate rather than by the GPU."""
         from . import dropout as D_
         assert self.flat.flat_p.is_cuda and not self.reducer.comm, "capture(): single-GPU training only"
-        assert self.overlap_optimizer, "capture(): needs the optimizer inside the backward pass (no gradient clipping)"
+        assert single_stream or self.overlap_optimizer, "capture(): needs the optimizer inside the backward pass (no gradient clipping)"
+        self._graph_single = bool(single_stream)
         D_.enable_device_salt(self.flat.flat_p.device)
         self._graph = None
         # warm up ON the capture stream: the library keeps its split-K workspace per stream and would otherwise
@@ -328,6 +353,16 @@ class Trainer:
     def _eager_step(self, feats, target, target_subclips):
         from . import dropout as D_
         D_.salt_step()
+        if getattr(self, "_graph_single", False):
+            was = rt.overlap_wgrad()
+            rt.set_overlap_wgrad(False)
+            try:
+                loss, parts = self.forward_backward(feats, target, target_subclips, optimize_in_backward=False)
+                g, scale = self.reducer.grad_for_optimizer()
+                self.opt.step(g, scale, grad_clip=self.grad_clip)
+            finally:
+                rt.set_overlap_wgrad(was)
+            return loss, parts
         return self.forward_backward(feats, target, target_subclips, optimize_in_backward=True)
 
     def _feed_graph(self, feats, target, target_subclips) -> bool:

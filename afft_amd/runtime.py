@@ -228,6 +228,20 @@ def set_wgrad_workgroups(n: int):
     _WGRAD_WGS = max(0, int(n))
 
 
+_COMPOSITE = os.environ.get("AFFT_COMPOSITE", "1") != "0"
+
+
+def composite() -> bool:
+    """Enqueue a whole sub-layer (forward or backward) through ONE composite C-ABI call (afft_*_sublayer_fwd / _bwd,
+    include/afft_hip.h) instead of one call per kernel: the same kernels in the same order, a fifth of the host work."""
+    return _COMPOSITE
+
+
+def set_composite(on: bool):
+    global _COMPOSITE
+    _COMPOSITE = bool(on)
+
+
 CAPTURING = False          # a hipGraph capture of the step is under way (afft_amd.parallel.Trainer.capture)
 KEEPALIVE: list = []       # tensors read on the auxiliary stream during a capture: kept until the capture ends, because
                            # inside a capture the allocator would hand their memory to a later main-stream allocation

@@ -40,9 +40,12 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--comm-dtype", default="bf16", choices=["bf16", "fp32"], help="gradient all-reduce payload")
+    ap.add_argument("--comm-algo", default="allreduce", choices=["allreduce", "rs_ag"],
+                    help="gradient exchange per bucket: one all-reduce, or reduce-scatter + all-gather (fallback)")
+    ap.add_argument("--no-comm-report", action="store_true", help="N > 1: skip the RCCL / exposed-communication / payload side measurements")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+loss+bwd(+all-reduce) only")
     ap.add_argument("--eval-drop", action="store_true", help="disable dropout (eval-mode layers) in the timed steps")
-    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off", "single"],
                     help="replay the step as one captured hipGraph (Trainer.capture); single GPU with the optimizer only; "
                          "auto = on for the configurations whose eager step is bound by the host's enqueue rate")
     ap.add_argument("--bucket-melems", type=int, default=32, help="gradient bucket size (Mi elements) of the all-reduce / SGD pipeline")
@@ -173,7 +176,9 @@ def cpu_baseline(name, B, steps=3):
     on a bounded sample of the same workload: fwd + loss + bwd, eval-mode math, cfg1 (B = 4) and the bench
     configuration (B = 16), 1 warm-up + >= 3 timed steps, at the best intra-op thread count of a short sweep on cfg1."""
     ncpu = os.cpu_count() or 1
-    cands = sorted({t for t in (16, 32, 64, 128, ncpu // 2, ncpu) if 1 <= t <= ncpu}) or [1]
+    # measured on the GPU box (2 x 64 cores, 256 threads): 16 intra-op threads are the best (13.7 clips/s on cfg1), 64 lose 2.6x
+    # and oversubscribing all 256 logical cores is 700x slower -- so the sweep stays at or below 64
+    cands = sorted({t for t in (8, 16, 32, 64) if 1 <= t <= ncpu}) or [1]
     sweep = {}
     for t in cands:
         torch.set_num_threads(t)
@@ -230,6 +235,70 @@ def parity_side_measurements(args, device, feats, tgt, sub, c):
     return out
 
 
+def comm_report(args, trainer, feats, tgt, sub, world, rank, device, ms_with_comm, rccl_log, sync_all):
+    """N > 1 side measurements, every rank takes part (collectives inside): what the gradient exchange costs and what the
+    library does for it.  (a) exposed communication = ms/step with the exchange - ms/step of the same ranks stepping without
+    it (buckets handed straight to the optimizer); (b) loss after 20 steps from the same start with fp32 and with bf16
+    gradient payloads (the reference all-reduces fp32, train.py:364-368); (c) RCCL's own words on topology / algorithm /
+    protocol, from its debug file."""
+    from afft_amd.parallel import Trainer
+    import afft_amd
+    rep = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "buckets": len(trainer.reducer.buckets),
+           "bucket_mib": round(4 * max(e - s for s, e in trainer.reducer.buckets) / 2 ** 20, 1),
+           "payload_gb_per_step": round(trainer.flat.total * (2 if args.comm_dtype == "bf16" else 4) / 1e9, 3)}
+    # (a) the same ranks without the exchange (replicas diverge from here on: this runs after the timed region)
+    was = trainer.reducer.comm
+    trainer.reducer.comm = False
+    for _ in range(3):
+        trainer.step(feats, tgt, sub)
+    sync_all()
+    t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        trainer.step(feats, tgt, sub)
+    sync_all()
+    t = torch.tensor([(time.perf_counter() - t0) / n * 1e3], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    trainer.reducer.comm = was
+    rep["ms_per_step_without_exchange"] = round(float(t), 3)
+    rep["exposed_comm_ms"] = round(ms_with_comm - float(t), 3)
+    # (b) payload precision: two fresh replicas of the model, 20 steps each
+    wts = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
+    losses = {}
+    for cd in ("fp32", "bf16"):
+        from afft_amd import dropout as D_
+        D_.manual_seed(42 + rank)
+        m, _ = build_model(args.config, device)
+        m.train(not args.eval_drop)
+        tr = Trainer(m, wts, comm_dtype=cd, bucket_elems=args.bucket_melems * 1024 * 1024, comm_algo=args.comm_algo)
+        for _ in range(20):
+            loss, _ = tr.step(feats, tgt, sub)
+        lt = loss.detach().double().reshape(1).clone()
+        dist.all_reduce(lt)
+        losses[cd] = float(lt) / world
+        del tr, m
+        torch.cuda.empty_cache()
+    rep["loss_after_20_steps"] = {k: round(v, 5) for k, v in losses.items()}
+    rep["loss_delta_bf16_vs_fp32_payload"] = round(losses["bf16"] - losses["fp32"], 6)
+    # (c) RCCL debug lines
+    if rank == 0 and rccl_log:
+        try:
+            import glob
+            import re
+            txt = "".join(open(f).read() for f in glob.glob(rccl_log + "*"))
+            pick = lambda pat: sorted(set(re.findall(pat, txt)))[:8]    # noqa: E731
+            rep["rccl"] = {"version": pick(r"(?:RCCL|NCCL) version ([^\n]+)"),
+                           "algo_proto_env": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS")},
+                           "channels": pick(r"(\d+ coll channels[^\n]*)"),
+                           "rings_trees": pick(r"(?:Ring|Trees?) \d+ :[^\n]{0,80}")[:4],
+                           "tuning": pick(r"(AllReduce[^\n]*(?:algo|Algo)[^\n]*|ReduceScatter[^\n]*(?:algo|Algo)[^\n]*|AllGather[^\n]*(?:algo|Algo)[^\n]*)"),
+                           "xgmi": pick(r"([^\n]*XGMI[^\n]{0,100})")[:4],
+                           "log_bytes": len(txt)}
+        except Exception as ex:  # noqa: BLE001
+            rep["rccl"] = {"error": repr(ex)}
+    return rep
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -239,8 +308,16 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    rccl_log = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not args.no_comm_report:
+            # which algorithm / protocol RCCL picks for the bucket sizes is decided inside the library: have it say so, into a
+            # per-process file (INIT + TUNING lines only) that rank 0 summarises after the timed region
+            rccl_log = f"/tmp/afft_rccl_{os.getpid()}.log"
+            os.environ.setdefault("NCCL_DEBUG", "INFO")
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING")
+            os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
         dist.init_process_group(backend="nccl", device_id=device)   # "nccl" == RCCL on ROCm
     assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -258,7 +335,8 @@ def main():
     B, T = args.batch, c["T"]
     feats, tgt, sub = make_inputs(c, B, T, rank, device)
     wts = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
-    trainer = Trainer(model, wts, comm_dtype=args.comm_dtype, bucket_elems=args.bucket_melems * 1024 * 1024)
+    trainer = Trainer(model, wts, comm_dtype=args.comm_dtype, bucket_elems=args.bucket_melems * 1024 * 1024,
+                      comm_algo=args.comm_algo)
     model.train(not args.eval_drop)
 
     def sync_all():
@@ -268,8 +346,8 @@ def main():
 
     captured = False
     if world == 1 and not args.no_optimizer and args.graph != "off":
-        if args.graph == "on" or args.config in GRAPH_AUTO:
-            trainer.capture(feats, tgt, sub, warmup=2)
+        if args.graph in ("on", "single") or args.config in GRAPH_AUTO:
+            trainer.capture(feats, tgt, sub, warmup=2, single_stream=(args.graph == "single"))
             captured = True
     for _ in range(args.warmup):
         trainer.step(feats, tgt, sub, optimize=not args.no_optimizer)
@@ -301,13 +379,20 @@ def main():
                                f"{'+allreduce' if world > 1 else ''}{'' if args.no_optimizer else '+nesterov-sgd'}",
                    "per_gpu_batch": B, "global_batch": B * world, "seq_len": T,
                    "parallelism": f"dp{world}", "grad_comm_dtype": args.comm_dtype if world > 1 else None,
-                   "step_launch": "hipGraph replay" if captured else "eager, 3 streams",
+                   "grad_comm_algo": args.comm_algo if world > 1 else None,
+                   "step_launch": ("hipGraph replay" + (", one stream" if args.graph == "single" else "")) if captured else "eager, 3 streams",
                    "wgrad_cu_cap": afft_amd.runtime.wgrad_workgroups() or None},
         "algorithmic_gflop_per_clip": round(gf, 2),
         "model_tflops": round(clips_s * gf / 1e3, 1),
         "mfma_frac_whole_step": round(clips_s * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
         "final_loss": round(loss_val, 4),
     }
+
+    if world > 1 and not args.no_comm_report:
+        try:     # deterministic on every rank (same code path), so a failure cannot leave a collective half-entered
+            result["comm"] = comm_report(args, trainer, feats, tgt, sub, world, rank, device, ms_per_step, rccl_log, sync_all)
+        except Exception as ex:  # noqa: BLE001
+            result["comm"] = {"error": repr(ex)}
 
     # the instrumented step for the roofline object runs on EVERY rank (its gradient all-reduce is a collective);
     # only rank 0 keeps the timings

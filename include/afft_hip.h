@@ -256,6 +256,110 @@ int afft_sgd_nesterov(float* p, const void* g, int32_t g_dtype, float* buf, void
 int afft_sumsq(const void* x, int32_t dtype, int64_t n, float scale, float* out, void* stream);
 int afft_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream);
 
+/* ------------------------------------------------------------------ composite entry points: one call = one sub-layer
+ * SURVEY.md 8(b) "minimum exports": a whole pre-LN transformer sub-layer, forward or backward, enqueued by ONE call.
+ * They launch exactly the kernels the primitive entry points above launch, in the same order, with the same arguments
+ * (afft_amd/functional.py is the call-by-call version of the same sequences): the point is the host -- a training step
+ * of the reference's EK100 configuration is ~370 kernel launches and becomes ~60 calls.
+ *
+ * bf16 speed mode only: GEMM operands are bf16 buffers whose leading dimensions are multiples of 64 and whose rows are
+ * padded to multiples of 64 WITH ZEROS (they are the K dimension of the weight-gradient GEMMs); residual stream, LayerNorm
+ * statistics, probabilities and every gradient of a parameter are fp32.  Weights are the bf16 IMAGES of the fp32
+ * parameters ([out, in] for nn.Linear, [in, out] for HF Conv1D when `conv1d`), leading dimensions ldw*.
+ * Backward: weight / bias gradients are written (acc_* = 0) or added (acc_* = 1) into the fp32 gradient buffers; NULL
+ * gradient pointer = that parameter does not exist (no bias) or needs no gradient.  `aux_stream` (may equal `stream` or
+ * be NULL): the weight-gradient GEMMs and bias column sums are enqueued there, ordered behind the producing kernels by
+ * events; NOTHING on `stream` waits for them -- the caller joins the streams when its backward pass is over.
+ * `wgrad_workgroups`: afft_gemm_t.max_workgroups of those GEMMs.
+ * Saved by forward for backward (caller-owned, see each struct): the bf16 activations, mean / rstd, probs.            */
+
+typedef struct {       /* y = x + drop(proj(attention(split(qkv(LN(x))))))                                          */
+  /* Block / DecoderBlock self-attention half: models/transformerblock.py:19-36,131-133,158-159 ; HF GPT2Block attn half  */
+  int32_t rows, d, L, H;                 /* rows = nseq * L tokens; H heads of d / H                                   */
+  int32_t conv1d, mask, mask_period;     /* AFFT_MASK_*                                                                */
+  float eps, scale;
+  const float* x;                        /* [rows, d] fp32, dense                                                      */
+  const float* ln_w; const float* ln_b;  /* [d] (NULL: no affine)                                                      */
+  const void* w_qkv; int64_t ldw_qkv; const float* b_qkv;      /* bf16 image; bias [3d] or NULL                        */
+  const void* w_proj; int64_t ldw_proj; const float* b_proj;
+  float p_attn; uint32_t k_attn;         /* attention-probability dropout                                              */
+  afft_dropout_t out_drop;               /* projection dropout + DropPath                                              */
+  /* forward outputs, saved for backward */
+  void* xn; void* qkv; void* ao;         /* bf16 [rows_pad, d], [rows_pad, 3d], [rows_pad, d], dense, zero row tails   */
+  float* mean; float* rstd;              /* [rows]                                                                     */
+  float* probs;                          /* [nseq, H, L, L]                                                            */
+  float* y;                              /* [rows, d] fp32 (forward only)                                              */
+  /* backward only */
+  const float* dy;                       /* [rows, d] fp32                                                             */
+  void* dya;                             /* bf16 [rows_pad, d]: dy with out_drop replayed; dya_ready = 1: already holds it */
+  int32_t dya_ready;                     /*   (handed over by the LayerNorm backward downstream, with the b_proj gradient) */
+  void* dao; void* dqkv; void* dxn;      /* bf16 scratch [rows_pad, d], [rows_pad, 3d], [rows_pad, d] (zero row tails) */
+  float* g_w_qkv; int32_t acc_w_qkv; float* g_b_qkv; int32_t acc_b_qkv;
+  float* g_w_proj; int32_t acc_w_proj; float* g_b_proj; int32_t acc_b_proj;     /* g_b_proj NULL when handed over      */
+  float* g_ln_w; float* g_ln_b; int32_t acc_ln;
+  float* dx;                             /* [rows, d] fp32 = dy + LN'(...)                                             */
+  void* dx_bf16; const afft_dropout_t* up_drop; float* up_dcol;   /* optional hand-over emission (afft_layernorm_bwd)   */
+  float* ln_partial;                     /* afft_layernorm_bwd workspace                                               */
+  void* gemm_ws; int64_t gemm_ws_bytes;  /* afft_gemm_t.workspace of `stream`                                          */
+  void* gemm_ws_aux; int64_t gemm_ws_aux_bytes;   /* ... of `aux_stream`                                                */
+  int32_t wgrad_workgroups;
+} afft_attn_sublayer_t;
+int afft_attn_sublayer_fwd(const afft_attn_sublayer_t* s, void* stream);
+int afft_attn_sublayer_bwd(const afft_attn_sublayer_t* s, void* stream, void* aux_stream);
+
+typedef struct {       /* y = x + drop(fc2(gelu(fc1(LN(x)))))                                                         */
+  /* MLP half of Block / DecoderBlock: models/transformerblock.py:84-93,134,161 (erf GELU) ; HF GPT2MLP (gelu_new)        */
+  int32_t rows, d, hidden, conv1d;
+  int32_t gelu;                          /* AFFT_ACT_GELU_ERF or AFFT_ACT_GELU_TANH                                    */
+  float eps;
+  const float* x; const float* ln_w; const float* ln_b;
+  const void* w1; int64_t ldw1; const float* b1;
+  const void* w2; int64_t ldw2; const float* b2;
+  afft_dropout_t out_drop;
+  void* xn; void* u; void* h;            /* bf16 [rows_pad, d], [rows_pad, hidden] (pre-activation), [rows_pad, hidden]  */
+  float* mean; float* rstd;
+  float* y;
+  const float* dy; void* dya; int32_t dya_ready;
+  void* du; void* dxn;                   /* bf16 scratch [rows_pad, hidden], [rows_pad, d]                              */
+  float* g_w1; int32_t acc_w1; float* g_b1; int32_t acc_b1;
+  float* g_w2; int32_t acc_w2; float* g_b2; int32_t acc_b2;
+  float* g_ln_w; float* g_ln_b; int32_t acc_ln;
+  float* dx;
+  void* dx_bf16; const afft_dropout_t* up_drop; float* up_dcol;
+  float* ln_partial;
+  void* gemm_ws; int64_t gemm_ws_bytes; void* gemm_ws_aux; int64_t gemm_ws_aux_bytes;
+  int32_t wgrad_workgroups;
+} afft_mlp_sublayer_t;
+int afft_mlp_sublayer_fwd(const afft_mlp_sublayer_t* s, void* stream);
+int afft_mlp_sublayer_bwd(const afft_mlp_sublayer_t* s, void* stream, void* aux_stream);
+
+typedef struct {       /* y = x + drop(proj(attention(q = w_q LN_q(x), k = w_k LN_kv(mem), v = w_v LN_kv(mem))))      */
+  /* DecoderBlock cross-attention half (CA-Fuser): models/transformerblock.py:56-76,160 ; bias-free w_q / w_k / w_v      */
+  int32_t rows, d, L, H, mask, mask_period;
+  float eps, scale;
+  const float* x; const float* mem;      /* [rows, d] fp32 each                                                        */
+  const float* nq_w; const float* nq_b; const float* nkv_w; const float* nkv_b;
+  const void* w_q; const void* w_k; const void* w_v; const void* w_proj; int64_t ldw;   /* four [d, d] bf16 images     */
+  const float* b_proj;
+  float p_attn; uint32_t k_attn; afft_dropout_t out_drop;
+  void* xq; void* mkv; void* q; void* k; void* v; void* ao;    /* bf16 [rows_pad, d] each                              */
+  float* mean_q; float* rstd_q; float* mean_kv; float* rstd_kv; float* probs;
+  float* y;
+  const float* dy; void* dya; int32_t dya_ready;
+  void* dao; void* dq; void* dk; void* dv; void* dxq;          /* bf16 scratch [rows_pad, d]                           */
+  float* dmkv;                           /* fp32 scratch [rows, d]                                                     */
+  float* g_w_q; int32_t acc_w_q; float* g_w_k; int32_t acc_w_k; float* g_w_v; int32_t acc_w_v;
+  float* g_w_proj; int32_t acc_w_proj; float* g_b_proj; int32_t acc_b_proj;
+  float* g_nq_w; float* g_nq_b; int32_t acc_nq; float* g_nkv_w; float* g_nkv_b; int32_t acc_nkv;
+  float* dx; float* dmem;                /* [rows, d] fp32 each                                                        */
+  void* dx_bf16; const afft_dropout_t* up_drop; float* up_dcol;
+  float* ln_partial; float* ln_partial2;
+  void* gemm_ws; int64_t gemm_ws_bytes; void* gemm_ws_aux; int64_t gemm_ws_aux_bytes;
+  int32_t wgrad_workgroups;
+} afft_cross_attn_sublayer_t;
+int afft_cross_attn_sublayer_fwd(const afft_cross_attn_sublayer_t* s, void* stream);
+int afft_cross_attn_sublayer_bwd(const afft_cross_attn_sublayer_t* s, void* stream, void* aux_stream);
+
 #ifdef __cplusplus
 }
 #endif

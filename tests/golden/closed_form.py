@@ -82,3 +82,35 @@ def labels_for(tag: str, B: int, T: int, num_classes: int, ignore_frac: float = 
     u3 = _hash_uniform(B * T, _key(tag + ".ignore"))
     sub[(u3 + 0.5) < ignore_frac] = -1
     return tgt, torch.from_numpy(sub.reshape(B, T, 1))
+
+
+def eval_inputs(N=48, A=30, V=7, Nn=11, seed=0):
+    """closed-form inputs of the eval-path fixture: action logits, one-hot action -> verb / noun maps, labels"""
+    logits = (8.0 * _hash_uniform(N * A, 0xE7A1 + seed)).astype(np.float32).reshape(N, A)
+    a = np.arange(A)
+    verb_of, noun_of = (a * 3 + 1) % V, (a * 5 + 2) % Nn
+    mv = np.zeros((A, V), np.float32)
+    mv[a, verb_of] = 1
+    mn = np.zeros((A, Nn), np.float32)
+    mn[a, noun_of] = 1
+    labels = (np.arange(N) * 7 + 3) % A
+    labels[::4] = logits[::4].argmax(1)          # some clips are predicted right
+    return logits, mv, mn, labels, verb_of[labels], noun_of[labels]
+
+
+
+
+def reader_stores(C_rgb=12, C_audio=6):
+    """closed-form RULSTM-style feature stores for the reader fixture: key "<video>_frame_{:010d}.jpg" -> float32 bytes.
+    'rgb' store (30 fps ids): frames 3.. of P01_101 stored except every 7th and a hole of 12 (beyond the 9-frame search);
+    'audio' store (indexed in the ORIGINAL video's 50 fps for the EPIC-100 name P01_101): every second frame stored."""
+    vid = "P01_101"
+    rgb, audio = {}, {}
+    for f in range(3, 140):
+        if f % 7 == 0 or 60 <= f < 72:
+            continue
+        rgb[f"{vid}_frame_{f:010d}.jpg".encode()] = (_hash_uniform(C_rgb, 0xA000 + f)).astype(np.float32).tobytes()
+    for f in range(2, 260, 2):
+        audio[f"{vid}_frame_{f:010d}.jpg".encode()] = (_hash_uniform(C_audio, 0xB000 + f)).astype(np.float32).tobytes()
+    queries = [(0.05, 0.9), (1.0, 2.45), (1.9, 2.5), (2.0, 4.0)]      # (start_sec, end_sec); the first clamps ids < 1
+    return vid, {"rgb": rgb, "audio": audio}, queries

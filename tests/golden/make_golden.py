@@ -275,6 +275,80 @@ def run_case(name: str, c: dict):
     np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **arrays)
 
 
+def run_eval_case():
+    """m0_marginalize: the reference's challenge.marginalize_verb_noun (challenge.py:196-210) + its accuracy bookkeeping
+    (compute_accuracies_epic :161-193, common/utils.py:19-56) on a stub dataset object."""
+    import pandas as pd
+    _mod("h5py")
+    _mod("numpyencoder", NumpyEncoder=object)
+    import challenge as RC
+    from oracle import afft_oracle as O
+    from closed_form import eval_inputs
+    logits, mv, mn, a_lab, v_lab, n_lab = eval_inputs()
+
+    class _DS:
+        class_mappings = {("verb", "action"): torch.from_numpy(mv), ("noun", "action"): torch.from_numpy(mn)}
+        df = pd.DataFrame(dict(verb_class=v_lab, noun_class=n_lab, action_class=a_lab))
+        classes_manyshot = {}
+        version = RC.EPIC100_VERSION
+    acc, scores = RC.marginalize_verb_noun(logits.copy(), _DS, to_prob=True)
+    oacc, oscores = O.marginalize_verb_noun(logits.copy(), mv, mn, v_lab, n_lab, a_lab)
+    for r, o in zip(scores, oscores):
+        assert np.allclose(r, o, rtol=1e-6, atol=1e-7)
+    for k, v in acc.items():
+        assert (np.isnan(v) and np.isnan(oacc[k])) or abs(v - oacc[k]) < 1e-9, (k, v, oacc[k])
+    print("[m0_marginalize] oracle == reference:", {k: round(float(v), 3) for k, v in acc.items() if not np.isnan(v)})
+    np.savez_compressed(os.path.join(HERE, "m0_marginalize.npz"), verb=np.asarray(scores[0], np.float32),
+                        noun=np.asarray(scores[1], np.float32), action=np.asarray(scores[2], np.float32),
+                        acc_names=np.asarray(sorted(acc)), acc_values=np.asarray([float(acc[k]) for k in sorted(acc)], np.float64),
+                        meta=np.asarray(json.dumps(dict(case="m0_marginalize", torch=torch.__version__, numpy=np.__version__,
+                                                        reference="zeyun-zhong/AFFT @ /root/reference (v1)"))))
+
+
+def run_reader_case():
+    """r0_reader: the reference's EpicRULSTMFeatsReader (datasets/reader_fns.py:41-157) over dict-backed fake LMDB
+    environments (the `lmdb` / torchvision packages are stubbed; the reader only calls env.begin().get(key))."""
+    from closed_form import reader_stores
+    vid, stores, queries = reader_stores()
+
+    class _Txn:
+        def __init__(self, d):
+            self.d = d
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def get(self, k):
+            return self.d.get(k)
+
+    class _Env:
+        def __init__(self, d):
+            self.d = d
+
+        def begin(self):
+            return _Txn(self.d)
+
+    _mod("lmdb", open=lambda path, readonly=True, lock=False: _Env(stores["audio" if "audio" in str(path) else "rgb"]))
+    _mod("torchvision")
+    sys.modules["omegaconf"].OmegaConf.get_type = staticmethod(lambda x: type(x))
+    import datasets.reader_fns as RR
+    import logging
+    logging.disable(logging.CRITICAL)
+    out = {}
+    for tag, paths in (("rgb", ["/data/rgb_lmdb"]), ("rgb_audio", ["/data/rgb_lmdb", "/data/audio_lmdb"])):
+        rd = RR.EpicRULSTMFeatsReader(lmdb_path=paths, warn_if_using_closeby_frame=True)
+        for qi, (a, b) in enumerate(queries):
+            feat, _, _, _ = rd(f"/videos/{vid}.MP4", a, b, 30.0, None)
+            out[f"{tag}:{qi}"] = feat.numpy()
+    logging.disable(logging.NOTSET)
+    np.savez_compressed(os.path.join(HERE, "r0_reader.npz"), **out,
+                        meta=np.asarray(json.dumps(dict(case="r0_reader", reference="zeyun-zhong/AFFT @ /root/reference (v1)"))))
+    print("[r0_reader]", {k: v.shape for k, v in out.items()})
+
+
 def main():
     install_stubs()
     from cases import CASES
@@ -283,6 +357,10 @@ def main():
         if only and name not in only:
             continue
         run_case(name, c)
+    if not only or "m0_marginalize" in only:
+        run_eval_case()
+    if not only or "r0_reader" in only:
+        run_reader_case()
 
 
 if __name__ == "__main__":

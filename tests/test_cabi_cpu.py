@@ -53,6 +53,27 @@ int main(){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(afft_gemm_t), offsetof(af
     assert got == want
 
 
+@pytest.mark.parametrize("cname,pyname", [("afft_gemm_t", "GemmDesc"), ("afft_dropout_t", "Dropout"),
+                                          ("afft_attn_sublayer_t", "AttnSublayer"), ("afft_mlp_sublayer_t", "MLPSublayer"),
+                                          ("afft_cross_attn_sublayer_t", "CrossAttnSublayer")])
+def test_every_struct_field_matches_c_layout(built_lib, cname, pyname):
+    """sizeof and the offset of EVERY field of each ctypes mirror against what the C compiler lays out for the header."""
+    import tempfile
+    S = getattr(built_lib, pyname)
+    names = [f[0] for f in S._fields_]
+    body = "".join(f'printf("%zu\\n", offsetof({cname}, {n}));' for n in names)
+    src = f'#include <stddef.h>\n#include <stdio.h>\n#include "afft_hip.h"\nint main(){{ printf("%zu\\n", sizeof({cname})); {body} return 0; }}\n'
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(td, "t")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        got = [int(x) for x in subprocess.check_output([exe]).split()]
+    assert got[0] == ctypes.sizeof(S), (got[0], ctypes.sizeof(S))
+    for n, off in zip(names, got[1:]):
+        assert getattr(S, n).offset == off, (n, getattr(S, n).offset, off)
+
+
 def test_no_gpu_means_loud_failure(built_lib):
     import torch
     if torch.cuda.is_available():

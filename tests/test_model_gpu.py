@@ -237,6 +237,67 @@ def test_train_mode_dropout_statistics():
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
 
 
+@pytest.mark.parametrize("train", [False, True])
+@pytest.mark.parametrize("name", ["t3_m5", "t1_ca", "t2_flt"])
+def test_composite_entry_points_equal_call_by_call_path(name, train):
+    """afft_{attn,mlp,cross_attn}_sublayer_{fwd,bwd} (one C-ABI call per sub-layer) enqueue the same kernels with the same
+    arguments in the same order as the call-by-call path of afft_amd/functional.py: outputs, loss and every gradient are
+    BITWISE equal, in eval mode and in train mode (dropout / DropPath keys are drawn by the modules, before either path)."""
+    import afft_amd
+    from afft_amd import dropout as D_, runtime as rt
+    from afft_amd.common.runner import BasicLossAccuracy, Runner
+    c, state, data, tgt, sub = case_tensors(name)
+    dev = torch.device("cuda:0")
+    res = {}
+    for comp in (True, False):
+        rt.set_composite(comp)
+        D_.manual_seed(123)
+        model = build(c, "bf16")
+        model.load_state_dict(state)
+        model = model.cuda().train(train)
+        rt.SINK.begin_step()
+        out, out_t = model({m: d.to(dev) for m, d in data.items()}, mixup_fn=None, target={"action": tgt.to(dev)},
+                           target_subclips={"action": sub.to(dev)}, target_subclips_ignore_index=None)
+        losses, _ = BasicLossAccuracy(False)(out, out_t["target"], out_t["target_subclips"])
+        total, _ = Runner._reduce_loss(losses, {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}, sync=False)
+        total.backward()
+        rt.SINK.finish_step(list(model.parameters()))
+        torch.cuda.synchronize()
+        res[comp] = (flatten_outputs(out), float(total), {k: p.grad.clone() for k, p in model.named_parameters()})
+    rt.set_composite(True)
+    (o1, l1, g1), (o0, l0, g0) = res[True], res[False]
+    assert l1 == l0
+    for k in o0:
+        assert torch.equal(o1[k], o0[k]), k
+    assert g1.keys() == g0.keys()
+    for k in g0:
+        assert torch.equal(g1[k], g0[k]), k
+
+
+def test_marginalize_verb_noun_matches_reference_golden():
+    """afft_amd.challenge.marginalize_verb_noun (row softmax kernel + two exact-fp32 MFMA GEMMs on the device, then the
+    host-side accuracy bookkeeping) against tests/golden/m0_marginalize.npz, which the reference's own
+    challenge.marginalize_verb_noun (challenge.py:196-210) produced on the same closed-form inputs."""
+    import os
+    import numpy as np
+    import pandas as pd
+    from afft_amd import challenge as CH
+    from closed_form import eval_inputs
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "m0_marginalize.npz"))
+    logits, mv, mn, a_lab, v_lab, n_lab = eval_inputs()
+
+    class _DS:
+        class_mappings = {("verb", "action"): torch.from_numpy(mv), ("noun", "action"): torch.from_numpy(mn)}
+        df = pd.DataFrame(dict(verb_class=v_lab, noun_class=n_lab, action_class=a_lab))
+        classes_manyshot = {}
+    acc, scores = CH.marginalize_verb_noun(torch.from_numpy(logits).cuda(), _DS, to_prob=True)
+    for got, key in zip(scores, ("verb", "noun", "action")):
+        assert got.shape == z[key].shape
+        assert rel_l2(torch.from_numpy(got), torch.from_numpy(z[key])) < 1e-6, key
+    for k, v in zip([str(k) for k in z["acc_names"]], z["acc_values"]):
+        assert (np.isnan(v) and np.isnan(acc[k])) or abs(acc[k] - v) < 1e-9, (k, acc[k], v)
+
+
 def test_public_drop_path_module_is_differentiable():
     """models.transformerblock.DropPath in train mode (the standalone form; inside Block it is fused into the GEMM epilogue):
     one keep/drop decision per dim-0 sample, survivors scaled by 1/(1-p), and the gradient flows back through the SAME mask

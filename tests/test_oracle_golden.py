@@ -74,3 +74,35 @@ def test_kat_activations_and_softmax():
     assert not torch.equal(y5, y6) and torch.allclose(y5, y6, atol=1e-5)
     oh = O.one_hot(torch.tensor([2]), 4, 0.4)
     assert torch.allclose(oh, torch.tensor([[0.1, 0.1, 0.7, 0.1]]))
+
+
+def _eval_fixture():
+    import os
+    import numpy as np
+    from closed_form import eval_inputs
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "m0_marginalize.npz"))
+    return z, eval_inputs()
+
+
+def test_eval_path_oracle_and_host_metrics_match_reference_golden():
+    """m0_marginalize.npz = the reference's challenge.marginalize_verb_noun on a stub dataset: the oracle restatement and the
+    product's host-side accuracy bookkeeping (afft_amd.challenge: numpy, no GPU involved) reproduce it."""
+    import numpy as np
+    import pandas as pd
+    from afft_amd import challenge as CH
+    from oracle import afft_oracle as O
+    z, (logits, mv, mn, a_lab, v_lab, n_lab) = _eval_fixture()
+    acc, scores = O.marginalize_verb_noun(logits, mv, mn, v_lab, n_lab, a_lab)
+    for got, key in zip(scores, ("verb", "noun", "action")):
+        assert np.allclose(got, z[key], rtol=1e-6, atol=1e-7), key
+    want = dict(zip([str(k) for k in z["acc_names"]], z["acc_values"]))
+    for k, v in want.items():
+        assert (np.isnan(v) and np.isnan(acc[k])) or abs(acc[k] - v) < 1e-9, k
+
+    class _DS:
+        df = pd.DataFrame(dict(verb_class=v_lab, noun_class=n_lab, action_class=a_lab))
+        classes_manyshot = {}
+    got = CH.compute_accuracies_epic([z["verb"], z["noun"], z["action"]], _DS)
+    assert set(got) == set(want)
+    for k, v in want.items():
+        assert (np.isnan(v) and np.isnan(got[k])) or abs(got[k] - v) < 1e-9, (k, got[k], v)

@@ -124,7 +124,7 @@ def _afft_model(c, state, precision):
 WTS = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
 
 
-def _afft_worker(rank, world, port, out, comm_dtype):
+def _afft_worker(rank, world, port, out, comm_dtype, comm_algo="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sys
@@ -141,7 +141,8 @@ def _afft_worker(rank, world, port, out, comm_dtype):
             with torch.no_grad():
                 for p in model.parameters():
                     p.add_(0.05)
-        tr = Trainer(model, WTS, lr=1e-2, momentum=0.9, weight_decay=1e-4, bucket_elems=8192, comm_dtype=comm_dtype)
+        tr = Trainer(model, WTS, lr=1e-2, momentum=0.9, weight_decay=1e-4, bucket_elems=8192, comm_dtype=comm_dtype,
+                     comm_algo=comm_algo)
         assert len(tr.reducer.buckets) >= 3
         h = data[next(iter(data))].shape[0] // world
         sl = slice(rank * h, (rank + 1) * h)
@@ -164,7 +165,8 @@ def _afft_worker(rank, world, port, out, comm_dtype):
     dist.destroy_process_group()
 
 
-def test_two_rank_trainer_real_model_matches_single_process(tmp_path):
+@pytest.mark.parametrize("comm_algo", ["allreduce", "rs_ag"])
+def test_two_rank_trainer_real_model_matches_single_process(tmp_path, comm_algo):
     """world_size 2 over gloo with the REAL BaseModel / functional sink / GradReducer / per-bucket fused SGD (the kernels
     replaced by the torch test double): rank 1 starts from different weights and must be overwritten by the construction-time
     broadcast; after 3 steps on half-batches both replicas hold bitwise-identical weights, equal to a single process
@@ -172,7 +174,7 @@ def test_two_rank_trainer_real_model_matches_single_process(tmp_path):
     import cpu_ops
     from afft_amd.parallel import Trainer
     out = str(tmp_path / "afft_r0.pt")
-    mp.spawn(_afft_worker, args=(2, _free_port(), out, "fp32"), nprocs=2, join=True)
+    mp.spawn(_afft_worker, args=(2, _free_port(), out, "fp32", comm_algo), nprocs=2, join=True)
     got = torch.load(out)
     c, state, data, tgt, sub = _afft_case()
     with cpu_ops.installed():

@@ -65,3 +65,59 @@ def test_feature_batcher_layout_and_ragged_last_batch():
     assert out2["rgb"].shape[0] == 2
     with pytest.raises(AssertionError):
         fb.collate([{m: torch.zeros(4, C) for m, C in dims.items()}])
+
+
+def test_reader_matches_reference_golden_bit_exact():
+    """tests/golden/r0_reader.npz = the reference's EpicRULSTMFeatsReader (datasets/reader_fns.py:41-157) run over dict-backed
+    fake LMDB environments on closed-form stores with holes (a 9-frame back-search, a 12-frame gap -> zeros, ids < 1
+    clamped) and an 'audio' store in the original video's 50 fps: our reader returns the same bytes."""
+    import logging
+    import os
+    import numpy as np
+    from closed_form import reader_stores
+    from afft_amd.datasets.reader_fns import DictStore, EpicRULSTMFeatsReader
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "r0_reader.npz"))
+    vid, stores, queries = reader_stores()
+    logging.disable(logging.CRITICAL)
+    try:
+        for tag, names in (("rgb", ["/data/rgb_lmdb"]), ("rgb_audio", ["/data/rgb_lmdb", "/data/audio_lmdb"])):
+            rd = EpicRULSTMFeatsReader([DictStore(stores["audio" if "audio" in n else "rgb"]) for n in names], store_names=names)
+            for qi, (a, b) in enumerate(queries):
+                feat, _, _, _ = rd(f"/videos/{vid}.MP4", a, b, 30.0, None)
+                want = z[f"{tag}:{qi}"]
+                assert feat.shape == want.shape and feat.dtype == torch.float32
+                assert np.array_equal(feat.numpy(), want), (tag, qi)
+    finally:
+        logging.disable(logging.NOTSET)
+
+
+def test_open_lmdb_binding_over_a_stand_in_lmdb_module(monkeypatch):
+    """open_lmdb: the LMDB binding itself (readonly, lock-free environment; one read transaction per get), exercised with a
+    stand-in `lmdb` module of the same interface (the package is not in the image)."""
+    import sys
+    import types
+    from afft_amd.datasets import reader_fns as R
+    data = {b"k1": b"abcd"}
+    opened = {}
+
+    class _Txn:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def get(self, k):
+            return data.get(k)
+
+    class _Env:
+        def begin(self):
+            return _Txn()
+
+    def _open(path, readonly=False, lock=True):
+        opened.update(path=path, readonly=readonly, lock=lock)
+        return _Env()
+    monkeypatch.setitem(sys.modules, "lmdb", types.SimpleNamespace(open=_open))
+    st = R.open_lmdb("/data/x_lmdb")
+    assert opened == dict(path="/data/x_lmdb", readonly=True, lock=False)
+    assert st.get(b"k1") == b"abcd" and st.get(b"nope") is None
