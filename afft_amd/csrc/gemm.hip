@@ -252,11 +252,19 @@ int choose_splitk(int variant, int M, int N, int K) {
     else if (g_splitk_mode > 1 && nk >= 2 * g_splitk_mode) s = g_splitk_mode == 4 ? 3 : 2;
     return (s > 1 && t3 <= kMaxSplitTiles) ? s : 1;
   }
-  // 128x128 tiles, small grids: <= 128 tiles leave half of the CUs without a workgroup, and what bounds such a launch
-  // is the LDS fill rate of the CUs that have one -- more CUs pulling is the lever.  Cut K in 2 (4 when K is long).
+  // 128x128 tiles (2 workgroups per CU = 512 slots): a grid that leaves slots empty is bound by the LDS fill rate of the CUs
+  // that have a workgroup -- more workgroups pulling is the lever.  Cut K so that tiles x slices approaches 512, keeping at
+  // least 16 K-steps (K = 1024) per slice: <= 128 tiles -> 2 slices (4 when K >= 6144), and -- round 2, measured on the
+  // K = 5120 weight gradients of the d = 1024 and d = 2048 models (profiles/r02_gemm_ek100_shapes.txt: 3072x1024x5120
+  // 70 -> 49 us, 4096x1024x5120 74 -> 54 us, 1024x1024x5120 39 -> 30 us) -- <= 256 tiles with K >= 4096 -> 2 slices,
+  // <= 64 tiles with K >= 4096 -> 4.
   const int64_t t1 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
   int s = 1;
-  if (g_splitk_mode == 1) s = (t1 <= 128 && nk >= 32) ? ((nk >= 96 && t1 * 4 <= 512) ? 4 : 2) : 1;
+  if (g_splitk_mode == 1) {
+    if (t1 <= 128 && nk >= 32) s = (nk >= 96 && t1 * 4 <= 512) ? 4 : 2;
+    if (t1 <= 64 && nk >= 64) s = 4;
+    if (t1 > 128 && t1 <= 256 && nk >= 64) s = 2;
+  }
   else if (t1 * g_splitk_mode <= kMaxSplitTiles && nk >= 2 * g_splitk_mode) s = g_splitk_mode;
   while (s > 1 && nk % s != 0) s >>= 1;
   return (s > 1 && t1 <= kMaxSplitTiles) ? s : 1;
@@ -302,8 +310,13 @@ int choose_variant(int M, int N, int K, bool A_KS, bool B_KS) {
   // 128x128 workgroups per CU win.  The 256x128 3-stage shape (variant 2) never wins and is kept for reference.
   const int64_t t3 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
   if (t3 < 160) return 1;
-  if (t3 < 256 && K < 4096 && !A_KS && !B_KS) return 1;   // short-K NT GEMM on a partial wave of 256x256 tiles
-  return 3;
+  // Both shapes waste the slots of their last, partial round (256 slots of one 256x256 tile, 512 of two 128x128 tiles per
+  // CU); per FLOP the big tile is ~1.25x as efficient.  Round 2 (profiles/r02_gemm_ek100_shapes.txt): 5120x4096x1024 is 320
+  // big tiles = 1.25 rounds (57 us on 128x128 tiles, 66 us on 256x256), 5120x3072x1024 is 240 = one nearly full round (45
+  // vs 38 us); 5120x2048x2048 (160 big tiles) 60 vs 55 us.
+  const int64_t t1 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
+  const double u3 = (double)t3 / (256.0 * ((t3 + 255) / 256)), u1 = (double)t1 / (512.0 * ((t1 + 511) / 512));
+  return u3 * 1.25 >= u1 ? 3 : 1;
 }
 
 }  // namespace
