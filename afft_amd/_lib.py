@@ -23,6 +23,13 @@ class Dropout(C.Structure):
     _fields_ = [("p", f32), ("key", C.c_uint32), ("path_p", f32), ("path_key", C.c_uint32), ("path_group", i32)]
 
 
+class SgdFused(C.Structure):      # afft_sgd_fused_t
+    _fields_ = [("p", vp), ("buf", vp), ("p_bf16", vp), ("lr", f32), ("mom", f32), ("wd", f32), ("gscale", f32), ("first_step", i32)]
+
+
+SgdP = C.POINTER(SgdFused)
+
+
 class GemmDesc(C.Structure):
     _fields_ = [
         ("M", i32), ("N", i32), ("K", i32), ("dtype", i32),
@@ -42,6 +49,7 @@ class GemmDesc(C.Structure):
         ("workspace", vp), ("workspace_bytes", i64),
         ("max_workgroups", i32),
         ("split3", i32), ("a_lo", i64), ("b_lo", i64),
+        ("sgd", SgdP),
     ]
 
 
@@ -68,7 +76,7 @@ class AttnSublayer(C.Structure):      # afft_attn_sublayer_t
         ("g_w_qkv", vp), ("acc_w_qkv", i32), ("g_b_qkv", vp), ("acc_b_qkv", i32),
         ("g_w_proj", vp), ("acc_w_proj", i32), ("g_b_proj", vp), ("acc_b_proj", i32),
         ("g_ln_w", vp), ("g_ln_b", vp), ("acc_ln", i32),
-        ("dx", vp)] + _HAND + [("ln_partial", vp)] + _WS
+        ("dx", vp)] + _HAND + [("ln_partial", vp)] + _WS + [("sgd_w_qkv", SgdP), ("sgd_w_proj", SgdP)]
 
 
 class MLPSublayer(C.Structure):       # afft_mlp_sublayer_t
@@ -86,7 +94,7 @@ class MLPSublayer(C.Structure):       # afft_mlp_sublayer_t
         ("g_w1", vp), ("acc_w1", i32), ("g_b1", vp), ("acc_b1", i32),
         ("g_w2", vp), ("acc_w2", i32), ("g_b2", vp), ("acc_b2", i32),
         ("g_ln_w", vp), ("g_ln_b", vp), ("acc_ln", i32),
-        ("dx", vp)] + _HAND + [("ln_partial", vp)] + _WS
+        ("dx", vp)] + _HAND + [("ln_partial", vp)] + _WS + [("sgd_w1", SgdP), ("sgd_w2", SgdP)]
 
 
 class CrossAttnSublayer(C.Structure):  # afft_cross_attn_sublayer_t
@@ -107,7 +115,13 @@ class CrossAttnSublayer(C.Structure):  # afft_cross_attn_sublayer_t
         ("g_w_q", vp), ("acc_w_q", i32), ("g_w_k", vp), ("acc_w_k", i32), ("g_w_v", vp), ("acc_w_v", i32),
         ("g_w_proj", vp), ("acc_w_proj", i32), ("g_b_proj", vp), ("acc_b_proj", i32),
         ("g_nq_w", vp), ("g_nq_b", vp), ("acc_nq", i32), ("g_nkv_w", vp), ("g_nkv_b", vp), ("acc_nkv", i32),
-        ("dx", vp), ("dmem", vp)] + _HAND + [("ln_partial", vp), ("ln_partial2", vp)] + _WS
+        ("dx", vp), ("dmem", vp)] + _HAND + [("ln_partial", vp), ("ln_partial2", vp)] + _WS + [
+            ("sgd_w_q", SgdP), ("sgd_w_k", SgdP), ("sgd_w_v", SgdP), ("sgd_w_proj", SgdP)]
+
+
+class GemmTraceRec(C.Structure):   # afft_gemm_trace_rec_t
+    _fields_ = [("M", i32), ("N", i32), ("K", i32), ("a_kstrided", i32), ("b_kstrided", i32), ("variant", i32), ("splitk", i32),
+                ("split3", i32), ("capped", i32), ("fused_update", i32), ("ms", f32)]
 
 
 _SIGS = {
@@ -117,6 +131,8 @@ _SIGS = {
     "afft_set_gemm_splitk": ([C.c_int], C.c_int),
     "afft_gemm_variant_for": ([C.c_int, C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
     "afft_gemm_splitk_for": ([C.c_int, C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
+    "afft_gemm_trace_begin": ([i32], C.c_int),
+    "afft_gemm_trace_end": ([C.POINTER(GemmTraceRec), i32], C.c_int),
     "afft_gemm_workspace_bytes": ([C.c_int, C.c_int, C.c_int, C.c_int, C.c_int], i64),
     "afft_split_bf16": ([vp, i64, i32, i32, vp, i64, i32, i64, vp], C.c_int),
     "afft_layernorm_fwd": ([vp, i64, vp, vp, f32, i32, i32, vp, i64, i32, vp, vp, vp], C.c_int),
@@ -135,6 +151,7 @@ _SIGS = {
     "afft_add_rows_periodic": ([vp, i64, vp, i64, i32, i32, i32, vp, i64, vp], C.c_int),
     "afft_reduce_rows_periodic": ([vp, i64, i32, i32, i32, vp, i64, vp], C.c_int),
     "afft_sgd_nesterov": ([vp, vp, i32, vp, vp, i64, f32, f32, f32, f32, vp, i32, vp], C.c_int),
+    "afft_sgd_nesterov_runs": ([vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, i32, vp], C.c_int),
     "afft_sumsq": ([vp, i32, i64, f32, vp, vp], C.c_int),
     "afft_group_sum": ([vp, i32, i32, i64, f32, vp, vp], C.c_int),
     "afft_set_dropout_salt": ([vp], C.c_int),

@@ -148,6 +148,16 @@ __device__ __forceinline__ float dgelu_tanh_f(float x) {
   return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.79788456080286536f * (1.0f + 3.0f * 0.044715f * x2);
 }
 
+// ---- Nesterov-SGD update of one element, shared by the stand-alone update kernels and the fused GEMM epilogue: every
+//      rounding is pinned (explicit fma / mul), so both give bit-identical parameters
+__device__ __forceinline__ void sgd_update(float& p, float& buf, float g, float lr, float mom, float wd, float gscale, bool first) {
+  const float gg = __fmaf_rn(g, gscale, __fmul_rn(wd, p));
+  const float bb = first ? gg : __fmaf_rn(mom, buf, gg);
+  buf = bb;
+  p = __fmaf_rn(-lr, __fmaf_rn(mom, bb, gg), p);
+}
+struct SgdEpi { float* p; float* buf; bf16_t* p16; float lr, mom, wd, gscale; int first; };
+
 // ---- GEMM epilogue shared by the bf16 fast path and the fp32 path ------------------------------
 struct EpiParams {
   int M, N;
@@ -164,6 +174,7 @@ struct EpiParams {
   int vec4;  // host-verified: every ld % 4 == 0 and bases 16-byte aligned -> 4-wide accesses legal
   int vec8;  // host-verified: every ld % 8 == 0 and bases 16-byte aligned -> 8-wide accesses legal (16-B bf16 stores)
   DropParams drop;  // dropout on the (activated) GEMM output + DropPath row scale, before the residual add
+  SgdEpi sgd;       // sgd.p != NULL: the result is a weight gradient consumed by the update of p (layout of out); nothing is stored to out
 };
 
 __device__ __forceinline__ void store4(void* base, int64_t idx, int dtype, const float (&v)[4]) {
@@ -207,6 +218,27 @@ __device__ __forceinline__ float apply_act(int act, float v, float aux) {
 __device__ __forceinline__ void epilogue4(const EpiParams& e, const DropParams& dp, int m, int n, float (&v)[4]) {
   if (m >= e.M || n >= e.N) return;
   const bool full = e.vec4 && (n + 3 < e.N);
+  if (e.sgd.p) {     // fused optimizer: v is the gradient of p[m, n .. n+3]
+    const int64_t idx = (int64_t)m * e.ldo + n;
+    if (full) {
+      float pv[4], bv[4];
+      load4(e.sgd.p, idx, AFFT_F32, pv);
+      load4(e.sgd.buf, idx, AFFT_F32, bv);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sgd_update(pv[r], bv[r], v[r] * e.alpha, e.sgd.lr, e.sgd.mom, e.sgd.wd, e.sgd.gscale, e.sgd.first);
+      store4(e.sgd.p, idx, AFFT_F32, pv);
+      store4(e.sgd.buf, idx, AFFT_F32, bv);
+      if (e.sgd.p16) store4(e.sgd.p16, idx, AFFT_BF16, pv);
+    } else {
+      for (int r = 0; r < 4 && n + r < e.N; ++r) {
+        float pv = e.sgd.p[idx + r], bv = e.sgd.buf[idx + r];
+        sgd_update(pv, bv, v[r] * e.alpha, e.sgd.lr, e.sgd.mom, e.sgd.wd, e.sgd.gscale, e.sgd.first);
+        e.sgd.p[idx + r] = pv; e.sgd.buf[idx + r] = bv;
+        if (e.sgd.p16) e.sgd.p16[idx + r] = f2bf(pv);
+      }
+    }
+    return;
+  }
   const float rs = (e.rowscale ? e.rowscale[m] : 1.0f) * drop_row_scale(dp, m);
   const bool scaled = e.rowscale || dp.path_thresh;
   if (full) {
@@ -297,6 +329,18 @@ __device__ __forceinline__ void epilogue8(const EpiParams& e, const DropParams& 
     float lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
     epilogue4(e, dp, m, n, lo);
     epilogue4(e, dp, m, n + 4, hi);
+    return;
+  }
+  if (e.sgd.p) {     // fused optimizer, 8 parameters per lane: 16-byte accesses throughout
+    const int64_t idx = (int64_t)m * e.ldo + n;
+    float pv[8], bv[8];
+    load8(e.sgd.p, idx, AFFT_F32, pv);
+    load8(e.sgd.buf, idx, AFFT_F32, bv);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) sgd_update(pv[r], bv[r], v[r] * e.alpha, e.sgd.lr, e.sgd.mom, e.sgd.wd, e.sgd.gscale, e.sgd.first);
+    store8(e.sgd.p, idx, AFFT_F32, pv);
+    store8(e.sgd.buf, idx, AFFT_F32, bv);
+    if (e.sgd.p16) store8(e.sgd.p16, idx, AFFT_BF16, pv);
     return;
   }
   const float rs = (e.rowscale ? e.rowscale[m] : 1.0f) * drop_row_scale(dp, m);

@@ -201,30 +201,52 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const v
       load4(g_, i, g_dtype, g4);
       const float4 gv = make_float4(g4[0], g4[1], g4[2], g4[3]);
       float4 bv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *(float4*)(buf + i);
-      float gg[4] = {gv.x * gscale + wd * pv.x, gv.y * gscale + wd * pv.y, gv.z * gscale + wd * pv.z, gv.w * gscale + wd * pv.w};
+      float gg[4] = {gv.x, gv.y, gv.z, gv.w};
       float bb[4] = {bv.x, bv.y, bv.z, bv.w};
       float pp[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        bb[r] = first ? gg[r] : mom * bb[r] + gg[r];
-        pp[r] -= lr * (gg[r] + mom * bb[r]);
-      }
+      for (int r = 0; r < 4; ++r) sgd_update(pp[r], bb[r], gg[r], lr, mom, wd, gscale, first != 0);
       *(float4*)(buf + i) = make_float4(bb[0], bb[1], bb[2], bb[3]);
       *(float4*)(p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
       if (p16) store4(p16, i, AFFT_BF16, pp);
     } else {
       for (int64_t j = i; j < n; ++j) {
-        const float gg = ld_any(g_, j, g_dtype) * gscale + wd * p[j];
-        const float bb = first ? gg : mom * buf[j] + gg;
-        buf[j] = bb;
-        p[j] -= lr * (gg + mom * bb);
-        if (p16) p16[j] = f2bf(p[j]);
+        float pj = p[j], bj = first ? 0.f : buf[j];
+        sgd_update(pj, bj, ld_any(g_, j, g_dtype), lr, mom, wd, gscale, first != 0);
+        buf[j] = bj;
+        p[j] = pj;
+        if (p16) p16[j] = f2bf(pj);
       }
     }
   }
 }
 
+// the same update over a table of runs {start, length}: block b owns run b (runs are short: biases, LayerNorm weights)
+__global__ __launch_bounds__(256) void sgd_runs_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                       bf16_t* __restrict__ p16, const int64_t* __restrict__ runs, float lr, float mom,
+                                                       float wd, float gscale, int first) {
+  const int64_t s0 = runs[2 * blockIdx.x], len = runs[2 * blockIdx.x + 1];
+  for (int64_t j = s0 + threadIdx.x; j < s0 + len; j += 256) {
+    float pj = p[j], bj = first ? 0.f : buf[j];
+    sgd_update(pj, bj, g[j], lr, mom, wd, gscale, first != 0);
+    buf[j] = bj;
+    p[j] = pj;
+    if (p16) p16[j] = f2bf(pj);
+  }
+}
+
 }  // namespace
+
+extern "C" int afft_sgd_nesterov_runs(float* p, const float* g, float* buf, void* p_bf16, const int64_t* runs, int32_t nruns,
+                                      float lr, float mom, float wd, float gscale, int32_t first_step, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(p && g && buf && (runs || nruns == 0), "sgd_runs: null pointer");
+  if (nruns <= 0) return 0;
+  hipLaunchKernelGGL(sgd_runs_kernel, dim3(nruns), dim3(256), 0, stream, p, g, buf, (bf16_t*)p_bf16, runs, lr, mom, wd, gscale,
+                     first_step);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int afft_cast(const float* src, int64_t lds_, int32_t rows, int32_t cols, void* dst, int64_t ldd,
                          int32_t dst_dtype, void* dst_t, int64_t ldt, int32_t zero_pad, const afft_dropout_t* drop,

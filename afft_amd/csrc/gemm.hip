@@ -21,6 +21,7 @@
 // Replaces nn.Linear / HF Conv1D forward, dgrad and wgrad on the AFFT path (see include/afft_hip.h).
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 #include "gemm_tiles.h"
 
@@ -217,6 +218,12 @@ int g_pp_split_min_nk = [] { const char* e = getenv("AFFT_PP_SPLIT_MIN_NK"); ret
 // bytes of arrival counters (zero between launches) followed by the fp32 partial tiles.  Nothing is allocated here.
 constexpr int kMaxSplitTiles = AFFT_GEMM_WS_HEADER / (int)sizeof(int);
 
+// ---- measurement hook: event pairs around fast-path launches while a trace is open (afft_gemm_trace_begin / _end)
+struct TraceRec { afft_gemm_trace_rec_t r; hipEvent_t a, b; };
+std::mutex g_trace_mu;
+std::vector<TraceRec>* g_trace = nullptr;
+size_t g_trace_cap = 0;
+
 int g_variant = 0;  // 0 auto, 1 = 128x128 tile, 2 = 256x128 tile, 3 = 256x256 ping-pong (tuning / tests)
 
 template <int WM, int WN, int STAGES, bool A_KS, bool B_KS, bool SPLITK, bool X3 = false>
@@ -280,7 +287,31 @@ int64_t splitk_bytes(int variant, int M, int N, int K, int* slices) {
 }
 
 template <bool A_KS, bool B_KS>
+int launch_layout_impl(GemmFast& g, hipStream_t stream, const afft_gemm_t* d);
+
+template <bool A_KS, bool B_KS>
 int launch_layout(GemmFast& g, hipStream_t stream, const afft_gemm_t* d) {
+  if (!g_trace) return launch_layout_impl<A_KS, B_KS>(g, stream, d);
+  TraceRec t = {};
+  {
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    if (!g_trace || g_trace->size() >= g_trace_cap) return launch_layout_impl<A_KS, B_KS>(g, stream, d);
+  }
+  if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) { (void)hipGetLastError(); return launch_layout_impl<A_KS, B_KS>(g, stream, d); }
+  (void)hipEventRecord(t.a, stream);
+  const int rc = launch_layout_impl<A_KS, B_KS>(g, stream, d);
+  (void)hipEventRecord(t.b, stream);
+  const int variant = choose_variant(g.e.M, g.e.N, g.K, A_KS, B_KS);
+  const int tiles = ((g.e.M + 255) / 256) * ((g.e.N + 255) / 256), cap = d->max_workgroups & ~7;
+  t.r = afft_gemm_trace_rec_t{g.e.M, g.e.N, d->K, A_KS, B_KS, variant, g.splitk, d->split3,
+                              variant == 3 && A_KS && B_KS && !d->split3 && g.splitk == 1 && cap >= 8 && cap < tiles, d->sgd != nullptr, 0.f};
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  if (g_trace) g_trace->push_back(t);
+  return rc;
+}
+
+template <bool A_KS, bool B_KS>
+int launch_layout_impl(GemmFast& g, hipStream_t stream, const afft_gemm_t* d) {
   const int variant = choose_variant(g.e.M, g.e.N, g.K, A_KS, B_KS);
   g.splitk = 1;
   g.ws = nullptr;
@@ -336,6 +367,39 @@ extern "C" int afft_gemm_splitk_for(int M, int N, int K, int a_kstrided, int b_k
   return v >= 4 ? 1 : choose_splitk(v, M, N, K);
 }
 
+extern "C" int afft_gemm_trace_begin(int32_t capacity) {
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  AFFT_CHECK(!g_trace, "afft_gemm_trace_begin: a trace is already open");
+  AFFT_CHECK(capacity > 0, "afft_gemm_trace_begin: capacity must be positive");
+  g_trace = new std::vector<TraceRec>();
+  g_trace->reserve(capacity);
+  g_trace_cap = (size_t)capacity;
+  return 0;
+}
+
+extern "C" int afft_gemm_trace_end(afft_gemm_trace_rec_t* out, int32_t capacity) {
+  std::vector<TraceRec>* tr;
+  {
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    tr = g_trace;
+    g_trace = nullptr;
+  }
+  if (!tr) { afft_set_error("afft_gemm_trace_end: no trace is open"); return -1; }
+  int n = 0;
+  for (TraceRec& t : *tr) {
+    float ms = 0.f;
+    if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess && out && n < capacity) {
+      t.r.ms = ms;
+      out[n++] = t.r;
+    }
+    (void)hipEventDestroy(t.a);
+    (void)hipEventDestroy(t.b);
+  }
+  (void)hipGetLastError();
+  delete tr;
+  return n;
+}
+
 extern "C" int afft_set_gemm_splitk(int mode) {
   if (mode != 0 && mode != 1 && mode != 2 && mode != 4) { afft_set_error("afft_set_gemm_splitk: %d is not 0, 1, 2 or 4", mode); return 1; }
   g_splitk_mode = mode;
@@ -369,6 +433,14 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
   e.out2 = d->out2; e.ldo2 = d->ldo2; e.out2_dtype = d->out2_dtype;
   AFFT_CHECK(d->drop.p >= 0.f && d->drop.p < 1.f && d->drop.path_p >= 0.f && d->drop.path_p < 1.f, "afft_gemm: dropout p outside [0,1)");
   e.drop = make_drop(&d->drop);
+  e.sgd = SgdEpi{nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 1.f, 0};
+  if (d->sgd) {
+    AFFT_CHECK(d->sgd->p && d->sgd->buf, "afft_gemm: fused update without parameter / momentum buffers");
+    AFFT_CHECK(!d->accumulate && !d->bias && d->act == AFFT_ACT_NONE && !d->residual && !d->rowscale && !d->pre && !d->out2 &&
+               d->drop.p == 0.f && d->drop.path_p == 0.f, "afft_gemm: a fused update takes the plain product (no other epilogue stage)");
+    e.sgd = SgdEpi{d->sgd->p, d->sgd->buf, (bf16_t*)d->sgd->p_bf16, d->sgd->lr, d->sgd->mom, d->sgd->wd, d->sgd->gscale,
+                   d->sgd->first_step};
+  }
   auto ok4 = [](const void* p, int64_t ld, int dtype) {
     if (!p) return true;
     const uintptr_t align = dtype == AFFT_F32 ? 16 : 8;
@@ -376,8 +448,9 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
   };
   auto ok8 = [](const void* p, int64_t ld) { return !p || ((ld % 8 == 0) && ((((uintptr_t)p) & 15) == 0)); };
   e.vec8 = ok8(d->out, d->ldo) && ok8(d->out2, d->ldo2) && ok8(d->pre, d->ldpre) && ok8(d->aux, d->ldaux) &&
-           ok8(d->residual, d->ldres) && ok8(d->bias, 8);
-  e.vec4 = ok4(d->out, d->ldo, d->out_dtype) && ok4(d->out2, d->ldo2, d->out2_dtype) &&
+           ok8(d->residual, d->ldres) && ok8(d->bias, 8) && ok8(e.sgd.p, d->ldo) && ok8(e.sgd.buf, d->ldo) && ok8(e.sgd.p16, d->ldo);
+  e.vec4 = ok4(e.sgd.p, d->ldo, AFFT_F32) && ok4(e.sgd.buf, d->ldo, AFFT_F32) && ok4(e.sgd.p16, d->ldo, AFFT_BF16) &&
+           ok4(d->out, d->ldo, d->out_dtype) && ok4(d->out2, d->ldo2, d->out2_dtype) &&
            ok4(d->pre, d->ldpre, d->pre_dtype) && ok4(d->aux, d->ldaux, d->aux_dtype) &&
            ok4(d->residual, d->ldres, AFFT_F32) && ok4(d->bias, 4, AFFT_F32);
 

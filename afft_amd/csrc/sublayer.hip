@@ -55,7 +55,7 @@ afft_gemm_t lin_dgrad(const void* dy, int64_t lddy, int rows, int n_out, const v
 }
 // dW (+)= dy^T x ([n_out, k_in], nn.Linear) or x^T dy ([k_in, n_out], Conv1D); the reduction runs over the padded rows
 int wgrad(const void* dy, int64_t lddy, int n_out, const void* x, int64_t ldx, int k_in, int rows, bool conv1d, float* g_out,
-          int acc, Ws ws, int max_wg, hipStream_t st) {
+          int acc, Ws ws, int max_wg, hipStream_t st, const afft_sgd_fused_t* sgd = nullptr) {
   if (!g_out) return 0;
   const void* a = conv1d ? x : dy; const void* b = conv1d ? dy : x;
   const int64_t lda = conv1d ? ldx : lddy, ldb = conv1d ? lddy : ldx;
@@ -66,6 +66,10 @@ int wgrad(const void* dy, int64_t lddy, int n_out, const void* x, int64_t ldx, i
   g.out = g_out; g.ldo = N; g.out_dtype = AFFT_F32;
   g.accumulate = acc;
   g.max_workgroups = max_wg;
+  if (sgd) {      // the update consumes the gradient in the epilogue: first (and only) contribution of the step
+    AFFT_CHECK(!acc, "sublayer: a fused update needs the weight's only gradient contribution of the step");
+    g.sgd = sgd;
+  }
   return afft_gemm(&g, st);
 }
 
@@ -125,25 +129,37 @@ extern "C" int afft_attn_sublayer_bwd(const afft_attn_sublayer_t* s, void* strea
   }
   TRY(zero_row_tail(s->dao, R, d, st));
   TRY(zero_row_tail(s->dqkv, R, 3 * d, st));
-  TRY(stream_follows(aux, st));
-  TRY(wgrad(s->dya, d, d, s->ao, d, d, R, s->conv1d, s->g_w_proj, s->acc_w_proj, wsa, s->wgrad_workgroups, aux));
-  if (s->g_b_proj) {
-    if (od) TRY(afft_colsum(s->dya, d, AFFT_BF16, R, d, s->g_b_proj, s->acc_b_proj, aux));
-    else TRY(afft_colsum(s->dy, d, AFFT_F32, R, d, s->g_b_proj, s->acc_b_proj, aux));
-  }
+  // A weight gradient with a fused update rewrites the weight's bf16 image: it is enqueued BEHIND the data-gradient GEMM that
+  // reads that image (one event later than the plain form, which starts beside it).
+  auto side_proj = [&]() -> int {
+    TRY(stream_follows(aux, st));
+    TRY(wgrad(s->dya, d, d, s->ao, d, d, R, s->conv1d, s->g_w_proj, s->acc_w_proj, wsa, s->wgrad_workgroups, aux, s->sgd_w_proj));
+    if (s->g_b_proj) {
+      if (od) TRY(afft_colsum(s->dya, d, AFFT_BF16, R, d, s->g_b_proj, s->acc_b_proj, aux));
+      else TRY(afft_colsum(s->dy, d, AFFT_F32, R, d, s->g_b_proj, s->acc_b_proj, aux));
+    }
+    return 0;
+  };
+  if (!s->sgd_w_proj) TRY(side_proj());
   afft_gemm_t g = lin_dgrad(s->dya, d, R, d, s->w_proj, s->ldw_proj, d, s->conv1d, ws);
   g.out = s->dao; g.ldo = d; g.out_dtype = AFFT_BF16;
   TRY(afft_gemm(&g, st));
+  if (s->sgd_w_proj) TRY(side_proj());
   const char* q = (const char*)s->qkv;
   char* dq = (char*)s->dqkv;
   TRY(afft_attention_bwd(s->dao, d, q, 3 * d, q + 2 * d, 3 * d, q + 4 * d, 3 * d, AFFT_BF16, s->probs, R / s->L, s->L, s->H,
                          d / s->H, s->scale, s->p_attn, s->k_attn, dq, 3 * d, dq + 2 * d, 3 * d, dq + 4 * d, 3 * d, st));
-  TRY(stream_follows(aux, st));
-  TRY(wgrad(s->dqkv, 3 * d, 3 * d, s->xn, d, d, R, s->conv1d, s->g_w_qkv, s->acc_w_qkv, wsa, s->wgrad_workgroups, aux));
-  if (s->g_b_qkv) TRY(afft_colsum(s->dqkv, 3 * d, AFFT_BF16, R, 3 * d, s->g_b_qkv, s->acc_b_qkv, aux));
+  auto side_qkv = [&]() -> int {
+    TRY(stream_follows(aux, st));
+    TRY(wgrad(s->dqkv, 3 * d, 3 * d, s->xn, d, d, R, s->conv1d, s->g_w_qkv, s->acc_w_qkv, wsa, s->wgrad_workgroups, aux, s->sgd_w_qkv));
+    if (s->g_b_qkv) TRY(afft_colsum(s->dqkv, 3 * d, AFFT_BF16, R, 3 * d, s->g_b_qkv, s->acc_b_qkv, aux));
+    return 0;
+  };
+  if (!s->sgd_w_qkv) TRY(side_qkv());
   g = lin_dgrad(s->dqkv, 3 * d, R, 3 * d, s->w_qkv, s->ldw_qkv, d, s->conv1d, ws);
   g.out = s->dxn; g.ldo = d; g.out_dtype = AFFT_BF16;
   TRY(afft_gemm(&g, st));
+  if (s->sgd_w_qkv) TRY(side_qkv());
   return afft_layernorm_bwd(s->dxn, d, AFFT_BF16, s->x, d, s->ln_w, s->mean, s->rstd, R, d, s->dy, s->dx, d, s->dx_bf16, s->up_drop,
                             s->g_ln_w, s->g_ln_b, s->acc_ln, s->up_dcol, 0, s->ln_partial, st);
 }
@@ -186,23 +202,33 @@ extern "C" int afft_mlp_sublayer_bwd(const afft_mlp_sublayer_t* s, void* stream_
     TRY(afft_cast(s->dy, d, R, d, s->dya, d, AFFT_BF16, nullptr, 0, 0, od ? &s->out_drop : nullptr, st));
   }
   TRY(zero_row_tail(s->du, R, hd, st));
-  TRY(stream_follows(aux, st));
-  TRY(wgrad(s->dya, d, d, s->h, hd, hd, R, s->conv1d, s->g_w2, s->acc_w2, wsa, s->wgrad_workgroups, aux));
-  if (s->g_b2) {
-    if (od) TRY(afft_colsum(s->dya, d, AFFT_BF16, R, d, s->g_b2, s->acc_b2, aux));
-    else TRY(afft_colsum(s->dy, d, AFFT_F32, R, d, s->g_b2, s->acc_b2, aux));
-  }
+  auto side_fc2 = [&]() -> int {      // see afft_attn_sublayer_bwd for the ordering of a fused update
+    TRY(stream_follows(aux, st));
+    TRY(wgrad(s->dya, d, d, s->h, hd, hd, R, s->conv1d, s->g_w2, s->acc_w2, wsa, s->wgrad_workgroups, aux, s->sgd_w2));
+    if (s->g_b2) {
+      if (od) TRY(afft_colsum(s->dya, d, AFFT_BF16, R, d, s->g_b2, s->acc_b2, aux));
+      else TRY(afft_colsum(s->dy, d, AFFT_F32, R, d, s->g_b2, s->acc_b2, aux));
+    }
+    return 0;
+  };
+  if (!s->sgd_w2) TRY(side_fc2());
   afft_gemm_t g = lin_dgrad(s->dya, d, R, d, s->w2, s->ldw2, hd, s->conv1d, ws);
   g.act = s->gelu == AFFT_ACT_GELU_ERF ? AFFT_ACT_DGELU_ERF : AFFT_ACT_DGELU_TANH;
   g.aux = s->u; g.ldaux = hd; g.aux_dtype = AFFT_BF16;
   g.out = s->du; g.ldo = hd; g.out_dtype = AFFT_BF16;
   TRY(afft_gemm(&g, st));
-  TRY(stream_follows(aux, st));
-  TRY(wgrad(s->du, hd, hd, s->xn, d, d, R, s->conv1d, s->g_w1, s->acc_w1, wsa, s->wgrad_workgroups, aux));
-  if (s->g_b1) TRY(afft_colsum(s->du, hd, AFFT_BF16, R, hd, s->g_b1, s->acc_b1, aux));
+  if (s->sgd_w2) TRY(side_fc2());
+  auto side_fc1 = [&]() -> int {
+    TRY(stream_follows(aux, st));
+    TRY(wgrad(s->du, hd, hd, s->xn, d, d, R, s->conv1d, s->g_w1, s->acc_w1, wsa, s->wgrad_workgroups, aux, s->sgd_w1));
+    if (s->g_b1) TRY(afft_colsum(s->du, hd, AFFT_BF16, R, hd, s->g_b1, s->acc_b1, aux));
+    return 0;
+  };
+  if (!s->sgd_w1) TRY(side_fc1());
   g = lin_dgrad(s->du, hd, R, hd, s->w1, s->ldw1, d, s->conv1d, ws);
   g.out = s->dxn; g.ldo = d; g.out_dtype = AFFT_BF16;
   TRY(afft_gemm(&g, st));
+  if (s->sgd_w1) TRY(side_fc1());
   return afft_layernorm_bwd(s->dxn, d, AFFT_BF16, s->x, d, s->ln_w, s->mean, s->rstd, R, d, s->dy, s->dx, d, s->dx_bf16, s->up_drop,
                             s->g_ln_w, s->g_ln_b, s->acc_ln, s->up_dcol, 0, s->ln_partial, st);
 }
@@ -251,21 +277,31 @@ extern "C" int afft_cross_attn_sublayer_bwd(const afft_cross_attn_sublayer_t* s,
   }
   void* bufs[4] = {s->dao, s->dq, s->dk, s->dv};
   for (void* b : bufs) TRY(zero_row_tail(b, R, d, st));
-  TRY(stream_follows(aux, st));
-  TRY(wgrad(s->dya, d, d, s->ao, d, d, R, false, s->g_w_proj, s->acc_w_proj, wsa, s->wgrad_workgroups, aux));
-  if (s->g_b_proj) {
-    if (od) TRY(afft_colsum(s->dya, d, AFFT_BF16, R, d, s->g_b_proj, s->acc_b_proj, aux));
-    else TRY(afft_colsum(s->dy, d, AFFT_F32, R, d, s->g_b_proj, s->acc_b_proj, aux));
-  }
+  auto side_proj = [&]() -> int {      // see afft_attn_sublayer_bwd for the ordering of a fused update
+    TRY(stream_follows(aux, st));
+    TRY(wgrad(s->dya, d, d, s->ao, d, d, R, false, s->g_w_proj, s->acc_w_proj, wsa, s->wgrad_workgroups, aux, s->sgd_w_proj));
+    if (s->g_b_proj) {
+      if (od) TRY(afft_colsum(s->dya, d, AFFT_BF16, R, d, s->g_b_proj, s->acc_b_proj, aux));
+      else TRY(afft_colsum(s->dy, d, AFFT_F32, R, d, s->g_b_proj, s->acc_b_proj, aux));
+    }
+    return 0;
+  };
+  if (!s->sgd_w_proj) TRY(side_proj());
   afft_gemm_t g = lin_dgrad(s->dya, d, R, d, s->w_proj, s->ldw, d, false, ws);
   g.out = s->dao; g.ldo = d; g.out_dtype = AFFT_BF16;
   TRY(afft_gemm(&g, st));
+  if (s->sgd_w_proj) TRY(side_proj());
   TRY(afft_attention_bwd(s->dao, d, s->q, d, s->k, d, s->v, d, AFFT_BF16, s->probs, R / s->L, s->L, s->H, d / s->H, s->scale,
                          s->p_attn, s->k_attn, s->dq, d, s->dk, d, s->dv, d, st));
-  TRY(stream_follows(aux, st));
-  TRY(wgrad(s->dq, d, d, s->xq, d, d, R, false, s->g_w_q, s->acc_w_q, wsa, s->wgrad_workgroups, aux));
-  TRY(wgrad(s->dk, d, d, s->mkv, d, d, R, false, s->g_w_k, s->acc_w_k, wsa, s->wgrad_workgroups, aux));
-  TRY(wgrad(s->dv, d, d, s->mkv, d, d, R, false, s->g_w_v, s->acc_w_v, wsa, s->wgrad_workgroups, aux));
+  const bool fused_qkv = s->sgd_w_q || s->sgd_w_k || s->sgd_w_v;
+  auto side_qkv = [&]() -> int {
+    TRY(stream_follows(aux, st));
+    TRY(wgrad(s->dq, d, d, s->xq, d, d, R, false, s->g_w_q, s->acc_w_q, wsa, s->wgrad_workgroups, aux, s->sgd_w_q));
+    TRY(wgrad(s->dk, d, d, s->mkv, d, d, R, false, s->g_w_k, s->acc_w_k, wsa, s->wgrad_workgroups, aux, s->sgd_w_k));
+    TRY(wgrad(s->dv, d, d, s->mkv, d, d, R, false, s->g_w_v, s->acc_w_v, wsa, s->wgrad_workgroups, aux, s->sgd_w_v));
+    return 0;
+  };
+  if (!fused_qkv) TRY(side_qkv());
   g = lin_dgrad(s->dk, d, R, d, s->w_k, s->ldw, d, false, ws);
   g.out = s->dmkv; g.ldo = d; g.out_dtype = AFFT_F32;
   TRY(afft_gemm(&g, st));
@@ -276,6 +312,7 @@ extern "C" int afft_cross_attn_sublayer_bwd(const afft_cross_attn_sublayer_t* s,
   g = lin_dgrad(s->dq, d, R, d, s->w_q, s->ldw, d, false, ws);
   g.out = s->dxq; g.ldo = d; g.out_dtype = AFFT_BF16;
   TRY(afft_gemm(&g, st));
+  if (fused_qkv) TRY(side_qkv());
   TRY(afft_layernorm_bwd(s->dmkv, d, AFFT_F32, s->mem, d, s->nkv_w, s->mean_kv, s->rstd_kv, R, d, nullptr, s->dmem, d, nullptr, nullptr,
                          s->g_nkv_w, s->g_nkv_b, s->acc_nkv, nullptr, 0, s->ln_partial2, st));
   return afft_layernorm_bwd(s->dxq, d, AFFT_BF16, s->x, d, s->nq_w, s->mean_q, s->rstd_q, R, d, s->dy, s->dx, d, s->dx_bf16, s->up_drop,

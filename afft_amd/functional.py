@@ -561,6 +561,18 @@ def _keep_for_aux(aux, *tensors):
                 t.record_stream(aux)
 
 
+def _fuse_updates(s, weights) -> list:
+    """weights: (struct field, parameter, accumulate flag).  For every weight the Trainer updates in the epilogue of its
+    gradient GEMM (runtime.GradSink.fused_desc) point the field at its afft_sgd_fused_t; returns what must outlive the call."""
+    keep = []
+    for field, w, acc in weights:
+        d = rt.SINK.fused_desc(w) if rt.grad_mode() == "sink" else None
+        if d is not None and not acc:
+            setattr(s, field, C.pointer(d))
+            keep.append(d)
+    return keep
+
+
 def _ln_partial(rows: int, d: int, dev) -> Tensor:
     return torch.empty(L_.lib().afft_layernorm_bwd_nparts(rows) * 3 * d, dtype=torch.float32, device=dev)
 
@@ -642,6 +654,7 @@ def _attn_bwd_c(ctx, dy):
     g_wp, s.acc_w_proj = _grad_slot(w_proj, fresh)
     g_lw, g_lb, s.acc_ln = _ln_grad_slots(ln_w, ln_b, fresh)
     s.g_w_qkv, s.g_b_qkv, s.g_w_proj, s.g_ln_w, s.g_ln_b = _ptr(g_wq), _ptr(g_bq), _ptr(g_wp), _ptr(g_lw), _ptr(g_lb)
+    keep = _fuse_updates(s, (("sgd_w_qkv", w_qkv, s.acc_w_qkv), ("sgd_w_proj", w_proj, s.acc_w_proj)))
     dx = torch.empty(R, d, dtype=torch.float32, device=dev)
     s.dx = dx.data_ptr()
     ho = _plan_handover(ctx.up, R, d, dev)
@@ -736,6 +749,7 @@ def _mlp_bwd_c(ctx, dy):
     g_w2, s.acc_w2 = _grad_slot(w2, fresh)
     g_lw, g_lb, s.acc_ln = _ln_grad_slots(ln_w, ln_b, fresh)
     s.g_w1, s.g_b1, s.g_w2, s.g_ln_w, s.g_ln_b = _ptr(g_w1), _ptr(g_b1), _ptr(g_w2), _ptr(g_lw), _ptr(g_lb)
+    keep = _fuse_updates(s, (("sgd_w1", w1, s.acc_w1), ("sgd_w2", w2, s.acc_w2)))
     dx = torch.empty(R, d, dtype=torch.float32, device=dev)
     s.dx = dx.data_ptr()
     ho = _plan_handover(ctx.up, R, d, dev)
@@ -844,6 +858,8 @@ def _cross_bwd_c(ctx, dy):
     g_qw, g_qb, s.acc_nq = _ln_grad_slots(nq_w, nq_b, fresh)
     g_kw, g_kb, s.acc_nkv = _ln_grad_slots(nkv_w, nkv_b, fresh)
     s.g_w_q, s.g_w_k, s.g_w_v, s.g_w_proj = _ptr(g_q), _ptr(g_k), _ptr(g_v), _ptr(g_wp)
+    keep = _fuse_updates(s, (("sgd_w_q", w_q, s.acc_w_q), ("sgd_w_k", w_k, s.acc_w_k), ("sgd_w_v", w_v, s.acc_w_v),
+                             ("sgd_w_proj", w_proj, s.acc_w_proj)))
     s.g_nq_w, s.g_nq_b, s.g_nkv_w, s.g_nkv_b = _ptr(g_qw), _ptr(g_qb), _ptr(g_kw), _ptr(g_kb)
     dx = torch.empty(R, d, dtype=torch.float32, device=dev)
     dmem = torch.empty(R, d, dtype=torch.float32, device=dev)

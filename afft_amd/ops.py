@@ -284,6 +284,15 @@ def sgd_nesterov(p: Tensor, g: Tensor, buf: Tensor, lr: float, mom: float, wd: f
                                       _p(gscale_dev), 1 if first else 0, _stream()), "sgd_nesterov")
 
 
+def sgd_nesterov_runs(p: Tensor, g: Tensor, buf: Tensor, runs: Tensor, lr: float, mom: float, wd: float, gscale: float, first: bool,
+                      p_bf16: Optional[Tensor] = None):
+    """the same update over the runs {start, length} (int64 [nruns, 2] on the device) of whole flat buffers"""
+    assert runs.dtype == torch.int64 and runs.dim() == 2 and runs.shape[1] == 2 and runs.is_contiguous()
+    assert p.dtype == g.dtype == buf.dtype == torch.float32
+    L.check(L.lib().afft_sgd_nesterov_runs(_p(p), _p(g), _p(buf), _p(p_bf16), _p(runs), runs.shape[0], lr, mom, wd, gscale,
+                                           1 if first else 0, _stream()), "sgd_nesterov_runs")
+
+
 def sumsq(x: Tensor, out: Tensor, scale: float = 1.0):
     """out[0] += scale * sum(x^2) over a flat fp32 / bf16 buffer."""
     assert x.is_contiguous() and out.dtype == torch.float32

@@ -228,8 +228,18 @@ class FusedSGD:
         self.flat, self.lr, self.momentum, self.wd = flat, lr, momentum, weight_decay
         self.buf = torch.zeros_like(flat.flat_p)
         self.steps = 0
+        self.runs: Optional[Dict[tuple, Tensor]] = None    # per bucket (s, e): the runs NOT updated in a GEMM epilogue
 
     def step_range(self, s: int, e: int, grad: Tensor, gscale: float, gscale_dev: Optional[Tensor] = None):
+        if self.runs is not None and gscale_dev is None and grad.dtype == torch.float32:
+            # the big weights of this bucket are updated in their weight-gradient epilogues (Trainer._enable_fused): one
+            # launch over what is left of the bucket -- LayerNorm weights, biases, tokens, multiply-used weights
+            runs = self.runs.get((s, e))
+            if runs is not None:
+                if runs.shape[0]:
+                    ops.sgd_nesterov_runs(self.flat.flat_p, self.flat.flat_g, self.buf, runs, self.lr, self.momentum, self.wd,
+                                          gscale, self.steps == 0, p_bf16=self.flat.flat_p16)
+                return
         p16 = self.flat.flat_p16[s:e] if self.flat.flat_p16 is not None else None
         ops.sgd_nesterov(self.flat.flat_p[s:e], grad, self.buf[s:e], self.lr, self.momentum, self.wd, gscale,
                          self.steps == 0, p_bf16=p16, gscale_dev=gscale_dev)
@@ -277,6 +287,7 @@ class Trainer:
         self.loss_wts = loss_wts
         self.grad_clip = grad_clip     # opt.grad_clip of the reference's config; needs the whole gradient first
         self.overlap_optimizer = overlap_optimizer and self.flat.flat_p.is_cuda and grad_clip is None
+        self._fused: Optional[Dict[int, object]] = None    # id(weight) -> _lib.SgdFused, once learned (see _enable_fused)
 
     def sync_parameters(self, group=None, src: int = 0):
         """Every replica starts from rank `src`'s parameters and momentum (what torch DDP does at construction,
@@ -292,17 +303,74 @@ class Trainer:
         self.opt.steps = int(steps)
         self.flat.refresh_images()
 
+    # ---- optimizer fused into the weight-gradient GEMM epilogues (single GPU)
+    def _can_fuse(self) -> bool:
+        return (rt.fused_sgd() and rt.composite() and rt.precision() == "bf16" and rt.grad_mode() == "sink"
+                and self.flat.flat_p.is_cuda and self.flat.flat_p16 is not None and self.flat.flat_pT16 is None
+                and not self.reducer.comm and self.grad_clip is None and not rt.CAPTURING)
+
+    def _enable_fused(self):
+        """After a step with the optimizer inside the backward pass: every GEMM weight that (a) went through a composite
+        backward, (b) received exactly ONE gradient contribution and (c) owns a bf16 image in the flat buffers is from now on
+        updated in the epilogue of its own weight-gradient GEMM (afft_sgd_fused_t): its gradient never goes to HBM and the
+        per-bucket update kernel only walks what is left of the bucket (`runs`).  N = 1 only: with more ranks the summed
+        gradient has to exist before the update."""
+        from . import _lib as L_
+        flat, fused = self.flat, {}
+        for p, o in zip(flat.params, flat.offsets):
+            img = getattr(p, "_afft_img", None)
+            if (p.dim() == 2 and id(p) in rt.SINK.composite_weights and rt.SINK.touch_count.get(id(p), 0) == 1
+                    and img is not None and img.external):
+                d = L_.SgdFused()
+                d.p, d.buf, d.p_bf16 = flat.flat_p.data_ptr() + 4 * o, self.opt.buf.data_ptr() + 4 * o, flat.flat_p16.data_ptr() + 2 * o
+                fused[id(p)] = d
+        CH = 16384       # a run is one 256-thread block of the runs kernel: keep them short
+        runs = {}
+        for (s, e) in self.reducer.buckets:
+            segs, cur = [], None
+            for p, o in zip(flat.params, flat.offsets):
+                if not (s <= o < e):
+                    continue
+                n = _align(p.numel())
+                if id(p) in fused:
+                    cur = None
+                    continue
+                if cur is not None and cur[0] + cur[1] == o:
+                    cur[1] += n
+                else:
+                    cur = [o, n]
+                    segs.append(cur)
+            chunks = [(a + k, min(CH, n - k)) for a, n in segs for k in range(0, n, CH)]
+            runs[(s, e)] = torch.tensor(chunks, dtype=torch.int64, device=flat.flat_p.device).reshape(-1, 2)
+        self._fused = fused
+        self.opt.runs = runs
+
+    def _fused_desc(self, p: Tensor):
+        d = self._fused.get(id(p))
+        if d is not None:
+            d.lr, d.mom, d.wd, d.gscale, d.first_step = self.opt.lr, self.opt.momentum, self.opt.wd, 1.0, 0
+        return d
+
     def forward_backward(self, feats: Dict[str, Tensor], target, target_subclips, optimize_in_backward: bool = False):
         self.reducer.on_bucket = self.opt.step_range if optimize_in_backward else None
-        self.reducer.begin_step()
-        outputs, out_t = self.model(feats, mixup_fn=None, target=target, target_subclips=target_subclips,
-                                    target_subclips_ignore_index=None)
-        losses, _ = self.loss_fn(outputs, out_t['target'], out_t['target_subclips'])
-        loss, parts = self._reduce(losses, self.loss_wts, sync=False)
-        loss.backward()
-        self.reducer.finish_step()
+        fuse = optimize_in_backward and self._fused is not None and self._can_fuse()
+        rt.SINK.fused = self._fused_desc if fuse else None
+        saved_runs, self.opt.runs = self.opt.runs, (self.opt.runs if fuse else None)
+        try:
+            self.reducer.begin_step()
+            outputs, out_t = self.model(feats, mixup_fn=None, target=target, target_subclips=target_subclips,
+                                        target_subclips_ignore_index=None)
+            losses, _ = self.loss_fn(outputs, out_t['target'], out_t['target_subclips'])
+            loss, parts = self._reduce(losses, self.loss_wts, sync=False)
+            loss.backward()
+            self.reducer.finish_step()
+        finally:
+            rt.SINK.fused = None
+            self.opt.runs = saved_runs
         if optimize_in_backward:
             self.opt.end_step()
+            if self._fused is None and self._can_fuse():
+                self._enable_fused()
         return loss.detach(), parts
 
     # ---- captured step (hipGraph): for configurations whose step is bound by the host's enqueue rate

@@ -164,12 +164,26 @@ class GradSink:
     def __init__(self):
         self.touched: Dict[int, bool] = {}
         self.on_grad_ready = None  # callback(param) fired after a parameter's gradient has been produced
+        self.touch_count: Dict[int, int] = {}   # gradient contributions per parameter in the current step
+        self.composite_weights: set = set()     # ids of the weights whose gradient GEMM ran inside a composite backward
+        self.fused = None          # callable(param) -> _lib.SgdFused or None: the optimizer fused into that weight's gradient GEMM
 
     def begin_step(self):
         self.touched.clear()
+        self.touch_count.clear()
+        self.composite_weights.clear()     # ids are only meaningful within the step that recorded them
+
+    def fused_desc(self, p: Tensor):
+        """The fused-update descriptor (afft_sgd_fused_t) for weight p, or None: set by afft_amd.parallel.Trainer for the
+        duration of a step whose optimizer runs inside the backward pass (single GPU, no clipping), for the weights it has
+        seen receive exactly one gradient contribution per step."""
+        self.composite_weights.add(id(p))
+        f = self.fused
+        return f(p) if f is not None else None
 
     def grad_buffer(self, p: Tensor):
         """(grad tensor, accumulate?)"""
+        self.touch_count[id(p)] = self.touch_count.get(id(p), 0) + 1
         if p.grad is None:
             p.grad = torch.zeros_like(p)
             self.touched[id(p)] = True
@@ -240,6 +254,19 @@ def composite() -> bool:
 def set_composite(on: bool):
     global _COMPOSITE
     _COMPOSITE = bool(on)
+
+
+_FUSED_SGD = os.environ.get("AFFT_FUSED_SGD", "1") != "0"
+
+
+def fused_sgd() -> bool:
+    """Let the Trainer fuse the optimizer into the weight-gradient GEMM epilogues (single GPU, no gradient clipping)."""
+    return _FUSED_SGD
+
+
+def set_fused_sgd(on: bool):
+    global _FUSED_SGD
+    _FUSED_SGD = bool(on)
 
 
 CAPTURING = False          # a hipGraph capture of the step is under way (afft_amd.parallel.Trainer.capture)

@@ -80,70 +80,42 @@ def build_model(name, device, drop=0.1):
 
 # ----------------------------------------------------------------------------- roofline of the dominant kernel
 class GemmTimer:
-    """Wraps afft_amd.ops.gemm for ONE instrumented step: a HIP event pair on the launch stream around every
-    GEMM, so the average launch duration of the dominant kernel (gemm_bf16_kernel<NT>, forward + dgrad) and its
-    algorithmic FLOPs per launch are measured live, on the same workload as the timed region."""
-
-    def __init__(self):
-        self.records = []
+    """The library's own measurement hook (afft_gemm_trace_begin / _end, include/afft_hip.h) around ONE instrumented step: a HIP
+    event pair on the launch stream around every bf16 GEMM launch, whichever entry point it comes from (the composite
+    sub-layer calls included), so the average launch duration of the dominant kernel and its algorithmic FLOPs per launch are
+    measured live, on the same workload and the same kernel sequence as the timed region."""
+    CAP = 4096
 
     def __enter__(self):
-        from afft_amd import _lib, ops
-        self.ops = ops
-        self.orig = ops.gemm
-        timer = self
-
-        def timed(a, b, out, **kw):
-            a_t, b_t = kw.get("a_t", False), kw.get("b_t", False)
-            x3 = not torch.is_tensor(a)      # ops.Split operands: the bf16x3 GEMM (algorithmic FLOPs stay 2*M*N*K)
-            if x3:
-                M, K = (a.cols, a.planes.shape[1]) if a_t else (a.rows, a.planes.shape[2])
-                N = b.rows if b_t else b.cols
-            else:
-                M, K = (a.shape[1], a.shape[0]) if a_t else (a.shape[0], a.shape[1])
-                N = b.shape[0] if b_t else b.shape[1]
-            fast = x3 or (a.dtype == torch.bfloat16 and K % 64 == 0)
-            a_ks, b_ks = bool(a_t), not bool(b_t)
-            if not fast or (a_ks and not b_ks):
-                kind = "gemm_f32_kernel"
-            elif x3:
-                var = _lib.lib().afft_gemm_variant_for(M, N, 3 * K, int(a_ks), int(b_ks))
-                lay = "%s, %s" % ("true" if a_ks else "false", "true" if b_ks else "false")
-                kind = ("gemm_bf16_pp_kernel<%s, false, true, false>" % lay) if var == 3 else \
-                    ("gemm_bf16_kernel<2, 2, 2, %s, false, true>" % lay)
-            else:
-                var = _lib.lib().afft_gemm_variant_for(M, N, K, int(a_ks), int(b_ks))
-                sk = "true" if _lib.lib().afft_gemm_splitk_for(M, N, K, int(a_ks), int(b_ks)) > 1 else "false"
-                lay = "%s, %s" % ("true" if a_ks else "false", "true" if b_ks else "false")
-                capped = var == 3 and a_ks and b_ks and sk == "false" and 8 <= (kw.get("max_workgroups", 0) & ~7) < \
-                    ((M + 255) // 256) * ((N + 255) // 256)
-                kind = ("gemm_bf16_pp_kernel<%s, %s, false, %s>" % (lay, sk, "true" if capped else "false")) if var == 3 else \
-                    ("gemm_bf16_kernel<2, 2, 2, %s, %s, false>" % (lay, sk))
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = timer.orig(a, b, out, **kw)
-            e.record()
-            timer.records.append((kind, 2.0 * M * N * K, s, e))
-            return r
-
-        ops.gemm = timed
-        import afft_amd.functional as F_
-        F_.ops.gemm = timed
+        from afft_amd import _lib
+        self.lib = _lib
+        _lib.check(_lib.lib().afft_gemm_trace_begin(self.CAP), "gemm_trace_begin")
+        self.records = None
         return self
 
     def __exit__(self, *exc):
-        self.ops.gemm = self.orig
-        import afft_amd.functional as F_
-        F_.ops.gemm = self.orig
+        torch.cuda.synchronize()
+        buf = (self.lib.GemmTraceRec * self.CAP)()
+        n = self.lib.lib().afft_gemm_trace_end(buf, self.CAP)
+        if n < 0:
+            raise RuntimeError("afft_gemm_trace_end failed: " + self.lib.lib().afft_last_error().decode())
+        self.records = [buf[i] for i in range(n)]
+
+    @staticmethod
+    def symbol(r) -> str:
+        b = lambda x: "true" if x else "false"    # noqa: E731
+        if r.variant == 3:
+            return f"gemm_bf16_pp_kernel<{b(r.a_kstrided)}, {b(r.b_kstrided)}, {b(r.splitk > 1)}, {b(r.split3)}, {b(r.capped)}>"
+        return f"gemm_bf16_kernel<2, 2, 2, {b(r.a_kstrided)}, {b(r.b_kstrided)}, {b(r.splitk > 1)}, {b(r.split3)}>"
 
     def summary(self):
-        torch.cuda.synchronize()
         out = {}
-        for kind, fl, s, e in self.records:
-            d = out.setdefault(kind, {"launches": 0, "flops": 0.0, "ms": 0.0})
+        for r in self.records:
+            d = out.setdefault(self.symbol(r), {"launches": 0, "flops": 0.0, "ms": 0.0, "fused_update_launches": 0})
             d["launches"] += 1
-            d["flops"] += fl
-            d["ms"] += s.elapsed_time(e)
+            d["flops"] += 2.0 * r.M * r.N * r.K
+            d["ms"] += r.ms
+            d["fused_update_launches"] += r.fused_update
         return out
 
 
@@ -398,8 +370,8 @@ def main():
     # only rank 0 keeps the timings
     summ = None
     if not args.no_roofline:
-        with GemmTimer() as gt:
-            trainer.step(feats, tgt, sub, optimize=False)
+        with GemmTimer() as gt:      # the same kernel sequence as a timed step (fused optimizer epilogues included)
+            trainer.step(feats, tgt, sub, optimize=not args.no_optimizer)
         summ = gt.summary()
 
     if rank == 0:
@@ -431,19 +403,24 @@ def main():
             avg_fl = d["flops"] / d["launches"]
             ach = avg_fl / (avg_ms * 1e-3) / 1e12
             dtype_peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3
-            traffic = None
-            try:   # HBM-side bytes per launch from separate rocprofv3 --pmc passes (tools/traffic_summary.py), committed
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic_pmc.json")))
-                traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
-            except Exception:  # noqa: BLE001
-                traffic = None
+            traffic, traffic_src = None, None
+            for fn in ("r02_gemm_hbm_traffic_pmc.json", "r01_gemm_hbm_traffic_pmc.json"):
+                try:   # HBM-side bytes per launch from separate rocprofv3 --pmc passes (tools/traffic_summary.py), committed
+                    tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                    hit = [v for k, v in tj.items() if isinstance(v, dict) and (k == dom or dom.startswith(k.rstrip(">")))]
+                    if hit:
+                        traffic, traffic_src = hit[0].get("hbm_bytes_per_launch"), fn
+                        break
+                except Exception:  # noqa: BLE001
+                    pass
             result["roofline"] = {
-                "kernel": dom + " (bf16 MFMA GEMM, v_mfma_f32_16x16x32_bf16; template <A k-strided, B k-strided>: "
-                          "false,false = NT, false,true = NN, true,true = TN weight gradient; third flag = split-K build)",
+                "kernel": dom + " (bf16 MFMA GEMM, v_mfma_f32_16x16x32_bf16; template <A k-strided, B k-strided, split-K, bf16x3, capped "
+                          "grid>: A,B = false,false NT forward / false,true NN data gradient / true,true TN weight gradient)",
                 "bound": "mfma", "achieved": round(ach, 1), "peak": dtype_peak, "unit": "TFLOP/s",
                 "frac": round(ach / dtype_peak, 4), "traffic": traffic,
-                "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate --pmc passes of this command "
-                                "(profiles/r01_gemm_hbm_traffic_pmc.json); fabric-side, includes Infinity-Cache hits",
+                "traffic_note": f"bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate --pmc passes of this command "
+                                f"(profiles/{traffic_src}); fabric-side, includes Infinity-Cache hits",
+                "fused_optimizer_epilogue": bool(d.get("fused_update_launches")),
                 "launches_per_step": d["launches"], "avg_launch_ms": round(avg_ms, 4),
                 "avg_algorithmic_gflop_per_launch": round(avg_fl / 1e9, 2),
                 "by_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),

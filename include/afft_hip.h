@@ -87,7 +87,21 @@ typedef struct {
    * The kernel accumulates A_hi*B_hi + A_lo*B_hi + A_hi*B_lo in one pass over a 3x longer K (fp32 accumulate):
    * products exact to ~2^-17 relative, the precision mode whose logits meet the 1e-3 tolerance at MFMA speed. */
   int32_t split3; int64_t a_lo, b_lo;
+  /* Optional: apply the optimizer IN the epilogue instead of storing the result (see afft_sgd_fused_t below): the GEMM is a
+   * weight gradient whose value is consumed once, by the update of that weight.  Needs accumulate = 0, no bias / act. */
+  const struct afft_sgd_fused* sgd;
 } afft_gemm_t;
+/* Nesterov-SGD update fused into the epilogue of the weight-gradient GEMM that produces the gradient (single-GPU training, no
+ * gradient clipping, a weight that receives exactly one gradient contribution per step): element [m, n] of the result is the
+ * gradient g of p[m * ldo + n] and is never stored;  g' = gscale*g + wd*p ; buf = mom*buf + g' (g' on the first step) ;
+ * p -= lr*(g' + mom*buf) ; p_bf16 = bf16(p)  -- bit for bit what afft_sgd_nesterov computes from a stored gradient (one shared
+ * device function).  p / buf / p_bf16 have the layout of the GEMM output (row stride ldo).  Saves the gradient's round trip
+ * through HBM (8 of 26 bytes per parameter and step) and the separate update kernels.  The caller orders the launch behind the
+ * kernels of the same step that still read p_bf16 (the data-gradient GEMM of the same layer). */
+typedef struct afft_sgd_fused {
+  float* p; float* buf; void* p_bf16;
+  float lr, mom, wd, gscale; int32_t first_step;
+} afft_sgd_fused_t;
 enum { AFFT_GEMM_WS_HEADER = 4096 };
 /* bytes of afft_gemm_t.workspace that let this problem use split-K under the current mode (0 = it would not split) */
 int64_t afft_gemm_workspace_bytes(int M, int N, int K, int a_kstrided, int b_kstrided);
@@ -104,6 +118,16 @@ int afft_set_gemm_splitk(int mode);
 int afft_gemm_variant_for(int M, int N, int K, int a_kstrided, int b_kstrided);
 /* K-slices afft_gemm uses for that problem under the current split-K mode (1 = none). */
 int afft_gemm_splitk_for(int M, int N, int K, int a_kstrided, int b_kstrided);
+/* Measurement hook (bench.py's roofline object): while a trace is open, every afft_gemm launch of the bf16 fast path --
+ * from any entry point, the composite ones included -- is bracketed by a HIP event pair ON THE STREAM IT IS LAUNCHED ON.
+ * afft_gemm_trace_end synchronises those events and returns the records (at most `capacity`; return value = count, < 0 on
+ * error).  One trace at a time, process-wide.  variant: 1 = 128x128 tile, 3 = 256x256 ping-pong (4-6: experiments). */
+typedef struct {
+  int32_t M, N, K, a_kstrided, b_kstrided, variant, splitk, split3, capped, fused_update;
+  float ms;
+} afft_gemm_trace_rec_t;
+int afft_gemm_trace_begin(int32_t capacity);
+int afft_gemm_trace_end(afft_gemm_trace_rec_t* out, int32_t capacity);
 
 /* ------------------------------------------------------------------ LayerNorm
  * nn.LayerNorm(eps) fwd/bwd: models/fusion.py:281,362 ; transformerblock.py:122,127,150-152 ;
@@ -250,6 +274,11 @@ int afft_group_bcast(const float* dy, int32_t G, int32_t S, int64_t W, float sca
  *   gscale_dev (optional device scalar) multiplies gscale: the gradient-clipping coefficient of afft_clip_coef. */
 int afft_sgd_nesterov(float* p, const void* g, int32_t g_dtype, float* buf, void* p_bf16, int64_t n, float lr, float mom,
                       float wd, float gscale, const float* gscale_dev, int32_t first_step, void* stream);
+/* The same update over `nruns` separate runs of ONE set of flat buffers: runs = device array of nruns x {start, length}
+ * (int64 elements, starts multiples of 4).  One launch for all the small parameters of a gradient bucket (LayerNorm
+ * weights, biases, tokens) whose big neighbours are updated in their weight-gradient epilogues (afft_sgd_fused_t). */
+int afft_sgd_nesterov_runs(float* p, const float* g, float* buf, void* p_bf16, const int64_t* runs, int32_t nruns, float lr,
+                           float mom, float wd, float gscale, int32_t first_step, void* stream);
 /* Gradient clipping by global norm (train.py:254-260, torch.nn.utils.clip_grad_norm_), without a host sync:
  *   afft_sumsq: *out += scale * sum x[i]^2 over a flat fp32/bf16 buffer (scale = gscale^2 of the optimizer);
  *   afft_clip_coef: *coef = min(1, max_norm / (sqrt(*sumsq) + 1e-6)), *norm_out (optional) = sqrt(*sumsq). */
@@ -303,6 +332,9 @@ typedef struct {       /* y = x + drop(proj(attention(split(qkv(LN(x))))))      
   void* gemm_ws; int64_t gemm_ws_bytes;  /* afft_gemm_t.workspace of `stream`                                          */
   void* gemm_ws_aux; int64_t gemm_ws_aux_bytes;   /* ... of `aux_stream`                                                */
   int32_t wgrad_workgroups;
+  /* optional fused optimizer (afft_sgd_fused_t) per weight: that weight's gradient GEMM then runs BEHIND the data-gradient
+   * GEMM that reads the weight and updates it in its epilogue; its g_w_* buffer is not written */
+  const afft_sgd_fused_t* sgd_w_qkv; const afft_sgd_fused_t* sgd_w_proj;
 } afft_attn_sublayer_t;
 int afft_attn_sublayer_fwd(const afft_attn_sublayer_t* s, void* stream);
 int afft_attn_sublayer_bwd(const afft_attn_sublayer_t* s, void* stream, void* aux_stream);
@@ -329,6 +361,7 @@ typedef struct {       /* y = x + drop(fc2(gelu(fc1(LN(x)))))                   
   float* ln_partial;
   void* gemm_ws; int64_t gemm_ws_bytes; void* gemm_ws_aux; int64_t gemm_ws_aux_bytes;
   int32_t wgrad_workgroups;
+  const afft_sgd_fused_t* sgd_w1; const afft_sgd_fused_t* sgd_w2;       /* as in afft_attn_sublayer_t */
 } afft_mlp_sublayer_t;
 int afft_mlp_sublayer_fwd(const afft_mlp_sublayer_t* s, void* stream);
 int afft_mlp_sublayer_bwd(const afft_mlp_sublayer_t* s, void* stream, void* aux_stream);
@@ -356,6 +389,8 @@ typedef struct {       /* y = x + drop(proj(attention(q = w_q LN_q(x), k = w_k L
   float* ln_partial; float* ln_partial2;
   void* gemm_ws; int64_t gemm_ws_bytes; void* gemm_ws_aux; int64_t gemm_ws_aux_bytes;
   int32_t wgrad_workgroups;
+  const afft_sgd_fused_t* sgd_w_q; const afft_sgd_fused_t* sgd_w_k; const afft_sgd_fused_t* sgd_w_v;
+  const afft_sgd_fused_t* sgd_w_proj;                                    /* as in afft_attn_sublayer_t */
 } afft_cross_attn_sublayer_t;
 int afft_cross_attn_sublayer_fwd(const afft_cross_attn_sublayer_t* s, void* stream);
 int afft_cross_attn_sublayer_bwd(const afft_cross_attn_sublayer_t* s, void* stream, void* aux_stream);

@@ -53,7 +53,7 @@ int main(){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(afft_gemm_t), offsetof(af
     assert got == want
 
 
-@pytest.mark.parametrize("cname,pyname", [("afft_gemm_t", "GemmDesc"), ("afft_dropout_t", "Dropout"),
+@pytest.mark.parametrize("cname,pyname", [("afft_gemm_t", "GemmDesc"), ("afft_dropout_t", "Dropout"), ("afft_sgd_fused_t", "SgdFused"),
                                           ("afft_attn_sublayer_t", "AttnSublayer"), ("afft_mlp_sublayer_t", "MLPSublayer"),
                                           ("afft_cross_attn_sublayer_t", "CrossAttnSublayer")])
 def test_every_struct_field_matches_c_layout(built_lib, cname, pyname):

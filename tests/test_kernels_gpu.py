@@ -446,6 +446,24 @@ def test_softmax_ce_out_of_range_label_poisons_the_row():
     assert rel_l2(rl[[0, 2, 4]], ref) < 1e-5
 
 
+def test_sgd_runs_equals_sgd_over_the_same_ranges():
+    """afft_sgd_nesterov_runs over a table of runs == afft_sgd_nesterov over each range, bit for bit; elements outside the runs
+    are untouched"""
+    from afft_amd import ops
+    n = 40000
+    g = torch.Generator().manual_seed(9)
+    p0, gr, b0 = (torch.randn(n, generator=g).to(dev()) for _ in range(3))
+    runs = [(0, 64), (128, 5000), (5184, 16384), (30016, 4)]
+    ref_p, ref_b, ref_16 = p0.clone(), b0.clone(), torch.zeros(n, dtype=torch.bfloat16, device=dev())
+    for s, ln in runs:
+        ops.sgd_nesterov(ref_p[s:s + ln], gr[s:s + ln], ref_b[s:s + ln], 0.01, 0.9, 1e-4, 0.5, False, p_bf16=ref_16[s:s + ln])
+    p, b, p16 = p0.clone(), b0.clone(), torch.zeros(n, dtype=torch.bfloat16, device=dev())
+    ops.sgd_nesterov_runs(p, gr, b, torch.tensor(runs, dtype=torch.int64, device=dev()), 0.01, 0.9, 1e-4, 0.5, False, p_bf16=p16)
+    torch.cuda.synchronize()
+    assert torch.equal(p, ref_p) and torch.equal(b, ref_b) and torch.equal(p16, ref_16)
+    assert torch.equal(p[64:128], p0[64:128]) and torch.equal(p[30020:], p0[30020:])
+
+
 def test_mse_and_elementwise():
     from afft_amd import ops
     rows, d = 45, 64

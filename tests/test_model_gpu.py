@@ -298,6 +298,63 @@ def test_marginalize_verb_noun_matches_reference_golden():
         assert (np.isnan(v) and np.isnan(acc[k])) or abs(acc[k] - v) < 1e-9, (k, acc[k], v)
 
 
+@pytest.mark.parametrize("name", ["t3_m5", "t1_ca"])
+def test_fused_optimizer_epilogue_equals_separate_update(name):
+    """Trainer on one GPU: from step 2 on the Nesterov update of every sub-layer GEMM weight runs in the epilogue of that
+    weight's gradient GEMM (afft_sgd_fused_t; the gradient never goes to HBM) and the bucket update kernel only walks the small
+    parameters (afft_sgd_nesterov_runs).  Parameters, momentum and bf16 images after 4 steps are BITWISE those of the separate
+    update kernels (one shared device function, pinned roundings)."""
+    import afft_amd
+    from afft_amd import dropout as D_, runtime as rt
+    from afft_amd.parallel import Trainer
+    c, state, data, tgt, sub = case_tensors(name)
+    dev = torch.device("cuda:0")
+    wts = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
+    feats = {m: d.to(dev) for m, d in data.items()}
+    res = {}
+    for fused in (True, False):
+        rt.set_fused_sgd(fused)
+        D_.manual_seed(5)
+        model = build(c, "bf16")
+        model.load_state_dict(state)
+        model = model.cuda().train()
+        tr = Trainer(model, wts, lr=1e-2, momentum=0.9, weight_decay=1e-4, bucket_elems=1 << 15)
+        for _ in range(4):
+            loss, _ = tr.step(feats, {"action": tgt.to(dev)}, {"action": sub.to(dev)})
+        torch.cuda.synchronize()
+        if fused:
+            assert tr._fused and len(tr._fused) >= 8, "no weight took the fused path"
+            assert any(r.shape[0] for r in tr.opt.runs.values())
+        else:
+            assert tr._fused is None
+        res[fused] = (tr.flat.flat_p.clone(), tr.opt.buf.clone(), tr.flat.flat_p16.clone(), float(loss))
+    rt.set_fused_sgd(True)
+    for a, b, what in zip(res[True], res[False], ("parameters", "momentum", "bf16 images", "loss")):
+        assert (a == b) if isinstance(a, float) else torch.equal(a, b), what
+
+
+def test_gemm_trace_hook_brackets_every_launch():
+    """afft_gemm_trace_begin / _end (bench.py's roofline source): one record per bf16 fast-path launch, from afft_gemm and from
+    inside a composite call alike, with plausible durations."""
+    import ctypes
+    from afft_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    a = torch.randn(512, 256, device=dev).to(torch.bfloat16)
+    b = torch.randn(384, 256, device=dev).to(torch.bfloat16)
+    out = torch.empty(512, 384, dtype=torch.bfloat16, device=dev)
+    _lib.check(_lib.lib().afft_gemm_trace_begin(16))
+    for _ in range(3):
+        ops.gemm(a, b, out, b_t=True)
+    ops.gemm(a.float(), b.float(), out.float(), b_t=True)      # exact-fp32 path: not traced
+    buf = (_lib.GemmTraceRec * 16)()
+    n = _lib.lib().afft_gemm_trace_end(buf, 16)
+    assert n == 3
+    for i in range(n):
+        r = buf[i]
+        assert (r.M, r.N, r.K, r.a_kstrided, r.b_kstrided, r.variant) == (512, 384, 256, 0, 0, 1) and 0.0 < r.ms < 5.0
+    assert _lib.lib().afft_gemm_trace_end(buf, 16) < 0       # no trace open
+
+
 def test_public_drop_path_module_is_differentiable():
     """models.transformerblock.DropPath in train mode (the standalone form; inside Block it is fused into the GEMM epilogue):
     one keep/drop decision per dim-0 sample, survivors scaled by 1/(1-p), and the gradient flows back through the SAME mask
