@@ -220,6 +220,8 @@ def comm_report(args, trainer, feats, tgt, sub, world, rank, device, ms_with_com
            "payload_gb_per_step": round(trainer.flat.total * (2 if args.comm_dtype == "bf16" else 4) / 1e9, 3)}
     # (a) the same ranks without the exchange (replicas diverge from here on: this runs after the timed region)
     was = trainer.reducer.comm
+    fused_was = afft_amd.runtime.fused_sgd()
+    afft_amd.runtime.set_fused_sgd(False)     # same kernels as the step with the exchange (the fused update is single-GPU only)
     trainer.reducer.comm = False
     for _ in range(3):
         trainer.step(feats, tgt, sub)
@@ -232,6 +234,7 @@ def comm_report(args, trainer, feats, tgt, sub, world, rank, device, ms_with_com
     t = torch.tensor([(time.perf_counter() - t0) / n * 1e3], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     trainer.reducer.comm = was
+    afft_amd.runtime.set_fused_sgd(fused_was)
     rep["ms_per_step_without_exchange"] = round(float(t), 3)
     rep["exposed_comm_ms"] = round(ms_with_comm - float(t), 3)
     # (b) payload precision: two fresh replicas of the model, 20 steps each

@@ -197,3 +197,44 @@ def test_multi_crop_7d_input_averages_crops():
             assert torch.allclose(multi[key][m], want, atol=1e-6), key
     with pytest.raises(NotImplementedError):
         model({m: d[:, :, :, 0] for m, d in data.items()}, **kw)
+
+
+def test_two_threads_forward_concurrently_without_sharing_state():
+    """The reference's eval path is nn.DataParallel (test.py:130): one Python thread per replica calls forward at the same time.
+    Everything afft_amd.functional remembers between calls (noted sub-layer output for the hand-over, side-stream block,
+    pending notifications) is per thread: two threads running different models interleaved get the results of running them
+    one after the other."""
+    import threading
+    import afft_amd
+    cases = ["t0_sa", "t1_ca"]
+    built = {}
+    with cpu_ops.installed():
+        for name in cases:
+            c, state, data, tgt, sub = case_tensors(name)
+            m = _build(c, "bf16")
+            m.load_state_dict(state)
+            built[name] = (m.eval(), data, tgt, sub)
+        kw = lambda tgt, sub: dict(mixup_fn=None, target={"action": tgt}, target_subclips={"action": sub},   # noqa: E731
+                                   target_subclips_ignore_index=None)
+        with torch.no_grad():
+            serial = {n: flatten_outputs(m(d, **kw(t, s))[0]) for n, (m, d, t, s) in built.items()}
+        got, errs = {}, []
+        gate = threading.Barrier(2)
+
+        def run(name):
+            try:
+                m, d, t, s = built[name]
+                gate.wait()
+                with torch.no_grad():
+                    for _ in range(3):
+                        got[name] = flatten_outputs(m(d, **kw(t, s))[0])
+            except Exception as e:      # noqa: BLE001
+                errs.append(e)
+        ths = [threading.Thread(target=run, args=(n,)) for n in cases]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+    afft_amd.set_precision("bf16")
+    assert not errs, errs
+    for n in cases:
+        for k, v in serial[n].items():
+            assert torch.equal(got[n][k], v), (n, k)

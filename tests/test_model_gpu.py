@@ -729,6 +729,54 @@ def test_captured_step_graph_equals_eager_and_masks_change():
         D_.disable_device_salt()
 
 
+def test_captured_graph_takes_new_batches_by_copy():
+    """Trainer.step() with a captured graph and FRESH tensors (the normal data-loader pattern: new feature and label tensors every
+    step): every incoming tensor is copied into the tensors the graph reads -- labels included (the round-1 replay compared only the
+    ids of the feature tensors and silently trained on the labels frozen at capture time) -- and a batch of another shape falls
+    back to an eager step."""
+    import afft_amd
+    from afft_amd import dropout as D_, runtime as rt
+    from afft_amd.config import make_model_cfg
+    from afft_amd.models.base_model import BaseModel
+    from afft_amd.parallel import Trainer
+    afft_amd.set_precision("bf16")
+    rt.set_grad_mode("sink")
+    dev = torch.device("cuda:0")
+    mods = {"rgb": 128, "flow": 128}
+    B, T, K = 8, 8, 31
+    g = torch.Generator().manual_seed(21)
+    mk = lambda: ({m: torch.randn(B, T, C, 1, 1, 1, generator=g).to(dev) for m, C in mods.items()},       # noqa: E731
+                  {"action": torch.randint(0, K, (B,), generator=g).to(dev)},
+                  {"action": torch.randint(0, K, (B, T, 1), generator=g).to(dev)})
+    batches = [mk() for _ in range(4)]
+    wts = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
+    try:
+        out = {}
+        for mode in ("eager", "graph"):
+            torch.manual_seed(3)
+            cfg = make_model_cfg(mods, 128, 256, depth=1, fp_layers=1, fp_heads=4, drop=0.0)
+            model = BaseModel(cfg, {"action": K}, {}).to(dev).eval()
+            tr = Trainer(model, wts, lr=0.05, bucket_elems=1 << 16)
+            if mode == "graph":
+                f0, t0, s0 = (dict((k, v.clone()) for k, v in d.items()) for d in batches[0])
+                tr.capture(f0, t0, s0, warmup=2)           # 2 eager steps on batch 0
+            else:
+                for _ in range(2):
+                    tr.step(*batches[0])
+            losses = [float(tr.step(*b)[0]) for b in batches[1:]]          # fresh tensors every step
+            torch.cuda.synchronize()
+            out[mode] = (losses, tr.flat.flat_p.clone())
+        assert rel_l2(out["graph"][1], out["eager"][1]) < 5e-5
+        for a, b in zip(out["graph"][0], out["eager"][0]):
+            assert abs(a - b) < 1e-3 * max(1.0, abs(b)), (out["graph"][0], out["eager"][0])
+        small = ({m: v[:4].contiguous() for m, v in batches[1][0].items()}, {"action": batches[1][1]["action"][:4].contiguous()},
+                 {"action": batches[1][2]["action"][:4].contiguous()})
+        loss, _ = tr.step(*small)                          # other shapes: eager fall-back, no replay on stale tensors
+        assert torch.isfinite(loss)
+    finally:
+        D_.disable_device_salt()
+
+
 def test_overlapped_optimizer_and_wgrad_streams_equal_serial():
     """Per-bucket SGD on the side stream (under backward) and weight-gradient GEMMs on the auxiliary stream must give
     the same parameters as the fully serial schedule (same kernels, same order of accumulation)."""
