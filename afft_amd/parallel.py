@@ -160,10 +160,12 @@ class GradReducer:
     def _launch(self, b: int):
         self._launched[b] = True
         s, e = self.buckets[b]
-        if not self._use_cuda:
+        if not self._use_cuda:     # CPU tensors (gloo; the build container's tests): same protocol, no streams
             if self.comm:
-                if self.comm_algo == "rs_ag":
-                    self._reduce(self.flat.flat_g[s:e])
+                if self.flat_g16 is not None:      # bf16 payload
+                    self.flat_g16[s:e].copy_(self.flat.flat_g[s:e])
+                if self.comm_algo == "rs_ag" or self.flat_g16 is not None:
+                    self._reduce(self._grad_slice(s, e))
                 else:
                     self._handles.append(dist.all_reduce(self.flat.flat_g[s:e], group=self.group, async_op=True))
             return

@@ -207,7 +207,7 @@ def parity_side_measurements(args, device, feats, tgt, sub, c):
     return out
 
 
-def comm_report(args, trainer, feats, tgt, sub, world, rank, device, ms_with_comm, rccl_log, sync_all):
+def comm_report(args, trainer, feats, tgt, sub, world, rank, device, ms_with_comm, rccl_log, sync_all, n_noexch=10, n_payload=20):
     """N > 1 side measurements, every rank takes part (collectives inside): what the gradient exchange costs and what the
     library does for it.  (a) exposed communication = ms/step with the exchange - ms/step of the same ranks stepping without
     it (buckets handed straight to the optimizer); (b) loss after 20 steps from the same start with fp32 and with bf16
@@ -227,7 +227,7 @@ def comm_report(args, trainer, feats, tgt, sub, world, rank, device, ms_with_com
         trainer.step(feats, tgt, sub)
     sync_all()
     t0 = time.perf_counter()
-    n = 10
+    n = n_noexch
     for _ in range(n):
         trainer.step(feats, tgt, sub)
     sync_all()
@@ -246,14 +246,14 @@ def comm_report(args, trainer, feats, tgt, sub, world, rank, device, ms_with_com
         m, _ = build_model(args.config, device)
         m.train(not args.eval_drop)
         tr = Trainer(m, wts, comm_dtype=cd, bucket_elems=args.bucket_melems * 1024 * 1024, comm_algo=args.comm_algo)
-        for _ in range(20):
+        for _ in range(n_payload):
             loss, _ = tr.step(feats, tgt, sub)
         lt = loss.detach().double().reshape(1).clone()
         dist.all_reduce(lt)
         losses[cd] = float(lt) / world
         del tr, m
         torch.cuda.empty_cache()
-    rep["loss_after_20_steps"] = {k: round(v, 5) for k, v in losses.items()}
+    rep["loss_after_%d_steps" % n_payload] = {k: round(v, 5) for k, v in losses.items()}
     rep["loss_delta_bf16_vs_fp32_payload"] = round(losses["bf16"] - losses["fp32"], 6)
     # (c) RCCL debug lines
     if rank == 0 and rccl_log:

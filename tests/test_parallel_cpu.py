@@ -187,3 +187,48 @@ def test_two_rank_trainer_real_model_matches_single_process(tmp_path, comm_algo)
     err = float((got["flat"] - tr.flat.flat_p).norm() / tr.flat.flat_p.norm())
     assert err < 1e-6, err
     assert got["early"][0] == 0 and all(e >= 1 for e in got["early"][1:]), got["early"]
+
+
+# ----------------------------------------------------------------------------- bench.py's N > 1 report, over gloo
+def _bench_report_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import argparse
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.join(here, "golden"), os.path.dirname(here)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import bench
+    import cpu_ops
+    import afft_amd
+    from afft_amd import config as CFG
+    from afft_amd.parallel import Trainer
+    CFG.BASELINE_CONFIGS["tiny"] = dict(modal_dims={"rgb": 64, "flow": 64}, common_dim=64, fp_inter_dim=64, fuser="sa", T=4)
+    args = argparse.Namespace(config="tiny", comm_dtype="fp32", comm_algo="allreduce", bucket_melems=1, eval_drop=True)
+    with cpu_ops.installed():
+        afft_amd.set_precision("fp32")
+        model, c = bench.build_model("tiny", "cpu", drop=0.0)
+        model.eval()
+        feats, tgt, sub = bench.make_inputs(c, 4, c["T"], rank, "cpu")
+        tr = Trainer(model, WTS, comm_dtype="fp32", bucket_elems=1 << 16)
+        for _ in range(2):
+            tr.step(feats, tgt, sub)
+        rep = bench.comm_report(args, tr, feats, tgt, sub, world, rank, torch.device("cpu"), 123.0, None, dist.barrier,
+                                n_noexch=2, n_payload=4)
+    if rank == 0:
+        torch.save(rep, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_comm_report_runs_on_two_ranks(tmp_path):
+    """bench.py's N > 1 side measurements (exposed communication, payload-precision loss delta) cannot be run on the 1-GPU test
+    box: run the same function on 2 gloo ranks with the test double, so that a typo cannot take the driver's scaling run down."""
+    out = str(tmp_path / "rep.pt")
+    mp.spawn(_bench_report_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    rep = torch.load(out)
+    assert rep["world_size"] == 2 and rep["buckets"] >= 1
+    assert rep["ms_per_step_without_exchange"] > 0 and "exposed_comm_ms" in rep
+    assert set(rep["loss_after_4_steps"]) == {"fp32", "bf16"}
+    assert abs(rep["loss_delta_bf16_vs_fp32_payload"]) < 0.05 * abs(rep["loss_after_4_steps"]["fp32"])
