@@ -161,109 +161,101 @@ class BaseFuturePredictor(nn.Module):
 
 
 # --------------------------------------------------------------------------- cross-modal fusion + prediction
+# The attribute names below (mapping, fuser, dim_encoder, dim_decoder, future_predictor, classifiers[cls][modality]) and the
+# order in which they are registered are the reference's state_dict contract (models/future_prediction.py:19-186); how they
+# are built and how the outputs are assembled is this file's own organisation: small builders instead of overridable
+# _init_* hooks, one `_heads()` pass for every classifier application, one `_split_past_future()` for the bookkeeping.
+def _resize(n_in: int, n_out: int) -> nn.Module:
+    """bias-free width change of the GPT-2 side (dim_encoder / dim_decoder); nothing to do when the widths agree"""
+    return nn.Identity() if n_in == n_out else nn.Linear(n_in, n_out, bias=False)
+
+
+def _head(p_drop: float, n_in: int, n_classes: int) -> nn.Sequential:
+    return nn.Sequential(nn.Dropout(p_drop), nn.Linear(n_in, n_classes))
+
+
+def _as_rows_gemm(lin: nn.Module, x: Tensor) -> Tensor:
+    """a `_resize` module on (B, T, C) through the MFMA GEMM"""
+    if isinstance(lin, nn.Identity):
+        return x
+    B, T, C = x.shape
+    return F_.Linear.apply(x.reshape(B * T, C), lin.weight, None).view(B, T, -1)
+
+
+def _f32(t: Tensor) -> Tensor:
+    return t if t.dtype == torch.float32 else t.float()
+
+
 class CrossModalFusionPrediction(nn.Module, metaclass=abc.ABCMeta):
     """base class cross modality future predictor"""
 
-    def __init__(self, model_cfg, num_classes, instantiate_: bool = True):
+    # late-fusion variants keep one encoder / decoder pair (and, unless shared, one predictor) PER MODALITY in that
+    # modality's own width; the early-fusion variant has a single pair for the fused feature
+    per_modality_codec = True
+
+    def __init__(self, model_cfg, num_classes, instantiate_: bool = True, with_mapping_and_fuser: bool = True):
         super().__init__()
         assert is_dict_config(model_cfg.modal_dims), 'cfg.model.modal_dims must be a Dict!'
-        self.cfg = model_cfg
-        self.num_classes = num_classes
-        self.latent_dim = model_cfg.common.in_features
-        self.fp_inter_dim = model_cfg.common.fp_inter_dim
+        common = model_cfg.common
+        self.cfg, self.num_classes = model_cfg, num_classes
+        self.latent_dim, self.fp_inter_dim = common.in_features, common.fp_inter_dim
         self.modality_dims = model_cfg.modal_dims
-        self.common_predictor = model_cfg.common.share_predictors
-        self.common_classifier = model_cfg.common.share_classifiers
-        self.modality_cls = model_cfg.common.modality_cls
-        self.fusion_cls = model_cfg.common.fusion_cls
+        self.common_predictor, self.common_classifier = common.share_predictors, common.share_classifiers
+        self.modality_cls, self.fusion_cls = common.modality_cls, common.fusion_cls
+        if instantiate_ and with_mapping_and_fuser:
+            self.mapping = nn.ModuleDict()
+            for mod, width in self.modality_dims.items():
+                self.mapping[mod] = instantiate(model_cfg.mapping, in_features=width, out_features=self.latent_dim)
+                logging.info(f'Using {self.mapping[mod]} for {mod}')
+            self.fuser = instantiate(model_cfg.fuser, _recursive_=False)
         if instantiate_:
-            self.mapping = self._init_mapping_layer()
-            self.fuser = self._init_fuser(model_cfg)
-            self.future_predictor = self._init_future_predictor(model_cfg, self.common_predictor)
-        self.classifiers = self._init_classifiers(self.latent_dim, self.modality_dims, self.num_classes,
-                                                  self.common_classifier, self.cfg.dropout, self.modality_cls,
-                                                  self.fusion_cls)
+            self._build_predictor()
+        self._build_classifiers()
 
-    def _init_mapping_layer(self):
-        mapping_layer = nn.ModuleDict()
-        for mod in self.modality_dims.keys():
-            mapping_layer[mod] = instantiate(self.cfg.mapping, in_features=self.modality_dims[mod],
-                                             out_features=self.latent_dim)
-            logging.info(f'Using {mapping_layer[mod]} for {mod}')
-        return mapping_layer
+    # ---- construction
+    def _build_predictor(self):
+        D, cfg = self.fp_inter_dim, self.cfg
+        if self.per_modality_codec:
+            self.dim_encoder = nn.ModuleDict({m: _resize(w, D) for m, w in self.modality_dims.items()})
+            self.dim_decoder = nn.ModuleDict({m: _resize(D, w) for m, w in self.modality_dims.items()})
+        else:
+            self.dim_encoder, self.dim_decoder = _resize(self.latent_dim, D), _resize(D, self.latent_dim)
+        make = lambda: instantiate(cfg.future_predictor, in_features=D, dimension_mapping=False, _recursive_=False)   # noqa: E731
+        self.future_predictor = make() if self.common_predictor else nn.ModuleDict({m: make() for m in cfg.modal_dims.keys()})
 
-    @staticmethod
-    def _init_fuser(model_cfg):
-        return instantiate(model_cfg.fuser, _recursive_=False)
+    def _build_classifiers(self):
+        assert self.modality_cls or self.fusion_cls, 'Modality-level and / or fusion classification!'
+        p = self.cfg.dropout
+        self.classifiers = nn.ModuleDict()
+        for cls_type, n_cls in self.num_classes.items():
+            shared = _head(p, self.latent_dim, n_cls) if self.common_classifier else None
+            heads = nn.ModuleDict()
+            if self.modality_cls:
+                for m, width in self.modality_dims.items():
+                    heads[m] = shared if shared is not None else _head(p, width, n_cls)
+            if self.fusion_cls:
+                heads['all-fused'] = shared if shared is not None else _head(p, self.latent_dim, n_cls)
+            self.classifiers[cls_type] = heads
 
-    @staticmethod
-    def _init_dimension_encoder(modality_dims, inter_dim, latent_dim):
-        """replaces the encoder inside gpt2, enabling modality specific dimension encoding"""
-        del latent_dim
-        return nn.ModuleDict({modk: (nn.Linear(mod_dim, inter_dim, bias=False) if mod_dim != inter_dim
-                                     else nn.Identity()) for modk, mod_dim in modality_dims.items()})
-
-    @staticmethod
-    def _init_dimension_decoder(modality_dims, inter_dim, latent_dim):
-        """replaces the decoder inside gpt2, enabling modality specific dimension decoding"""
-        del latent_dim
-        return nn.ModuleDict({modk: (nn.Linear(inter_dim, mod_dim, bias=False) if mod_dim != inter_dim
-                                     else nn.Identity()) for modk, mod_dim in modality_dims.items()})
-
-    @staticmethod
-    def _project(lin, x: Tensor) -> Tensor:
-        """bias-free nn.Linear (or Identity) of the dimension encoder / decoder on (B, T, C), as an MFMA GEMM"""
-        if isinstance(lin, nn.Identity):
-            return x
-        B, T, C = x.shape
-        return F_.Linear.apply(x.reshape(B * T, C), lin.weight, None).view(B, T, -1)
-
-    def _init_future_predictor(self, model_cfg, common_predictor=False):
-        self.dim_encoder = self._init_dimension_encoder(self.modality_dims, self.fp_inter_dim, self.latent_dim)
-        self.dim_decoder = self._init_dimension_decoder(self.modality_dims, self.fp_inter_dim, self.latent_dim)
-        if common_predictor:  # a common future predictor, features are mapped
-            return instantiate(model_cfg.future_predictor, in_features=self.fp_inter_dim, dimension_mapping=False,
-                               _recursive_=False)
-        return nn.ModuleDict({modk: instantiate(model_cfg.future_predictor, in_features=self.fp_inter_dim,
-                                                dimension_mapping=False, _recursive_=False)
-                              for modk in model_cfg.modal_dims.keys()})
-
-    def _predict_unimodal(self, z: Dict[str, Tensor]):
-        """per-modality future prediction (models/future_prediction.py:204-217, :314-327)"""
-        z_hat, attentions = {}, {}
-        for modk, z_unimod in z.items():
-            z_enc = self._project(self.dim_encoder[modk], z_unimod if z_unimod.dtype == torch.float32 else z_unimod.float())
-            fp = self.future_predictor if self.common_predictor else self.future_predictor[modk]
-            z_hat_enc, atts = fp(z_enc, self.cfg.common.fp_output_len)
-            z_hat[modk] = self._project(self.dim_decoder[modk], z_hat_enc)
-            attentions[modk] = atts
-        return z_hat, attentions
-
-    @staticmethod
-    def _init_classifiers(latent_dim, modality_dims, num_classes, share_classifier, dropout, modality_cls,
-                          fusion_cls):
-        assert modality_cls or fusion_cls, 'Modality-level and / or fusion classification!'
-        classifiers = nn.ModuleDict()
-        for cls_type, cls_dim in num_classes.items():
-            mod_classifiers = nn.ModuleDict()
-            common_classifier = nn.Sequential(nn.Dropout(dropout), nn.Linear(latent_dim, cls_dim)
-                                              ) if share_classifier else None
-            if modality_cls:
-                for modk, mod_dim in modality_dims.items():
-                    mod_classifiers[modk] = nn.Sequential(nn.Dropout(dropout), nn.Linear(mod_dim, cls_dim)
-                                                          ) if not common_classifier else common_classifier
-            if fusion_cls:
-                mod_classifiers['all-fused'] = nn.Sequential(nn.Dropout(dropout), nn.Linear(latent_dim, cls_dim)
-                                                             ) if not common_classifier else common_classifier
-            classifiers.update({cls_type: mod_classifiers})
-        return classifiers
-
+    # ---- pieces of forward
     @staticmethod
     def ordered_feature_list(x_d: Dict[str, Tensor], feats_order: List) -> List[Tensor]:
         return [x_d[modk] for modk in feats_order]
 
+    def _modal_order(self, present) -> List[str]:
+        return [m for m in self.cfg.modal_feature_order if m in present]
+
     def feature_mapping(self, x_d: Dict[str, Tensor]) -> Dict[str, Tensor]:
         return {modk: self.mapping[modk](x) for modk, x in x_d.items()}
+
+    def _predict_unimodal(self, z: Dict[str, Tensor]):
+        """every modality through (its) GPT-2 predictor in the predictor's width (models/future_prediction.py:204-217, :314-327)"""
+        z_hat, attentions = {}, {}
+        for m, feat in z.items():
+            predictor = self.future_predictor if self.common_predictor else self.future_predictor[m]
+            h, attentions[m] = predictor(_as_rows_gemm(self.dim_encoder[m], _f32(feat)), self.cfg.common.fp_output_len)
+            z_hat[m] = _as_rows_gemm(self.dim_decoder[m], h)
+        return z_hat, attentions
 
     def _classify(self, head: nn.Sequential, feat: Tensor) -> Tensor:
         """Sequential(Dropout(p), Linear(d, classes)) on (B, T', d): dropout is applied while the features are
@@ -271,31 +263,33 @@ class CrossModalFusionPrediction(nn.Module, metaclass=abc.ABCMeta):
         drop, lin = head[0], head[1]
         B, Tn, C = feat.shape
         in_drop = D_.elementwise(drop.p) if (self.training and drop.p > 0) else None
-        y = F_.Linear.apply(feat.reshape(B * Tn, C), lin.weight, lin.bias, in_drop)
-        return y.view(B, Tn, -1)
+        return F_.Linear.apply(feat.reshape(B * Tn, C), lin.weight, lin.bias, in_drop).view(B, Tn, -1)
 
     def apply_classifier(self, input_feat, outputs_prefix=''):
+        """{prefix}logits/{class}: {modality: logits} for every classifier head that has an input (future_prediction.py:144-153)"""
         out = {}
-        for classk in self.num_classes.keys():
-            if classk in self.classifiers:
-                out[f'{outputs_prefix}logits/{classk}'] = {
-                    modk: self._classify(self.classifiers[classk][modk], input_feat[modk])
-                    for modk in self.classifiers[classk].keys() if modk in input_feat}
-            else:
+        for classk in self.num_classes:
+            if classk not in self.classifiers:
                 raise ValueError(f'Classifier for {classk} does not exist.')
+            heads = self.classifiers[classk]
+            out[f'{outputs_prefix}logits/{classk}'] = {m: self._classify(heads[m], input_feat[m]) for m in heads if m in input_feat}
         return out
 
     @staticmethod
     def prepare_output(z, z_hat, fusions):
-        """orig_past / future / all-fused / past_futures bookkeeping (models/future_prediction.py:155-182)."""
-        out = {'orig_past': z, 'future': z_hat, 'all-fused': fusions, 'past_futures': {}}
-        B, T, C = next(iter(z.values())).shape
-        for modk in out['future'].keys():
-            out['past_futures'][modk] = torch.cat([out['orig_past'][modk][:, :1],
-                                                   out['future'][modk][:, :(T - 1)]], dim=1)
-            out['future'][modk] = out['future'][modk][:, (T - 1):]
-        for modk in out['all-fused'].keys():
-            out['all-fused'][modk] = out['all-fused'][modk][:, (T - 1):]
+        """With T observed frames and predictions z_hat for frames 2 .. T + k (future_prediction.py:155-182):
+        orig_past = z; past_futures = [z_1, z_hat_2 .. z_hat_T] (the observed first frame, then what was predicted for the
+        other observed ones); future = z_hat_{T+1}.. ; all-fused = the fused feature from frame T on."""
+        T = next(iter(z.values())).shape[1]
+        cut = T - 1
+        return {'orig_past': z,
+                'future': {m: zh[:, cut:] for m, zh in z_hat.items()},
+                'all-fused': {m: f[:, cut:] for m, f in fusions.items()},
+                'past_futures': {m: torch.cat([z[m][:, :1], zh[:, :cut]], dim=1) for m, zh in z_hat.items()}}
+
+    def _with_logits(self, out: dict) -> dict:
+        out.update(self.apply_classifier(out['past_futures'], outputs_prefix=PAST_LOGITS_PREFIX))
+        out.update(self.apply_classifier(out['future']))
         return out
 
     @abc.abstractmethod
@@ -306,46 +300,23 @@ class CrossModalFusionPrediction(nn.Module, metaclass=abc.ABCMeta):
 class CMFPEarly(CrossModalFusionPrediction):
     """cross modality future predictor, early fusion version:
     features of different modalities are fused before the future prediction module"""
+    per_modality_codec = False
 
     def __init__(self, model_cfg, num_classes):
-        logger = logging.getLogger(__name__)
-        if not model_cfg.common.share_classifiers:
-            logger.warning("Enforcing shared classifier for early CMFP.")
-            model_cfg.common.share_classifiers = True
-        if not model_cfg.common.share_predictors:
-            logger.warning("Enforcing shared predictor for early CMFP.")
-            model_cfg.common.share_predictors = True
+        log = logging.getLogger(__name__)
+        for key, what in (('share_classifiers', 'classifier'), ('share_predictors', 'predictor')):
+            if not model_cfg.common[key]:
+                log.warning(f"Enforcing shared {what} for early CMFP.")
+                model_cfg.common[key] = True
         super().__init__(model_cfg, num_classes=num_classes)
 
-    @staticmethod
-    def _init_dimension_encoder(modality_dims, inter_dim, latent_dim):
-        del modality_dims
-        return nn.Linear(latent_dim, inter_dim, bias=False) if latent_dim != inter_dim else nn.Identity()
-
-    @staticmethod
-    def _init_dimension_decoder(modality_dims, inter_dim, latent_dim):
-        del modality_dims
-        return nn.Linear(inter_dim, latent_dim, bias=False) if latent_dim != inter_dim else nn.Identity()
-
     def forward(self, feats: Dict[str, torch.Tensor]) -> Dict[str, Dict[str, torch.Tensor]]:
-        feats_order = [mod for mod in self.cfg.modal_feature_order if mod in feats]
-        x_hat = self.feature_mapping(feats)
-        order_feature_func = partial(self.ordered_feature_list, feats_order=feats_order)
-        z, modality_attns = self.fuser(x_hat, order_feature_func)
-
-        z_enc = self._project(self.dim_encoder, z)
-        z_hat_enc, temporal_attns = self.future_predictor(z_enc, self.cfg.common.fp_output_len)
-        z_hat = self._project(self.dim_decoder, z_hat_enc)
-
-        z = {"all-fused": z}
-        z_hat = {"all-fused": z_hat}
-        attentions = {"all-fused": {'modality_attns': modality_attns, 'temporal_attns': temporal_attns}}
-        fusion = {k: v[:] for k, v in z.items()}
-        out = self.prepare_output(z, z_hat, fusion)
-        feats_final = out["future"]
-        out.update(self.apply_classifier(out["past_futures"], outputs_prefix=PAST_LOGITS_PREFIX))
-        out.update(self.apply_classifier(feats_final))
-        out['attentions'] = attentions
+        order = self._modal_order(feats)
+        z, modality_attns = self.fuser(self.feature_mapping(feats), partial(self.ordered_feature_list, feats_order=order))
+        h, temporal_attns = self.future_predictor(_as_rows_gemm(self.dim_encoder, z), self.cfg.common.fp_output_len)
+        z_hat = _as_rows_gemm(self.dim_decoder, h)
+        out = self._with_logits(self.prepare_output({'all-fused': z}, {'all-fused': z_hat}, {'all-fused': z}))
+        out['attentions'] = {'all-fused': {'modality_attns': modality_attns, 'temporal_attns': temporal_attns}}
         return out
 
 
@@ -355,17 +326,12 @@ class IndividualFuturePrediction(CrossModalFusionPrediction):
 
     def __init__(self, model_cfg, num_classes):
         assert not model_cfg.common.fusion_cls   # individual forwarding, fusion not possible
-        super().__init__(model_cfg, num_classes=num_classes, instantiate_=False)
-        self.future_predictor = self._init_future_predictor(model_cfg, self.common_predictor)
+        super().__init__(model_cfg, num_classes=num_classes, with_mapping_and_fuser=False)
 
     def forward(self, z: Dict[str, torch.Tensor]) -> Dict[str, Dict[str, torch.Tensor]]:
-        z = {k: (v if v.dtype == torch.float32 else v.float()) for k, v in z.items()}
+        z = {k: _f32(v) for k, v in z.items()}
         z_hat, _ = self._predict_unimodal(z)
-        out = self.prepare_output(z, z_hat, {})   # in this case no fusion results
-        feats_final = out["future"]
-        out.update(self.apply_classifier(out["past_futures"], outputs_prefix=PAST_LOGITS_PREFIX))
-        out.update(self.apply_classifier(feats_final))
-        return out
+        return self._with_logits(self.prepare_output(z, z_hat, {}))   # no fusion results in this case
 
 
 class CMFPScoreFusion(CrossModalFusionPrediction):
@@ -373,34 +339,25 @@ class CMFPScoreFusion(CrossModalFusionPrediction):
     are mixed with the modality weights of the fuser (MATT) -- one fused weighted-sum kernel per logits tensor."""
 
     def __init__(self, model_cfg, num_classes):
-        logger = logging.getLogger(__name__)
         assert not model_cfg.common.fusion_cls   # the classification scores are fused directly
         if not model_cfg.common.modality_cls:
-            logger.warning("Enforcing modality classification for CMFPScoreFusion.")
+            logging.getLogger(__name__).warning("Enforcing modality classification for CMFPScoreFusion.")
             model_cfg.common.modality_cls = True
         super().__init__(model_cfg, num_classes=num_classes)
 
     def forward(self, z: Dict[str, torch.Tensor]) -> Dict[str, Dict[str, torch.Tensor]]:
-        feats_order = [mod for mod in self.cfg.modal_feature_order if mod in z]
-        z = {k: (v if v.dtype == torch.float32 else v.float()) for k, v in z.items()}
+        order = self._modal_order(z)
+        z = {k: _f32(v) for k, v in z.items()}
         z_hat, _ = self._predict_unimodal(z)
-        # the first frame concatenated with the predicted frames, mapped to the common dim, gives the modality weights
-        z_hat_cat = self.feature_mapping({modk: torch.cat([z[modk][:, :1, :], z_hat[modk]], dim=1) for modk in z})
-        order_feature_func = partial(self.ordered_feature_list, feats_order=feats_order)
-        modality_attns = self.fuser(z_hat_cat, order_feature_func)           # (B, T', M)
-        out = self.prepare_output(z, z_hat, fusions={})
-        logits_past = self.apply_classifier(out["past_futures"], outputs_prefix=PAST_LOGITS_PREFIX)
-        logits_future = self.apply_classifier(out['future'])
-        M = len(feats_order)
-        w_past = modality_attns[:, :-1, :].reshape(-1, M)
-        w_future = modality_attns[:, -1:, :].reshape(-1, M)
-        for classk in self.num_classes.keys():
-            lp = logits_past[f'{PAST_LOGITS_PREFIX}logits/{classk}']
-            lf = logits_future[f'logits/{classk}']
-            B, Tp, C = lp[feats_order[0]].shape
-            past = F_.WeightedSum.apply(w_past, *[lp[m].reshape(B * Tp, C) for m in feats_order]).view(B, Tp, C)
-            Tf = lf[feats_order[0]].shape[1]
-            fut = F_.WeightedSum.apply(w_future, *[lf[m].reshape(B * Tf, C) for m in feats_order]).view(B, Tf, C)
-            out[f'{PAST_LOGITS_PREFIX}logits/{classk}'] = {'all-fused': past}
-            out[f'logits/{classk}'] = {'all-fused': fut}
+        # modality weights: the first observed frame followed by the predicted frames, mapped to the common width -> MATT
+        seen_then_predicted = {m: torch.cat([z[m][:, :1, :], z_hat[m]], dim=1) for m in z}
+        weights = self.fuser(self.feature_mapping(seen_then_predicted), partial(self.ordered_feature_list, feats_order=order))
+        M = len(order)
+        out = self._with_logits(self.prepare_output(z, z_hat, fusions={}))
+        for classk in self.num_classes:
+            for key, w in ((f'{PAST_LOGITS_PREFIX}logits/{classk}', weights[:, :-1, :]), (f'logits/{classk}', weights[:, -1:, :])):
+                per_mod = out[key]
+                B, Tn, C = per_mod[order[0]].shape
+                mixed = F_.WeightedSum.apply(w.reshape(-1, M), *[per_mod[m].reshape(B * Tn, C) for m in order])
+                out[key] = {'all-fused': mixed.view(B, Tn, C)}
         return out

@@ -130,6 +130,9 @@ class GradReducer:
         self._handles: List = []
         self._use_cuda = flat.flat_g.is_cuda
         self.side_stream = torch.cuda.Stream() if self._use_cuda else None
+        # with a gradient exchange the per-bucket optimizer gets a stream of its own: on one stream bucket b+1's all-reduce
+        # would queue behind bucket b's update and the two (xGMI-bound and HBM-bound) would never overlap each other
+        self.opt_stream = torch.cuda.Stream() if (self._use_cuda and self.comm) else None
         self.flat_g16 = (torch.empty(flat.total, dtype=torch.bfloat16, device=flat.flat_g.device)
                          if (comm_dtype == "bf16" and self.comm) else None)
         self.on_bucket: Optional[Callable[[int, int, Tensor, float], None]] = None
@@ -182,7 +185,14 @@ class GradReducer:
                 # RCCL enqueues behind the work already on this stream; later work on this stream follows it
                 self._reduce(self._grad_slice(s, e))
             if self.on_bucket is not None:
-                self.on_bucket(s, e, self._grad_slice(s, e), 1.0 / self.world)
+                if self.comm and self.opt_stream is not None:
+                    done = torch.cuda.Event()
+                    done.record()
+                    self.opt_stream.wait_event(done)
+                    with torch.cuda.stream(self.opt_stream):
+                        self.on_bucket(s, e, self._grad_slice(s, e), 1.0 / self.world)
+                else:
+                    self.on_bucket(s, e, self._grad_slice(s, e), 1.0 / self.world)
 
     def _reduce(self, g: Tensor):
         """sum `g` (a contiguous bucket of the flat gradient buffer) over the ranks, in place"""
@@ -213,6 +223,8 @@ class GradReducer:
             h.wait()
         if self._use_cuda:
             torch.cuda.current_stream().wait_stream(self.side_stream)
+            if self.opt_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.opt_stream)
 
     def grad_for_optimizer(self):
         """(flat gradient tensor, scale): summed over ranks; the optimizer applies 1/world."""
