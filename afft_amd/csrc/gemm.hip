@@ -15,6 +15,11 @@
 //      shapes:  256x128 tile, 8 waves, 3 stages (144 KiB LDS, 1 workgroup/CU)   -- large GEMMs
 //               128x128 tile, 4 waves, 2 stages ( 64 KiB LDS, 2 workgroups/CU)  -- small grids / tails
 //    XCD-aware grouped tile order (workgroups b and b+8 share an XCD and its L2).
+//    X3 instantiations (afft_gemm_t.split3, "bf16x3"): A and B are two-plane hi / lo splits of fp32 matrices; the K loop runs
+//    three segments (hi*hi, lo*hi, hi*lo) with the operand planes chosen per K-step on the SALU -- fp32-grade products.
+//    Every epilogue can end in the fused optimizer update instead of a store (afft_sgd_fused_t, common.h: SgdEpi).
+//    Dispatch (choose_variant / choose_splitk): 256x256 ping-pong tiles (gemm_pp.hip) when the utilisation of their last
+//    round beats that of the 128x128 grid (x1.25); split-K into caller-provided scratch (afft_gemm_t.workspace).
 //  * gemm_f32_kernel: exact fp32 (v_mfma_f32_32x32x2_f32), any strides / sizes; the parity mode
 //    and the fallback for shapes the fast path does not take.
 //

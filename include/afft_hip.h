@@ -53,7 +53,8 @@ int afft_version(void);
  *   models/future_prediction.py:108-121,246-255 ; HF modeling_gpt2.py Conv1D (c_attn, c_proj, c_fc)
  * and their backward (dgrad: dX = dY*W ; wgrad: dW = dY^T*X).
  * epilogue order: v = alpha*acc ; v += bias[n] ; pre[m,n] = v ; v = act(v | aux[m,n]) ; v = dropout(v) ;
- *                 v *= rowscale[m]*droppath(m) ; v += residual[m,n] ; v += out[m,n] if accumulate ; store out, out2.
+ *                 v *= rowscale[m]*droppath(m) ; v += residual[m,n] ; v += out[m,n] if accumulate ; store out, out2
+ *                 (with `sgd` set: v = alpha*acc is consumed by the optimizer update of p[m,n] and nothing is stored).
  * dtype = operand dtype of A and B (both the same).  With AFFT_BF16 operands, k-contiguous
  * ("NT": a_cs==1,b_rs==1) and k-strided ("TN": a_rs==1,b_cs==1) layouts with K%64==0 and 16-byte
  * aligned rows take the MFMA bf16 fast path (fp32 accumulate); anything else, and every AFFT_F32 call,
