@@ -110,8 +110,8 @@ int afft_gemm(const afft_gemm_t* g, void* stream);
 /* Tuning / test hook: force the bf16 kernel (0 = auto, 1 = 128x128x64 2-stage, 3 = 256x256x64 ping-pong, 4 = 128x128x64 4-stage,
  * 5 / 6 = experimental 256x256x64 four-wave kernels with LDS-DMA / register-staged operands). */
 int afft_set_gemm_variant(int variant);
-/* Split-K for small grids of the 128x128 kernel (<= 128 tiles, K >= 2048): K is cut into 2 or 4 slices, every slice
- * parks its fp32 partial tile in a per-stream workspace and the slice that arrives last adds them up in slice order
+/* Split-K for small grids of the 128x128 kernel (<= 128 tiles with K >= 2048, <= 256 tiles with K >= 4096): K is cut into 2 or 4 slices, every slice
+ * parks its fp32 partial tile in the caller's workspace (afft_gemm_t.workspace) and the slice that arrives last adds them up in slice order
  * and runs the epilogue (no waiting, any epilogue, bitwise repeatable).  mode: 0 off, 1 auto (default), 2 / 4 force. */
 int afft_set_gemm_splitk(int mode);
 /* Which bf16 tile shape afft_gemm picks for a fast-path problem (1 / 3 as above); used by bench.py to attribute
