@@ -91,7 +91,7 @@ def gemm(a, b, out: Tensor, *, a_t: bool = False, b_t: bool = False, bias: Optio
          act: int = ACT_NONE, aux: Optional[Tensor] = None, pre: Optional[Tensor] = None,
          rowscale: Optional[Tensor] = None, residual: Optional[Tensor] = None, accumulate: bool = False,
          out2: Optional[Tensor] = None, alpha: float = 1.0, drop: Optional["L.Dropout"] = None,
-         max_workgroups: int = 0) -> Tensor:
+         max_workgroups: int = 0, sgd: Optional["L.SgdFused"] = None) -> Tensor:
     """out = epilogue(alpha * A @ B).  A = a (or a.T if a_t), B = b (or b.T if b_t); a, b 2-D views -- or both `Split`
     (two-plane bf16 splits of fp32 matrices): the bf16x3 GEMM, fp32-accurate products on the bf16 MFMA path."""
     d = L.GemmDesc()
@@ -121,6 +121,8 @@ def gemm(a, b, out: Tensor, *, a_t: bool = False, b_t: bool = False, bias: Optio
         ws = gemm_workspace(a.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     d.max_workgroups = max_workgroups
+    if sgd is not None:       # afft_sgd_fused_t: the result is a weight gradient consumed by the update of sgd.p (layout of `out`)
+        d.sgd = C.pointer(sgd)
     d.alpha = alpha
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()

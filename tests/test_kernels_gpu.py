@@ -446,6 +446,45 @@ def test_softmax_ce_out_of_range_label_poisons_the_row():
     assert rel_l2(rl[[0, 2, 4]], ref) < 1e-5
 
 
+@pytest.mark.parametrize("case", [("pp", 3, 1, 2048, 1024, 640), ("pp_tail", 3, 1, 2048, 1100, 640), ("small", 1, 1, 384, 256, 320),
+                                  ("small_splitk", 1, 2, 512, 512, 1024), ("pp_capped", 3, 1, 2048, 1024, 640)],
+                         ids=lambda c: c[0])
+def test_gemm_fused_sgd_epilogue_equals_gemm_then_update(case):
+    """afft_gemm_t.sgd: the Nesterov update applied in the weight-gradient GEMM's epilogue (parameters, momentum and bf16 image
+    written, gradient never stored) == the same GEMM storing the gradient followed by afft_sgd_nesterov, bit for bit: 256x256
+    and 128x128 tiles, column tails (scalar epilogue path), split-K (the last-arriving slice runs the fused epilogue), capped grid."""
+    from afft_amd import _lib, ops
+    name, variant, splitk, M, N, K = case
+    _lib.check(_lib.lib().afft_set_gemm_variant(variant))
+    _lib.check(_lib.lib().afft_set_gemm_splitk(splitk))
+    ld = (N + 63) // 64 * 64
+    a = bfr(rnd(K, M, seed=41)).to(torch.bfloat16).to(dev())
+    bb = torch.zeros(K, ld, dtype=torch.bfloat16, device=dev())
+    bb[:, :N] = bfr(rnd(K, N, seed=42)).to(torch.bfloat16).to(dev())
+    b = bb[:, :N]
+    p0, m0 = rnd(M, ld, seed=43).to(dev()), rnd(M, ld, seed=44).to(dev())
+    lr, mom, wd, gs = 0.05, 0.9, 1e-3, 0.5
+    # reference: store the gradient, then the stand-alone update kernel
+    g = torch.zeros(M, ld, device=dev())
+    ops.gemm(a, b, g[:, :N], a_t=True)
+    p_ref, m_ref, p16_ref = p0.clone(), m0.clone(), torch.zeros(M, ld, dtype=torch.bfloat16, device=dev())
+    ops.sgd_nesterov(p_ref.view(-1), g.view(-1), m_ref.view(-1), lr, mom, wd, gs, False, p_bf16=p16_ref.view(-1))
+    # fused
+    p, m, p16 = p0.clone(), m0.clone(), torch.zeros(M, ld, dtype=torch.bfloat16, device=dev())
+    d = _lib.SgdFused()
+    d.p, d.buf, d.p_bf16, d.lr, d.mom, d.wd, d.gscale, d.first_step = p.data_ptr(), m.data_ptr(), p16.data_ptr(), lr, mom, wd, gs, 0
+    gout = torch.full((M, ld), 7.0, device=dev())
+    ops.gemm(a, b, gout[:, :N], a_t=True, sgd=d, max_workgroups=16 if name == "pp_capped" else 0)
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().afft_set_gemm_splitk(1))
+    _lib.check(_lib.lib().afft_set_gemm_variant(0))
+    assert torch.equal(p[:, :N], p_ref[:, :N]) and torch.equal(m[:, :N], m_ref[:, :N]) and torch.equal(p16[:, :N], p16_ref[:, :N])
+    assert torch.equal(p[:, N:], p0[:, N:]) and torch.equal(m[:, N:], m0[:, N:])      # padding columns untouched by the fused form
+    assert float(gout.min()) == 7.0 and float(gout.max()) == 7.0                      # the gradient is never stored
+    with pytest.raises(RuntimeError, match="fused update"):
+        ops.gemm(a, b, gout[:, :N], a_t=True, sgd=d, accumulate=True)
+
+
 def test_sgd_runs_equals_sgd_over_the_same_ranges():
     """afft_sgd_nesterov_runs over a table of runs == afft_sgd_nesterov over each range, bit for bit; elements outside the runs
     are untouched"""
