@@ -545,9 +545,10 @@ def test_full_width_matches_oracle(name, precision):
     afft_amd.set_precision("bf16")
 
 
-def test_full_size_batch_split_invariants():
-    """Size-independent properties at the bench's full size (cfg2: 4 modalities x T=16 x d=D=2048, 6+6 layers, 64 clips, bf16
-    operands, dropout off), no oracle involved.  Clips are independent, so (1) a clip's logits do not depend on which batch it
+@pytest.mark.parametrize("name", ["cfg2", "cfg4", "cfg5", "ek100"])
+def test_full_size_batch_split_invariants(name):
+    """Size-independent properties at the FULL bench size of every 1-GPU BASELINE configuration and of the reference's EK100
+    widths (64 clips, bf16 operands, dropout off; cfg2: 4 modalities x T=16 x d=D=2048, 6+6 layers), no oracle involved.  Clips are independent, so (1) a clip's logits do not depend on which batch it
     sits in -- the batch of 64 runs on the 256x256 GEMM kernels, batches of 32 / 8 on other tile paths and split-K -- and (2) the
     data-parallel identity holds: the gradient of the mean loss over 64 clips is the average of the gradients over its two halves
     (what an all-reduce over two ranks computes)."""
@@ -556,13 +557,13 @@ def test_full_size_batch_split_invariants():
     from afft_amd.common.runner import BasicLossAccuracy, Runner
     from afft_amd.config import BASELINE_CONFIGS, make_model_cfg
     from afft_amd.models.base_model import BaseModel
-    c = BASELINE_CONFIGS["cfg2"]
+    c = BASELINE_CONFIGS[name]
     B, T, K = 64, c["T"], 3806
     afft_amd.set_precision("bf16")
     rt.set_grad_mode("sink")
     torch.manual_seed(3)
     dev = torch.device("cuda:0")
-    cfg = make_model_cfg(c["modal_dims"], c["common_dim"], c["fp_inter_dim"], fuser="sa", T=T, drop=0.0)
+    cfg = make_model_cfg(c["modal_dims"], c["common_dim"], c["fp_inter_dim"], fuser=c["fuser"], T=T, drop=0.0)
     model = BaseModel(cfg, {"action": K}, {}).to(dev).eval()
     g = torch.Generator().manual_seed(4)
     data = {m: torch.randn(B, T, C, 1, 1, 1, generator=g).to(dev) for m, C in c["modal_dims"].items()}
