@@ -147,7 +147,7 @@ _SIGS = {
     "afft_mse": ([vp, i64, vp, i64, i32, i32, f32, vp, f32, vp, vp, i64, vp, i64, vp], C.c_int),
     "afft_cast": ([vp, i64, i32, i32, vp, i64, i32, vp, i64, i32, C.POINTER(Dropout), vp], C.c_int),
     "afft_assemble_tokens": ([C.POINTER(vp), C.POINTER(i64), i32, vp, i64, vp, i32, i32, i32, vp, vp], C.c_int),
-    "afft_colsum": ([vp, i64, i32, i32, i32, vp, i32, vp], C.c_int),
+    "afft_colsum": ([vp, i64, i32, i32, i32, vp, i32, vp, i64, vp], C.c_int),
     "afft_add_rows_periodic": ([vp, i64, vp, i64, i32, i32, i32, vp, i64, vp], C.c_int),
     "afft_reduce_rows_periodic": ([vp, i64, i32, i32, i32, vp, i64, vp], C.c_int),
     "afft_sgd_nesterov": ([vp, vp, i32, vp, vp, i64, f32, f32, f32, f32, vp, i32, vp], C.c_int),

@@ -128,39 +128,120 @@ __global__ __launch_bounds__(256) void assemble_kernel(Modal8 mods, int S, const
   }
 }
 
-__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ src, int64_t lds_, int dtype, int rows,
-                                                     int cols, int rows_per_block, float* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+// Column sums without float atomics, so that two runs of a training step give bit-identical bias gradients.
+// Form 1 (caller gave a workspace): the rows are cut into blocks; workgroup (strip x, row block y) of the first kernel sums its
+// rows of a 256-column strip and parks the partial sums in the workspace, a second kernel adds the partials up in block order
+// (a kernel boundary between writer and reader: no cross-XCD visibility question) -- as many workgroups as the atomic form had,
+// and its memset traded for the second launch.
+template <bool V4>
+__global__ __launch_bounds__(256) void colsum_blocks_kernel(const void* __restrict__ src, int64_t lds_, int dtype, int rows,
+                                                            int cols, int rows_per_block, int accumulate,
+                                                            float* __restrict__ out, float* __restrict__ part) {
+  __shared__ float sh[4][256];
+  const int tid = threadIdx.x;
   const int r0 = blockIdx.y * rows_per_block;
   const int r1 = min(rows, r0 + rows_per_block);
-  float s = 0.f;
-  for (int r = r0; r < r1; ++r) s += ld_any(src, (int64_t)r * lds_ + c, dtype);
-  atomicAdd(out + c, s);
+  const int cc = blockIdx.x * 256 + tid;
+  float t = 0.f;
+  if (V4) {      // 64 column-quads x 4 row-lanes
+    const int qd = tid & 63, rl = tid >> 6;
+    const int c = (blockIdx.x * 64 + qd) * 4;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < cols)
+      for (int r = r0 + rl; r < r1; r += 4) {
+        float v[4];
+        load4(src, (int64_t)r * lds_ + c, dtype, v);
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+      }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sh[rl][qd * 4 + k] = s[k];
+    __syncthreads();
+    t = (sh[0][tid] + sh[1][tid]) + (sh[2][tid] + sh[3][tid]);
+  } else if (cc < cols) {
+    for (int r = r0; r < r1; ++r) t += ld_any(src, (int64_t)r * lds_ + cc, dtype);
+  }
+  if (gridDim.y > 1) part[((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 256 + tid] = t;
+  else if (cc < cols) out[cc] = accumulate ? out[cc] + t : t;
 }
 
-// vectorized form (cols % 4 == 0, 4-wide aligned rows): 64 column-quads x 4 row-lanes per workgroup
+__global__ __launch_bounds__(256) void colsum_combine_kernel(const float* __restrict__ part, int nby, int cols, int accumulate,
+                                                             float* __restrict__ out) {
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc >= cols) return;
+  const float* p = part + (int64_t)blockIdx.x * nby * 256 + threadIdx.x;
+  float sum = 0.f;
+  int y = 0;
+  for (; y + 7 < nby; y += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(y + u) * 256];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum += v[u];
+  }
+  for (; y < nby; ++y) sum += p[y * 256];
+  out[cc] = accumulate ? out[cc] + sum : sum;
+}
+
+// Form 2 (no workspace): every output column is summed by ONE workgroup over all rows -- fewer workgroups, ~1.5x the time on the
+// step's [5120, 8192] sums.  Generic form: one thread per column walks all rows.
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ src, int64_t lds_, int dtype, int rows,
+                                                     int cols, int accumulate, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = 0;
+  for (; r + 3 < rows; r += 4) {
+    s0 += ld_any(src, (int64_t)r * lds_ + c, dtype);
+    s1 += ld_any(src, (int64_t)(r + 1) * lds_ + c, dtype);
+    s2 += ld_any(src, (int64_t)(r + 2) * lds_ + c, dtype);
+    s3 += ld_any(src, (int64_t)(r + 3) * lds_ + c, dtype);
+  }
+  for (; r < rows; ++r) s0 += ld_any(src, (int64_t)r * lds_ + c, dtype);
+  const float t = (s0 + s1) + (s2 + s3);
+  out[c] = accumulate ? out[c] + t : t;
+}
+
+// vectorized form (cols % 4 == 0, 4-wide aligned rows): a workgroup owns QUADS column-quads (128-byte row segments: 16 quads
+// of bf16, 8 of fp32) and ALL rows, RL = 256 / QUADS row lanes x 4 rows in flight each; the lane partials are added in lane order.
+template <int QUADS>
 __global__ __launch_bounds__(256) void colsum4_kernel(const void* __restrict__ src, int64_t lds_, int dtype, int rows,
-                                                      int cols, int rows_per_block, float* __restrict__ out) {
-  __shared__ float sh[4][256];
-  const int qd = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = (blockIdx.x * 64 + qd) * 4;
-  const int r0 = blockIdx.y * rows_per_block;
-  const int r1 = min(rows, r0 + rows_per_block);
-  float s[4] = {0.f, 0.f, 0.f, 0.f};
-  if (c < cols)
-    for (int r = r0 + rl; r < r1; r += 4) {
+                                                      int cols, int accumulate, float* __restrict__ out) {
+  constexpr int RL = 256 / QUADS, CW = QUADS * 4;
+  __shared__ float sh[RL][CW];
+  const int qd = threadIdx.x % QUADS, rl = threadIdx.x / QUADS;
+  const int c = (blockIdx.x * QUADS + qd) * 4;
+  float s[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[u][k] = 0.f;
+  if (c < cols) {
+    int r = rl;
+    for (; r + 3 * RL < rows; r += 4 * RL) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float v[4];
+        load4(src, (int64_t)(r + RL * u) * lds_ + c, dtype, v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[u][k] += v[k];
+      }
+    }
+    for (; r < rows; r += RL) {
       float v[4];
       load4(src, (int64_t)r * lds_ + c, dtype, v);
-      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
-    }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) sh[rl][qd * 4 + k] = s[k];
+      for (int k = 0; k < 4; ++k) s[0][k] += v[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sh[rl][qd * 4 + k] = (s[0][k] + s[1][k]) + (s[2][k] + s[3][k]);
   __syncthreads();
-  const int cc = blockIdx.x * 256 + threadIdx.x;
-  if (cc < cols) {
-    const float t = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
-    atomicAdd(out + cc, t);
+  const int cc = blockIdx.x * CW + threadIdx.x;
+  if (threadIdx.x < CW && cc < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < RL; ++l) t += sh[l][threadIdx.x];
+    out[cc] = accumulate ? out[cc] + t : t;
   }
 }
 
@@ -309,19 +390,44 @@ extern "C" int afft_assemble_tokens(const float* const* feats, const int64_t* ld
 }
 
 extern "C" int afft_colsum(const void* src, int64_t lds_, int32_t dtype, int32_t rows, int32_t cols, float* out,
-                           int32_t accumulate, void* stream_) {
+                           int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(src && out, "colsum: null pointer");
+  AFFT_CHECK(rows >= 0 && cols >= 0 && lds_ >= cols, "colsum: bad sizes");
+  AFFT_CHECK(!workspace || (((uintptr_t)workspace) & 15) == 0, "colsum: workspace must be 16-byte aligned");
   if (cols == 0) return 0;
-  if (!accumulate) {
-    if (hipMemsetAsync(out, 0, sizeof(float) * cols, stream) != hipSuccess) { afft_set_error("colsum: memset failed"); return 2; }
+  if (rows == 0) {
+    if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * cols, stream) != hipSuccess) { afft_set_error("colsum: memset failed"); return 2; }
+    return 0;
   }
-  if (rows == 0) return 0;
   const bool v4 = cols % 4 == 0 && lds_ % 4 == 0 && (((uintptr_t)src) & (dtype == AFFT_F32 ? 15 : 7)) == 0;
-  const int rpb = v4 ? 128 : 64;
-  dim3 grid((cols + 255) / 256, (rows + rpb - 1) / rpb);
-  if (v4) hipLaunchKernelGGL(colsum4_kernel, grid, dim3(256), 0, stream, src, lds_, dtype, rows, cols, rpb, out);
-  else hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, src, lds_, dtype, rows, cols, rpb, out);
+  const int strips = (cols + 255) / 256;
+  // row blocks the workspace has room for: 1 KiB of partials per (strip, block), behind the header the split-K GEMMs of the
+  // same stream keep their counters in (so that one scratch buffer per stream serves both)
+  static const bool use_ws = [] { const char* e = getenv("AFFT_COLSUM_BLOCKS"); return !(e && e[0] == '0'); }();   // experiments: 0 = form 2 always
+  int64_t room = 0;
+  if (use_ws && workspace && workspace_bytes > AFFT_GEMM_WS_HEADER) room = (workspace_bytes - AFFT_GEMM_WS_HEADER) / ((int64_t)strips * 1024);
+  int rpb = v4 ? 128 : 64;
+  int nby = (rows + rpb - 1) / rpb;
+  if (nby > 1 && room < nby) {
+    if (room >= 2) { rpb = (int)((rows + room - 1) / room); rpb = (rpb + 3) / 4 * 4; nby = (rows + rpb - 1) / rpb; }
+    else nby = 0;     // no (usable) workspace
+  }
+  if (nby >= 1) {
+    float* part = workspace ? (float*)((char*)workspace + AFFT_GEMM_WS_HEADER) : nullptr;
+    dim3 grid(strips, nby);
+    if (v4) hipLaunchKernelGGL(colsum_blocks_kernel<true>, grid, dim3(256), 0, stream, src, lds_, dtype, rows, cols, rpb, accumulate, out, part);
+    else hipLaunchKernelGGL(colsum_blocks_kernel<false>, grid, dim3(256), 0, stream, src, lds_, dtype, rows, cols, rpb, accumulate, out, part);
+    AFFT_LAUNCH_CHECK();
+    if (nby > 1) {
+      hipLaunchKernelGGL(colsum_combine_kernel, dim3(strips), dim3(256), 0, stream, part, nby, cols, accumulate, out);
+      AFFT_LAUNCH_CHECK();
+    }
+    return 0;
+  }
+  if (v4 && dtype == AFFT_BF16) hipLaunchKernelGGL(colsum4_kernel<16>, dim3((cols + 63) / 64), dim3(256), 0, stream, src, lds_, dtype, rows, cols, accumulate, out);
+  else if (v4) hipLaunchKernelGGL(colsum4_kernel<8>, dim3((cols + 31) / 32), dim3(256), 0, stream, src, lds_, dtype, rows, cols, accumulate, out);
+  else hipLaunchKernelGGL(colsum_kernel, dim3((cols + 255) / 256), dim3(256), 0, stream, src, lds_, dtype, rows, cols, accumulate, out);
   AFFT_LAUNCH_CHECK();
   return 0;
 }
@@ -344,9 +450,9 @@ extern "C" int afft_reduce_rows_periodic(const float* src, int64_t lds_, int32_t
   if (rows == 0 || d == 0) return 0;
   // dense rows: row r = k * period + p is row k, columns p*d.. of the [rows/period, period*d] view, so the sums are the
   // column sums of that view (many workgroups, coalesced); period 1 is a plain column sum at any row stride
-  if (period == 1) return afft_colsum(src, lds_, AFFT_F32, rows, d, out, 1, stream_);
+  if (period == 1) return afft_colsum(src, lds_, AFFT_F32, rows, d, out, 1, nullptr, 0, stream_);
   if (lds_ == d && ldo == d && rows % period == 0)
-    return afft_colsum(src, (int64_t)period * d, AFFT_F32, rows / period, period * d, out, 1, stream_);
+    return afft_colsum(src, (int64_t)period * d, AFFT_F32, rows / period, period * d, out, 1, nullptr, 0, stream_);
   dim3 grid((d + 255) / 256, period);
   hipLaunchKernelGGL(reduce_rows_periodic_kernel, grid, dim3(256), 0, stream, src, lds_, rows, period, d, out, ldo);
   AFFT_LAUNCH_CHECK();

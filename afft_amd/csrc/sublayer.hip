@@ -135,8 +135,8 @@ extern "C" int afft_attn_sublayer_bwd(const afft_attn_sublayer_t* s, void* strea
     TRY(stream_follows(aux, st));
     TRY(wgrad(s->dya, d, d, s->ao, d, d, R, s->conv1d, s->g_w_proj, s->acc_w_proj, wsa, s->wgrad_workgroups, aux, s->sgd_w_proj));
     if (s->g_b_proj) {
-      if (od) TRY(afft_colsum(s->dya, d, AFFT_BF16, R, d, s->g_b_proj, s->acc_b_proj, aux));
-      else TRY(afft_colsum(s->dy, d, AFFT_F32, R, d, s->g_b_proj, s->acc_b_proj, aux));
+      if (od) TRY(afft_colsum(s->dya, d, AFFT_BF16, R, d, s->g_b_proj, s->acc_b_proj, wsa.p, wsa.bytes, aux));
+      else TRY(afft_colsum(s->dy, d, AFFT_F32, R, d, s->g_b_proj, s->acc_b_proj, wsa.p, wsa.bytes, aux));
     }
     return 0;
   };
@@ -152,7 +152,7 @@ extern "C" int afft_attn_sublayer_bwd(const afft_attn_sublayer_t* s, void* strea
   auto side_qkv = [&]() -> int {
     TRY(stream_follows(aux, st));
     TRY(wgrad(s->dqkv, 3 * d, 3 * d, s->xn, d, d, R, s->conv1d, s->g_w_qkv, s->acc_w_qkv, wsa, s->wgrad_workgroups, aux, s->sgd_w_qkv));
-    if (s->g_b_qkv) TRY(afft_colsum(s->dqkv, 3 * d, AFFT_BF16, R, 3 * d, s->g_b_qkv, s->acc_b_qkv, aux));
+    if (s->g_b_qkv) TRY(afft_colsum(s->dqkv, 3 * d, AFFT_BF16, R, 3 * d, s->g_b_qkv, s->acc_b_qkv, wsa.p, wsa.bytes, aux));
     return 0;
   };
   if (!s->sgd_w_qkv) TRY(side_qkv());
@@ -206,8 +206,8 @@ extern "C" int afft_mlp_sublayer_bwd(const afft_mlp_sublayer_t* s, void* stream_
     TRY(stream_follows(aux, st));
     TRY(wgrad(s->dya, d, d, s->h, hd, hd, R, s->conv1d, s->g_w2, s->acc_w2, wsa, s->wgrad_workgroups, aux, s->sgd_w2));
     if (s->g_b2) {
-      if (od) TRY(afft_colsum(s->dya, d, AFFT_BF16, R, d, s->g_b2, s->acc_b2, aux));
-      else TRY(afft_colsum(s->dy, d, AFFT_F32, R, d, s->g_b2, s->acc_b2, aux));
+      if (od) TRY(afft_colsum(s->dya, d, AFFT_BF16, R, d, s->g_b2, s->acc_b2, wsa.p, wsa.bytes, aux));
+      else TRY(afft_colsum(s->dy, d, AFFT_F32, R, d, s->g_b2, s->acc_b2, wsa.p, wsa.bytes, aux));
     }
     return 0;
   };
@@ -221,7 +221,7 @@ extern "C" int afft_mlp_sublayer_bwd(const afft_mlp_sublayer_t* s, void* stream_
   auto side_fc1 = [&]() -> int {
     TRY(stream_follows(aux, st));
     TRY(wgrad(s->du, hd, hd, s->xn, d, d, R, s->conv1d, s->g_w1, s->acc_w1, wsa, s->wgrad_workgroups, aux, s->sgd_w1));
-    if (s->g_b1) TRY(afft_colsum(s->du, hd, AFFT_BF16, R, hd, s->g_b1, s->acc_b1, aux));
+    if (s->g_b1) TRY(afft_colsum(s->du, hd, AFFT_BF16, R, hd, s->g_b1, s->acc_b1, wsa.p, wsa.bytes, aux));
     return 0;
   };
   if (!s->sgd_w1) TRY(side_fc1());
@@ -281,8 +281,8 @@ extern "C" int afft_cross_attn_sublayer_bwd(const afft_cross_attn_sublayer_t* s,
     TRY(stream_follows(aux, st));
     TRY(wgrad(s->dya, d, d, s->ao, d, d, R, false, s->g_w_proj, s->acc_w_proj, wsa, s->wgrad_workgroups, aux, s->sgd_w_proj));
     if (s->g_b_proj) {
-      if (od) TRY(afft_colsum(s->dya, d, AFFT_BF16, R, d, s->g_b_proj, s->acc_b_proj, aux));
-      else TRY(afft_colsum(s->dy, d, AFFT_F32, R, d, s->g_b_proj, s->acc_b_proj, aux));
+      if (od) TRY(afft_colsum(s->dya, d, AFFT_BF16, R, d, s->g_b_proj, s->acc_b_proj, wsa.p, wsa.bytes, aux));
+      else TRY(afft_colsum(s->dy, d, AFFT_F32, R, d, s->g_b_proj, s->acc_b_proj, wsa.p, wsa.bytes, aux));
     }
     return 0;
   };

@@ -256,10 +256,13 @@ def assemble_tokens(feats: Sequence[Tensor], token: Tensor, tok_stride_t: int, m
 
 
 def colsum(src: Tensor, out: Tensor, accumulate: bool = False):
+    """out[n] (+)= sum_m src[m, n] without float atomics (bit-identical from run to run); the row blocks' partial sums go through
+    the current stream's scratch (gemm_workspace)."""
     rows, cols = src.shape
     assert out.dtype == torch.float32 and out.numel() >= cols
+    ws = gemm_workspace(src.device)
     L.check(L.lib().afft_colsum(_p(src), _rowmajor(src, "src"), _dt(src), rows, cols, _p(out),
-                                1 if accumulate else 0, _stream()), "colsum")
+                                1 if accumulate else 0, _p(ws), ws.numel(), _stream()), "colsum")
     return out
 
 

@@ -281,19 +281,28 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # Rehearsal of the N > 1 path on a ONE-GPU box (tests/test_model_gpu.py): AFFT_BENCH_SHARE_GPU=1 puts every rank on the
+    # GPUs that exist, AFFT_BENCH_BACKEND=gloo exchanges through the host (RCCL refuses two ranks on one device).  The line such
+    # a run prints says so ("rehearsal") and is not a measurement.
+    backend = os.environ.get("AFFT_BENCH_BACKEND", "nccl")
+    share = os.environ.get("AFFT_BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     rccl_log = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if not args.no_comm_report:
+        if backend != "nccl":
+            dist.init_process_group(backend=backend)
+        elif not args.no_comm_report:
             # which algorithm / protocol RCCL picks for the bucket sizes is decided inside the library: have it say so, into a
             # per-process file (INIT + TUNING lines only) that rank 0 summarises after the timed region
             rccl_log = f"/tmp/afft_rccl_{os.getpid()}.log"
             os.environ.setdefault("NCCL_DEBUG", "INFO")
             os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING")
             os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
-        dist.init_process_group(backend="nccl", device_id=device)   # "nccl" == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)   # "nccl" == RCCL on ROCm
     assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import afft_amd
@@ -347,7 +356,8 @@ def main():
         "metric": "clips/sec (fwd+bwd) EK100 SA-Fuser 4-mod T=16", "value": round(clips_s, 2), "unit": "clips/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
-        "data": "synthetic",
+        "data": "synthetic" if backend == "nccl" and not share else
+                f"synthetic -- REHEARSAL, not a measurement: backend {backend}, ranks share {torch.cuda.device_count()} GPU(s)",
         "config": {"workload": f"{args.config}: {c['fuser'].upper()}-Fuser {len(c['modal_dims'])}-modality T={T} "
                                f"d={c['common_dim']} D={c['fp_inter_dim']} depth 6+6, 3806 classes, train mode "
                                f"(dropout {'off' if args.eval_drop else 'on'}), step = fwd+loss+bwd"

@@ -210,9 +210,14 @@ int afft_split_bf16(const float* src, int64_t lds, int32_t rows, int32_t cols, v
 int afft_assemble_tokens(const float* const* feats, const int64_t* ldf, int32_t n_mod, const float* token,
                          int64_t tok_stride_t, const float* mod_embed, int32_t BT, int32_t T, int32_t d,
                          float* X, void* stream);
-/* column sums: out[n] (+)= sum_m src[m, n]   (bias gradients; src dtype selectable) */
+/* column sums: out[n] (+)= sum_m src[m, n]   (bias gradients; src dtype selectable).  No float atomics: the result is
+ * bit-identical from run to run (and with it the whole training step -- every other reduction of the path is ordered too).
+ * workspace (optional): scratch of `stream`; the first AFFT_GEMM_WS_HEADER bytes are not touched (the split-K scratch of the
+ * same stream, afft_gemm_t.workspace, can be passed), then room for partial sums: 1 KiB per 256-column strip and block of 128
+ * rows (fewer, longer row blocks if it is smaller).  Row blocks are then summed by separate workgroups and a second kernel adds
+ * them up in block order.  NULL: one workgroup per column strip walks all the rows (~1.5x the time on a [5120, 8192] input). */
 int afft_colsum(const void* src, int64_t lds, int32_t dtype, int32_t rows, int32_t cols, float* out,
-                int32_t accumulate, void* stream);
+                int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 /* y[r, :] = x[r, :] + table[(r % period), :]   (GPT-2 wpe / CA-Fuser position embedding; fp32) */
 int afft_add_rows_periodic(const float* x, int64_t ldx, const float* table, int64_t ldt, int32_t rows,
                            int32_t period, int32_t d, float* y, int64_t ldy, void* stream);

@@ -485,6 +485,44 @@ def test_gemm_fused_sgd_epilogue_equals_gemm_then_update(case):
         ops.gemm(a, b, gout[:, :N], a_t=True, sgd=d, accumulate=True)
 
 
+@pytest.mark.parametrize("rows,cols,dt", [(5120, 2048, "bf16"), (1000, 520, "f32"), (333, 130, "bf16"), (77, 3806, "f32"), (5, 64, "bf16")])
+def test_colsum_is_exact_enough_and_run_to_run_identical(rows, cols, dt):
+    """bias-gradient column sums: no float atomics (row blocks are added up in block order by a second kernel, or one
+    workgroup walks a column strip), so repeated launches give bit-identical results -- and with them the whole training step,
+    every other reduction being ordered."""
+    from afft_amd import _lib, ops
+    src = rnd(rows, cols, seed=51)
+    s = (src.to(torch.bfloat16) if dt == "bf16" else src).to(dev())
+    ref = (bfr(src) if dt == "bf16" else src).double().sum(0).float()
+    out = torch.full((cols,), 3.0, device=dev())
+    ops.colsum(s, out, accumulate=False)            # row blocks through the stream's scratch, added up in block order
+    first = out.clone()
+    assert rel_l2(first.cpu(), ref) < 1e-5
+    for _ in range(5):
+        out.fill_(-1.0)
+        ops.colsum(s, out, accumulate=False)
+        assert torch.equal(out, first)
+    ops.colsum(s, out, accumulate=True)
+    assert rel_l2(out.cpu(), 2 * ref) < 1e-5
+    assert int(ops.gemm_workspace(s.device)[:4096].view(torch.int32).abs().sum()) == 0     # the split-K counters are not touched
+    # without a workspace (one workgroup per column strip) and with one too small for 128-row blocks (fewer, longer blocks)
+    stream = torch.cuda.current_stream().cuda_stream
+    small = torch.zeros(4096 + 3 * ((cols + 255) // 256) * 1024, dtype=torch.uint8, device=dev())
+    for ws, nbytes in ((None, 0), (small, small.numel())):
+        o = torch.full((cols,), 7.0, device=dev())
+        _lib.check(_lib.lib().afft_colsum(s.data_ptr(), s.stride(0), 1 if dt == "bf16" else 0, rows, cols, o.data_ptr(), 0,
+                                          ws.data_ptr() if ws is not None else None, nbytes, stream), "colsum")
+        o2 = torch.empty_like(o)
+        _lib.check(_lib.lib().afft_colsum(s.data_ptr(), s.stride(0), 1 if dt == "bf16" else 0, rows, cols, o2.data_ptr(), 0,
+                                          ws.data_ptr() if ws is not None else None, nbytes, stream), "colsum")
+        assert rel_l2(o.cpu(), ref) < 1e-5 and torch.equal(o, o2)
+    if cols > 8:        # a column-offset view (unaligned rows): the generic one-thread-per-column form
+        v = s[:, 1:cols - 2]
+        o2 = torch.zeros(cols - 3, device=dev())
+        ops.colsum(v, o2)
+        assert rel_l2(o2.cpu(), ref[1:cols - 2]) < 1e-5
+
+
 def test_sgd_runs_equals_sgd_over_the_same_ranges():
     """afft_sgd_nesterov_runs over a table of runs == afft_sgd_nesterov over each range, bit for bit; elements outside the runs
     are untouched"""

@@ -333,6 +333,55 @@ def test_fused_optimizer_epilogue_equals_separate_update(name):
         assert (a == b) if isinstance(a, float) else torch.equal(a, b), what
 
 
+@pytest.mark.parametrize("name", ["cfg2", "ek100"])
+def test_full_size_training_is_bitwise_reproducible_and_fused_update_bitwise_equal(name):
+    """At the bench's full size (64 clips, dropout on, three streams busy: 256x256 and split-K weight-gradient epilogues updating
+    388-614 M parameters beside the data-gradient chain) every reduction of the path is ordered (split-K slices are added up in
+    slice order by the last workgroup to arrive, bias column sums in block order by a second kernel; no float atomics), so: (1) two runs of three
+    training steps give BIT-IDENTICAL parameters and momentum, and (2) so does the optimizer fused into the weight-gradient
+    epilogues against the separate update kernels -- a fused update that started before the data gradient of the same layer had
+    read the weight's bf16 image would show up here."""
+    import afft_amd
+    from afft_amd import dropout as D_, runtime as rt
+    from afft_amd.config import BASELINE_CONFIGS, make_model_cfg
+    from afft_amd.models.base_model import BaseModel
+    from afft_amd.parallel import Trainer
+    c = BASELINE_CONFIGS[name]
+    B, T, K = 64, c["T"], 3806
+    afft_amd.set_precision("bf16")
+    rt.set_grad_mode("sink")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(8)
+    feats = {m: torch.randn(B, T, C, 1, 1, 1, generator=g).to(dev) for m, C in c["modal_dims"].items()}
+    tgt = {"action": torch.randint(0, K, (B,), generator=g).to(dev)}
+    sub = {"action": torch.randint(0, K, (B, T, 1), generator=g).to(dev)}
+    wts = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
+
+    def run(fused):
+        rt.set_fused_sgd(fused)
+        D_.manual_seed(17)
+        torch.manual_seed(9)
+        cfg = make_model_cfg(c["modal_dims"], c["common_dim"], c["fp_inter_dim"], fuser=c["fuser"], T=T)
+        model = BaseModel(cfg, {"action": K}, {}).to(dev).train()
+        tr = Trainer(model, wts, lr=1e-2)
+        for _ in range(3):
+            tr.step(feats, tgt, sub)
+        torch.cuda.synchronize()
+        assert (tr._fused is not None) == fused
+        out = tr.flat.flat_p.clone(), tr.opt.buf.clone()
+        del tr, model
+        torch.cuda.empty_cache()
+        return out
+
+    try:
+        s1, s2, f1 = run(False), run(False), run(True)
+    finally:
+        rt.set_fused_sgd(True)
+    for i, what in enumerate(("parameters", "momentum")):
+        assert torch.equal(s1[i], s2[i]), f"{what}: two runs of the separate update differ"
+        assert torch.equal(f1[i], s1[i]), f"{what}: fused update differs from the separate update"
+
+
 def test_gemm_trace_hook_brackets_every_launch():
     """afft_gemm_trace_begin / _end (bench.py's roofline source): one record per bf16 fast-path launch, from afft_gemm and from
     inside a composite call alike, with plausible durations."""
@@ -865,3 +914,36 @@ def test_rccl_path_single_rank():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """The N > 1 leg of bench.py as the driver launches it (python -m torch.distributed.run, one process per rank), rehearsed
+    on this one-GPU box: both ranks on cuda:0, gradient exchange over gloo (RCCL refuses two ranks on a device).  Everything but
+    the RCCL calls themselves is the 8-GPU path: parameter broadcast, bucketed reducer on its side stream with the optimizer
+    behind it, barriers, max-over-ranks timing, the communication report.  Checks the JSON line's bookkeeping (whole-job value =
+    2 ranks' clips), that the exchange really ran (world size 2, >= 1 bucket, finite losses for both payload types), and that
+    the line is marked as a rehearsal."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AFFT_BENCH_BACKEND="gloo", AFFT_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--config", "ek100", "--batch", "8", "--no-parity-mode", "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "REHEARSAL" in d["data"]
+    assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 16 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3
+    comm = d["comm"]
+    assert comm["world_size"] == 2 and comm["backend"] == "gloo" and comm["buckets"] >= 1
+    losses = comm["loss_after_20_steps"]
+    assert all(v == v and abs(v) < 1e4 for v in losses.values())
+    assert abs(comm["loss_delta_bf16_vs_fp32_payload"]) < 0.05 * abs(losses["fp32"])
