@@ -485,6 +485,45 @@ def test_gemm_fused_sgd_epilogue_equals_gemm_then_update(case):
         ops.gemm(a, b, gout[:, :N], a_t=True, sgd=d, accumulate=True)
 
 
+@pytest.mark.parametrize("variant,M,N,K,mode", [(1, 1024, 1024, 512, 4), (1, 2048, 1024, 1024, 2), (3, 1024, 2048, 768, 4)])
+def test_splitk_handoff_stress(variant, M, N, K, mode):
+    """The split-K hand-off (slices park their partial tile with write-through stores, the slice that arrives last adds them up in
+    slice order) under the worst timing: SHORT slices (2-4 K-tiles, the last store of a slice is a few hundred nanoseconds before
+    the last arriver's loads), 400 launches back to back, while a second stream keeps every XCD busy with large GEMMs (as the
+    data-gradient chain does beside the weight gradients of a training step).  Every launch must reproduce the first one bit for
+    bit -- a partial read before it became visible would show as a difference."""
+    from afft_amd import _lib, ops
+    a = bfr(rnd(K, M, seed=61)).to(torch.bfloat16).to(dev())
+    b = bfr(rnd(K, N, seed=62)).to(torch.bfloat16).to(dev())
+    big_a = torch.randn(4096, 2048, device=dev()).to(torch.bfloat16)
+    big_b = torch.randn(4096, 2048, device=dev()).to(torch.bfloat16)
+    big_o = torch.empty(4096, 4096, dtype=torch.bfloat16, device=dev())
+    out = torch.empty(M, N, dtype=torch.float32, device=dev())
+    bad = torch.zeros((), dtype=torch.int64, device=dev())
+    side = torch.cuda.Stream()
+    _lib.check(_lib.lib().afft_set_gemm_variant(variant))
+    _lib.check(_lib.lib().afft_set_gemm_splitk(mode))
+    ops.set_workspace_bytes(128 << 20)
+    try:
+        ops.gemm(a, b, out, a_t=True)
+        first = out.clone()
+        ref = (a.float().t().double() @ b.float().double()).float()
+        assert rel_l2(first.cpu(), ref.cpu()) < 1e-5
+        torch.cuda.synchronize()
+        for i in range(400):
+            if i % 4 == 0:
+                with torch.cuda.stream(side):
+                    ops.gemm(big_a, big_b, big_o, b_t=True)
+            ops.gemm(a, b, out, a_t=True)
+            bad += (out != first).sum()
+        torch.cuda.synchronize()
+        assert int(bad) == 0, f"{int(bad)} elements differed over 400 launches"
+    finally:
+        ops.set_workspace_bytes(48 << 20)
+        _lib.check(_lib.lib().afft_set_gemm_splitk(1))
+        _lib.check(_lib.lib().afft_set_gemm_variant(0))
+
+
 @pytest.mark.parametrize("rows,cols,dt", [(5120, 2048, "bf16"), (1000, 520, "f32"), (333, 130, "bf16"), (77, 3806, "f32"), (5, 64, "bf16")])
 def test_colsum_is_exact_enough_and_run_to_run_identical(rows, cols, dt):
     """bias-gradient column sums: no float atomics (row blocks are added up in block order by a second kernel, or one
