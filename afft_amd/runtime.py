@@ -206,6 +206,7 @@ SINK = GradSink()
 
 _AUX_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 _OVERLAP_WGRAD = os.environ.get("AFFT_OVERLAP_WGRAD", "1") != "0"
+_AUX_PRIORITY = int(os.environ.get("AFFT_AUX_PRIORITY", "0"))     # HIP stream priority of the auxiliary stream (lower = served first)
 
 
 def aux_stream(device) -> "torch.cuda.Stream":
@@ -213,7 +214,7 @@ def aux_stream(device) -> "torch.cuda.Stream":
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _AUX_STREAMS.get(idx)
     if st is None:
-        st = torch.cuda.Stream(device=idx)
+        st = torch.cuda.Stream(device=idx, priority=_AUX_PRIORITY)
         _AUX_STREAMS[idx] = st
     return st
 

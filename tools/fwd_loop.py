@@ -21,12 +21,14 @@ torch.manual_seed(42)
 cfg = make_model_cfg(c["modal_dims"], c["common_dim"], c["fp_inter_dim"], fuser=c["fuser"], T=c["T"])
 model = BaseModel(cfg, {"action": 3806}, {}).to(dev).eval()
 feats = {m: torch.randn(B, c["T"], C, 1, 1, 1, device=dev) for m, C in c["modal_dims"].items()}
+tgt = {"action": torch.randint(0, 3806, (B,), device=dev)}
+sub = {"action": torch.randint(0, 3806, (B, c["T"], 1), device=dev)}
 ts = []
 with torch.no_grad():
     for i in range(n + 5):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        model(feats)
+        model(feats, mixup_fn=None, target=tgt, target_subclips=sub, target_subclips_ignore_index=None)
         t1 = time.perf_counter()          # host enqueue done
         torch.cuda.synchronize()
         t2 = time.perf_counter()

@@ -64,6 +64,15 @@ def main():
                 both += t - last
         active[q] += dlt
         last = t
+    # the largest idle intervals (no queue busy) with the kernels either side of them: where the step waits for the host or a join
+    gaps = []
+    end_so_far, last_name = t0, "(window start)"
+    for s_, e_, q_, n_ in sorted(ks):
+        if s_ > end_so_far:
+            gaps.append((s_ - end_so_far, (end_so_far - t0) / 1e6, last_name, family(n_)))
+        if e_ > end_so_far:
+            end_so_far, last_name = e_, family(n_)
+    gaps.sort(reverse=True)
     busy = defaultdict(int)
     fam = defaultdict(lambda: defaultdict(lambda: [0, 0]))
     for s, e, q, n in ks:
@@ -74,6 +83,8 @@ def main():
     res = {
         "step_ms": (t1 - t0) / 1e6, "union_busy_ms": union / 1e6, "idle_ms": (t1 - t0 - union) / 1e6,
         "overlapped_ms": both / 1e6,
+        "idle_gaps": {"count": len(gaps), "over_10us": sum(1 for g in gaps if g[0] > 10000), "sum_over_10us_ms": sum(g[0] for g in gaps if g[0] > 10000) / 1e6,
+                      "largest": [{"us": round(g[0] / 1e3, 1), "at_ms": round(g[1], 3), "after": g[2][:50], "before": g[3][:50]} for g in gaps[:12]]},
         "queues": {str(q): {"busy_ms": busy[q] / 1e6, "alone_ms": only[q] / 1e6, "kernels": sum(v[0] for v in fam[q].values()),
                             "families": {k: {"n": v[0], "ms": round(v[1] / 1e6, 3)}
                                          for k, v in sorted(fam[q].items(), key=lambda kv: -kv[1][1])[:25]}}
