@@ -62,8 +62,9 @@ def evaluate_scores(model, class_mappings, data_loader: Iterable, device, to_pro
 
 
 def store_append(endpoints: Dict[str, np.ndarray], output_dir: str, save_file_name: str) -> str:
-    """test.py:20-31 (append-able, gzip-9, chunked h5 datasets keyed like 'logits/action_<modk>') when h5py is available;
-    otherwise the same keys in an .npz that is re-written with the rows appended."""
+    """test.py:20-31: append-able, gzip-9, chunked HDF5 datasets keyed like 'logits/action_<modk>', first dimension unlimited.
+    Through h5py when it is installed, otherwise through afft_amd.h5lite, which writes the same file format itself (h5py reads and
+    extends its files, tests/test_h5lite_cpu.py)."""
     os.makedirs(output_dir, exist_ok=True)
     path = os.path.join(output_dir, save_file_name)
     try:
@@ -80,13 +81,24 @@ def store_append(endpoints: Dict[str, np.ndarray], output_dir: str, save_file_na
                     fout[key].resize((fout[key].shape[0] + val.shape[0],) + val.shape[1:])
                     fout[key][-val.shape[0]:, ...] = val
         return path
-    path = path if path.endswith(".npz") else path + ".npz"
-    old = dict(np.load(path)) if os.path.exists(path) else {}
-    for key, val in endpoints.items():
-        k = key.replace('/', '__')          # npz member names cannot hold '/'
-        old[k] = np.concatenate([old[k], val], axis=0) if k in old else val
-    np.savez_compressed(path, **old)
+    from . import h5lite  # noqa: PLC0415
+    h5lite.append(path, {k: np.asarray(v) for k, v in endpoints.items()})
     return path
+
+
+def load_logits(path: str, key: Optional[str] = None):
+    """The stored logits back (what challenge.py does with h5py for ensembling): one dataset, or {key: array} for all."""
+    try:
+        import h5py  # noqa: PLC0415
+    except ImportError:
+        from . import h5lite  # noqa: PLC0415
+        return h5lite.read(path, key)
+    with h5py.File(path, 'r') as fin:
+        if key is not None:
+            return fin[key][...]
+        out = {}
+        fin.visititems(lambda name, obj: out.__setitem__(name, obj[...]) if isinstance(obj, h5py.Dataset) else None)
+        return out
 
 
 @torch.no_grad()

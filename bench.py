@@ -187,11 +187,11 @@ def parity_side_measurements(args, device, feats, tgt, sub, c):
         if mode == "bf16x3":
             model.train(not args.eval_drop)
             tr = Trainer(model, wts, bucket_elems=args.bucket_melems * 1024 * 1024)
-            for _ in range(2):
+            for _ in range(3):
                 tr.step(feats, tgt, sub)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            n = 5
+            n = 10
             for _ in range(n):
                 tr.step(feats, tgt, sub)
             torch.cuda.synchronize()

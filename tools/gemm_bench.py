@@ -9,10 +9,11 @@ from afft_amd import _lib, ops  # noqa: E402
 
 
 def bench(layout, M, N, K, variant, iters=20):
-    """variant: 1 / 3 (tile shape) with automatic split-K; 10 = 128x128 tile without split-K; 12 / 14 = 128x128, split-K 2 / 4 forced"""
+    """variant: 1 / 3 (tile shape) with automatic split-K; 10 = 128x128 tile without split-K; 12 / 14 = 128x128, split-K 2 / 4 forced;
+    30 = 256x256 tile without split-K; 32 / 33 = 256x256, split-K 2 / 3 forced"""
     dev = "cuda:0"
-    _lib.check(_lib.lib().afft_set_gemm_splitk({10: 0, 12: 2, 14: 4}.get(variant, 1)))
-    variant = 1 if variant >= 10 else variant      # 0 = the library's own choice
+    _lib.check(_lib.lib().afft_set_gemm_splitk({10: 0, 12: 2, 14: 4, 30: 0, 32: 2, 33: 4}.get(variant, 1)))
+    variant = 3 if variant >= 30 else 1 if variant >= 10 else variant      # 0 = the library's own choice
     _lib.check(_lib.lib().afft_set_gemm_variant(variant))
     g = torch.Generator().manual_seed(0)
     if layout == "nt":
@@ -74,6 +75,12 @@ if __name__ == "__main__":
                   ("nt", 1024, 2048, 1024), ("nt", 1024, 1024, 2048), ("nn", 1024, 1024, 2048), ("nn", 1024, 2048, 1024),
                   ("tn", 2048, 1024, 1024), ("tn", 1024, 2048, 1024), ("nt", 1024, 1024, 384), ("nt", 1088, 3840, 1024),
                   ("nn", 1024, 2048, 6144), ("nn", 1024, 8192, 2048), ("nn", 1024, 2048, 8192), ("nn", 1024, 2048, 2048)]
+    if os.environ.get("SHAPESET") == "pp_split":    # candidates for 256x256 tiles cut into K-slices: <= 85 tiles, long K
+        shapes = [("nt", 5120, 1024, 4096), ("nn", 5120, 1024, 4096), ("nn", 5120, 1024, 3072), ("nt", 5120, 1024, 1024),
+                  ("tn", 3072, 1024, 5120), ("tn", 4096, 1024, 5120), ("tn", 1024, 4096, 5120), ("tn", 1024, 1024, 5120),
+                  ("tn", 2048, 2048, 5120), ("nn", 1024, 2048, 8192), ("nn", 1024, 2048, 6144), ("nt", 1024, 2048, 8192),
+                  ("nt", 5120, 2048, 8192), ("nn", 5120, 2048, 8192), ("nn", 5120, 2048, 6144)]
+        ops.set_workspace_bytes(256 << 20)
     variants = [int(v) for v in os.environ.get("VARIANTS", "1,3").split(",")]
     blas = os.environ.get("BLAS", "0") == "1"
     print(f"{'layout':6} {'M':>6} {'N':>6} {'K':>6} | " + " | ".join(f"v{v} ms    v{v} TF" for v in variants)
