@@ -29,7 +29,7 @@ def run_smoke():
     ocfg = dict(fuser="sa", depth=2, num_heads=4, fp_layers=2, fp_heads=4, fp_output_len=1,
                 num_classes={"action": K})
     results = {}
-    for prec, tol in (("fp32", 1e-3), ("bf16x3", 1e-3), ("bf16", 5e-2)):
+    for prec, tol in (("fp32", 1e-3), ("bf16x3", 1e-3), ("bf16", 2e-2)):
         afft_amd.set_precision(prec)
         rt.set_grad_mode("sink")
         torch.manual_seed(0)

@@ -2,8 +2,10 @@
 (a) the golden vectors produced by the reference itself and (b) the CPU oracle on the same inputs.
 
 Tolerances (north_star: logits within 1e-3 relative fp32): parity (fp32) mode 1e-3 on every output tensor,
-loss and gradient -- measured ~1e-6..1e-5; bf16 speed mode is reported against 5e-2 (bf16 operand rounding;
-SURVEY.md 7 hard part 1 measured 1e-2 for bf16 autocast of the reference itself)."""
+loss and gradient -- measured ~1e-6..1e-5; the bf16x3 mode against the same 1e-3 (measured ~1e-5); the bf16 speed mode is
+reported against 2e-2 on outputs and 2.5e-2 on gradients (bf16 operand rounding: measured 4e-3..1.1e-2 and 7e-3..1.25e-2 over all
+fixtures and the four full-width configurations; SURVEY.md 7 hard part 1 measured 1e-2 for bf16 autocast of the reference
+itself), except the score-fusion fixtures, where a bf16 rounding that flips a ReLU gate of MATT moves gradients by up to 8e-2."""
 import pytest
 import torch
 
@@ -12,7 +14,8 @@ pytestmark = pytest.mark.gpu
 from cases import CASES, oracle_cfg  # noqa: E402
 from helpers import case_tensors, flatten_outputs, load_golden, max_rel, rel_l2, surrogate  # noqa: E402
 
-TOL = {"fp32": 1e-3, "bf16": 5e-2, "bf16x3": 1e-3}
+TOL = {"fp32": 1e-3, "bf16": 2e-2, "bf16x3": 1e-3}
+GTOL_BF16 = 2.5e-2
 
 
 def build(c, precision):
@@ -104,12 +107,17 @@ def test_model_matches_reference_golden(name, precision):
     torch.cuda.synchronize()
     params = dict(model.named_parameters())
     ng = 0
-    gtol = 8e-2 if precision == "bf16" else tol
+    gworst, gworst_matt = 0.0, 0.0
+    gtol = (8e-2 if c.get("cmfp") == "score" else GTOL_BF16) if precision == "bf16" else tol
     for k in z.files:
         if k.startswith("grad:"):
             g = params[k[5:]].grad
             assert g is not None, k
             e = rel_l2(g.cpu(), torch.from_numpy(z[k]))
+            if ".fuser.matt." in k or ".mapping." in k:
+                gworst_matt = max(gworst_matt, e)
+            else:
+                gworst = max(gworst, e)
             # MATT (two tiny ReLU layers feeding a softmax) and the mapping layers that only feed it: a bf16 rounding
             # that flips one ReLU gate moves their gradients
             kt = gtol * 2 if (precision == "bf16" and c.get("cmfp") == "score" and (".fuser.matt." in k or ".mapping." in k)) else gtol
@@ -122,7 +130,7 @@ def test_model_matches_reference_golden(name, precision):
         assert g is not None, nm
         kt = gtol * 2 if (precision == "bf16" and c.get("cmfp") == "score" and (".fuser.matt." in nm or ".mapping." in nm)) else gtol
         assert abs(float(g.norm()) - gn) < kt * max(gn, 1e-3) * 2, (nm, float(g.norm()), gn)
-    print(f"[{name}/{precision}] worst output error {worst:.2e}")
+    print(f"[{name}/{precision}] worst output error {worst:.2e} worst gradient error {gworst:.2e} (matt/mapping {gworst_matt:.2e})")
 
 
 def test_autograd_grad_mode_equals_sink():
@@ -575,20 +583,26 @@ def test_full_width_matches_oracle(name, precision):
     ototal, olosses = O.loss(oout, tgt, sub)
     ototal.backward()
     tol = TOL[precision]
+    worst = 0.0
     for key in ("logits/action", "past_logits/action", "past_futures", "orig_past", "future"):
         e = rel_l2(out[key]["all-fused"].float().cpu(), oout[key]["all-fused"])
+        worst = max(worst, e)
         assert e < tol, (key, e)
     if fuser == "sa":   # attention weights (B, depth, T, H, S, S) returned like the reference
         e = rel_l2(out["attentions"]["all-fused"]["modality_attns"].float().cpu(), oout["attentions"]["all-fused"]["modality_attns"])
+        worst = max(worst, e)
         assert e < tol, ("modality_attns", e)
     assert abs(float(total) - float(ototal)) < tol * max(1.0, abs(float(ototal)))
     for k, v in olosses.items():
         assert abs(float(losses[k].mean()) - float(v)) < tol * max(1.0, abs(float(v))), k
     params = dict(model.named_parameters())
-    gtol = 8e-2 if precision == "bf16" else tol
+    gtol = GTOL_BF16 if precision == "bf16" else tol
+    gworst = 0.0
     for k in gkeys:
         e = rel_l2(params[k].grad.cpu(), P[k].grad)
+        gworst = max(gworst, e)
         assert e < gtol, (k, e)
+    print(f"[full-width/{precision}] worst output error {worst:.2e} worst gradient error {gworst:.2e}")
     del model, P, state
     torch.cuda.empty_cache()
     afft_amd.set_precision("bf16")
