@@ -57,6 +57,27 @@ CASES = {
                       mapping_layernorm=True),
 }
 
+# Full-size fixtures (SURVEY.md 8c "F"): the REFERENCE itself run at the real widths -- head dims 256 / 512, 3806 classes, 6 + 6
+# layers, 388-614 M parameters -- stored compactly (small tensors whole; large ones as norm + sum + a strided sample; every
+# parameter's gradient as norm + a 256-element strided sample).  B = 2 so that reference and oracle take seconds on a CPU.
+_DEPTH66 = dict(depth=6, num_heads=4, fp_layers=6, fp_heads=4, num_classes=3806, fp_output_len=1)
+FULL_CASES = {
+    # BASELINE configs[0]: rgb + flow, T = 8, d = 1024, D = 2048, B = 4 (the reference's own CPU-runnable case)
+    "f_cfg1": dict(fuser="sa", modal_dims={"rgb": 1024, "flow": 1024}, d=1024, D=2048, T=8, B=4, **_DEPTH66),
+    # what expts/01_SA-Fuser_ek100_train.txt trains: 1024 / 352 / 1024 / 1024 -> d = 1024, D = 2048, T = 16
+    "f_ek100": dict(fuser="sa", modal_dims={"rgb": 1024, "objects": 352, "audio": 1024, "flow": 1024}, d=1024, D=2048,
+                    T=16, B=2, **_DEPTH66),
+    # BASELINE configs[1] (the bench workload): every width 2048
+    "f_cfg2": dict(fuser="sa", modal_dims={"rgb": 2048, "objects": 2048, "audio": 2048, "flow": 2048}, d=2048, D=2048,
+                   T=16, B=2, **_DEPTH66),
+    # BASELINE configs[3]: CA-Fuser (TemporalCrossAttentFuser, depth M - 1 = 3) at the bench widths
+    "f_cfg4": dict(fuser="ca", modal_dims={"rgb": 2048, "objects": 2048, "audio": 2048, "flow": 2048}, d=2048, D=2048,
+                   T=16, B=2, num_heads=4, fp_layers=6, fp_heads=4, num_classes=3806, fp_output_len=1),
+}
+FULL_MAX_WHOLE = 70000      # tensors up to this many elements are stored whole
+FULL_SAMPLES = 16384        # larger ones: this many strided samples
+FULL_GRAD_SAMPLES = 256
+
 GRAD_KEYS_SA = [
     "future_predictor.fuser.modal_token",
     "future_predictor.fuser.blocks.0.attn.qkv.weight",

@@ -275,6 +275,81 @@ def run_case(name: str, c: dict):
     np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **arrays)
 
 
+def run_full_case(name: str, c: dict):
+    """A full-size fixture (cases.FULL_CASES): the reference's forward + loss + backward at the real widths on closed-form
+    weights, cross-checked against the oracle, stored compactly."""
+    import closed_form as cf
+    from cases import FULL_GRAD_SAMPLES, oracle_cfg
+    from helpers import compact_entry, strided_sample
+    from models.base_model import BaseModel
+    from common.runner import BasicLossAccuracy, Runner
+    from oracle import afft_oracle as O
+
+    torch.manual_seed(0)
+    with CudaToCpu():
+        model = BaseModel(build_model_cfg(c), num_classes={"action": c["num_classes"]}, class_mappings={})
+    model.eval()
+    sd = model.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in sd.items() if v.dtype.is_floating_point and not k.endswith(".attn.bias")
+              and not k.endswith("masked_bias")}
+    state = cf.fill_state(shapes)
+    missing = model.load_state_dict(state, strict=False)
+    assert not missing.unexpected_keys, missing
+    B, T, K = c["B"], c["T"], c["num_classes"]
+    data = cf.inputs_for(name, c["modal_dims"], B, T)
+    tgt, sub = cf.labels_for(name, B, T, K, c.get("ignore_frac", 0.25))
+    with CudaToCpu():
+        outputs, out_t = model({m: d.clone() for m, d in data.items()}, mixup_fn=None, target={"action": tgt},
+                               target_subclips={"action": sub}, target_subclips_ignore_index=None)
+        losses, _ = BasicLossAccuracy()(outputs, out_t["target"], out_t["target_subclips"], mixup_enable=False,
+                                         target_subclips_ignore_index=out_t["target_subclips_ignore_index"])
+    total, _ = Runner._reduce_loss(losses, {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0})
+    model.zero_grad()
+    total.backward()
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    P = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    oout = O.base_model_forward(P, {m: d.clone() for m, d in data.items()}, oracle_cfg(c))
+    ototal, _ = O.loss(oout, tgt, sub)
+    ototal.backward()
+    ref_flat, ora_flat = flatten_outputs(outputs), flatten_outputs(oout)
+    worst = 0.0
+    for k, v in ref_flat.items():
+        if k == "attentions/modality_attns" and c["fuser"] == "ca":
+            continue
+        e = float((ora_flat[k].detach() - v.detach()).norm() / (v.detach().norm() + 1e-30))
+        worst = max(worst, e)
+        assert e < 2e-5, (name, k, e)
+    assert abs(float(ototal) - float(total)) < 2e-5 * max(1.0, abs(float(total)))
+    gmed = float(np.median([float(g.norm()) for g in grads.values()]))
+    for k, g in grads.items():
+        e = float((P[k].grad - g).norm() / max(float(g.norm()), 1e-6 * gmed))
+        worst = max(worst, e)
+        assert e < 1e-4, (name, "grad", k, e)
+    print(f"[{name}] oracle == reference at full size: worst rel-L2 {worst:.2e}; loss {float(total):.6f}; {len(grads)} gradients")
+
+    arrays = {}
+    for k, v in ref_flat.items():
+        if k == "attentions/modality_attns" and c["fuser"] == "ca":
+            continue
+        for kk, a in compact_entry(v).items():
+            arrays[f"out:{k}:{kk}"] = a
+    for k, v in losses.items():
+        arrays["loss:" + k] = np.asarray(float(torch.mean(v)), dtype=np.float64)
+    arrays["loss:total"] = np.asarray(float(total), dtype=np.float64)
+    names = list(grads.keys())
+    samples = [strided_sample(grads[k].double(), FULL_GRAD_SAMPLES).float().numpy() for k in names]
+    arrays["gradnames"] = np.asarray(names)
+    arrays["gradnorm"] = np.asarray([float(grads[k].double().norm()) for k in names], dtype=np.float64)
+    arrays["gradsamples"] = np.concatenate(samples)
+    arrays["gradsample_offsets"] = np.cumsum([0] + [len(x) for x in samples]).astype(np.int64)
+    arrays["shapes"] = np.asarray(json.dumps({k: list(s) for k, s in shapes.items()}))
+    arrays["meta"] = np.asarray(json.dumps(dict(case=name, cfg=c, torch=torch.__version__, transformers=transformers.__version__,
+                                                  parameters=int(sum(int(np.prod(s)) for s in shapes.values())),
+                                                  reference="zeyun-zhong/AFFT @ /root/reference (v1)")))
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **arrays)
+
+
 def run_eval_case():
     """m0_marginalize: the reference's challenge.marginalize_verb_noun (challenge.py:196-210) + its accuracy bookkeeping
     (compute_accuracies_epic :161-193, common/utils.py:19-56) on a stub dataset object."""
@@ -351,12 +426,17 @@ def run_reader_case():
 
 def main():
     install_stubs()
-    from cases import CASES
+    sys.path.insert(0, os.path.dirname(HERE))       # tests/helpers.py
+    from cases import CASES, FULL_CASES
     only = sys.argv[1:]
     for name, c in CASES.items():
         if only and name not in only:
             continue
         run_case(name, c)
+    for name, c in FULL_CASES.items():
+        if only and name not in only:
+            continue
+        run_full_case(name, c)
     if not only or "m0_marginalize" in only:
         run_eval_case()
     if not only or "r0_reader" in only:

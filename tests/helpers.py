@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 import closed_form as cf
-from cases import CASES, oracle_cfg
+from cases import CASES, FULL_CASES, FULL_GRAD_SAMPLES, FULL_MAX_WHOLE, FULL_SAMPLES, oracle_cfg
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -55,3 +55,61 @@ def flatten_outputs(out: dict) -> dict:
 def surrogate(out: dict):
     return (out["logits/action"]["all-fused"].pow(2).mean() + out["past_logits/action"]["all-fused"].pow(2).mean()
             + out["past_futures"]["all-fused"].pow(2).mean())
+
+
+# ---- full-size fixtures (compact storage, cases.FULL_CASES)
+
+def strided_sample(t, n: int):
+    """At most n elements of the flattened tensor at a fixed stride (the first of every ceil(numel / n))."""
+    flat = t.reshape(-1)
+    step = max(1, -(-flat.numel() // n))
+    return flat[::step]
+
+
+def compact_entry(t: torch.Tensor, max_whole: int = FULL_MAX_WHOLE, n: int = FULL_SAMPLES) -> dict:
+    """What a full-size fixture keeps of a tensor: all of it if small, else norm, sum and a strided sample."""
+    t = t.detach().double().cpu()
+    if t.numel() <= max_whole:
+        return {"whole": t.float().numpy()}
+    return {"norm": np.asarray(float(t.norm())), "sum": np.asarray(float(t.sum())), "sample": strided_sample(t, n).float().numpy()}
+
+
+def compact_error(got: torch.Tensor, z, prefix: str, n: int = FULL_SAMPLES) -> float:
+    """Worst relative deviation of `got` from the fixture entry `prefix` (whole tensor, or norm + strided sample)."""
+    got = got.detach().double().cpu()
+    if prefix + ":whole" in z.files:
+        ref = torch.from_numpy(z[prefix + ":whole"]).double()
+        assert tuple(got.shape) == tuple(ref.shape), (prefix, got.shape, ref.shape)
+        return float((got - ref).norm() / (ref.norm() + 1e-30))
+    rn = float(z[prefix + ":norm"])
+    ref = torch.from_numpy(z[prefix + ":sample"]).double()
+    smp = strided_sample(got, n)
+    assert smp.shape == ref.shape, (prefix, smp.shape, ref.shape)
+    return max(abs(float(got.norm()) - rn) / (rn + 1e-30), float((smp - ref).norm() / (ref.norm() + 1e-30)))
+
+
+def full_case_tensors(name: str):
+    """(case dict, fixture, state dict, inputs, target, target_subclips) of a full-size fixture, regenerated from closed form."""
+    c = FULL_CASES[name]
+    z, shapes = load_golden(name)
+    state = cf.fill_state(shapes)
+    data = cf.inputs_for(name, c["modal_dims"], c["B"], c["T"])
+    tgt, sub = cf.labels_for(name, c["B"], c["T"], c["num_classes"], c.get("ignore_frac", 0.25))
+    return c, z, state, data, tgt, sub
+
+
+def full_gradient_errors(named_grads: dict, z) -> dict:
+    """{parameter name: worst relative deviation (norm, 256-element strided sample)} against a full-size fixture."""
+    names = [str(s) for s in z["gradnames"]]
+    norms, samples, offs = z["gradnorm"], z["gradsamples"], z["gradsample_offsets"]
+    out = {}
+    for i, nm in enumerate(names):
+        g = named_grads[nm].detach().double().cpu()
+        ref = torch.from_numpy(samples[offs[i]:offs[i + 1]]).double()
+        smp = strided_sample(g, FULL_GRAD_SAMPLES)
+        assert smp.shape == ref.shape, (nm, smp.shape, ref.shape)
+        # tiny gradients (a bias behind a softmax that ignores it) are compared on the scale of the typical parameter gradient
+        scale = max(float(norms[i]), 1e-6 * float(np.median(norms)))
+        out[nm] = max(abs(float(g.norm()) - float(norms[i])) / scale,
+                      float((smp - ref).norm()) / max(float(ref.norm()), scale * (smp.numel() / g.numel()) ** 0.5))
+    return out

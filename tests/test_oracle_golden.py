@@ -3,8 +3,9 @@
 import pytest
 import torch
 
-from cases import CASES, oracle_cfg
-from helpers import case_tensors, flatten_outputs, load_golden, rel_l2, surrogate
+from cases import CASES, FULL_CASES, oracle_cfg
+from helpers import (case_tensors, compact_error, flatten_outputs, full_case_tensors, full_gradient_errors, load_golden, rel_l2,
+                     surrogate)
 from oracle import afft_oracle as O
 
 TOL = 2e-5  # fp32 reference vs fp32 restatement; measured worst 1.4e-6
@@ -55,6 +56,30 @@ def test_oracle_matches_reference_golden(name):
     names = [str(s) for s in z["gradnames"]]
     for nm, gn in zip(names, z["gradnorm"]):
         assert abs(float(P[nm].grad.norm()) - gn) < 1e-4 * max(gn, 1e-3), nm
+
+
+@pytest.mark.parametrize("name", list(FULL_CASES))
+def test_oracle_matches_reference_at_full_size(name):
+    """The reference itself at the real widths (cases.FULL_CASES: BASELINE cfg1, the EK100 widths of expts/01, cfg2 = the bench
+    workload, cfg4 = CA-Fuser; 388-614 M parameters, head dims 256 / 512, 3806 classes, 6 + 6 layers): every output tensor, the
+    three losses and the gradient of EVERY parameter (norm + a 256-element strided sample) of the oracle against the fixture."""
+    c, z, state, data, tgt, sub = full_case_tensors(name)
+    P = {k: v.requires_grad_(True) for k, v in state.items()}
+    out = O.base_model_forward(P, data, oracle_cfg(c))
+    total, losses = O.loss(out, tgt, sub)
+    flat = flatten_outputs(out)
+    keys = sorted({k.split(":")[1] for k in z.files if k.startswith("out:")})
+    assert len(keys) >= 6
+    for key in keys:
+        assert compact_error(flat[key], z, "out:" + key) < TOL, key
+    assert abs(float(total) - float(z["loss:total"])) < TOL * max(1.0, abs(float(z["loss:total"])))
+    for k, v in losses.items():
+        assert abs(float(v) - float(z["loss:" + k])) < TOL * max(1.0, abs(float(z["loss:" + k]))), k
+    total.backward()
+    errs = full_gradient_errors({k: p.grad for k, p in P.items() if p.grad is not None}, z)
+    assert len(errs) >= 140
+    worst = max(errs, key=errs.get)
+    assert errs[worst] < 1e-4, (worst, errs[worst])
 
 
 def test_kat_activations_and_softmax():
