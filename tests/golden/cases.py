@@ -74,6 +74,9 @@ FULL_CASES = {
     "f_cfg4": dict(fuser="ca", modal_dims={"rgb": 2048, "objects": 2048, "audio": 2048, "flow": 2048}, d=2048, D=2048,
                    T=16, B=2, num_heads=4, fp_layers=6, fp_heads=4, num_classes=3806, fp_output_len=1),
 }
+# BASELINE configs[4]: five modalities (+ poses), T = 32 (two 16-row attention tiles per sequence in the predictor, S = 6 packing)
+FULL_CASES["f_cfg5"] = dict(fuser="sa", modal_dims={"rgb": 2048, "objects": 2048, "audio": 2048, "poses": 2048, "flow": 2048},
+                            d=2048, D=2048, T=32, B=2, **_DEPTH66)
 FULL_MAX_WHOLE = 70000      # tensors up to this many elements are stored whole
 FULL_SAMPLES = 16384        # larger ones: this many strided samples
 FULL_GRAD_SAMPLES = 256

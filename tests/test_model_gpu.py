@@ -546,7 +546,7 @@ _FULL_CACHE = {}
 @pytest.mark.parametrize("name", list(FULL_CASES))
 def test_full_size_matches_reference_fixture(name, precision):
     """The HIP path against the REFERENCE ITSELF at the real widths (tests/golden/f_*.npz, made by running the reference on
-    closed-form weights: BASELINE cfg1, the EK100 widths of expts/01, cfg2 = the bench workload, cfg4 = CA-Fuser; 388-614 M
+    closed-form weights: BASELINE cfg1, the EK100 widths of expts/01, cfg2 = the bench workload, cfg4 = CA-Fuser, cfg5 = five modalities at T = 32; 388-614 M
     parameters): every output tensor, the three losses, and the gradient of EVERY parameter (norm + 256-element strided sample).
     fp32 and bf16x3 modes within the north-star 1e-3 (measured: outputs 2.7e-6 / 1.4e-5, worst gradient 4.3e-6 / 2.8e-5); bf16
     within the bf16 bars (measured 5.7e-3..8.1e-3 and 9.3e-3..1.45e-2)."""

@@ -61,7 +61,7 @@ def test_oracle_matches_reference_golden(name):
 @pytest.mark.parametrize("name", list(FULL_CASES))
 def test_oracle_matches_reference_at_full_size(name):
     """The reference itself at the real widths (cases.FULL_CASES: BASELINE cfg1, the EK100 widths of expts/01, cfg2 = the bench
-    workload, cfg4 = CA-Fuser; 388-614 M parameters, head dims 256 / 512, 3806 classes, 6 + 6 layers): every output tensor, the
+    workload, cfg4 = CA-Fuser, cfg5 = five modalities at T = 32; 388-614 M parameters, head dims 256 / 512, 3806 classes, 6 + 6 layers): every output tensor, the
     three losses and the gradient of EVERY parameter (norm + a 256-element strided sample) of the oracle against the fixture."""
     c, z, state, data, tgt, sub = full_case_tensors(name)
     P = {k: v.requires_grad_(True) for k, v in state.items()}
