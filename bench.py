@@ -111,9 +111,13 @@ class GemmTimer:
     def summary(self):
         out = {}
         for r in self.records:
-            d = out.setdefault(self.symbol(r), {"launches": 0, "flops": 0.0, "ms": 0.0, "fused_update_launches": 0})
+            d = out.setdefault(self.symbol(r), {"launches": 0, "flops": 0.0, "ms": 0.0, "fused_update_launches": 0, "bytes": 0.0})
             d["launches"] += 1
             d["flops"] += 2.0 * r.M * r.N * r.K
+            # algorithmic HBM bytes: both bf16 operands once + the output -- bf16 activations (2 B), an fp32 weight gradient
+            # (4 B), or, with the optimizer in the epilogue, parameter and momentum read and written plus the bf16 image (18 B)
+            wgrad = r.a_kstrided and r.b_kstrided
+            d["bytes"] += 2.0 * r.K * (r.M + r.N) + r.M * r.N * (18.0 if r.fused_update else 4.0 if wgrad else 2.0)
             d["ms"] += r.ms
             d["fused_update_launches"] += r.fused_update
         return out
@@ -431,6 +435,7 @@ def main():
                           "grid>: A,B = false,false NT forward / false,true NN data gradient / true,true TN weight gradient)",
                 "bound": "mfma", "achieved": round(ach, 1), "peak": dtype_peak, "unit": "TFLOP/s",
                 "frac": round(ach / dtype_peak, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(d["bytes"] / d["launches"]),
                 "traffic_note": f"bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate --pmc passes of this command "
                                 f"(profiles/{traffic_src}); fabric-side, includes Infinity-Cache hits",
                 "fused_optimizer_epilogue": bool(d.get("fused_update_launches")),
