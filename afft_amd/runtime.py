@@ -207,6 +207,26 @@ SINK = GradSink()
 _AUX_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 _OVERLAP_WGRAD = os.environ.get("AFFT_OVERLAP_WGRAD", "1") != "0"
 _AUX_PRIORITY = int(os.environ.get("AFFT_AUX_PRIORITY", "0"))     # HIP stream priority of the auxiliary stream (lower = served first)
+_AUX_CUS = int(os.environ.get("AFFT_AUX_CUS", "0"))               # experiment: CU mask of the auxiliary stream (0 = all CUs)
+_MASKED_STREAMS = []                                              # raw masked streams are never destroyed (process lifetime)
+
+
+def _cu_masked_stream(idx: int, n_cus: int) -> "torch.cuda.Stream":
+    """A HIP stream whose kernels may only use the first n_cus bits of the CU mask (hipExtStreamCreateWithCUMask; the driver deals
+    mask bits round-robin over the XCDs, so a prefix of n bits leaves (256 - n) / 8 CUs of every XCD to the other streams)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    words = (n_cus + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for b in range(n_cus):
+        mask[b // 32] |= 1 << (b % 32)
+    raw = ctypes.c_void_p()
+    with torch.cuda.device(idx):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(raw), ctypes.c_uint32(words), mask)
+    if rc != 0 or not raw.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask({n_cus} CUs) failed: {rc}")
+    _MASKED_STREAMS.append(raw)
+    return torch.cuda.ExternalStream(raw.value, device=idx)
 
 
 def aux_stream(device) -> "torch.cuda.Stream":
@@ -214,7 +234,7 @@ def aux_stream(device) -> "torch.cuda.Stream":
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _AUX_STREAMS.get(idx)
     if st is None:
-        st = torch.cuda.Stream(device=idx, priority=_AUX_PRIORITY)
+        st = _cu_masked_stream(idx, _AUX_CUS) if _AUX_CUS > 0 else torch.cuda.Stream(device=idx, priority=_AUX_PRIORITY)
         _AUX_STREAMS[idx] = st
     return st
 
