@@ -531,10 +531,10 @@ def _publish_handover(ho: _HandOut, up: Optional[_Up], dx: Tensor):
                              None if sink else ho.gbu, ho.direct, ho.tmp if sink else None)
 
 
-def _streams(dev):
+def _streams(dev, rows: int = 1 << 30):
     """(raw main stream, raw auxiliary stream or None, torch auxiliary stream or None)"""
     main = ops._stream()
-    if rt.overlap_wgrad():
+    if rt.overlap_wgrad() and rows >= rt.side_min_rows():
         aux = rt.aux_stream(dev)
         return main, aux.cuda_stream, aux
     return main, None, None
@@ -624,7 +624,7 @@ def _attn_bwd_c(ctx, dy):
     dy = dy.contiguous()
     od = _out_drop(drop)
     sh = _take_shadow(dy, od, b_proj)
-    main_raw, aux_raw, aux = _streams(dev)
+    main_raw, aux_raw, aux = _streams(dev, R)
     fresh: list = []
     scratch = torch.empty(pr * 6 * d, dtype=torch.bfloat16, device=dev)      # dya | dao | dqkv | dxn
     s = L_.AttnSublayer()
@@ -721,7 +721,7 @@ def _mlp_bwd_c(ctx, dy):
     dy = dy.contiguous()
     od = _out_drop(drop)
     sh = _take_shadow(dy, od, b2)
-    main_raw, aux_raw, aux = _streams(dev)
+    main_raw, aux_raw, aux = _streams(dev, R)
     fresh: list = []
     scratch = torch.empty(pr * (2 * d + hidden), dtype=torch.bfloat16, device=dev)    # dya | dxn | du
     s = L_.MLPSublayer()
@@ -825,7 +825,7 @@ def _cross_bwd_c(ctx, dy):
     dy = dy.contiguous()
     od = _out_drop(drop)
     sh = _take_shadow(dy, od, b_proj)
-    main_raw, aux_raw, aux = _streams(dev)
+    main_raw, aux_raw, aux = _streams(dev, R)
     fresh: list = []
     scratch = torch.empty(pr * 6 * d, dtype=torch.bfloat16, device=dev)       # dya | dao | dq | dk | dv | dxq
     dmkv = torch.empty(R, d, dtype=torch.float32, device=dev)

@@ -263,6 +263,20 @@ def set_wgrad_workgroups(n: int):
     _WGRAD_WGS = max(0, int(n))
 
 
+_SIDE_MIN_ROWS = int(os.environ.get("AFFT_SIDE_MIN_ROWS", "0"))
+
+
+def side_min_rows() -> int:
+    """Sub-layers with fewer rows than this keep their weight gradients on the main stream (composite path): two streams of
+    SMALL GEMMs (the predictor's M = 1024 launches) slow each other by more than the overlap gains.  0 = every sub-layer overlaps."""
+    return _SIDE_MIN_ROWS
+
+
+def set_side_min_rows(n: int):
+    global _SIDE_MIN_ROWS
+    _SIDE_MIN_ROWS = max(0, int(n))
+
+
 _COMPOSITE = os.environ.get("AFFT_COMPOSITE", "1") != "0"
 
 
