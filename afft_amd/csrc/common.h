@@ -148,6 +148,41 @@ __device__ __forceinline__ float dgelu_tanh_f(float x) {
   return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.79788456080286536f * (1.0f + 3.0f * 0.044715f * x2);
 }
 
+// ---- the same activations for the epilogues of the bf16-operand GEMM kernels (flag AFFT_ACT_FAST on the activation code): a
+//      library erff / tanhf is 45-80 VALU instructions per element with divergent branches, and an epilogue applies it to 128
+//      elements per thread -- measured +64 us on the 177-us fc1 GEMM, +106 us on its data gradient, +140 us on the predictor's.
+//      erf: Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7) on v_rcp_f32 / v_exp_f32; tanh(u) = 1 - 2 / (1 + exp(2u)).  Absolute
+//      errors of ~2e-7, far inside what the bf16 operands of these kernels leave; the exact-fp32 GEMM keeps the library functions.
+__device__ __forceinline__ float erf_as7126(float z, float e /* = exp(-z*z) */) {
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, fabsf(z), 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  return copysignf(1.0f - p * t * e, z);
+}
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float z = x * 0.70710678118654752f;
+  return 0.5f * x * (1.0f + erf_as7126(z, __expf(-z * z)));
+}
+__device__ __forceinline__ float dgelu_erf_fast(float x) {
+  const float z = x * 0.70710678118654752f;
+  const float e = __expf(-z * z);                       // exp(-x^2 / 2): shared by erf and the density term
+  return 0.5f * (1.0f + erf_as7126(z, e)) + x * 0.39894228040143268f * e;
+}
+__device__ __forceinline__ float tanh_fast(float u) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * u)); }
+__device__ __forceinline__ float gelu_tanh_fast(float x) {
+  const float u = 0.79788456080286536f * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.0f + tanh_fast(u));
+}
+__device__ __forceinline__ float dgelu_tanh_fast(float x) {
+  const float x2 = x * x;
+  const float u = 0.79788456080286536f * (x + 0.044715f * x * x2);
+  const float t = tanh_fast(u);
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.79788456080286536f * (1.0f + 3.0f * 0.044715f * x2);
+}
+constexpr int AFFT_ACT_FAST = 0x100;
+
 // ---- Nesterov-SGD update of one element, shared by the stand-alone update kernels and the fused GEMM epilogue: every
 //      rounding is pinned (explicit fma / mul), so both give bit-identical parameters
 __device__ __forceinline__ void sgd_update(float& p, float& buf, float g, float lr, float mom, float wd, float gscale, bool first) {
@@ -199,6 +234,7 @@ __device__ __forceinline__ void load4(const void* base, int64_t idx, int dtype, 
 }
 
 __host__ __device__ __forceinline__ bool act_needs_aux(int act) {
+  act &= 0xff;
   return act == AFFT_ACT_DGELU_ERF || act == AFFT_ACT_DGELU_TANH || act == AFFT_ACT_SIGMOID_GATE;
 }
 __device__ __forceinline__ float apply_act(int act, float v, float aux) {
@@ -207,6 +243,12 @@ __device__ __forceinline__ float apply_act(int act, float v, float aux) {
     case AFFT_ACT_GELU_TANH: return gelu_tanh_f(v);
     case AFFT_ACT_DGELU_ERF: return v * dgelu_erf_f(aux);
     case AFFT_ACT_DGELU_TANH: return v * dgelu_tanh_f(aux);
+    case AFFT_ACT_GELU_ERF | AFFT_ACT_FAST: return gelu_erf_fast(v);
+    case AFFT_ACT_GELU_TANH | AFFT_ACT_FAST: return gelu_tanh_fast(v);
+    case AFFT_ACT_DGELU_ERF | AFFT_ACT_FAST: return v * dgelu_erf_fast(aux);
+    case AFFT_ACT_DGELU_TANH | AFFT_ACT_FAST: return v * dgelu_tanh_fast(aux);
+    case AFFT_ACT_RELU | AFFT_ACT_FAST: return v > 0.f ? v : 0.f;
+    case AFFT_ACT_SIGMOID_GATE | AFFT_ACT_FAST: return aux / (1.0f + __expf(-v));
     case AFFT_ACT_RELU: return v > 0.f ? v : 0.f;
     case AFFT_ACT_SIGMOID_GATE: return aux / (1.0f + __expf(-v));
     default: return v;

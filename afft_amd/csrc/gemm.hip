@@ -476,6 +476,10 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
     g.nk_seg = d->K / BK;
     g.a_lo = d->a_lo; g.b_lo = d->b_lo;
     g.e = e;
+    // bf16-operand kernels: activation math on v_exp_f32 / v_rcp_f32 (common.h: AFFT_ACT_FAST, |error| ~2e-7) instead of the
+    // library's erff / tanhf, whose 45-80 instructions per element showed as +64..140 us per launch; AFFT_EXACT_ACT=1 keeps them
+    static const bool exact_act = [] { const char* v = getenv("AFFT_EXACT_ACT"); return v && v[0] == '1'; }();
+    if (g.e.act != AFFT_ACT_NONE && !exact_act) g.e.act |= AFFT_ACT_FAST;
     const bool A_KS = !a_kc, B_KS = !b_kc;
     if (!A_KS && !B_KS) return launch_layout<false, false>(g, stream, d);
     if (!A_KS && B_KS) return launch_layout<false, true>(g, stream, d);

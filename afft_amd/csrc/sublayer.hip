@@ -167,13 +167,13 @@ extern "C" int afft_attn_sublayer_bwd(const afft_attn_sublayer_t* s, void* strea
 // ======================================================================================= MLP sub-layer
 extern "C" int afft_mlp_sublayer_fwd(const afft_mlp_sublayer_t* s, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
-  AFFT_CHECK(s && s->x && s->w1 && s->w2 && s->xn && s->u && s->h && s->mean && s->rstd && s->y, "mlp_sublayer_fwd: null pointer");
+  AFFT_CHECK(s && s->x && s->w1 && s->w2 && s->xn && s->h && s->mean && s->rstd && s->y, "mlp_sublayer_fwd: null pointer");   // u may be NULL
   AFFT_CHECK(s->rows > 0 && s->d % 64 == 0 && s->hidden % 64 == 0, "mlp_sublayer_fwd: bad geometry");
   AFFT_CHECK(s->gelu == AFFT_ACT_GELU_ERF || s->gelu == AFFT_ACT_GELU_TANH, "mlp_sublayer_fwd: gelu must be GELU_ERF or GELU_TANH");
   const int R = s->rows, d = s->d, hd = s->hidden;
   const Ws ws = {s->gemm_ws, s->gemm_ws_bytes};
   TRY(zero_row_tail(s->xn, R, d, st));
-  TRY(zero_row_tail(s->u, R, hd, st));
+  if (s->u) TRY(zero_row_tail(s->u, R, hd, st));
   TRY(zero_row_tail(s->h, R, hd, st));
   TRY(afft_layernorm_fwd(s->x, d, s->ln_w, s->ln_b, s->eps, R, d, s->xn, d, AFFT_BF16, s->mean, s->rstd, st));
   afft_gemm_t g = lin_fwd(s->xn, d, R, d, s->w1, s->ldw1, hd, s->conv1d, ws);

@@ -354,7 +354,8 @@ typedef struct {       /* y = x + drop(fc2(gelu(fc1(LN(x)))))                   
   const void* w1; int64_t ldw1; const float* b1;
   const void* w2; int64_t ldw2; const float* b2;
   afft_dropout_t out_drop;
-  void* xn; void* u; void* h;            /* bf16 [rows_pad, d], [rows_pad, hidden] (pre-activation), [rows_pad, hidden]  */
+  void* xn; void* u; void* h;            /* bf16 [rows_pad, d], [rows_pad, hidden] (pre-activation), [rows_pad, hidden];
+                                          * forward-only callers may pass u = NULL: the pre-activation is then not stored     */
   float* mean; float* rstd;
   float* y;
   const float* dy; void* dya; int32_t dya_ready;

@@ -1014,3 +1014,22 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     losses = comm["loss_after_20_steps"]
     assert all(v == v and abs(v) < 1e4 for v in losses.values())
     assert abs(comm["loss_delta_bf16_vs_fp32_payload"]) < 0.05 * abs(losses["fp32"])
+
+
+def test_forward_under_no_grad_equals_forward_with_grad():
+    """A forward nobody will differentiate skips what only backward reads (the MLP's pre-activation store, u = NULL in
+    afft_mlp_sublayer_fwd): every output must be bit-identical to the forward of a differentiated pass."""
+    c, state, data, tgt, sub = case_tensors("t0_sa")
+    model = build(c, "bf16")
+    model.load_state_dict(state)
+    dev = torch.device("cuda:0")
+    model = model.to(dev).eval()
+    kw = dict(mixup_fn=None, target={"action": tgt.to(dev)}, target_subclips={"action": sub.to(dev)}, target_subclips_ignore_index=None)
+    feats = {m: d.to(dev) for m, d in data.items()}
+    with_grad, _ = model(feats, **kw)
+    with torch.no_grad():
+        without, _ = model(feats, **kw)
+    fa, fb = flatten_outputs(with_grad), flatten_outputs(without)
+    assert fa["logits/action/all-fused"].requires_grad and not fb["logits/action/all-fused"].requires_grad
+    for k in fa:
+        assert torch.equal(fa[k].detach(), fb[k]), k

@@ -24,15 +24,22 @@ for _ in range(6):
     tr.step(feats, tgt, sub)
 torch.cuda.synchronize()
 agg = defaultdict(lambda: [0, 0.0])
+EVAL = os.environ.get("EVAL") == "1"        # EVAL=1: eval-mode forwards only (no pre-activation stores, nothing beside them)
+if EVAL:
+    model.eval()
 for _ in range(5):
     with B.GemmTimer() as gt:
-        tr.step(feats, tgt, sub)
+        if EVAL:
+            with torch.no_grad():
+                model(feats, mixup_fn=None, target=tgt, target_subclips=sub, target_subclips_ignore_index=None)
+        else:
+            tr.step(feats, tgt, sub)
     for r in gt.records:
         lay = ("t" if r.a_kstrided else "n") + ("n" if r.b_kstrided else "t")
         k = (lay, r.M, r.N, r.K, r.variant, r.splitk, r.fused_update)
         agg[k][0] += 1
         agg[k][1] += r.ms
-print(f"{name} B={batch}: in-step GEMM launches, 5 instrumented steps (layout: nt forward of nn.Linear / dgrad of Conv1D, nn dgrad of nn.Linear / forward of Conv1D, tn weight gradient)")
+print(f"{name} B={batch}: {'eval-mode forward' if EVAL else 'in-step'} GEMM launches, 5 instrumented {'forwards' if EVAL else 'steps'} (layout: nt forward of nn.Linear / dgrad of Conv1D, nn dgrad of nn.Linear / forward of Conv1D, tn weight gradient)")
 print(f"{'layout':6} {'M':>6} {'N':>6} {'K':>6} {'tile':>5} {'splitK':>6} {'fusedSGD':>8} {'n/step':>6} {'avg us':>8} {'TFLOP/s':>8}")
 tot = 0.0
 for k, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
