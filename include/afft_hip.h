@@ -66,7 +66,11 @@ typedef struct {
   const void* B; int64_t b_rs, b_cs;
   float alpha;
   const float* bias;                 /* [N] or NULL */
-  int32_t act;
+  int32_t act;                       /* AFFT_ACT_*.  The bf16-operand kernels evaluate erf (Abramowitz & Stegun 7.1.26) and tanh
+                                      * (1 - 2 / (1 + exp 2u)) on the hardware exp / reciprocal: absolute error 2e-7 (GELU) to 2e-6
+                                      * (GELU' of gelu_new), far inside their operands' rounding; the exact-fp32 kernel (dtype
+                                      * AFFT_F32, or any shape off the fast path) uses the library's erff / tanhf, and
+                                      * AFFT_EXACT_ACT=1 in the environment makes every kernel use them.                       */
   const void* aux; int64_t ldaux; int32_t aux_dtype;   /* read by DGELU_* */
   void* pre; int64_t ldpre; int32_t pre_dtype;         /* optional store of the pre-activation */
   const float* rowscale;             /* [M] or NULL (DropPath / per-row loss weights) */
