@@ -196,6 +196,8 @@ def lib():
             fn = getattr(_lib, name)
             fn.argtypes = args
             fn.restype = res
+        if os.environ.get("AFFT_GEMM_SPLITK"):      # 0 off, 1 automatic (default), 2 / 4 forced
+            check(_lib.afft_set_gemm_splitk(int(os.environ["AFFT_GEMM_SPLITK"])), "set_gemm_splitk")
         if os.environ.get("AFFT_GEMM_VARIANT"):
             check(_lib.afft_set_gemm_variant(int(os.environ["AFFT_GEMM_VARIANT"])), "set_gemm_variant")
     return _lib
