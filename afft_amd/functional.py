@@ -902,6 +902,9 @@ class AttnSublayer(torch.autograd.Function):
         nseq, hd = R // L, d // H
         dev = x.device
         ctx.composite = False
+        # probs is returned for the caller's attention maps and takes no gradient: without this autograd hands backward a
+        # freshly ZERO-FILLED tensor of its shape for it on every call (a fill kernel per attention sub-layer and step)
+        ctx.set_materialize_grads(False)
         if _composite_ok(x, pre_ln, d):
             return _attn_fwd_c(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, eps, conv1d, scale, drop)
         ctx.up = _upstream_of(x) if pre_ln else None
@@ -930,6 +933,8 @@ class AttnSublayer(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dprobs):
+        if dy is None:          # (set_materialize_grads(False)) nobody used y
+            return (None,) * 15
         if ctx.composite:
             return _attn_bwd_c(ctx, dy)
         x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, mean, rstd, probs = ctx.saved_tensors
