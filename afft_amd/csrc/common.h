@@ -153,33 +153,42 @@ __device__ __forceinline__ float dgelu_tanh_f(float x) {
 //      elements per thread -- measured +64 us on the 177-us fc1 GEMM, +106 us on its data gradient, +140 us on the predictor's.
 //      erf: Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7) on v_rcp_f32 / v_exp_f32; tanh(u) = 1 - 2 / (1 + exp(2u)).  Absolute
 //      errors of ~2e-7, far inside what the bf16 operands of these kernels leave; the exact-fp32 GEMM keeps the library functions.
+// Every rounding is pinned (explicit fma / mul / add, as in sgd_update): the 4-wide and 8-wide epilogues, packed or scalar
+// instructions, composite or call-by-call launches all give bit-identical results.
 __device__ __forceinline__ float erf_as7126(float z, float e /* = exp(-z*z) */) {
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, fabsf(z), 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  return copysignf(1.0f - p * t * e, z);
+  const float t = __builtin_amdgcn_rcpf(__fmaf_rn(0.3275911f, fabsf(z), 1.0f));
+  float p = __fmaf_rn(1.061405429f, t, -1.453152027f);
+  p = __fmaf_rn(p, t, 1.421413741f);
+  p = __fmaf_rn(p, t, -0.284496736f);
+  p = __fmaf_rn(p, t, 0.254829592f);
+  return copysignf(__fmaf_rn(-__fmul_rn(p, t), e, 1.0f), z);
 }
 __device__ __forceinline__ float gelu_erf_fast(float x) {
-  const float z = x * 0.70710678118654752f;
-  return 0.5f * x * (1.0f + erf_as7126(z, __expf(-z * z)));
+  const float z = __fmul_rn(x, 0.70710678118654752f);
+  const float hx = __fmul_rn(0.5f, x);
+  return __fmaf_rn(hx, erf_as7126(z, __expf(-__fmul_rn(z, z))), hx);
 }
 __device__ __forceinline__ float dgelu_erf_fast(float x) {
-  const float z = x * 0.70710678118654752f;
-  const float e = __expf(-z * z);                       // exp(-x^2 / 2): shared by erf and the density term
-  return 0.5f * (1.0f + erf_as7126(z, e)) + x * 0.39894228040143268f * e;
+  const float z = __fmul_rn(x, 0.70710678118654752f);
+  const float e = __expf(-__fmul_rn(z, z));               // exp(-x^2 / 2): shared by erf and the density term
+  return __fmaf_rn(__fmul_rn(x, 0.39894228040143268f), e, __fmaf_rn(0.5f, erf_as7126(z, e), 0.5f));
 }
-__device__ __forceinline__ float tanh_fast(float u) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * u)); }
+__device__ __forceinline__ float tanh_fast(float u) {
+  return __fmaf_rn(-2.0f, __builtin_amdgcn_rcpf(__fadd_rn(1.0f, __expf(__fmul_rn(2.0f, u)))), 1.0f);
+}
+__device__ __forceinline__ float gelu_new_arg(float x, float x2) {   // sqrt(2/pi) (x + 0.044715 x^3)
+  return __fmul_rn(0.79788456080286536f, __fmaf_rn(__fmul_rn(0.044715f, x2), x, x));
+}
 __device__ __forceinline__ float gelu_tanh_fast(float x) {
-  const float u = 0.79788456080286536f * (x + 0.044715f * x * x * x);
-  return 0.5f * x * (1.0f + tanh_fast(u));
+  const float hx = __fmul_rn(0.5f, x);
+  return __fmaf_rn(hx, tanh_fast(gelu_new_arg(x, __fmul_rn(x, x))), hx);
 }
 __device__ __forceinline__ float dgelu_tanh_fast(float x) {
-  const float x2 = x * x;
-  const float u = 0.79788456080286536f * (x + 0.044715f * x * x2);
-  const float t = tanh_fast(u);
-  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.79788456080286536f * (1.0f + 3.0f * 0.044715f * x2);
+  const float x2 = __fmul_rn(x, x);
+  const float t = tanh_fast(gelu_new_arg(x, x2));
+  const float sech2 = __fmaf_rn(-t, t, 1.0f);
+  const float du = __fmul_rn(0.79788456080286536f, __fmaf_rn(3.0f * 0.044715f, x2, 1.0f));
+  return __fmaf_rn(__fmul_rn(__fmul_rn(0.5f, x), sech2), du, __fmaf_rn(0.5f, t, 0.5f));
 }
 constexpr int AFFT_ACT_FAST = 0x100;
 
@@ -245,14 +254,41 @@ __device__ __forceinline__ float apply_act(int act, float v, float aux) {
     case AFFT_ACT_DGELU_TANH: return v * dgelu_tanh_f(aux);
     case AFFT_ACT_GELU_ERF | AFFT_ACT_FAST: return gelu_erf_fast(v);
     case AFFT_ACT_GELU_TANH | AFFT_ACT_FAST: return gelu_tanh_fast(v);
-    case AFFT_ACT_DGELU_ERF | AFFT_ACT_FAST: return v * dgelu_erf_fast(aux);
-    case AFFT_ACT_DGELU_TANH | AFFT_ACT_FAST: return v * dgelu_tanh_fast(aux);
+    case AFFT_ACT_DGELU_ERF | AFFT_ACT_FAST: return __fmul_rn(v, dgelu_erf_fast(aux));
+    case AFFT_ACT_DGELU_TANH | AFFT_ACT_FAST: return __fmul_rn(v, dgelu_tanh_fast(aux));
     case AFFT_ACT_RELU | AFFT_ACT_FAST: return v > 0.f ? v : 0.f;
     case AFFT_ACT_SIGMOID_GATE | AFFT_ACT_FAST: return aux / (1.0f + __expf(-v));
     case AFFT_ACT_RELU: return v > 0.f ? v : 0.f;
     case AFFT_ACT_SIGMOID_GATE: return aux / (1.0f + __expf(-v));
     default: return v;
   }
+}
+
+// the same for N elements with the switch taken ONCE (the compiler does not unswitch the unrolled element loop by itself: it
+// left a scalar compare-and-branch chain per element, about as expensive as the activation): one straight-line block per
+// activation, whose N independent chains also hide the quarter-rate v_exp_f32 / v_rcp_f32 behind each other
+template <int N>
+__device__ __forceinline__ void apply_act_n(int act, float (&v)[N], const float (&a)[N]) {
+#define AFFT_ACT_CASE(code, expr)            \
+  case code:                                 \
+    _Pragma("unroll") for (int r = 0; r < N; ++r) v[r] = (expr); \
+    break;
+  switch (act) {
+    AFFT_ACT_CASE(AFFT_ACT_GELU_ERF, gelu_erf_f(v[r]))
+    AFFT_ACT_CASE(AFFT_ACT_GELU_TANH, gelu_tanh_f(v[r]))
+    AFFT_ACT_CASE(AFFT_ACT_DGELU_ERF, v[r] * dgelu_erf_f(a[r]))
+    AFFT_ACT_CASE(AFFT_ACT_DGELU_TANH, v[r] * dgelu_tanh_f(a[r]))
+    AFFT_ACT_CASE(AFFT_ACT_GELU_ERF | AFFT_ACT_FAST, gelu_erf_fast(v[r]))
+    AFFT_ACT_CASE(AFFT_ACT_GELU_TANH | AFFT_ACT_FAST, gelu_tanh_fast(v[r]))
+    AFFT_ACT_CASE(AFFT_ACT_DGELU_ERF | AFFT_ACT_FAST, __fmul_rn(v[r], dgelu_erf_fast(a[r])))
+    AFFT_ACT_CASE(AFFT_ACT_DGELU_TANH | AFFT_ACT_FAST, __fmul_rn(v[r], dgelu_tanh_fast(a[r])))
+    case AFFT_ACT_RELU | AFFT_ACT_FAST:
+    AFFT_ACT_CASE(AFFT_ACT_RELU, v[r] > 0.f ? v[r] : 0.f)
+    case AFFT_ACT_SIGMOID_GATE | AFFT_ACT_FAST:
+    AFFT_ACT_CASE(AFFT_ACT_SIGMOID_GATE, a[r] / (1.0f + __expf(-v[r])))
+    default: break;
+  }
+#undef AFFT_ACT_CASE
 }
 
 // v[0..3] = accumulators for C[m, n..n+3]
@@ -294,8 +330,7 @@ __device__ __forceinline__ void epilogue4(const EpiParams& e, const DropParams& 
     if (e.act != AFFT_ACT_NONE) {
       float a[4] = {0.f, 0.f, 0.f, 0.f};
       if (act_needs_aux(e.act)) load4(e.aux, (int64_t)m * e.ldaux + n, e.aux_dtype, a);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = apply_act(e.act, v[r], a[r]);
+      apply_act_n<4>(e.act, v, a);
     }
     if (dp.thresh) {
 #pragma unroll
@@ -399,8 +434,7 @@ __device__ __forceinline__ void epilogue8(const EpiParams& e, const DropParams& 
   if (e.act != AFFT_ACT_NONE) {
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (act_needs_aux(e.act)) load8(e.aux, (int64_t)m * e.ldaux + n, e.aux_dtype, a);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = apply_act(e.act, v[r], a[r]);
+    apply_act_n<8>(e.act, v, a);
   }
   if (dp.thresh) {
 #pragma unroll

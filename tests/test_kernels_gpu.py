@@ -485,6 +485,43 @@ def test_gemm_fused_sgd_epilogue_equals_gemm_then_update(case):
         ops.gemm(a, b, gout[:, :N], a_t=True, sgd=d, accumulate=True)
 
 
+@pytest.mark.parametrize("variant", [1, 3])
+def test_epilogue_activation_accuracy(variant):
+    """The activation math of the bf16-operand GEMM epilogues (erf by Abramowitz & Stegun 7.1.26, tanh by exp, on the hardware exp
+    and reciprocal; include/afft_hip.h, afft_gemm_t.act) against float64 erf / tanh on a dense grid of bf16-representable
+    arguments in [-9, 9]: the product is made exact (A = grid values, B = identity), so what is compared is the activation alone.
+    Absolute error <= 1e-6 for both GELUs and the erf derivative, <= 4e-6 for the derivative of gelu_new."""
+    import math
+    from afft_amd import _lib, ops
+    M, K = 1024, 64
+    grid = torch.linspace(-9.0, 9.0, M * K).to(torch.bfloat16)
+    a = grid.view(M, K).to(dev())
+    eye = torch.eye(K, dtype=torch.bfloat16, device=dev())
+    x = grid.view(M, K).double()
+    ones_a = torch.zeros(M, K, dtype=torch.bfloat16, device=dev())
+    ones_a[:, 0] = 1.0
+    ones_b = torch.zeros(K, K, dtype=torch.bfloat16, device=dev())
+    ones_b[0, :] = 1.0
+    phi = 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+    u = math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3)
+    t = torch.tanh(u)
+    ref = {ops.ACT_GELU_ERF: x * phi, ops.ACT_GELU_TANH: 0.5 * x * (1.0 + t),
+           ops.ACT_DGELU_ERF: phi + x * torch.exp(-0.5 * x * x) / math.sqrt(2.0 * math.pi),
+           ops.ACT_DGELU_TANH: 0.5 * (1.0 + t) + 0.5 * x * (1.0 - t * t) * math.sqrt(2.0 / math.pi) * (1.0 + 3 * 0.044715 * x * x)}
+    _lib.check(_lib.lib().afft_set_gemm_variant(variant))
+    try:
+        for act, want in ref.items():
+            out = torch.empty(M, K, dtype=torch.float32, device=dev())
+            if act in (ops.ACT_DGELU_ERF, ops.ACT_DGELU_TANH):      # product = 1 everywhere, the argument comes in as aux
+                ops.gemm(ones_a, ones_b, out, act=act, aux=a)
+            else:
+                ops.gemm(a, eye, out, act=act)
+            err = float((out.double().cpu() - want).abs().max())
+            assert err < (4e-6 if act == ops.ACT_DGELU_TANH else 1e-6), (act, err)
+    finally:
+        _lib.check(_lib.lib().afft_set_gemm_variant(0))
+
+
 @pytest.mark.parametrize("variant,M,N,K,mode", [(1, 1024, 1024, 512, 4), (1, 2048, 1024, 1024, 2), (3, 1024, 2048, 768, 4)])
 def test_splitk_handoff_stress(variant, M, N, K, mode):
     """The split-K hand-off (slices park their partial tile with write-through stores, the slice that arrives last adds them up in

@@ -21,6 +21,12 @@ def run(layout, M, N, K, epi, variant, iters=30):
     out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     if epi == "gelu_erf+pre":
         kw.update(bias=torch.randn(N, device=dev), act=ops.ACT_GELU_ERF, pre=torch.empty(M, N, dtype=torch.bfloat16, device=dev))
+    elif epi == "gelu_erf":
+        kw.update(bias=torch.randn(N, device=dev), act=ops.ACT_GELU_ERF)
+    elif epi == "bias+pre":
+        kw.update(bias=torch.randn(N, device=dev), pre=torch.empty(M, N, dtype=torch.bfloat16, device=dev))
+    elif epi == "bias":
+        kw.update(bias=torch.randn(N, device=dev))
     elif epi == "gelu_tanh+pre":
         kw.update(bias=torch.randn(N, device=dev), act=ops.ACT_GELU_TANH, pre=torch.empty(M, N, dtype=torch.bfloat16, device=dev))
     elif epi == "dgelu_erf":
@@ -47,6 +53,8 @@ if __name__ == "__main__":
     cases = [("nt", 5120, 8192, 2048, "gelu_erf+pre"), ("nn", 5120, 8192, 2048, "dgelu_erf"), ("nt", 5120, 2048, 8192, "bias+res_f32"),
              ("nt", 5120, 2048, 2048, "bias+res_f32"), ("nn", 1024, 8192, 2048, "gelu_tanh+pre"), ("nt", 1024, 8192, 2048, "dgelu_tanh"),
              ("nn", 1024, 2048, 8192, "bias+res_f32"), ("nt", 5120, 4096, 1024, "gelu_erf+pre"), ("nn", 5120, 4096, 1024, "dgelu_erf")]
+    if os.environ.get("DECOMPOSE") == "1":
+        cases = [("nt", 5120, 8192, 2048, e) for e in ("bias", "gelu_erf", "bias+pre", "gelu_erf+pre")] + [("nn", 5120, 8192, 2048, "dgelu_erf")]
     print(f"{'layout':6} {'M':>6} {'N':>6} {'K':>6} {'epilogue':>14} | 128x128: plain us  with epilogue | 256x256: plain us  with epilogue")
     for lay, M, N, K, epi in cases:
         r = [run(lay, M, N, K, e, v) for v in (1, 3) for e in ("plain", epi)]
