@@ -13,6 +13,9 @@ using namespace afft_gemm_detail;
 #ifndef AFFT_PP_CLAMP
 #define AFFT_PP_CLAMP 2       // 2 = branch-free wait: 256-byte dummy LDS-DMA past the end of K (see issue()); 1 = re-read the last K-tile; 0 = guarded issue + run-time wait selection
 #endif
+#ifndef AFFT_PP_EPI_UNROLL
+#define AFFT_PP_EPI_UNROLL 2  // row steps of the epilogue in flight per thread: 2 takes 8-12 us off the GELU epilogues of a 5120x8192 output, 4 loses again
+#endif
 #ifndef AFFT_PP_DIAG
 #define AFFT_PP_DIAG 0    // diagnostic builds only (wrong results): 1 = no fragment reads, 2 = no LDS-DMA in the loop, 4 = no MFMA,
                           // 8 = no global accesses in the epilogue, 16 = no epilogue at all
@@ -285,6 +288,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
     });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#pragma unroll AFFT_PP_EPI_UNROLL
     for (int rr = 0; rr < 8; ++rr) {     // two rows per step: a lane owns 8 consecutive columns (16-byte bf16 stores)
       const int row = wave * 16 + rr * 2 + (lane >> 5);
       const int c8 = lane & 31;
