@@ -35,6 +35,10 @@ using namespace afft_gemm_detail;
 int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream, int x3, int max_wg);
 int afft_gemm_launch_w4(int a_ks, int b_ks, int reg_staged, afft_gemm_detail::GemmFast& g, hipStream_t stream);
 
+#ifndef AFFT_G128_EPI_UNROLL
+#define AFFT_G128_EPI_UNROLL 1   // 2 (what pays in gemm_pp.hip) measured 1-3 % slower on the EK100-width and cfg4 steps
+#endif
+
 namespace {
 
 template <int WM, int WN, int STAGES, bool A_KS, bool B_KS, bool SPLITK, bool X3 = false>
@@ -145,6 +149,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf1
   const DropParams dp = with_salt(g.e.drop);
   constexpr int LPR = BN / 8;            // lanes per row (8 columns each: 16-byte bf16 stores)
   constexpr int RPI = 64 / LPR;          // rows per wave-iteration
+#pragma unroll AFFT_G128_EPI_UNROLL      // row steps in flight per thread, as in gemm_pp.hip
   for (int it = 0; it < BM / NW / RPI; ++it) {
     const int row = wave * (BM / NW) + it * RPI + lane / LPR;
     const int c8 = lane % LPR;
