@@ -90,3 +90,31 @@ def marginalize_verb_noun(res_action, dataset, to_prob: bool = True, compute_man
     verb, noun, action = marginalize_scores(x.float(), dataset.class_mappings, to_prob=to_prob)
     scores = [t.detach().cpu().numpy() for t in (verb, noun, action.reshape(-1, action.shape[-1]))]
     return compute_accuracies_epic(scores, dataset, compute_manyshot_unseen_tail), scores
+
+
+LOGITS_DIR = 'logits'        # challenge.py:28
+PREFIX_H5 = 'test'           # challenge.py:32
+
+
+def gen_load_resfiles(resdir: str):
+    """challenge.py:79-91: every '<PREFIX_H5>*h5' logits file of a run directory as {leaf key: array} (through h5py when it is
+    installed, else through afft_amd.h5lite, which reads the same files)."""
+    import glob  # noqa: PLC0415
+    import os.path as osp  # noqa: PLC0415
+    from .evaluate import load_logits  # noqa: PLC0415
+    resfiles = sorted(glob.glob(osp.join(resdir, PREFIX_H5 + '*h5')))
+    if len(resfiles) == 0:
+        raise ValueError(f'Didnt find any resfiles in {resdir}')
+    for resfile in resfiles:
+        yield load_logits(resfile)
+
+
+def get_epic_marginalize_verb_noun(resdir: str, dataset):
+    """challenge.py:213-222: verb / noun scores from the action logits stored in a run directory."""
+    res = next(gen_load_resfiles(resdir))
+    res_action = None
+    for key, val in res.items():
+        if key.startswith('logits/action'):
+            res_action = val
+    assert res_action is not None, 'Can not find logits/action in h5.'
+    return marginalize_verb_noun(res_action, dataset)

@@ -130,6 +130,19 @@ def test_evaluate_store_append_writes_hdf5(tmp_path):
     assert list(E.load_logits(path)) == [KEY]
 
 
+def test_challenge_loader_reads_the_stored_logits(tmp_path):
+    """challenge.gen_load_resfiles (challenge.py:79-91): the 'test*h5' files of a run directory as {leaf key: array}."""
+    from afft_amd import challenge as CH, evaluate as E
+    a = _batch(5, 6, 13)
+    E.store_append({KEY: a}, str(tmp_path), "test_run.h5")
+    E.store_append({KEY: a[:2]}, str(tmp_path), "test_run.h5")
+    (tmp_path / "notes.txt").write_text("not a result file")
+    res = list(CH.gen_load_resfiles(str(tmp_path)))
+    assert len(res) == 1 and list(res[0]) == [KEY] and np.array_equal(res[0][KEY], np.concatenate([a, a[:2]]))
+    with pytest.raises(ValueError):
+        next(CH.gen_load_resfiles(str(tmp_path / "nothing_here")))
+
+
 @needs_h5py
 def test_h5py_reads_what_h5lite_writes_and_appends_to_it(tmp_path):
     p = str(tmp_path / "lite.h5")
