@@ -28,6 +28,7 @@ from torch import Tensor
 
 from .. import dropout as D_
 from .. import functional as F_
+from .. import runtime as rt
 from .._hydra_compat import instantiate, is_dict_config
 
 PAST_LOGITS_PREFIX = 'past_'
@@ -288,8 +289,20 @@ class CrossModalFusionPrediction(nn.Module, metaclass=abc.ABCMeta):
                 'past_futures': {m: torch.cat([z[m][:, :1], zh[:, :cut]], dim=1) for m, zh in z_hat.items()}}
 
     def _with_logits(self, out: dict) -> dict:
-        out.update(self.apply_classifier(out['past_futures'], outputs_prefix=PAST_LOGITS_PREFIX))
-        out.update(self.apply_classifier(out['future']))
+        """past_logits/* from past_futures and logits/* from future (future_prediction.py:283-285 applies the SAME heads to both):
+        one GEMM per head over the rows of both -- the future is 1-3 frames per clip, a GEMM of its own would be all launch and
+        tail -- and two views of its output."""
+        past, fut = out['past_futures'], out['future']
+        if rt.merge_heads() and past.keys() == fut.keys():
+            T = next(iter(past.values())).shape[1]
+            both = self.apply_classifier({m: torch.cat([past[m], fut[m]], dim=1) for m in past})
+            for key, per_mod in both.items():
+                out[PAST_LOGITS_PREFIX + key] = {m: v[:, :T] for m, v in per_mod.items()}
+            for key, per_mod in both.items():
+                out[key] = {m: v[:, T:] for m, v in per_mod.items()}
+            return out
+        out.update(self.apply_classifier(past, outputs_prefix=PAST_LOGITS_PREFIX))
+        out.update(self.apply_classifier(fut))
         return out
 
     @abc.abstractmethod

@@ -277,6 +277,19 @@ def set_side_min_rows(n: int):
     _SIDE_MIN_ROWS = max(0, int(n))
 
 
+_MERGE_HEADS = os.environ.get("AFFT_MERGE_HEADS", "1") != "0"
+
+
+def merge_heads() -> bool:
+    """One classifier GEMM over the rows of past_futures and future together (models/future_prediction.py) instead of one each."""
+    return _MERGE_HEADS
+
+
+def set_merge_heads(on: bool):
+    global _MERGE_HEADS
+    _MERGE_HEADS = bool(on)
+
+
 _COMPOSITE = os.environ.get("AFFT_COMPOSITE", "1") != "0"
 
 
