@@ -18,8 +18,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 constexpr int BK = 64;
 #ifndef AFFT_GROUP_M
-#define AFFT_GROUP_M 8
-#endif
+#define AFFT_GROUP_M 6     // tile rows per column group inside an XCD's chunk.  Alone every path shape is flat over 4..12 (round 1 took 8); inside
+#endif                     // the step, beside the other stream, 4-6 are 1-2.3 % ahead of 8 on cfg2 / EK100 / cfg4 (profiles/r02_knob_sweeps.txt)
 constexpr int GROUP_M = AFFT_GROUP_M;
 
 struct GemmFast {
