@@ -144,7 +144,7 @@ _SIGS = {
     "afft_attention_bwd": ([vp, i64, vp, i64, vp, i64, vp, i64, i32, vp, i32, i32, i32, i32, f32, f32, C.c_uint32,
                             vp, i64, vp, i64, vp, i64, vp], C.c_int),
     "afft_softmax_ce": ([vp, i64, i32, i32, vp, vp, i64, vp, f32, vp, vp, vp, i64, i32, vp, vp], C.c_int),
-    "afft_mse": ([vp, i64, vp, i64, i32, i32, f32, vp, f32, vp, vp, i64, vp, i64, vp], C.c_int),
+    "afft_mse": ([vp, i64, vp, i64, i32, i32, f32, vp, f32, vp, vp, i64, vp, i64, vp, i64, vp], C.c_int),
     "afft_cast": ([vp, i64, i32, i32, vp, i64, i32, vp, i64, i32, C.POINTER(Dropout), vp], C.c_int),
     "afft_assemble_tokens": ([C.POINTER(vp), C.POINTER(i64), i32, vp, i64, vp, i32, i32, i32, vp, vp], C.c_int),
     "afft_colsum": ([vp, i64, i32, i32, i32, vp, i32, vp, i64, vp], C.c_int),
@@ -152,7 +152,7 @@ _SIGS = {
     "afft_reduce_rows_periodic": ([vp, i64, i32, i32, i32, vp, i64, vp], C.c_int),
     "afft_sgd_nesterov": ([vp, vp, i32, vp, vp, i64, f32, f32, f32, f32, vp, i32, vp], C.c_int),
     "afft_sgd_nesterov_runs": ([vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, i32, vp], C.c_int),
-    "afft_sumsq": ([vp, i32, i64, f32, vp, vp], C.c_int),
+    "afft_sumsq": ([vp, i32, i64, f32, vp, vp, i64, vp], C.c_int),
     "afft_group_sum": ([vp, i32, i32, i64, f32, vp, vp], C.c_int),
     "afft_set_dropout_salt": ([vp], C.c_int),
     "afft_dropout_salt_step": ([vp, vp], C.c_int),

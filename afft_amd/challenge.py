@@ -35,15 +35,13 @@ def marginalize_scores(res_action: torch.Tensor, class_mappings: Dict[Tuple[str,
 
 
 def topk_accuracy(scores: np.ndarray, labels: np.ndarray, ks, selected_class=None):
-    """common/utils.py:19-42: share of rows whose label is among the k best scores (argpartition instead of a full sort)"""
+    """common/utils.py:19-42: share of rows whose label is among the k best scores.  Ties rank as in the reference's
+    `scores.argsort()[:, ::-1]`: among equal scores the HIGHER class index comes first."""
     if selected_class is not None:
         keep = labels == selected_class
         scores, labels = scores[keep], labels[keep]
     kmax = int(max(ks))
-    order = np.argsort(-scores, axis=1, kind="stable")[:, :kmax] if scores.shape[1] <= 4 * kmax else None
-    if order is None:
-        part = np.argpartition(-scores, kmax - 1, axis=1)[:, :kmax]
-        order = np.take_along_axis(part, np.argsort(-np.take_along_axis(scores, part, 1), axis=1, kind="stable"), 1)
+    order = np.argsort(scores, axis=1, kind="stable")[:, ::-1][:, :kmax]
     hit = order == labels.reshape(-1, 1)
     return [hit[:, :k].any(axis=1).mean() for k in ks]
 

@@ -73,6 +73,23 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Second stage of every scalar reduction on the path (MSE, sum of squares, summed row losses): ONE workgroup adds n partial
+// sums in an order that depends on n only - lane t takes t, t + 256, ... front to back, then a fixed tree - and does
+// *out (+)= scale * total.  No float atomics anywhere: the same inputs give the same bits on every run.
+static __global__ __launch_bounds__(256) void ordered_sum_kernel(const float* __restrict__ partials, int64_t n, float scale,
+                                                                 float* __restrict__ out, int accumulate) {
+  __shared__ float sh_[4];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += partials[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh_[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = ((sh_[0] + sh_[1]) + (sh_[2] + sh_[3])) * scale;
+    *out = accumulate ? *out + t : t;
+  }
+}
+
 // ---- counter-based dropout RNG: keep(idx) is a pure function of (key, element index), so backward regenerates
 //      the forward mask instead of storing it. key is drawn per call site and step on the host.
 __device__ __forceinline__ unsigned mix32(unsigned x) {

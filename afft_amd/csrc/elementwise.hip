@@ -815,9 +815,11 @@ extern "C" int afft_group_bcast(const float* dy, int32_t G, int32_t S, int64_t W
   return 0;
 }
 
-// sum of squares of a flat gradient buffer (fp32 or bf16), added to *out: one float atomic per workgroup
-__global__ __launch_bounds__(256) void sumsq_kernel(const void* __restrict__ x, int dtype, int64_t n, float scale,
-                                                    float* __restrict__ out) {
+// sum of squares of a flat gradient buffer (fp32 or bf16): one partial per workgroup into the caller's scratch, added up in
+// workgroup order by ordered_sum_kernel behind it (no float atomics: the clipping coefficient, hence the parameters, are
+// bit-reproducible)
+__global__ __launch_bounds__(256) void sumsq_kernel(const void* __restrict__ x, int dtype, int64_t n,
+                                                    float* __restrict__ partials) {
   __shared__ float sh[4];
   float s = 0.f;
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
@@ -832,7 +834,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const void* __restrict__ x, 
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, ((sh[0] + sh[1]) + (sh[2] + sh[3])) * scale);
+  if (threadIdx.x == 0) partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 __global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ coef,
@@ -843,15 +845,21 @@ __global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm
   *coef = c < 1.0f ? c : 1.0f;
 }
 
-extern "C" int afft_sumsq(const void* x, int32_t dtype, int64_t n, float scale, float* out, void* stream_) {
+extern "C" int afft_sumsq(const void* x, int32_t dtype, int64_t n, float scale, float* out, void* workspace,
+                          int64_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(x && out, "sumsq: null pointer");
   AFFT_CHECK(dtype == AFFT_F32 || dtype == AFFT_BF16, "sumsq: bad dtype");
   AFFT_CHECK((((uintptr_t)x) & 15) == 0, "sumsq: buffer must be 16-byte aligned");
   if (n == 0) return 0;
   int64_t blocks = (n + 1023) / 1024;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(sumsq_kernel, dim3((int)blocks), dim3(256), 0, stream, x, dtype, n, scale, out);
+  if (blocks > AFFT_REDUCE_PARTIALS) blocks = AFFT_REDUCE_PARTIALS;
+  AFFT_CHECK(workspace && workspace_bytes >= AFFT_GEMM_WS_HEADER + 4 * blocks,
+             "sumsq: needs the stream's workspace (header + AFFT_REDUCE_PARTIALS floats)");
+  float* scratch = (float*)((char*)workspace + AFFT_GEMM_WS_HEADER);
+  hipLaunchKernelGGL(sumsq_kernel, dim3((int)blocks), dim3(256), 0, stream, x, dtype, n, scratch);
+  AFFT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(256), 0, stream, scratch, blocks, scale, out, 1);
   AFFT_LAUNCH_CHECK();
   return 0;
 }

@@ -339,7 +339,9 @@ int launch_layout_impl(GemmFast& g, hipStream_t stream, const afft_gemm_t* d) {
   }
   if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream, 0, d->max_workgroups);
   if (variant == 4) return launch_fast<2, 2, 4, A_KS, B_KS, false>(g, stream);
+#ifdef AFFT_BUILD_EXPERIMENTAL
   if (variant == 5 || variant == 6) return afft_gemm_launch_w4(A_KS, B_KS, variant == 6, g, stream);
+#endif
   if (g.splitk > 1) return launch_fast<2, 2, 2, A_KS, B_KS, true>(g, stream);
   return launch_fast<2, 2, 2, A_KS, B_KS, false>(g, stream);
 }
@@ -417,7 +419,12 @@ extern "C" int afft_set_gemm_splitk(int mode) {
 }
 
 extern "C" int afft_set_gemm_variant(int v) {
-  if (v != 0 && v != 1 && v != 3 && v != 4 && v != 5 && v != 6) { afft_set_error("afft_set_gemm_variant: %d is not 0 (auto), 1 (128x128), 3 (256x256 ping-pong), 4 (128x128, 4 stages), 5 or 6 (256x256 four-wave)", v); return 1; }
+#ifdef AFFT_BUILD_EXPERIMENTAL
+  const bool w4 = v == 5 || v == 6;
+#else
+  const bool w4 = false;   // gemm_w4.hip is only in `make EXPERIMENTAL=1` builds
+#endif
+  if (v != 0 && v != 1 && v != 3 && v != 4 && !w4) { afft_set_error("afft_set_gemm_variant: %d is not 0 (auto), 1 (128x128), 3 (256x256 ping-pong), 4 (128x128, 4 stages) [5 / 6 (256x256 four-wave): EXPERIMENTAL=1 builds only]", v); return 1; }
   g_variant = v;
   return 0;
 }

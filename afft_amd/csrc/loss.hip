@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
                                                          const float* __restrict__ soft, int64_t lds,
                                                          const uint8_t* __restrict__ keep, float gscale,
                                                          const float* __restrict__ row_g,
-                                                         float* __restrict__ loss_sum, void* __restrict__ dlogits,
+                                                         void* __restrict__ dlogits,
                                                          int64_t ldd, int d_dtype, float* __restrict__ row_loss) {
   __shared__ float sh[4];
   const int row = blockIdx.x, tid = threadIdx.x;
@@ -58,10 +58,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
     tsum = 1.f;
     loss = bad ? NAN : lse - x[lab];
   }
-  if (tid == 0) {
-    if (row_loss) row_loss[row] = loss;
-    if (loss_sum) atomicAdd(loss_sum, loss);
-  }
+  if (tid == 0 && row_loss) row_loss[row] = loss;
   if (dlogits) {
     const float inv = 1.0f / se;
     if (row_g) gscale *= row_g[row];
@@ -80,8 +77,9 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b,
                                                   int64_t ldb, int rows, int d, float gscale,
                                                   const float* __restrict__ g_dev, float lscale,
-                                                  float* __restrict__ loss_sum, float* __restrict__ da, int64_t ldda,
-                                                  float* __restrict__ db, int64_t lddb) {
+                                                  float* __restrict__ loss_sum, float* __restrict__ partials,
+                                                  float* __restrict__ da, int64_t ldda, float* __restrict__ db,
+                                                  int64_t lddb) {
   __shared__ float sh[4];
   float acc = 0.f;
   const int64_t total = (int64_t)rows * d;
@@ -94,8 +92,13 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, i
     if (da) da[(int64_t)r * ldda + c] += g;
     if (db) db[(int64_t)r * lddb + c] -= g;
   }
+  if (!loss_sum) return;
   acc = block_reduce(acc, sh, false);
-  if (threadIdx.x == 0 && loss_sum) atomicAdd(loss_sum, acc * lscale);
+  // one workgroup: it IS the sum.  More: the partial goes to the caller's scratch and ordered_sum_kernel adds them up in
+  // workgroup order behind this kernel (no float atomics: the loss scalar has the same bits on every run)
+  if (threadIdx.x == 0) {
+    if (gridDim.x == 1) *loss_sum += acc * lscale; else partials[blockIdx.x] = acc;
+  }
 }
 
 }  // namespace
@@ -108,24 +111,36 @@ extern "C" int afft_softmax_ce(const float* logits, int64_t ldl, int32_t rows, i
   AFFT_CHECK(logits, "softmax_ce: null logits");
   AFFT_CHECK((labels != nullptr) != (soft != nullptr), "softmax_ce: give exactly one of labels / soft targets");
   AFFT_CHECK(C > 0 && ldl >= C && (!dlogits || ldd >= C), "softmax_ce: bad sizes");
+  AFFT_CHECK(!loss_sum || row_loss, "softmax_ce: loss_sum is the ordered sum of row_loss: give row_loss as well");
   if (rows == 0) return 0;
   hipLaunchKernelGGL(softmax_ce_kernel, dim3(rows), dim3(256), 0, stream, logits, ldl, C, labels, soft, lds, keep,
-                     gscale, row_g, loss_sum, dlogits, ldd, d_dtype, row_loss);
+                     gscale, row_g, dlogits, ldd, d_dtype, row_loss);
   AFFT_LAUNCH_CHECK();
+  if (loss_sum) {
+    hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(256), 0, stream, row_loss, (int64_t)rows, 1.0f, loss_sum, 1);
+    AFFT_LAUNCH_CHECK();
+  }
   return 0;
 }
 
 extern "C" int afft_mse(const float* a, int64_t lda, const float* b, int64_t ldb, int32_t rows, int32_t d,
                         float gscale, const float* g_dev, float lscale, float* loss_sum, float* da, int64_t ldda,
-                        float* db, int64_t lddb, void* stream_) {
+                        float* db, int64_t lddb, void* workspace, int64_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(a && b, "mse: null pointer");
   if (rows == 0 || d == 0) return 0;
   const int64_t total = (int64_t)rows * d;
   int grid = (int)((total + 255) / 256);
-  if (grid > 2048) grid = 2048;
+  if (grid > AFFT_REDUCE_PARTIALS) grid = AFFT_REDUCE_PARTIALS;
+  AFFT_CHECK(!loss_sum || grid == 1 || (workspace && workspace_bytes >= AFFT_GEMM_WS_HEADER + 4 * (int64_t)grid),
+             "mse: the loss sum needs the stream's workspace (header + AFFT_REDUCE_PARTIALS floats)");
+  float* scratch = workspace ? (float*)((char*)workspace + AFFT_GEMM_WS_HEADER) : nullptr;
   hipLaunchKernelGGL(mse_kernel, dim3(grid), dim3(256), 0, stream, a, lda, b, ldb, rows, d, gscale, g_dev, lscale, loss_sum,
-                     da, ldda, db, lddb);
+                     scratch, da, ldda, db, lddb);
   AFFT_LAUNCH_CHECK();
+  if (loss_sum && grid > 1) {
+    hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(256), 0, stream, scratch, (int64_t)grid, lscale, loss_sum, 1);
+    AFFT_LAUNCH_CHECK();
+  }
   return 0;
 }

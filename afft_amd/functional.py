@@ -570,6 +570,7 @@ def _fuse_updates(s, weights) -> list:
         if d is not None and not acc:
             setattr(s, field, C.pointer(d))
             keep.append(d)
+            rt.SINK.fused_applied[id(w)] = rt.SINK.fused_applied.get(id(w), 0) + 1     # audited by Trainer._audit_fused_step
     return keep
 
 
@@ -934,6 +935,8 @@ class AttnSublayer(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dprobs):
         if dy is None:          # (set_materialize_grads(False)) nobody used y
+            _drop_shadow()      # a hand-over meant for this backward and queued notifications must not outlive it
+            flush_ready()
             return (None,) * 15
         if ctx.composite:
             return _attn_bwd_c(ctx, dy)

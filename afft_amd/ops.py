@@ -222,12 +222,16 @@ def softmax_ce(logits: Tensor, C_: int, *, labels: Optional[Tensor] = None, soft
 
 def mse(a: Tensor, b: Tensor, gscale: float, loss_sum: Optional[Tensor], da: Optional[Tensor], db: Optional[Tensor],
         g_dev: Optional[Tensor] = None, lscale: float = 1.0):
+    """loss_sum[0] += lscale * sum (a - b)^2 (ordered sum through the current stream's scratch: no float atomics), da / db +=
+    the gradient."""
     rows, d = a.shape
     assert a.dtype == b.dtype == torch.float32 and b.shape == a.shape
+    ws = gemm_workspace(a.device) if loss_sum is not None else None
     L.check(L.lib().afft_mse(_p(a), _rowmajor(a, "a"), _p(b), _rowmajor(b, "b"), rows, d, gscale, _p(g_dev), lscale,
                              _p(loss_sum),
                              _p(da), _rowmajor(da, "da") if da is not None else 0, _p(db),
-                             _rowmajor(db, "db") if db is not None else 0, _stream()), "mse")
+                             _rowmajor(db, "db") if db is not None else 0, _p(ws), ws.numel() if ws is not None else 0,
+                             _stream()), "mse")
 
 
 def cast(src: Tensor, dst: Optional[Tensor], dst_t: Optional[Tensor] = None, zero_pad: bool = False,
@@ -299,9 +303,10 @@ def sgd_nesterov_runs(p: Tensor, g: Tensor, buf: Tensor, runs: Tensor, lr: float
 
 
 def sumsq(x: Tensor, out: Tensor, scale: float = 1.0):
-    """out[0] += scale * sum(x^2) over a flat fp32 / bf16 buffer."""
+    """out[0] += scale * sum(x^2) over a flat fp32 / bf16 buffer (ordered sum through the current stream's scratch)."""
     assert x.is_contiguous() and out.dtype == torch.float32
-    L.check(L.lib().afft_sumsq(_p(x), _dt(x), x.numel(), scale, _p(out), _stream()), "sumsq")
+    ws = gemm_workspace(x.device)
+    L.check(L.lib().afft_sumsq(_p(x), _dt(x), x.numel(), scale, _p(out), _p(ws), ws.numel(), _stream()), "sumsq")
     return out
 
 

@@ -215,6 +215,7 @@ class GradReducer:
             return
         if self.expected is None:
             self.expected = list(self._count)
+            self._check_expected_agree()
         # fixed order on every rank: buckets are handed over last-to-first (the order backward completes them)
         for b in reversed(range(len(self.buckets))):
             if not self._launched[b]:
@@ -225,6 +226,21 @@ class GradReducer:
             torch.cuda.current_stream().wait_stream(self.side_stream)
             if self.opt_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.opt_stream)
+
+    def _check_expected_agree(self):
+        """The readiness counts learned on step 1 decide WHEN a bucket's collective is enqueued during backward; the ORDER of
+        the collectives must be the same on every rank or RCCL deadlocks.  With equal counts the order is a function of the
+        backward graph alone (the same on every replica), so: once, when the counts are learned, every rank checks that it
+        holds the same counts as the others (max == min == own) and raises instead of hanging later."""
+        if not (self.comm and self.world > 1):
+            return
+        mine = torch.tensor(self.expected, dtype=torch.int64, device=self.flat.flat_g.device)
+        hi, lo = mine.clone(), mine.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        if not (torch.equal(hi, mine) and torch.equal(lo, mine)):
+            raise RuntimeError(f"GradReducer: ranks disagree on the per-bucket gradient counts of a step (here {self.expected}, "
+                               f"max over ranks {hi.tolist()}, min {lo.tolist()}): the replicas do not run the same graph")
 
     def grad_for_optimizer(self):
         """(flat gradient tensor, scale): summed over ranks; the optimizer applies 1/world."""
@@ -306,7 +322,8 @@ class Trainer:
     def sync_parameters(self, group=None, src: int = 0):
         """Every replica starts from rank `src`'s parameters and momentum (what torch DDP does at construction,
         train.py:364-368): only gradients are exchanged afterwards, so replicas that differ here never meet again --
-        a checkpoint loaded on one rank, an unseeded init.  Refreshes the bf16 weight images from the received values."""
+        a checkpoint loaded on one rank, an unseeded init.  Refreshes the bf16 weight images from the received values.
+        Runs at construction; call it again after loading a checkpoint into an existing Trainer."""
         if not (dist.is_available() and dist.is_initialized()):
             return
         root = dist.get_global_rank(group, src) if group is not None else src
@@ -315,6 +332,11 @@ class Trainer:
         steps = torch.tensor([self.opt.steps], dtype=torch.int64, device=self.flat.flat_p.device)
         dist.broadcast(steps, src=root, group=group)
         self.opt.steps = int(steps)
+        # the rest of the module state, as DDP broadcasts it: frozen parameters (not in the flat buffers) and buffers
+        flat_ids = {id(p) for p in self.flat.params}
+        for t in list(self.model.parameters()) + list(self.model.buffers()):
+            if id(t) not in flat_ids:
+                dist.broadcast(t.data, src=root, group=group)
         self.flat.refresh_images()
 
     # ---- optimizer fused into the weight-gradient GEMM epilogues (single GPU)
@@ -338,6 +360,12 @@ class Trainer:
                 d = L_.SgdFused()
                 d.p, d.buf, d.p_bf16 = flat.flat_p.data_ptr() + 4 * o, self.opt.buf.data_ptr() + 4 * o, flat.flat_p16.data_ptr() + 2 * o
                 fused[id(p)] = d
+        self._fused = fused
+        self.opt.runs = self._runs_without(fused)
+
+    def _runs_without(self, fused) -> Dict[tuple, Tensor]:
+        """per bucket: the {start, length} runs of the flat buffers that are NOT updated in a GEMM epilogue"""
+        flat = self.flat
         CH = 16384       # a run is one 256-thread block of the runs kernel: keep them short
         runs = {}
         for (s, e) in self.reducer.buckets:
@@ -356,8 +384,39 @@ class Trainer:
                     segs.append(cur)
             chunks = [(a + k, min(CH, n - k)) for a, n in segs for k in range(0, n, CH)]
             runs[(s, e)] = torch.tensor(chunks, dtype=torch.int64, device=flat.flat_p.device).reshape(-1, 2)
-        self._fused = fused
-        self.opt.runs = runs
+        return runs
+
+    def _audit_fused_step(self):
+        """The set of epilogue-updated weights was learned on ONE step; a later step may route a weight differently (a branch
+        that is skipped, a sub-layer shared by two call sites, the call-by-call path).  After every fused step, on the host:
+        each such weight must have been updated in an epilogue exactly once and have had no other gradient contribution.
+        * not updated in an epilogue this step: its whole gradient sits in the flat buffer (the first contribution
+          overwrites, finish_step zeroes an untouched one) and the bucket kernel skipped it -> the regular update is applied
+          to its range now (behind every bucket update: finish_step has joined the streams) and the weight leaves the set;
+        * updated in an epilogue AND given a second contribution: the update already used a partial gradient -> error."""
+        flat, sink, stale = self.flat, rt.SINK, []
+        for p, o in zip(flat.params, flat.offsets):
+            pid = id(p)
+            if pid not in self._fused:
+                continue
+            applied, touches = sink.fused_applied.get(pid, 0), sink.touch_count.get(pid, 0)
+            if applied == 1 and touches == 1:
+                continue
+            if applied != 0:
+                name = next((k for k, q in self.model.named_parameters() if q is p), "?")
+                raise RuntimeError(f"fused optimizer: weight {name} was updated in its gradient GEMM's epilogue and then received "
+                                   f"{touches - applied} more gradient contribution(s) in the same step (the graph changed since "
+                                   "the fused set was learned); rebuild the Trainer or disable runtime.set_fused_sgd")
+            n = _align(p.numel())
+            ops.sgd_nesterov(flat.flat_p[o:o + n], flat.flat_g[o:o + n], self.opt.buf[o:o + n], self.opt.lr, self.opt.momentum,
+                             self.opt.wd, 1.0, self.opt.steps == 0, p_bf16=flat.flat_p16[o:o + n])
+            stale.append(pid)
+        if stale:
+            for pid in stale:
+                del self._fused[pid]
+            self.opt.runs = self._runs_without(self._fused)
+            return True
+        return False
 
     def _fused_desc(self, p: Tensor):
         d = self._fused.get(id(p))
@@ -378,6 +437,8 @@ class Trainer:
             loss, parts = self._reduce(losses, self.loss_wts, sync=False)
             loss.backward()
             self.reducer.finish_step()
+            if fuse and self._audit_fused_step():
+                saved_runs = self.opt.runs      # the set shrank: keep the rebuilt runs
         finally:
             rt.SINK.fused = None
             self.opt.runs = saved_runs

@@ -75,6 +75,14 @@ class _WImage:
 _wlist: list = []   # weak references to parameters that own an image (for invalidate_weight_images)
 
 
+def _register(p: Tensor):
+    """ONE weak reference per parameter, however often its image / split is rebuilt (a parameter whose split is dropped
+    after every optimizer step must not grow the list by an entry per step)"""
+    if not getattr(p, "_afft_listed", False):
+        _wlist.append(weakref.ref(p))
+        p._afft_listed = True
+
+
 def weight_images(p: Tensor):
     """(w16, wt16): bf16 images of a 2-D fp32 parameter, zero padded to multiples of 64 --
     w16 [pad(rows), pad(cols)] and its transpose wt16 [pad(cols), pad(rows)] (may be None).
@@ -94,7 +102,7 @@ def weight_images(p: Tensor):
         img.external = False
         img.ptr = p.data_ptr()
         p._afft_img = img
-        _wlist.append(weakref.ref(p))
+        _register(p)
     if img.version != ver:
         with torch.no_grad():
             ops.cast(p.detach(), img.w[:p.shape[0], :p.shape[1]], img.wt[:p.shape[1], :p.shape[0]])
@@ -110,8 +118,7 @@ def weight_split(p: Tensor):
     if ent is None or ent[0] != p._version or ent[1] != p.data_ptr():
         with torch.no_grad():
             sp = ops.Split(p.detach())
-        if ent is None:
-            _wlist.append(weakref.ref(p))
+        _register(p)
         ent = (p._version, p.data_ptr(), sp)
         p._afft_split = ent
     return ent[2]
@@ -137,7 +144,7 @@ def adopt_weight_image(p: Tensor, view16: Tensor, view16_t: Optional[Tensor] = N
     img.external = True
     img.ptr = p.data_ptr()
     p._afft_img = img
-    _wlist.append(weakref.ref(p))
+    _register(p)
 
 
 def invalidate_weight_images(include_external: bool = False):
@@ -153,6 +160,8 @@ def invalidate_weight_images(include_external: bool = False):
             p._afft_split = None
         if img is not None or hasattr(p, "_afft_split"):
             alive.append(r)
+        else:
+            p._afft_listed = False
     _wlist[:] = alive
 
 
@@ -167,11 +176,13 @@ class GradSink:
         self.touch_count: Dict[int, int] = {}   # gradient contributions per parameter in the current step
         self.composite_weights: set = set()     # ids of the weights whose gradient GEMM ran inside a composite backward
         self.fused = None          # callable(param) -> _lib.SgdFused or None: the optimizer fused into that weight's gradient GEMM
+        self.fused_applied: Dict[int, int] = {}  # weights whose update ran in a GEMM epilogue in the current step (-> count)
 
     def begin_step(self):
         self.touched.clear()
         self.touch_count.clear()
         self.composite_weights.clear()     # ids are only meaningful within the step that recorded them
+        self.fused_applied.clear()
 
     def fused_desc(self, p: Tensor):
         """The fused-update descriptor (afft_sgd_fused_t) for weight p, or None: set by afft_amd.parallel.Trainer for the

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- clips/sec (fwd+bwd) of the AFFT hot path on MI355X, BASELINE.json's metric.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without a launcher: starts its own ranks, below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -278,8 +278,28 @@ def comm_report(args, trainer, feats, tgt, sub, world, rank, device, ms_with_com
     return rep
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the ranks ourselves, as the reference does
+    (run.py:34-51 calls `torchrun --nproc_per_node=N` through subprocess).  The launcher is a CHILD process (never an exec: this
+    process must not be replaced, and nothing here has touched the GPU yet); its stdout -- rank 0's JSON line -- is ours, and
+    so is its return code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -375,6 +395,10 @@ def main():
         "model_tflops": round(clips_s * gf / 1e3, 1),
         "mfma_frac_whole_step": round(clips_s * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
         "final_loss": round(loss_val, 4),
+        # N = 1 updates the sub-layer weights inside their weight-gradient GEMM epilogues; with a gradient exchange the summed
+        # gradient has to exist first, so N > 1 runs the per-bucket update kernel (about +0.5 ms/step on cfg2): the N = 1 point
+        # of a scaling curve and the ranks of its N > 1 points differ by that, by construction
+        "optimizer_path": "none" if args.no_optimizer else "fused-epilogue" if trainer._fused else "separate",
     }
 
     if world > 1 and not args.no_comm_report:

@@ -182,18 +182,25 @@ int afft_attention_bwd(const void* dout, int64_t lddo, const void* q, int64_t ld
  *   hard: labels int64[rows], label -1 = ignored row (loss 0, grad 0); any other label outside [0, C) makes the row's
  *   loss and gradient NaN (torch raises a device-side assert there; nothing out of bounds is read);
  *   soft: targets fp32 [rows, C] and
- *   optional keep uint8[rows] (0 = row removed).  loss_sum += sum of row losses (fp32 atomic);
+ *   optional keep uint8[rows] (0 = row removed).  row_loss[r] = the row's loss; loss_sum (optional, needs row_loss)
+ *   += the sum of row_loss added up in row order by a second one-workgroup kernel (no float atomics);
  *   dlogits[r,:] = gscale * row_g[r] * (softmax*sum(target) - target) for kept rows, 0 otherwise (row_g NULL = 1:
  *   the per-row upstream gradient of a reduction='none' loss); columns C..ldd-1 are zeroed. */
 int afft_softmax_ce(const float* logits, int64_t ldl, int32_t rows, int32_t C, const int64_t* labels,
                     const float* soft, int64_t lds, const uint8_t* keep, float gscale, const float* row_g,
                     float* loss_sum, void* dlogits, int64_t ldd, int32_t d_dtype, float* row_loss, void* stream);
+/* Scalar reductions (the MSE loss, the gradient norm) are ORDERED: every workgroup writes one partial sum into the
+ * caller-provided per-stream workspace (the same buffer as afft_gemm_t.workspace / afft_colsum: the partials sit behind its
+ * AFFT_GEMM_WS_HEADER bytes of counters; at most AFFT_REDUCE_PARTIALS floats) and a second one-workgroup kernel adds them up
+ * in workgroup order.  Same inputs -> same bits, on every run. */
+#define AFFT_REDUCE_PARTIALS 2048
 /* MSE between a[rows,d] and b[rows,d] (fp32): loss_sum += lscale * sum (a-b)^2 ;
  * da += gscale*g_dev[0]*2*(a-b) ; db -= the same (common/runner.py:164-166: both sides carry gradient;
- * g_dev = device scalar upstream gradient or NULL = 1).  da/db may be NULL. */
+ * g_dev = device scalar upstream gradient or NULL = 1).  da/db may be NULL.  workspace: see above (only used when
+ * loss_sum != NULL and rows*d > 256). */
 int afft_mse(const float* a, int64_t lda, const float* b, int64_t ldb, int32_t rows, int32_t d, float gscale,
              const float* g_dev, float lscale, float* loss_sum, float* da, int64_t ldda, float* db, int64_t lddb,
-             void* stream);
+             void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ data movement / elementwise
  * fp32 [rows, cols] -> dst dtype copy; if dst_t != NULL also writes the transpose [cols, rows] (ld = ldt).
@@ -290,9 +297,11 @@ int afft_sgd_nesterov(float* p, const void* g, int32_t g_dtype, float* buf, void
 int afft_sgd_nesterov_runs(float* p, const float* g, float* buf, void* p_bf16, const int64_t* runs, int32_t nruns, float lr,
                            float mom, float wd, float gscale, int32_t first_step, void* stream);
 /* Gradient clipping by global norm (train.py:254-260, torch.nn.utils.clip_grad_norm_), without a host sync:
- *   afft_sumsq: *out += scale * sum x[i]^2 over a flat fp32/bf16 buffer (scale = gscale^2 of the optimizer);
+ *   afft_sumsq: *out += scale * sum x[i]^2 over a flat fp32/bf16 buffer (scale = gscale^2 of the optimizer), ordered
+ *   through the stream's workspace (see afft_mse) - the clipping coefficient is bit-reproducible;
  *   afft_clip_coef: *coef = min(1, max_norm / (sqrt(*sumsq) + 1e-6)), *norm_out (optional) = sqrt(*sumsq). */
-int afft_sumsq(const void* x, int32_t dtype, int64_t n, float scale, float* out, void* stream);
+int afft_sumsq(const void* x, int32_t dtype, int64_t n, float scale, float* out, void* workspace, int64_t workspace_bytes,
+               void* stream);
 int afft_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream);
 
 /* ------------------------------------------------------------------ composite entry points: one call = one sub-layer

@@ -238,3 +238,33 @@ def test_two_threads_forward_concurrently_without_sharing_state():
     for n in cases:
         for k, v in serial[n].items():
             assert torch.equal(got[n][k], v), (n, k)
+
+
+def test_weight_image_registry_does_not_grow_with_steps():
+    """runtime._wlist holds ONE weak reference per parameter: a bf16x3 split that is dropped after every optimizer step
+    (FusedSGD.end_step -> invalidate_weight_images) and rebuilt by the next forward must not append an entry per step
+    (the list - and the cost of invalidate - grew linearly with the steps taken)."""
+    from afft_amd import ops, runtime as rt
+
+    class FakeSplit:
+        def __init__(self, x):
+            self.planes, self.rows, self.cols = x.clone(), x.shape[0], x.shape[1]
+
+    saved, ops.Split = ops.Split, FakeSplit
+    try:
+        ws = [torch.nn.Parameter(torch.randn(8, 8)) for _ in range(3)]
+        before = len(rt._wlist)
+        for _ in range(6):
+            for w in ws:
+                sp = rt.weight_split(w)
+                assert rt.weight_split(w) is sp          # cached within a step
+            rt.invalidate_weight_images()
+            assert all(w._afft_split is None for w in ws)
+        assert len(rt._wlist) - before == 3
+        del ws, w, sp
+        import gc
+        gc.collect()
+        rt.invalidate_weight_images()
+        assert len(rt._wlist) == before
+    finally:
+        ops.Split = saved

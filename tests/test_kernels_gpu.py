@@ -89,7 +89,10 @@ def test_gemm(case):
     name, M, N, K, dt, layout, ep = case
     from afft_amd import _lib
     _lib.check(_lib.lib().afft_set_gemm_splitk(0 if "nosplit" in name else 4 if "pp_splitk3" in name else 1))   # 1 = auto (default)
-    _lib.check(_lib.lib().afft_set_gemm_variant(3 if "_pp" in name else 6 if "_w4r" in name else 5 if "_w4" in name else 0))
+    want = 3 if "_pp" in name else 6 if "_w4r" in name else 5 if "_w4" in name else 0
+    if _lib.lib().afft_set_gemm_variant(want) != 0:
+        assert want in (5, 6)
+        pytest.skip("four-wave kernels are in EXPERIMENTAL=1 builds only")
     tdt = torch.bfloat16 if dt == "bf16" else torch.float32
     a_t, b_t = layout[0] == "t", layout[1] == "t"
     lda_pad, ldb_pad = ep.get("lda_pad"), ep.get("ldb_pad")
@@ -597,6 +600,76 @@ def test_colsum_is_exact_enough_and_run_to_run_identical(rows, cols, dt):
         o2 = torch.zeros(cols - 3, device=dev())
         ops.colsum(v, o2)
         assert rel_l2(o2.cpu(), ref[1:cols - 2]) < 1e-5
+
+
+def _busy_neighbour(stream, n=6):
+    """a second stream that keeps the chip busy while the reductions under test run (arrival order of workgroups changes)"""
+    a = torch.randn(2048, 2048, device=dev())
+    with torch.cuda.stream(stream):
+        for _ in range(n):
+            a = torch.tanh(a * 1.0001)
+    return a
+
+
+@pytest.mark.parametrize("rows,d", [(9, 64), (21, 64), (960, 2048), (1984, 2048), (2047, 1030)])
+def test_mse_loss_scalar_is_bit_stable(rows, d):
+    """the MSE scalar of the loss (common/runner.py:164-166) is summed without float atomics: 200 launches on the sizes of the
+    goldens t2_flt (B 3 x (T-1) 3 rows of 64), t3_m5, and of the bench workload cfg2 (64 x 15 rows of 2048) / cfg5 give ONE bit
+    pattern, alone and beside a second busy stream; the value agrees with float64"""
+    from afft_amd import ops
+    a, b = rnd(rows, d, seed=61).to(dev()), rnd(rows, d, seed=62).to(dev())
+    ref = float(((a.double() - b.double()) ** 2).mean())
+    side = torch.cuda.Stream()
+    seen = set()
+    keep = []
+    for i in range(200):
+        if i % 20 == 10:
+            keep.append(_busy_neighbour(side))
+        ls = torch.zeros(1, device=dev())
+        ops.mse(a, b, 1.0, ls, None, None, lscale=1.0 / (rows * d))
+        seen.add(int(ls.view(torch.int32).item()))
+    torch.cuda.synchronize()
+    assert len(seen) == 1, seen
+    got = torch.tensor([seen.pop()], dtype=torch.int32).view(torch.float32).item()
+    assert abs(got - ref) < 2e-6 * abs(ref)
+    # accumulating form: a second call adds to the first
+    ls = torch.zeros(1, device=dev())
+    ops.mse(a, b, 1.0, ls, None, None, lscale=1.0 / (rows * d))
+    ops.mse(a, b, 1.0, ls, None, None, lscale=1.0 / (rows * d))
+    assert abs(float(ls) - 2 * ref) < 4e-6 * abs(ref)
+    assert int(ops.gemm_workspace(a.device)[:4096].view(torch.int32).abs().sum()) == 0     # the split-K counters are not touched
+
+
+@pytest.mark.parametrize("n,dt", [(1000, "f32"), (5_000_003, "f32"), (40_000_000, "bf16")])
+def test_sumsq_and_row_loss_sum_are_bit_stable(n, dt):
+    """gradient-norm partial sums (train.py:254-260 clip_grad_norm_) and the summed row losses of softmax_ce: ordered, so the
+    clipping coefficient - and with it the parameters - are bit-reproducible"""
+    from afft_amd import ops
+    x = rnd(n, seed=63)
+    xd = (x.to(torch.bfloat16) if dt == "bf16" else x).to(dev())
+    ref = float((xd.double() ** 2).sum()) * 0.25
+    side = torch.cuda.Stream()
+    seen, keep = set(), []
+    for i in range(100):
+        if i % 20 == 10:
+            keep.append(_busy_neighbour(side))
+        out = torch.zeros(1, device=dev())
+        ops.sumsq(xd, out, 0.25)
+        seen.add(int(out.view(torch.int32).item()))
+    assert len(seen) == 1, seen
+    got = torch.tensor([seen.pop()], dtype=torch.int32).view(torch.float32).item()
+    assert abs(got - ref) < 1e-5 * ref
+    if dt == "f32" and n == 1000:
+        rows, C = 1088, 3806
+        lg = rnd(rows, C, seed=64, scale=2.0).to(dev())
+        labels = torch.randint(0, C, (rows,), generator=torch.Generator().manual_seed(65)).to(dev())
+        seen = set()
+        for i in range(100):
+            ls, rl = torch.zeros(1, device=dev()), torch.empty(rows, device=dev())
+            ops.softmax_ce(lg, C, labels=labels, loss_sum=ls, row_loss=rl)
+            seen.add(int(ls.view(torch.int32).item()))
+        assert len(seen) == 1, seen
+        assert abs(float(ls) - float(rl.double().sum())) < 1e-5 * float(rl.double().sum())
 
 
 def test_sgd_runs_equals_sgd_over_the_same_ranges():

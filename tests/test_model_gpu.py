@@ -283,6 +283,32 @@ def test_composite_entry_points_equal_call_by_call_path(name, train):
         assert torch.equal(g1[k], g0[k]), k
 
 
+@pytest.mark.parametrize("name", ["t2_flt", "t3_m5", "t1_ca"])
+def test_total_loss_is_bit_stable_over_200_forwards(name):
+    """forward + the three-term loss 200 times on the same batch: ONE bit pattern for the total and for each term (every
+    reduction of the path is ordered; round 2's MSE scalar was a float atomicAdd over workgroups and flipped its last bit)"""
+    from afft_amd import runtime as rt
+    from afft_amd.common.runner import BasicLossAccuracy, Runner
+    c, state, data, tgt, sub = case_tensors(name)
+    dev = torch.device("cuda:0")
+    model = build(c, "bf16")
+    model.load_state_dict(state)
+    model = model.cuda().eval()
+    batch = {m: d.to(dev) for m, d in data.items()}
+    crit = BasicLossAccuracy(False)
+    seen = set()
+    with torch.no_grad():
+        for _ in range(200):
+            out, out_t = model(batch, mixup_fn=None, target={"action": tgt.to(dev)}, target_subclips={"action": sub.to(dev)},
+                               target_subclips_ignore_index=None)
+            losses, _ = crit(out, out_t["target"], out_t["target_subclips"])
+            total, means = Runner._reduce_loss(losses, {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}, sync=False)
+            assert len(means) == 3
+            bits = tuple(int(v.detach().reshape(1).view(torch.int32).item()) for v in [total] + [means[k] for k in sorted(means)])
+            seen.add(bits)
+    assert len(seen) == 1, seen
+
+
 def test_marginalize_verb_noun_matches_reference_golden():
     """afft_amd.challenge.marginalize_verb_noun (row softmax kernel + two exact-fp32 MFMA GEMMs on the device, then the
     host-side accuracy bookkeeping) against tests/golden/m0_marginalize.npz, which the reference's own
@@ -340,6 +366,59 @@ def test_fused_optimizer_epilogue_equals_separate_update(name):
     rt.set_fused_sgd(True)
     for a, b, what in zip(res[True], res[False], ("parameters", "momentum", "bf16 images", "loss")):
         assert (a == b) if isinstance(a, float) else torch.equal(a, b), what
+
+
+def test_fused_optimizer_audit_when_the_graph_changes_between_steps():
+    """The fused set is learned on one step: a later step that routes a weight differently must not lose its
+    update.  (1) A step that SKIPS a sub-layer (its weights get no gradient): the audit applies the regular update to them
+    (momentum decay + weight decay, as the bucket kernel would), drops them from the set, and parameters / momentum / bf16
+    images stay BITWISE those of a Trainer that never fused.  (2) A step that gives fused weights a SECOND contribution
+    (fp_output_len 1 -> 2 rolls the predictor out twice) raises instead of training on half a gradient."""
+    import types
+    from afft_amd import dropout as D_, functional as F_, runtime as rt
+    from afft_amd.parallel import Trainer
+    c, state, data, tgt, sub = case_tensors("t3_m5")
+    dev = torch.device("cuda:0")
+    wts = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
+    feats = {m: d.to(dev) for m, d in data.items()}
+    res = {}
+    for fused in (True, False):
+        rt.set_fused_sgd(fused)
+        D_.manual_seed(5)
+        model = build(c, "bf16")
+        model.load_state_dict(state)
+        model = model.cuda().eval()
+        tr = Trainer(model, wts, lr=1e-2, momentum=0.9, weight_decay=1e-4, bucket_elems=1 << 15)
+        blk = [m for m in model.modules() if hasattr(m, "forward_rows") and hasattr(m, "mlp")][-1]
+        mlp_ids = {id(blk.mlp.mlp[0].weight), id(blk.mlp.mlp[2].weight)}
+        orig = blk.forward_rows
+
+        def attention_only(self, x2, L, mask):
+            a = self.attn
+            return F_.AttnSublayer.apply(x2, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight,
+                                         a.proj.bias, L, a.num_heads, mask, self.norm1.eps, False, True, a.scale, None)
+        for step in range(5):
+            if step == 2:
+                if fused:
+                    assert mlp_ids <= set(tr._fused)
+                blk.forward_rows = types.MethodType(attention_only, blk)
+            elif step == 3:
+                blk.forward_rows = orig
+                if fused:
+                    assert not (mlp_ids & set(tr._fused)) and len(tr._fused) >= 6
+            tr.step(feats, {"action": tgt.to(dev)}, {"action": sub.to(dev)})
+        torch.cuda.synchronize()
+        res[fused] = (tr.flat.flat_p.clone(), tr.opt.buf.clone(), tr.flat.flat_p16.clone())
+        if fused:       # (2) a second gradient contribution to weights already updated in an epilogue
+            cm = [m for m in model.modules() if hasattr(m, "cfg") and hasattr(getattr(m, "cfg"), "common")][0]
+            cm.cfg.common.fp_output_len = 2
+            with pytest.raises(RuntimeError, match="fused optimizer"):
+                tr.step(feats, {"action": tgt.to(dev)}, {"action": sub.to(dev)})
+            torch.cuda.synchronize()
+    rt.set_fused_sgd(True)
+    rt.SINK.fused = None
+    for a, b, what in zip(res[True], res[False], ("parameters", "momentum", "bf16 images")):
+        assert torch.equal(a, b), what
 
 
 @pytest.mark.parametrize("name", ["cfg2", "ek100"])
@@ -1014,6 +1093,38 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     losses = comm["loss_after_20_steps"]
     assert all(v == v and abs(v) < 1e4 for v in losses.values())
     assert abs(comm["loss_delta_bf16_vs_fp32_payload"]) < 0.05 * abs(losses["fp32"])
+
+
+def test_bench_launches_itself_for_two_ranks():
+    """The BARE form `python bench.py --gpus 2` (no launcher, no WORLD_SIZE): bench.py starts `python -m torch.distributed.run`
+    itself as a child process (reference: run.py:34-51 does the same with torchrun), relays rank 0's JSON line and the return
+    code.  Rehearsal mode on this one-GPU box (both ranks on cuda:0, gloo).  `--gpus 1` stays a plain single process."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AFFT_BENCH_BACKEND="gloo", AFFT_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "LOCAL_WORLD_SIZE", "GROUP_RANK"):
+        env.pop(k, None)
+    common = ["--steps", "2", "--warmup", "1", "--config", "ek100", "--batch", "8", "--no-parity-mode", "--no-cpu-baseline"]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-roofline", "--no-comm-report"] + common,
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 16
+    assert d["optimizer_path"] == "separate" and "REHEARSAL" in d["data"]
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, cwd=root, env=env,
+                        capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
+    d1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])
+    assert d1["n_gpus"] == 1 and d1["optimizer_path"] == "fused-epilogue" and d1["roofline"]["frac"] > 0
+    # a failing rank's return code comes back through the launcher
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "no_such_config"] + common[:4],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert bad.returncode != 0
 
 
 def test_forward_under_no_grad_equals_forward_with_grad():

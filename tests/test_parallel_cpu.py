@@ -81,6 +81,81 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
         assert (launched_early == 0) if step == 0 else (launched_early >= 1)
 
 
+def _order_worker(rank, world, port, out, mismatch):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import random
+    import time
+    from afft_amd import runtime as rt
+    from afft_amd.parallel import FlatParams, GradReducer
+    model = _toy()
+    flat = FlatParams(model)
+    red = GradReducer(flat, bucket_elems=64)
+    assert len(red.buckets) >= 4
+    order, launch = [], red._launch
+
+    def recording_launch(b):
+        order[-1].append(b)
+        launch(b)
+    red._launch = recording_launch
+    on_ready = red._on_ready
+    rnd = random.Random(rank)
+
+    def slow_ready(p):           # rank 1's backward lags behind rank 0's by a random 0-20 ms per gradient
+        if rank == 1:
+            time.sleep(rnd.random() * 0.02)
+        on_ready(p)
+    red._on_ready = slow_ready
+    params = list(model.parameters())
+    err = None
+    for step in range(4):
+        x, y = _data(step)
+        xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+        order.append([])
+        red.begin_step()
+        flat.flat_g.zero_()
+        torch.nn.functional.mse_loss(model(xs), ys).backward()
+        ready = list(reversed(params))
+        if mismatch and rank == 1 and step == 0:
+            ready = ready[:-1]           # a replica whose graph misses one gradient: must be an error, not a hang
+        for p in ready:
+            rt.SINK.touched[id(p)] = True
+            if rt.SINK.on_grad_ready is not None:
+                rt.SINK.on_grad_ready(p)
+        try:
+            red.finish_step()
+        except RuntimeError as ex:
+            err = str(ex)
+            break
+    mine = [order, err]
+    both = [None, None]
+    dist.all_gather_object(both, mine)
+    if rank == 0:
+        torch.save(both, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mismatch", [False, True])
+def test_bucket_launch_order_is_the_same_on_a_lagging_rank(tmp_path, mismatch):
+    """The collectives of a step are enqueued per bucket as soon as the learned number of gradients has arrived
+    (GradReducer.expected).  RCCL needs the SAME order on every rank: with rank 1's backward delayed by random sleeps the
+    recorded launch order of every step is identical on both ranks (it depends on the order of the gradients, not on time),
+    and buckets do launch during backward from step 2 on.  A replica that counts differently on step 1 raises on every rank
+    (one all-reduce of the counts when they are learned) instead of deadlocking later.  Reference: train.py:364-368 (DDP)."""
+    out = str(tmp_path / "order.pt")
+    mp.spawn(_order_worker, args=(2, _free_port(), out, mismatch), nprocs=2, join=True)
+    (o0, e0), (o1, e1) = torch.load(out)
+    if mismatch:
+        assert e0 and e1 and "disagree" in e0 and "disagree" in e1
+        return
+    assert e0 is None and e1 is None
+    assert o0 == o1 and len(o0) == 4
+    nb = len(o0[0])
+    assert all(sorted(step) == list(range(nb)) for step in o0)          # every bucket exactly once per step
+    assert o0[0] == list(reversed(range(nb)))                           # step 1: handed over last-to-first after backward
+
+
 def test_flat_params_views_and_alignment():
     from afft_amd.parallel import FlatParams
     model = _toy(3)
