@@ -24,6 +24,7 @@
 //    and the fallback for shapes the fast path does not take.
 //
 // Replaces nn.Linear / HF Conv1D forward, dgrad and wgrad on the AFFT path (see include/afft_hip.h).
+#include <algorithm>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -66,20 +67,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf1
   const int nk = g.K / BK / g.splitk;          // K-steps of this slice
   const int ktbase = blockIdx.y * nk;          // split-K: slice z = blockIdx.y
   static_assert(BM == 128 && BN == 128, "staging helpers assume 128-row / 128-column operand tiles");
-  const unsigned lds0 = lds_addr(smem);
+  const unsigned lds_wave = lds_addr(smem) + wave * 1024;
   const unsigned lda2 = (unsigned)(g.lda * 2), ldb2 = (unsigned)(g.ldb * 2);
   const LaneOffsets lo = lane_offsets(wave, lane);
   const unsigned voffA = A_KS ? lo.ks_row * lda2 + lo.ks_c16 : lo.kc_row * lda2 + lo.kc_chunk16;
   const unsigned voffB = B_KS ? lo.ks_row * ldb2 + lo.ks_c16 : lo.kc_row * ldb2 + lo.kc_chunk16;
   auto stage = [&](int kt) {
-    const unsigned a = lds0 + (kt % STAGES) * STAGE_BYTES;
+    const unsigned a = (kt % STAGES) * STAGE_BYTES;      // bytes into the ring; lds_wave carries the ring's address
     const unsigned b = a + A_BYTES;
     int k0; const bf16_t *Ap, *Bp;
     seg_operands<X3>(g, ktbase + kt, k0, Ap, Bp);
-    if constexpr (A_KS) stage_ks<NW, 16 / NW>(Ap, g.lda, lda2, voffA, lo, m0, k0, a, wave);
-    else stage_kc<NW, 16 / NW>(Ap, g.lda, lda2, voffA, lo, m0, M, k0, a, wave);
-    if constexpr (B_KS) stage_ks<NW, 16 / NW>(Bp, g.ldb, ldb2, voffB, lo, n0, k0, b, wave);
-    else stage_kc<NW, 16 / NW>(Bp, g.ldb, ldb2, voffB, lo, n0, N, k0, b, wave);
+    if constexpr (A_KS) stage_ks<NW, 16 / NW>(Ap, g.lda, lda2, voffA, lo, m0, k0, a, wave, lds_wave);
+    else stage_kc<NW, 16 / NW>(Ap, g.lda, lda2, voffA, lo, m0, M, k0, a, wave, lds_wave);
+    if constexpr (B_KS) stage_ks<NW, 16 / NW>(Bp, g.ldb, ldb2, voffB, lo, n0, k0, b, wave, lds_wave);
+    else stage_kc<NW, 16 / NW>(Bp, g.ldb, ldb2, voffB, lo, n0, N, k0, b, wave, lds_wave);
   };
   // wait until all but the `ahead` most recently issued tiles of this wave have landed, then rendezvous
   auto wait_tiles_then_barrier = [&](int ahead) {
@@ -222,7 +223,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32 g) {
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 int g_splitk_mode = 1;   // 0 off, 1 auto, 2 / 4: force that many slices wherever the shape allows (tests, tuning)
-int g_pp_split_min_nk = [] { const char* e = getenv("AFFT_PP_SPLIT_MIN_NK"); return e ? atoi(e) : (1 << 30); }();
+// stream-K of the 256x256 kernel (choose_splitk): on when the plain grid's utilisation is below AFFT_SK_MAX_EFF and every
+// workgroup gets at least AFFT_SK_MIN_ITERS K-iterations.  Default 0 = never: measured on the path's shapes (profiles/
+// r03_streamk.txt) the balanced launch is 8-12 % SLOWER than the plain partial round -- a K-iteration takes 1.36 us with 160
+// CUs busy and 1.82 us with 256 (the part is power-limited: +60 % CUs buy +10-20 % throughput), and the hand-over of the parked
+// tiles costs 35 us of the rest.  Forced by afft_set_gemm_splitk(2 / 4) in the tests.
+double g_sk_max_eff = [] { const char* e = getenv("AFFT_SK_MAX_EFF"); return e ? atof(e) : 0.0; }();
+int g_sk_min_iters = [] { const char* e = getenv("AFFT_SK_MIN_ITERS"); return e ? atoi(e) : 8; }();
+
+// CUs of the current device (stream-K grids, tile-shape choice): asked once per device ordinal
+int cu_count() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
+  int n = cached[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+    cached[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
 
 // Split-K workspace: provided by the caller per launch (afft_gemm_t.workspace, private to the stream): AFFT_GEMM_WS_HEADER
 // bytes of arrival counters (zero between launches) followed by the fp32 partial tiles.  Nothing is allocated here.
@@ -253,21 +273,46 @@ int launch_fast(GemmFast& g, hipStream_t stream) {
 
 int choose_variant(int M, int N, int K, bool A_KS, bool B_KS);
 
+// stream-K of `tiles` 256x256 tiles of nk K-tiles over a grid of G workgroups (SkPlan, gemm_tiles.h): false when no XCD has a
+// partial round to cut or a piece would be empty; else the workspace geometry (leftover tiles per XCD, pieces per tile)
+bool sk_geometry(int tiles, int G, int nk, int* tlmax, int* smax) {
+  const int W = G >> 3, q = tiles >> 3, r = tiles & 7;
+  int tl_max = 0, s_max = 0;
+  for (int c = 0; c < 2; ++c) {
+    const int count = q + c;
+    if ((c == 1 && r == 0) || (c == 0 && r == 8) || count == 0) continue;
+    const SkPlan p = sk_plan(count, W, nk);
+    if (p.Tl == 0) continue;
+    if (p.Km < 1 || p.tail < 1 || (p.rem2 > 0 && p.rem2 < p.H)) return false;     // every piece at least one K-tile
+    tl_max = std::max(tl_max, p.Tl);
+    for (int il = 0; il < p.Tl; ++il) { int hf; s_max = std::max(s_max, sk_pieces(p, il, hf)); }
+  }
+  if (tl_max == 0) return false;
+  if (tlmax) *tlmax = tl_max;
+  if (smax) *smax = s_max;
+  return true;
+}
+
 // K-slices afft_gemm will use for a fast-path problem (1 = no split-K)
 int choose_splitk(int variant, int M, int N, int K) {
   if (!g_splitk_mode) return 1;
   const int nk = K / BK;
   if (variant == 3) {
-    // 256x256 tiles: a grid that leaves more than a third of the CUs without a tile (160 tiles: every N = 2048 GEMM
-    // of the fuser at B = 64) CAN be cut into 3 K-slices -- 480 workgroups = 2 rounds of a third of K each instead of
-    // 1 round of all of it.  Measured (5120x2048x8192): 194 -> 240 us, the 256-KiB partial tiles (164 MB written and
-    // read back per launch) cost more than the idle CUs; so the automatic mode never picks it (AFFT_PP_SPLIT_MIN_NK
-    // lowers the threshold for experiments) and it stays as a tested path for shapes with much longer K.
+    // 256x256 tiles, one workgroup per CU: STREAM-K (gemm_pp.hip) when the last round of the plain grid would leave the chip
+    // under-used -- 160 tiles (every N = 2048 GEMM of the fuser at B = 64) use 62 % of one round, 640 tiles 83 % of three.
+    // The return value is the stream-K grid: one workgroup per CU, a multiple of 8.  (Round 2's plain 3-slice split of these
+    // grids lost: 480 workgroups wrote and re-read 164 MB of partial tiles with 4-byte write-through stores.)
     const int64_t t3 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
-    int s = 1;
-    if (g_splitk_mode == 1) s = (t3 * 3 <= 512 && t3 > 128 && nk >= g_pp_split_min_nk) ? 3 : 1;
-    else if (g_splitk_mode > 1 && nk >= 2 * g_splitk_mode) s = g_splitk_mode == 4 ? 3 : 2;
-    return (s > 1 && t3 <= kMaxSplitTiles) ? s : 1;
+    const int ncu = cu_count() & ~7;
+    if (t3 > kMaxSplitTiles || ncu < 8) return 1;
+    if (!sk_geometry((int)t3, ncu, nk, nullptr, nullptr)) return 1;      // nothing to cut, or a piece would be empty
+    const int64_t rounds = (t3 + ncu - 1) / ncu;
+    const double eff = (double)t3 / (double)(rounds * ncu);
+    const int64_t per_wg = t3 * nk / ncu;          // K-iterations per workgroup
+    bool on = false;
+    if (g_splitk_mode == 1) on = eff < g_sk_max_eff && per_wg >= g_sk_min_iters;
+    else if (g_splitk_mode > 1) on = true;             // forced (tests, tuning)
+    return on ? ncu : 1;
   }
   // 128x128 tiles (2 workgroups per CU = 512 slots): a grid that leaves slots empty is bound by the LDS fill rate of the CUs
   // that have a workgroup -- more workgroups pulling is the lever.  Cut K so that tiles x slices approaches 512, keeping at
@@ -292,8 +337,13 @@ int64_t splitk_bytes(int variant, int M, int N, int K, int* slices) {
   const int s = variant >= 4 ? 1 : choose_splitk(variant, M, N, K);
   if (slices) *slices = s;
   if (s <= 1) return 0;
-  const int64_t tiles = variant == 3 ? (int64_t)((M + 255) / 256) * ((N + 255) / 256) : (int64_t)((M + 127) / 128) * ((N + 127) / 128);
-  return tiles * s * (variant == 3 ? 256 * 256 : 128 * 128) * (int64_t)sizeof(float);
+  if (variant == 3) {      // stream-K: parked tiles [8 XCDs][leftover tiles][pieces]
+    int tlmax = 0, smax = 0;
+    sk_geometry(((M + 255) / 256) * ((N + 255) / 256), s, K / BK, &tlmax, &smax);
+    return (int64_t)8 * tlmax * smax * 256 * 256 * (int64_t)sizeof(float);
+  }
+  const int64_t tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
+  return tiles * s * 128 * 128 * (int64_t)sizeof(float);
 }
 
 template <bool A_KS, bool B_KS>
@@ -336,6 +386,7 @@ int launch_layout_impl(GemmFast& g, hipStream_t stream, const afft_gemm_t* d) {
     g.counters = (int*)d->workspace;
     g.ws = (float*)((char*)d->workspace + AFFT_GEMM_WS_HEADER);
     g.splitk = s;
+    if (variant == 3) sk_geometry(((g.e.M + 255) / 256) * ((g.e.N + 255) / 256), s, g.K / BK, &g.sk_tlmax, &g.sk_smax);
   }
   if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream, 0, d->max_workgroups);
   if (variant == 4) return launch_fast<2, 2, 4, A_KS, B_KS, false>(g, stream);
@@ -358,7 +409,8 @@ int choose_variant(int M, int N, int K, bool A_KS, bool B_KS) {
   // big tiles = 1.25 rounds (57 us on 128x128 tiles, 66 us on 256x256), 5120x3072x1024 is 240 = one nearly full round (45
   // vs 38 us); 5120x2048x2048 (160 big tiles) 60 vs 55 us.
   const int64_t t1 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
-  const double u3 = (double)t3 / (256.0 * ((t3 + 255) / 256)), u1 = (double)t1 / (512.0 * ((t1 + 511) / 512));
+  const int ncu = cu_count();
+  const double u3 = (double)t3 / ((double)ncu * ((t3 + ncu - 1) / ncu)), u1 = (double)t1 / (2.0 * ncu * ((t1 + 2 * ncu - 1) / (2 * ncu)));
   return u3 * 1.25 >= u1 ? 3 : 1;
 }
 

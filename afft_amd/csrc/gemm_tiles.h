@@ -27,9 +27,11 @@ struct GemmFast {
   const bf16_t* B; int64_t ldb;  // k-contiguous: B[N][K] ; k-strided: B[K][N]
   int K;
   int tiles_m, tiles_n;
-  int splitk;   // K is cut into `splitk` slices along gridDim.y; 1 = off
-  float* ws;    // split-K: fp32 partial tiles [tile][slice][128*128]
-  int* counters;  // split-K: arrivals per tile (zero between launches)
+  int splitk;   // 128x128 kernel: K is cut into `splitk` slices along gridDim.y; 256x256 kernel: > 1 = stream-K over a grid of
+                // `splitk` workgroups (gemm_pp.hip); 1 = off
+  float* ws;    // split-K: fp32 partial tiles [tile][slice][128*128]; stream-K: [workgroup][2][256*256]
+  int* counters;  // split-K / stream-K: arrivals per tile (zero between launches)
+  int sk_tlmax, sk_smax;   // stream-K workspace geometry: parked tiles [xcd][sk_tlmax leftover tiles][sk_smax pieces][256*256]
   // bf16x3 (X3 instantiations): K counts the K-tiles of all three segments, nk_seg of them per segment; segment 0 reads
   // (A hi, B hi), 1 (A lo, B hi), 2 (A hi, B lo); the lo planes sit a_lo / b_lo elements behind A / B
   int nk_seg;
@@ -50,15 +52,15 @@ __device__ __forceinline__ void seg_operands(const GemmFast& g, int kt, int& k0,
   k0 = kt * BK;
 }
 
-// bid: the workgroup's (virtual) index -- blockIdx.x, or blockIdx.x + i * gridDim.x for the i-th tile of a workgroup of a
-// capped grid whose size is a multiple of 8 (the XCD of bid is then the XCD the workgroup really runs on)
-__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int bid, int& tm, int& tn) {
-  // XCD-aware remap: workgroups b and b+8 share an XCD (and its L2); give each XCD a contiguous
-  // chunk of the tile list, then walk that chunk in GROUP_M-tall column groups so that co-resident
-  // tiles share A row-panels and B column-panels in that XCD's L2.
-  const int nwg = tiles_m * tiles_n;
-  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-  int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+// XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2); each XCD gets a contiguous chunk of the tile list
+// (xcd_chunk), and a chunk is walked in GROUP_M-tall column groups (tile_from_id) so that co-resident tiles share A
+// row-panels and B column-panels in that XCD's L2.
+__device__ __forceinline__ void xcd_chunk(int ntiles, int xcd, int& first, int& count) {
+  const int q = ntiles >> 3, r = ntiles & 7;
+  first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  count = q + (xcd < r ? 1 : 0);
+}
+__device__ __forceinline__ void tile_from_id(int tiles_m, int tiles_n, int id, int& tm, int& tn) {
   const int width = GROUP_M * tiles_n;
   const int group = id / width;
   const int first_m = group * GROUP_M;
@@ -66,6 +68,39 @@ __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int bid, i
   const int in_group = id - group * width;
   tm = first_m + in_group % gsz;
   tn = in_group / gsz;
+}
+// bid: the workgroup's (virtual) index -- blockIdx.x, or blockIdx.x + i * gridDim.x for the i-th tile of a workgroup of a
+// capped grid whose size is a multiple of 8 (the XCD of bid is then the XCD the workgroup really runs on)
+__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int bid, int& tm, int& tn) {
+  int first, count;
+  xcd_chunk(tiles_m * tiles_n, bid & 7, first, count);
+  tile_from_id(tiles_m, tiles_n, first + (bid >> 3), tm, tn);
+}
+
+// ----- stream-K plan of the 256x256 kernel (gemm_pp.hip), per XCD: W workgroups share `count` tiles of nk K-tiles each.
+// R whole rounds are plain (workgroup j runs tiles j, j + W, ... with the ordinary epilogue, all at the same K offset at the
+// same time, so the XCD's L2 serves the shared A row / B column panels as in the plain kernel).  The Tl < W LEFTOVER tiles are
+// what a plain grid would run as a partial round: workgroups 0..Tl-1 ("mains") run the first Km = Tl * nk / W K-tiles of
+// leftover tile j -- again aligned in K -- and the H = W - Tl others ("helpers") share the tails [Km, nk): helper h first
+// takes the whole tail of tiles h, h + H, ... (F of them, aligned among the helpers), then a contiguous range of what is
+// left (Tr tails, cut evenly).  Everybody gets R * nk + Km iterations (+-1).  A first attempt that cut the tile-major
+// iteration space into equal contiguous ranges lost 25 % instead: neighbouring workgroups then sit at different K offsets
+// and nothing is shared in L2 any more (5120x2048x8192: 236 us against 185 us plain).
+struct SkPlan { int W, R, Tl, Km, tail, H, F, Tr, rem2; };
+__host__ __device__ __forceinline__ SkPlan sk_plan(int count, int W, int nk) {
+  SkPlan p;
+  p.W = W; p.R = count / W; p.Tl = count - p.R * W;
+  p.Km = (int)(((long long)p.Tl * nk) / W); p.tail = nk - p.Km; p.H = W - p.Tl;
+  p.F = p.Tl / p.H; p.Tr = p.Tl - p.F * p.H; p.rem2 = p.Tr * p.tail;
+  return p;
+}
+// pieces of leftover tile il (0 = the main's head, then the helpers' pieces in K order): how many, and the first helper
+__host__ __device__ __forceinline__ int sk_pieces(const SkPlan& p, int il, int& h_first) {
+  if (il < p.F * p.H) { h_first = il % p.H; return 2; }
+  const long long x0 = (long long)(il - p.F * p.H) * p.tail, x1 = x0 + p.tail - 1;
+  h_first = (int)(((x0 + 1) * p.H - 1) / p.rem2);           // helper h owns [h * rem2 / H, (h + 1) * rem2 / H)
+  const int h_last = (int)(((x1 + 1) * p.H - 1) / p.rem2);
+  return 2 + h_last - h_first;
 }
 
 // ----- LDS-DMA staging, scalar-base form: global_load_lds_dwordx4 voff32, s[base:base+1] with M0 = LDS destination.
@@ -92,12 +127,16 @@ __device__ __forceinline__ LaneOffsets lane_offsets(int wave, int lane) {   // N
   o.ks_c16 = (unsigned)((((((lane & 15) >> 1) ^ ((lane >> 4) | (((wave >> 1) & 1) << 2))) << 1) | (lane & 1)) << 4);
   return o;
 }
-__device__ __forceinline__ void glds16(const char* sbase, unsigned voff, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_dst) : "memory");
+// LDS destination = lds_wave (the one live scalar: the tile ring's LDS address + this wave's 1-KiB lane of every piece) + off (a
+// plain number: ring slot, piece).  Round 2 passed the sum: the compiler then kept one precomputed SGPR per (slot, piece) --
+// 16-22 of them -- alive across the main loop, and in the looping instantiations (stream-K, capped grid) spilled them to VGPR
+// lanes and read them back between the LDS-DMA issues (22 v_readlane per two K-tiles).  An immediate is rematerialised instead.
+__device__ __forceinline__ void glds16(const char* sbase, unsigned voff, unsigned lds_wave, unsigned off) {
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_wave), "s"(off) : "memory", "scc");
 }
 // 4 bytes per lane (256 B per wave-instruction): the cheapest operation that still counts in vmcnt (K-loop overshoot)
-__device__ __forceinline__ void glds4(const char* sbase, unsigned voff, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_dst) : "memory");
+__device__ __forceinline__ void glds4(const char* sbase, unsigned voff, unsigned lds_wave, unsigned off) {
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_wave), "s"(off) : "memory", "scc");
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(AFFT_LDS const char*)p; }
 
@@ -123,33 +162,36 @@ __device__ __forceinline__ void src_ks_piece(const bf16_t* __restrict__ G, int64
   voff = voff_full;
   if (limc < 240) voff = lo.ks_row * ld2 + min(lo.ks_c16, (unsigned)max(limc, 0));
 }
-// rows row0.. of a k-contiguous operand G[nrows][ld], K offset k0 -> PIECES pieces of this wave at LDS address dst
+// rows row0.. of a k-contiguous operand G[nrows][ld], K offset k0 -> PIECES pieces of this wave at byte `dst` of the ring
+// (lds_wave = LDS address of the ring + wave * 1024)
 template <int NW>
 __device__ __forceinline__ void stage_kc_piece(const bf16_t* __restrict__ G, int64_t ld, unsigned ld2, unsigned voff_full,
-                                               const LaneOffsets& lo, int row0, int nrows, int k0, unsigned dst, int wave, int jj) {
+                                               const LaneOffsets& lo, int row0, int nrows, int k0, unsigned dst, int wave, int jj,
+                                               unsigned lds_wave) {
   const char* sbase; unsigned voff;
   src_kc_piece<NW>(G, ld, ld2, voff_full, lo, row0, nrows, k0, wave, jj, sbase, voff);
-  glds16(sbase, voff, dst + (wave + jj * NW) * 1024);
+  glds16(sbase, voff, lds_wave, dst + jj * NW * 1024);
 }
 template <int NW, int PIECES>
 __device__ __forceinline__ void stage_kc(const bf16_t* __restrict__ G, int64_t ld, unsigned ld2, unsigned voff_full,
-                                         const LaneOffsets& lo, int row0, int nrows, int k0, unsigned dst, int wave) {
+                                         const LaneOffsets& lo, int row0, int nrows, int k0, unsigned dst, int wave, unsigned lds_wave) {
 #pragma unroll
-  for (int jj = 0; jj < PIECES; ++jj) stage_kc_piece<NW>(G, ld, ld2, voff_full, lo, row0, nrows, k0, dst, wave, jj);
+  for (int jj = 0; jj < PIECES; ++jj) stage_kc_piece<NW>(G, ld, ld2, voff_full, lo, row0, nrows, k0, dst, wave, jj, lds_wave);
 }
 // columns col0..col0+127 of a k-strided operand G[K][ld], K rows k0..k0+63
 template <int NW>
 __device__ __forceinline__ void stage_ks_piece(const bf16_t* __restrict__ G, int64_t ld, unsigned ld2, unsigned voff_full,
-                                               const LaneOffsets& lo, int col0, int k0, unsigned dst, int wave, int jj) {
+                                               const LaneOffsets& lo, int col0, int k0, unsigned dst, int wave, int jj,
+                                               unsigned lds_wave) {
   const char* sbase; unsigned voff;
   src_ks_piece<NW>(G, ld, ld2, voff_full, lo, col0, k0, wave, jj, sbase, voff);
-  glds16(sbase, voff, dst + (wave + jj * NW) * 1024);
+  glds16(sbase, voff, lds_wave, dst + jj * NW * 1024);
 }
 template <int NW, int PIECES>
 __device__ __forceinline__ void stage_ks(const bf16_t* __restrict__ G, int64_t ld, unsigned ld2, unsigned voff_full,
-                                         const LaneOffsets& lo, int col0, int k0, unsigned dst, int wave) {
+                                         const LaneOffsets& lo, int col0, int k0, unsigned dst, int wave, unsigned lds_wave) {
 #pragma unroll
-  for (int jj = 0; jj < PIECES; ++jj) stage_ks_piece<NW>(G, ld, ld2, voff_full, lo, col0, k0, dst, wave, jj);
+  for (int jj = 0; jj < PIECES; ++jj) stage_ks_piece<NW>(G, ld, ld2, voff_full, lo, col0, k0, dst, wave, jj, lds_wave);
 }
 __device__ __forceinline__ bf16x8 frag_kc(const char* lds_tile, int row, int chunk) {
   return *(const bf16x8*)(lds_tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
@@ -171,48 +213,75 @@ __device__ __forceinline__ bf16x8 frag_ks(const char* lds_tile, int kb, int unit
   return f;
 }
 
-// ----- split-K hand-over ("last arriver"): every slice of a tile parks its fp32 partial (NV f32x4 per thread, NT threads)
-// in the workspace with system-scope (write-through) stores and counts itself in; the slice whose count completes the
-// tile adds the partials in slice order -- bitwise the same sum whoever it is -- and returns true (it runs the
-// epilogue); the others return false and exit.  No workgroup waits for another, so nothing can deadlock, and there is
-// no release/acquire fence: an agent-scope release writes the whole L2 back and an acquire invalidates it, which costs
-// every other workgroup of the launch its cached operand tiles (measured +30 us per GEMM).
-// smem: at least 4 bytes of LDS nobody else touches between the two barriers inside.
+// ----- split-K / stream-K hand-over ("last arriver"): every K-segment of a tile parks its fp32 partial (NV f32x4 per thread,
+// NT threads) in the workspace and counts itself in; the segment whose count completes the tile adds the partials in
+// segment order -- bitwise the same sum whoever it is -- and returns true (it runs the epilogue); the others return false.
+// No workgroup waits for another, so nothing can deadlock, and there is no release/acquire fence (an agent-scope release
+// writes the whole L2 back and an acquire invalidates it: +30 us per GEMM measured).  The form is the guide's split-K seam
+// (MI355X_MICROARCH.md, visibility: first row of the sc1 table): EVERY payload store a 16-byte write-through buffer store,
+// every storing wave drains (s_waitcnt vmcnt(0)) before the workgroup barrier, ONE lane adds to the tile's counter (agent
+// scope), the workgroup whose add came last reads EVERY payload byte with 16-byte sc loads behind a barrier.  Round 2 stored
+// the partials as 4-byte system-scope atomics: one fabric write per dword, ~6x the time per byte of a 16-byte store.
+// slot(sl): wave-uniform base pointer of segment sl's partial [NV][NT] x 16 B.  smem: 4 bytes of LDS nobody else touches
+// between the two barriers inside.
+#ifndef AFFT_HANDOFF_AUX
+#define AFFT_HANDOFF_AUX 17      // cache policy of the payload stores and loads: 16 = sc1 (agent), 17 = sc0 sc1 (system)
+#endif
+#ifndef AFFT_HANDOFF_DIAG
+#define AFFT_HANDOFF_DIAG 0      // diagnostic builds only (wrong results): 1 = no payload stores, 2 = no payload loads
+#endif
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+template <int NV, int NT, class SlotFn>
+__device__ __forceinline__ bool handoff_combine(f32x4 (&acc)[NV], SlotFn&& slot, int* counter, int S, int me, int tid, char* smem) {
+  constexpr int SLICE_BYTES = NV * NT * 16;
+  // Segment 0 looks before it parks: if every other segment has already arrived it is the last one -- it keeps its
+  // accumulators, adds the others to them in K order (a + b = b + a bitwise) and nothing of its own goes to memory.  In the
+  // stream-K plan segment 0 is the main's head, which finishes after the helpers' tails: the common case.
+  bool last_without_parking = false;
+  if (me == 0) {
+    if (tid == 0) *(volatile int*)smem = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    last_without_parking = __builtin_amdgcn_readfirstlane(*(volatile int*)smem) == S - 1;
+    __syncthreads();
+  }
+  if (!last_without_parking) {
+    {
+      const __amdgpu_buffer_rsrc_t mine = __builtin_amdgcn_make_buffer_rsrc(slot(me), 0, SLICE_BYTES, 0x00020000);
+      static_for<0, NV>([&](auto idx) {
+        constexpr int v = decltype(idx)::value;
+        if (!(AFFT_HANDOFF_DIAG & 1))
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[v]), mine, tid * 16, v * NT * 16, AFFT_HANDOFF_AUX);
+      });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial has been written through
+    __syncthreads();
+    if (tid == 0) *(volatile int*)smem = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int arrived = __builtin_amdgcn_readfirstlane(*(volatile int*)smem);    // workgroup-uniform: callers branch on the result
+    if (arrived != S - 1) return false;
+  }
+  // every parked segment is read back from the workspace, this workgroup's own too (the same bits as its registers): no
+  // second set of NV accumulators -> no spills (256 accumulator + sum registers did not fit beside the 256x256 kernel's 128)
+  for (int sl = last_without_parking ? 1 : 0; sl < S; ++sl) {
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(slot(sl), 0, SLICE_BYTES, 0x00020000);
+    static_for<0, NV>([&](auto idx) {
+      constexpr int v = decltype(idx)::value;
+      f32x4 t = acc[v];
+      if (!(AFFT_HANDOFF_DIAG & 2))
+      t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(src, tid * 16, v * NT * 16, AFFT_HANDOFF_AUX));
+      acc[v] = sl == 0 ? t : acc[v] + t;
+    });
+  }
+  if (tid == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+  return true;
+}
+
+// plain split-K: the S slices of tile `tile` sit side by side in the workspace
 template <int NV, int NT>
 __device__ __forceinline__ bool splitk_combine(f32x4 (&acc)[NV], float* ws, int* counters, int tile, int S, int me, int tid,
                                                char* smem) {
   float* tile_ws = ws + (int64_t)tile * S * (NV * NT * 4);
-  float* mine = tile_ws + (int64_t)me * (NV * NT * 4);
-  static_for<0, NV>([&](auto idx) {
-    constexpr int v = decltype(idx)::value;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      __hip_atomic_store(mine + (v * 4 + r) * NT + tid, acc[v][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  });
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's partial has been written through
-  __syncthreads();
-  if (tid == 0) *(volatile int*)smem = __hip_atomic_fetch_add(counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  const int arrived = *(volatile int*)smem;
-  if (arrived != S - 1) return false;
-  f32x4 sum[NV];
-  static_for<0, NV>([&](auto idx) { sum[decltype(idx)::value] = f32x4{0.f, 0.f, 0.f, 0.f}; });
-  for (int sl = 0; sl < S; ++sl) {
-    const float* src = tile_ws + (int64_t)sl * (NV * NT * 4);
-    static_for<0, NV>([&](auto idx) {
-      constexpr int v = decltype(idx)::value;
-      f32x4 t = acc[v];
-      if (sl != me) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          t[r] = __hip_atomic_load(src + (v * 4 + r) * NT + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-      sum[v] += t;
-    });
-  }
-  static_for<0, NV>([&](auto idx) { acc[decltype(idx)::value] = sum[decltype(idx)::value]; });
-  if (tid == 0) __hip_atomic_store(counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
-  return true;
+  return handoff_combine<NV, NT>(acc, [&](int sl) { return tile_ws + (int64_t)sl * (NV * NT * 4); }, counters + tile, S, me, tid, smem);
 }
 
 template <int N>

@@ -114,15 +114,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmFast g) {
     // past the end of K the stream re-reads the last K-tile into the (dead) ring slot: no guard, and the number of
     // LDS-DMA instructions in flight is the same in every phase -> one constant counted wait, no scalar branch chain
     const int kt = min(m >> 2, nk - 1);
-    const unsigned dst = lds0 + (((m >> 2) & 1) * 4 + q) * HB;
+    const unsigned dst = (((m >> 2) & 1) * 4 + q) * HB, lds_wave = lds0 + wave * 1024;
     if (q == 0 || q == 3) {
       const int r0 = m0 + (q == 3 ? 128 : 0);
-      if constexpr (A_KS) stage_ks_piece<4>(g.A, g.lda, lda2, voffA, lo, r0, kt * BK, dst, wave, jj);
-      else stage_kc_piece<4>(g.A, g.lda, lda2, voffA, lo, r0, M, kt * BK, dst, wave, jj);
+      if constexpr (A_KS) stage_ks_piece<4>(g.A, g.lda, lda2, voffA, lo, r0, kt * BK, dst, wave, jj, lds_wave);
+      else stage_kc_piece<4>(g.A, g.lda, lda2, voffA, lo, r0, M, kt * BK, dst, wave, jj, lds_wave);
     } else {
       const int c0 = n0 + (q == 2 ? 128 : 0);
-      if constexpr (B_KS) stage_ks_piece<4>(g.B, g.ldb, ldb2, voffB, lo, c0, kt * BK, dst, wave, jj);
-      else stage_kc_piece<4>(g.B, g.ldb, ldb2, voffB, lo, c0, N, kt * BK, dst, wave, jj);
+      if constexpr (B_KS) stage_ks_piece<4>(g.B, g.ldb, ldb2, voffB, lo, c0, kt * BK, dst, wave, jj, lds_wave);
+      else stage_kc_piece<4>(g.B, g.ldb, ldb2, voffB, lo, c0, N, kt * BK, dst, wave, jj, lds_wave);
     }
   };
   auto issue = [&](int m, int q) {

@@ -48,7 +48,8 @@ def _rowmajor(t: Tensor, what: str):
 
 
 _WS: dict = {}      # (device index, raw stream) -> split-K scratch of that stream (afft_gemm_t.workspace), never shared
-_WS_BYTES = 48 << 20   # covers every split-K problem the automatic mode picks (<= 128 tiles x 4 slices x 64 KiB + header)
+_WS_BYTES = (132 << 20)   # header + stream-K of the 256x256 kernel (256 workgroups x 2 parked tiles x 256 KiB = 128 MiB); also covers every
+                          # split-K problem of the 128x128 kernel the automatic mode picks (<= 128 tiles x 4 slices x 64 KiB)
 
 
 def set_workspace_bytes(n: int):

@@ -58,11 +58,19 @@ GEMM_CASES = [
     ("nt_bf16_splitk2_gelu", 256, 256, 2048, "bf16", "nt", dict(bias=True, act=1, pre=True)),
     ("tn_bf16_splitk4_acc", 200, 130, 6144, "bf16", "tn", dict(out_f32=True, accumulate=True, lda_pad=256, ldb_pad=192)),
     ("nt_bf16_nosplit_gelu", 256, 256, 2048, "bf16", "nt", dict(bias=True, act=1)),
-    # 256x256 ping-pong kernel forced, 3 uneven K-slices (10 K-tiles -> 3 + 3 + 4), every layout
+    # 256x256 ping-pong kernel forced into STREAM-K (one workgroup per CU walks a range of the launch's K-iterations): a few
+    # tiles cut into many one-iteration segments, every layout
     ("nt_bf16_pp_splitk3", 512, 520, 640, "bf16", "nt", dict(bias=True, act=1, pre=True)),
     ("nn_bf16_pp_splitk3", 300, 512, 640, "bf16", "nn", dict(bias=True, residual=True, out_f32=True)),
     ("tn_bf16_pp_splitk3", 512, 264, 704, "bf16", "tn", dict(out_f32=True)),
     ("nt_bf16_pp", 300, 520, 192, "bf16", "nt", dict(bias=True, act=2, out2=True)),
+    # stream-K ranges that hold the tail of one tile, whole tiles and the head of the next (20 / 80 / 640 tiles, row and column
+    # tails, the weight-gradient layout accumulating into fp32)
+    ("nt_bf16_pp_splitk3_sk20", 1280, 1000, 1024, "bf16", "nt", dict(bias=True, residual=True, out_f32=True, rowscale=True)),
+    ("nn_bf16_pp_splitk3_sk80", 2500, 2048, 2048, "bf16", "nn", dict(act=3)),
+    ("tn_bf16_pp_splitk3_sk48_acc", 2048, 1536, 1088, "bf16", "tn", dict(out_f32=True, accumulate=True)),
+    ("nt_bf16_pp_splitk3_sk640", 5120, 8192, 512, "bf16", "nt", dict(bias=True, act=1, pre=True)),
+    ("nt_bf16_pp_splitk3_sk160", 5120, 2048, 1024, "bf16", "nt", dict(bias=True, residual=True, out_f32=True)),   # the fuser's 160-tile grid
     # 256x256 four-wave kernel (accumulators in AGPRs) forced: every layout, row / column tails, odd and even K-tile counts
     ("nt_bf16_w4", 300, 520, 192, "bf16", "nt", dict(bias=True, act=2, out2=True)),
     ("nt_bf16_w4_long", 512, 768, 1024, "bf16", "nt", dict(bias=True, act=1, pre=True)),

@@ -373,7 +373,7 @@ def test_fused_optimizer_audit_when_the_graph_changes_between_steps():
     update.  (1) A step that SKIPS a sub-layer (its weights get no gradient): the audit applies the regular update to them
     (momentum decay + weight decay, as the bucket kernel would), drops them from the set, and parameters / momentum / bf16
     images stay BITWISE those of a Trainer that never fused.  (2) A step that gives fused weights a SECOND contribution
-    (fp_output_len 1 -> 2 rolls the predictor out twice) raises instead of training on half a gradient."""
+    (a block applied twice in one forward) raises instead of training on half a gradient."""
     import types
     from afft_amd import dropout as D_, functional as F_, runtime as rt
     from afft_amd.parallel import Trainer
@@ -389,7 +389,8 @@ def test_fused_optimizer_audit_when_the_graph_changes_between_steps():
         model.load_state_dict(state)
         model = model.cuda().eval()
         tr = Trainer(model, wts, lr=1e-2, momentum=0.9, weight_decay=1e-4, bucket_elems=1 << 15)
-        blk = [m for m in model.modules() if hasattr(m, "forward_rows") and hasattr(m, "mlp")][-1]
+        from afft_amd.models.transformerblock import Block
+        blk = [m for m in model.modules() if isinstance(m, Block)][-1]
         mlp_ids = {id(blk.mlp.mlp[0].weight), id(blk.mlp.mlp[2].weight)}
         orig = blk.forward_rows
 
@@ -410,8 +411,9 @@ def test_fused_optimizer_audit_when_the_graph_changes_between_steps():
         torch.cuda.synchronize()
         res[fused] = (tr.flat.flat_p.clone(), tr.opt.buf.clone(), tr.flat.flat_p16.clone())
         if fused:       # (2) a second gradient contribution to weights already updated in an epilogue
-            cm = [m for m in model.modules() if hasattr(m, "cfg") and hasattr(getattr(m, "cfg"), "common")][0]
-            cm.cfg.common.fp_output_len = 2
+            def twice(self, x2, L, mask):
+                return orig(orig(x2, L, mask)[0], L, mask)
+            blk.forward_rows = types.MethodType(twice, blk)
             with pytest.raises(RuntimeError, match="fused optimizer"):
                 tr.step(feats, {"action": tgt.to(dev)}, {"action": sub.to(dev)})
             torch.cuda.synchronize()
