@@ -16,6 +16,12 @@ using namespace afft_gemm_detail;
 #ifndef AFFT_PP_EPI_UNROLL
 #define AFFT_PP_EPI_UNROLL 2  // row steps of the epilogue in flight per thread: 2 takes 8-12 us off the GELU epilogues of a 5120x8192 output, 4 loses again
 #endif
+#ifndef AFFT_PP_DMA_IN_C
+#define AFFT_PP_DMA_IN_C 0    // experiment: issue a phase's two LDS-DMA instructions INSIDE its MFMA segment (after AFFT_PP_DMA_AT MFMAs: the
+#endif                        // matrix pipe has queued work, the VMEM issue is free) instead of in the L segment, the longer of the two
+#ifndef AFFT_PP_DMA_AT
+#define AFFT_PP_DMA_AT 4
+#endif
 #ifndef AFFT_PP_DIAG
 #define AFFT_PP_DIAG 0    // diagnostic builds only (wrong results): 1 = no fragment reads, 2 = no LDS-DMA in the loop, 4 = no MFMA,
                           // 8 = no global accesses in the epilogue, 16 = no epilogue at all
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
   auto wait_then_barrier = [&](int n) {
     STAMP(t1);
 #if AFFT_PP_CLAMP
-    const int out = LEAD - 3; (void)n;
+    const int out = LEAD - 3 - (AFFT_PP_DMA_IN_C ? 1 : 0); (void)n;    // DMA in the C segment: the newest half-tile is issued one segment later
 #else
     const int last = min(n + LEAD, NH - 1);
     const int out = last - (n + 3);           // half-tiles allowed to stay in flight
@@ -258,8 +264,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
     STAMP(t3);
     sL += t1 - t0; sW += t2 - t1; sB1 += t3 - t2;
   };
-  auto compute = [&](auto ihc, auto jhc, auto slotc) {
+  auto compute = [&](auto ihc, auto jhc, auto slotc, int dma_m, int dma_q) {
     constexpr int ih = decltype(ihc)::value, jh = decltype(jhc)::value, slot = decltype(slotc)::value;
+    (void)dma_m; (void)dma_q;
     __builtin_amdgcn_sched_barrier(0);
     if (AFFT_PP_PRIO == 1) __builtin_amdgcn_s_setprio(1);
     if (!(AFFT_PP_DIAG & 4))
@@ -268,8 +275,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
+          if (AFFT_PP_DMA_IN_C && (s * 8 + i * 2 + j) == AFFT_PP_DMA_AT) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue(dma_m, dma_q);
+            __builtin_amdgcn_sched_barrier(0);
+          }
           acc[ih][jh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bF[slot][j][s], aF[i][s], acc[ih][jh][i][j], 0, 0, 0);
+        }
     if (AFFT_PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     STAMP(t4);
@@ -300,13 +313,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
     const int n = 4 * kt;
     auto L = [&](auto reads, int m, int q) {
       if (AFFT_PP_PRIO == 2) __builtin_amdgcn_s_setprio(1);
-      if (AFFT_PP_DMA_FIRST) { issue(m, q); reads(); } else { reads(); issue(m, q); }
+      if (AFFT_PP_DMA_IN_C) reads();
+      else if (AFFT_PP_DMA_FIRST) { issue(m, q); reads(); } else { reads(); issue(m, q); }
       if (AFFT_PP_PRIO == 2) __builtin_amdgcn_s_setprio(0);
     };
-    L([&] { load_a(kt, 0); }, n + 0 + LEAD, (0 + LEAD) & 3);            wait_then_barrier(n + 0); compute(I0{}, I0{}, SP{});
-    L([&] { load_b(kt, 1, SQ{}); }, n + 1 + LEAD, (1 + LEAD) & 3);      wait_then_barrier(n + 1); compute(I0{}, I1{}, SQ{});
-    L([&] { load_a(kt, 1); }, n + 2 + LEAD, (2 + LEAD) & 3);            wait_then_barrier(n + 2); compute(I1{}, I1{}, SQ{});
-    L([&] { load_b(kt + 1, 0, SQ{}); }, n + 3 + LEAD, (3 + LEAD) & 3);  wait_then_barrier(n + 3); compute(I1{}, I0{}, SP{});
+    L([&] { load_a(kt, 0); }, n + 0 + LEAD, (0 + LEAD) & 3);            wait_then_barrier(n + 0); compute(I0{}, I0{}, SP{}, n + 0 + LEAD, (0 + LEAD) & 3);
+    L([&] { load_b(kt, 1, SQ{}); }, n + 1 + LEAD, (1 + LEAD) & 3);      wait_then_barrier(n + 1); compute(I0{}, I1{}, SQ{}, n + 1 + LEAD, (1 + LEAD) & 3);
+    L([&] { load_a(kt, 1); }, n + 2 + LEAD, (2 + LEAD) & 3);            wait_then_barrier(n + 2); compute(I1{}, I1{}, SQ{}, n + 2 + LEAD, (2 + LEAD) & 3);
+    L([&] { load_b(kt + 1, 0, SQ{}); }, n + 3 + LEAD, (3 + LEAD) & 3);  wait_then_barrier(n + 3); compute(I1{}, I0{}, SP{}, n + 3 + LEAD, (3 + LEAD) & 3);
   };
   for (int kt = 0; kt < nk; kt += 2) {
     ktile(I0{}, kt);

@@ -91,6 +91,11 @@ GEMM_CASES = [
 ]
 
 
+# the four-wave kernels live in `make EXPERIMENTAL=1` builds only (never dispatched): their cases run with AFFT_TEST_EXPERIMENTAL=1
+if __import__("os").environ.get("AFFT_TEST_EXPERIMENTAL") != "1":
+    GEMM_CASES = [c for c in GEMM_CASES if "_w4" not in c[0]]
+
+
 @pytest.mark.parametrize("case", GEMM_CASES, ids=[c[0] for c in GEMM_CASES])
 def test_gemm(case):
     from afft_amd import ops

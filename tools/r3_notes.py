@@ -1,0 +1,65 @@
+"""Assembles profiles/r03_experiments.txt from the raw outputs of the round-3 experiment scripts in gpurun_out/."""
+import os
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+g = lambda f: open(os.path.join(R, "gpurun_out", f)).read()
+T = """Round 3 experiments on the GEMM side and the step schedule (one MI355X per run, boxes differ by a few %; cfg2 = the bench workload, B = 64).
+Every number below was measured with the tools named beside it; raw outputs in gpurun_out/ of the build container (scratch).
+
+== 1. Stream-K of the 256x256 ping-pong kernel (tools/gemm_bench.py VARIANTS=30,33 ; tools/sk_sweep.py ; tools/sk_diag.sh) -> built, tested, OFF by default
+Plan (csrc/gemm_tiles.h SkPlan): one workgroup per CU; whole rounds of tiles run plain; the tiles of the partial round are cut along K so that
+every workgroup gets the same number of K-iterations: "mains" take the head [0, Km) of one leftover tile each (aligned in K, so the XCD's L2 still
+serves shared panels), "helpers" share the tails; pieces are parked in the workspace with 16-byte write-through stores and the last piece of a
+tile to arrive adds them in K order and runs the epilogue (nobody waits; bitwise reproducible; tests: tests/test_kernels_gpu.py *_pp_splitk3_*).
+First form (tile-major iteration space cut into equal contiguous ranges): neighbouring workgroups sit at different K offsets, nothing is shared in
+L2 any more -> 5120x2048x8192 236 us against 185 us plain.  Aligned plan: 200-207 us.  Over K (NT / TN / NN, us):
+{sweep}
+Reading: plain = 1.36 us per K-iteration with 160 CUs busy + 10 us fixed; stream-K = 1.82 us per K-iteration with 256 CUs busy + 59 us fixed.
+The part is power-limited: +60 % busy CUs buy +20 % throughput (117 -> 141 tile-iterations per us).  Fixed cost by diagnostic builds
+(AFFT_HANDOFF_DIAG, wrong results; 5120x2048xK: K = 1024 | 2048 | 8192, then 5120x8192xK: K = 512 | 2048):
+{diag}
+-> reading the parked pieces back costs ~31 us, parking them ~12 us (115-190 MB through HBM, everybody at the same time); even with NO exchange
+the balanced launch gains only 10 % (165 vs 185 us).  Vendor library on the same shape: 137-140 us.  Conclusion: on this part the idle CUs of a
+partial round are worth far less than their count suggests; stream-K stays a tested option (afft_set_gemm_splitk(2 / 4), AFFT_SK_MAX_EFF) and the
+automatic mode never picks it.  Side results that were kept: (a) the split-K hand-over of BOTH kernels now uses 16-byte write-through buffer
+stores / loads (round 2: 4-byte system-scope atomics, ~6x the time per byte); (b) the LDS-DMA destination is passed as ONE live scalar (ring
+address + wave lane) plus an immediate -- round 2 kept 16-22 precomputed M0 values in SGPRs, which the looping instantiations (stream-K, capped
+grid) spilled to VGPR lanes and read back between the DMA issues (22 v_readlane per two K-tiles; per K-iteration 1.98 -> 1.82 us).
+
+== 2. LDS-DMA issued inside the MFMA segment instead of the L segment (AFFT_PP_DMA_IN_C, tools/pp_ab.sh) -> 10-18 % SLOWER, switch kept, default off
+Idea: the L segment (2 DMA issues + 4-8 fragment reads + counted wait) is the long pole of a phase (stamps: 470 vs 316 cycles); a VMEM issue between
+MFMAs is free if the matrix pipe has queued work.  Measured (NT, us; base = same sources, switch off; dmacN = issue after N MFMAs of the 16):
+{ab}
+-> the issuing wave stops feeding the matrix pipe for the ~100 cycles a global_load_lds takes to issue; in the L segment that time belongs to the
+other wave of the SIMD.  The ping-pong split of work is right; a dedicated loader wave per SIMD is not possible (VGPR allocation is per kernel:
+three waves of 248 registers do not fit a SIMD).
+
+== 3. Weight-gradient GEMMs with the optimizer in the epilogue, per tile shape (tools/wgrad_sgd_bench.py; every launch its own p / momentum buffers)
+{wg}
+-> the fused update costs +38-40 us per 16.8 M-element weight = 235 MB more HBM traffic at 6.2 TB/s: the optimizer's traffic runs at the HBM
+roofline inside the epilogues (36 launches x ~38 us = 1.4 ms per step on the auxiliary stream); 128x128 tiles (two workgroups per CU, one's
+epilogue under the other's main loop) do not beat 256x256 tiles on any of the large shapes; the K = 1024 weight gradients of the predictor are
+HBM-bound by their epilogue (90 us for 27 us of main loop).
+
+== 4. Schedule: CU cap of the weight-gradient GEMMs, serial weight gradients (tools/r3_cap.sh; clips/s, ms/step; cfg2)
+{cap}
+-> with the capped (persistent) instantiation no longer spilling in its main loop the caps lose less than in round 2 (cap 192: 15.97 vs 15.56 ms;
+round 2: 19.5 ms at cap 128) but still lose; serial weight gradients 17.1 ms.  Default stays: uncapped, two streams.
+
+== 5. Deferred weight gradients of the predictor (built, bitwise-equal in tests, then REMOVED: slower)
+The predictor's sub-layers (B*T = 1024 rows) come first in the backward pass; their weight-gradient GEMMs (optimizer traffic in the epilogue) run
+beside their own latency-bound data-gradient chain and slow it 2-3x (in-step 82 us for nt 1024x2048x2048 against 33 us alone).  Variant: the
+composite backward of small sub-layers skips its weight-gradient half (a defer flag + afft_*_sublayer_wgrad entry points) and every later LARGE
+sub-layer backward hands one queued half to the auxiliary stream, the rest at the end of the backward pass.  Parameters / momentum bitwise equal to
+the immediate form (t3_m5, t2_flt, 4 Trainer steps).  Same box, clips/s / ms per step: cfg2 4147 / 15.43 immediate vs 4072 / 15.72 deferred; EK100
+widths 6632 / 9.65 vs 6157 / 10.39.  The predictor chain does run alone, but the same work then lands beside the fuser's chain (the bulk of the
+step) and the tail grows.  Not kept (two more C-ABI entry points for a loss).
+
+== 6. Where the step stands (tools/r3_baseline.sh: rocprofv3 stream timelines; tools/gemm_insitu.py with AFFT_OVERLAP_WGRAD=0)
+With every kernel alone (serial weight gradients) the GEMM launches of a step add up to 14.5 ms (256x256 launches 11.1 ms = 836 TFLOP/s, the
+predictor's 128x128 launches 3.4 ms), the non-GEMM kernels to 2.7 ms, each within 10-20 % of its own roofline alone (LayerNorm backward 29 us =
+5.8 TB/s, attention backward 42 us, optimizer epilogues 6.2 TB/s).  The two-stream step (15.4-15.6 ms) hides 1.6 ms of that sum.  What is left is
+the main loop of the 256x256 kernel (65 % of the power-limited MFMA rate; LDS array and matrix pipe both ~100 % booked by construction: 192 KiB of
+fragment reads + 64 KiB of LDS-DMA writes per 2048 MFMA cycles) -- see DESIGN.md section 4.
+"""
+open(os.path.join(R, "profiles", "r03_experiments.txt"), "w").write(T.format(sweep=g("r3_sk_sweep2.txt"), diag=g("r3_sk_diag.txt"), ab=g("r3_pp_ab1.txt"),
+                                                                          wg=g("r3_wgrad_sgd.txt"), cap=g("r3_cap_sweep.txt")))
