@@ -200,8 +200,14 @@ def parity_side_measurements(args, device, feats, tgt, sub, c):
                 tr.step(feats, tgt, sub)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / n
+            from afft_amd.config import gflop_per_clip
+            useful = args.batch / dt * gflop_per_clip(args.config, fwd_bwd=True) / 1e3       # TFLOP/s of algorithmic work
             out["parity_mode"] = {"precision": "bf16x3", "clips_per_s": round(args.batch / dt, 1), "ms_per_step": round(dt * 1e3, 2),
-                                  "steps": n}
+                                  "steps": n,
+                                  # three bf16 MFMA passes per product: the useful-FLOP peak of this mode is a third of the dense peak
+                                  "roofline": {"bound": "mfma", "achieved": round(useful, 1), "peak": round(PEAK_BF16_TFLOPS / 3, 1),
+                                               "unit": "TFLOP/s (algorithmic, whole step)", "frac": round(useful / (PEAK_BF16_TFLOPS / 3), 4),
+                                               "executed_tflops": round(3 * useful, 1)}}
             del tr
         del model
         torch.cuda.empty_cache()
