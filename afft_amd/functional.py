@@ -1305,6 +1305,29 @@ class LayerNormRows(torch.autograd.Function):
         return dX, gw, gb, None, None
 
 
+class TakeRows(torch.autograd.Function):
+    """y[r] = X[r * stride_rows] as dense rows: token 0 of every frame.  The SA-Fuser's last block needs its MLP half on
+    these rows only -- the fuser returns token 0 (models/fusion.py:362-365), so the other S - 1 rows of the last block's
+    MLP never reach an output and receive an exactly-zero gradient; the reference computes them and throws them away.
+    Backward: zeros elsewhere (the rows that attention still sees as keys / values get their gradient through it)."""
+
+    @staticmethod
+    def forward(ctx, X, stride_rows):
+        Rall, d = X.shape
+        rows = Rall // stride_rows
+        _forget_output()
+        ctx.shape = (Rall, d, stride_rows)
+        return X.view(rows, stride_rows * d)[:, :d].contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        Rall, d, s = ctx.shape
+        _drop_shadow()
+        dX = torch.zeros(Rall, d, dtype=dy.dtype, device=dy.device)
+        dX.view(Rall // s, s * d)[:, :d].copy_(dy)
+        return dX, None
+
+
 # --------------------------------------------------------------------------- SA-Fuser token assembly
 class AssembleTokens(torch.autograd.Function):
     """X[(b,t), s, :] = [modal_token | feats...] (+ modality_embedding) -- models/fusion.py:338-352."""

@@ -20,6 +20,7 @@ from torch import Tensor
 
 from .. import dropout as D_
 from .. import functional as F_
+from .. import runtime as rt
 from .transformerblock import Block, DecoderBlock
 
 
@@ -128,10 +129,18 @@ class ModalTokenCMFuser(nn.Module):
             X = F_.ElementDropout.apply(X, D_.elementwise(self.embd_drop.p))
         mask = "diag" if self.cross_attn else "none"
         attn_weights = []
-        for blk in self.blocks:
-            X, probs = blk.forward_rows(X, S, mask)                                # probs [BT, H, S, S]
+        # Only token 0 of the last block's output is used (models/fusion.py:362-365): that block runs its MLP half on the
+        # token-0 rows alone (Block.forward_rows_first_token) -- 4/5 of one block's MLP, 7 % of the step's FLOPs at M = 4,
+        # that the reference computes and discards; every output and every gradient is unchanged.
+        dead_rows = rt.skip_dead_rows()
+        for i, blk in enumerate(self.blocks):
+            if dead_rows and i + 1 == len(self.blocks):
+                X, probs = blk.forward_rows_first_token(X, S, mask)                # X [BT, C]
+            else:
+                X, probs = blk.forward_rows(X, S, mask)                            # probs [BT, H, S, S]
             attn_weights.append(probs.view(B, T, *probs.shape[1:]))
-        z = F_.LayerNormRows.apply(X, self.norm.weight, self.norm.bias, self.norm.eps, S)   # token 0 of each frame
+        z = F_.LayerNormRows.apply(X, self.norm.weight, self.norm.bias, self.norm.eps,
+                                   1 if dead_rows and len(self.blocks) > 0 else S)  # token 0 of each frame
         return z.view(B, T, C), torch.stack(attn_weights).transpose(0, 1)
 
 

@@ -189,6 +189,22 @@ class Block(nn.Module):
                                   D_.with_path(self.mlp.drop_cfg(), dp, L))
         return x2, probs
 
+    def forward_rows_first_token(self, x2: Tensor, L: int, mask: str):
+        """forward_rows for a caller that only uses token 0 of every sequence afterwards (the SA-Fuser's last block,
+        models/fusion.py:362-365): attention over all L tokens, the MLP half on the nseq token-0 rows only.
+        Returns (rows [nseq, dim], probs [nseq, H, L, L]) -- the same numbers as forward_rows(...)[0][::L]."""
+        a = self.attn
+        dp = _dp_rate(self.drop_path)
+        x2, probs = F_.AttnSublayer.apply(x2, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias,
+                                          a.proj.weight, a.proj.bias, L, a.num_heads, mask, self.norm1.eps, False,
+                                          True, a.scale, D_.with_path(a.drop_cfg(), dp, L))
+        x0 = F_.TakeRows.apply(x2, L)
+        m = self.mlp.mlp
+        x0 = F_.MLPSublayer.apply(x0, self.norm2.weight, self.norm2.bias, m[0].weight, m[0].bias, m[2].weight,
+                                  m[2].bias, self.norm2.eps, "erf", False, True,
+                                  D_.with_path(self.mlp.drop_cfg(), dp, 1))
+        return x0, probs
+
     def forward(self, x, attn_mask: MaskArg = None):
         x2, B, N, C = _flat(x)
         y, probs = self.forward_rows(x2, N, mask_kind(attn_mask, N))

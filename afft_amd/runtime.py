@@ -260,6 +260,20 @@ def set_overlap_wgrad(on: bool):
 
 
 _WGRAD_WGS = int(os.environ.get("AFFT_WGRAD_WGS", "0"))
+_SKIP_DEAD_ROWS = os.environ.get("AFFT_SKIP_DEAD_ROWS", "1") != "0"
+
+
+def skip_dead_rows() -> bool:
+    """The SA-Fuser returns token 0 of its last block only (models/fusion.py:362-365): with this on (default) that block's
+    MLP half runs on the token-0 rows alone instead of all M + 1 tokens of a frame -- rows the reference computes and throws
+    away.  Outputs and gradients are unchanged; AFFT_SKIP_DEAD_ROWS=0 runs the reference's full row set (bench.py --full-rows)."""
+    return _SKIP_DEAD_ROWS
+
+
+def set_skip_dead_rows(on: bool):
+    global _SKIP_DEAD_ROWS
+    _SKIP_DEAD_ROWS = bool(on)
+
 
 
 def wgrad_workgroups() -> int:

@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16, help="clips per CPU-baseline step on the bench workload (SURVEY.md 8d: 16)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the bf16x3 (1e-3-accurate) throughput / error side measurements")
+    ap.add_argument("--full-rows", action="store_true",
+                    help="run the SA-Fuser's last block on every token row as the reference does (default: its MLP half on token 0 only, "
+                         "the only rows that reach an output; runtime.skip_dead_rows)")
     ap.add_argument("--wgrad-wgs", type=int, default=None, help="CU cap of the weight-gradient GEMMs on the auxiliary stream (default: runtime's)")
     return ap.parse_args()
 
@@ -201,7 +204,7 @@ def parity_side_measurements(args, device, feats, tgt, sub, c):
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / n
             from afft_amd.config import gflop_per_clip
-            useful = args.batch / dt * gflop_per_clip(args.config, fwd_bwd=True) / 1e3       # TFLOP/s of algorithmic work
+            useful = args.batch / dt * gflop_per_clip(args.config, fwd_bwd=True, executed=afft_amd.runtime.skip_dead_rows()) / 1e3   # TFLOP/s executed
             out["parity_mode"] = {"precision": "bf16x3", "clips_per_s": round(args.batch / dt, 1), "ms_per_step": round(dt * 1e3, 2),
                                   "steps": n,
                                   # three bf16 MFMA passes per product: the useful-FLOP peak of this mode is a third of the dense peak
@@ -343,6 +346,7 @@ def main():
     afft_amd.set_grad_mode("sink")
     if args.wgrad_wgs is not None:
         afft_amd.runtime.set_wgrad_workgroups(args.wgrad_wgs)
+    afft_amd.runtime.set_skip_dead_rows(not args.full_rows)
     D_.manual_seed(42 + rank)
 
     model, c = build_model(args.config, device)
@@ -380,7 +384,8 @@ def main():
         trainer.release_graph()
     ms_per_step = elapsed / args.steps * 1e3
     clips_s = world * B * args.steps / elapsed
-    gf = gflop_per_clip(args.config, fwd_bwd=True)
+    gf_ref = gflop_per_clip(args.config, fwd_bwd=True)             # what the reference executes per clip
+    gf = gflop_per_clip(args.config, fwd_bwd=True, executed=afft_amd.runtime.skip_dead_rows())    # what THIS step executes
 
     result = {
         "metric": "clips/sec (fwd+bwd) EK100 SA-Fuser 4-mod T=16", "value": round(clips_s, 2), "unit": "clips/s",
@@ -397,7 +402,12 @@ def main():
                    "grad_comm_algo": args.comm_algo if world > 1 else None,
                    "step_launch": ("hipGraph replay" + (", one stream" if args.graph == "single" else "")) if captured else "eager, 3 streams",
                    "wgrad_cu_cap": afft_amd.runtime.wgrad_workgroups() or None},
-        "algorithmic_gflop_per_clip": round(gf, 2),
+        # FLOP accounting: utilisation figures use the FLOPs this step EXECUTES.  The reference runs the last SA-Fuser block's MLP on
+        # all M + 1 tokens of a frame although only token 0 reaches an output (models/fusion.py:362-365); here those dead rows are
+        # not computed (same outputs, same gradients: tests/test_model_gpu.py), 7.4 % of the reference's FLOPs on this workload
+        "algorithmic_gflop_per_clip": round(gf_ref, 2),
+        "executed_gflop_per_clip": round(gf, 2),
+        "dead_rows_skipped": bool(afft_amd.runtime.skip_dead_rows()) and c["fuser"] == "sa",
         "model_tflops": round(clips_s * gf / 1e3, 1),
         "mfma_frac_whole_step": round(clips_s * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
         "final_loss": round(loss_val, 4),
@@ -451,7 +461,7 @@ def main():
             ach = avg_fl / (avg_ms * 1e-3) / 1e12
             dtype_peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3
             traffic, traffic_src = None, None
-            for fn in ("r02i_gemm_hbm_traffic_pmc.json", "r02h_gemm_hbm_traffic_pmc.json", "r02g_gemm_hbm_traffic_pmc.json", "r02_gemm_hbm_traffic_pmc.json", "r01_gemm_hbm_traffic_pmc.json"):
+            for fn in ("r03b_gemm_hbm_traffic_pmc.json", "r03a_gemm_hbm_traffic_pmc.json", "r02i_gemm_hbm_traffic_pmc.json", "r02h_gemm_hbm_traffic_pmc.json", "r02g_gemm_hbm_traffic_pmc.json", "r02_gemm_hbm_traffic_pmc.json", "r01_gemm_hbm_traffic_pmc.json"):
                 try:   # HBM-side bytes per launch from separate rocprofv3 --pmc passes (tools/traffic_summary.py), committed
                     tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
                     hit = [v for k, v in tj.items() if isinstance(v, dict) and (k == dom or dom.startswith(k.rstrip(">")))]
@@ -467,7 +477,8 @@ def main():
                 "frac": round(ach / dtype_peak, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(d["bytes"] / d["launches"]),
                 "traffic_note": f"bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate --pmc passes of this command "
-                                f"(profiles/{traffic_src}); fabric-side, includes Infinity-Cache hits",
+                                f"(profiles/{traffic_src}); fabric-side: includes Infinity-Cache hits, which the L2's counters cannot tell from HBM "
+                                f"reads (profiles/r03_l2_hit_pmc.txt: 70-79 % L2 hits, ~2 TB/s of fabric reads while the kernel runs: not time-relevant)",
                 "fused_optimizer_epilogue": bool(d.get("fused_update_launches")),
                 "launches_per_step": d["launches"], "avg_launch_ms": round(avg_ms, 4),
                 "avg_algorithmic_gflop_per_launch": round(avg_fl / 1e9, 2),

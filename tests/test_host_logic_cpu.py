@@ -252,6 +252,9 @@ def test_weight_image_registry_does_not_grow_with_steps():
 
     saved, ops.Split = ops.Split, FakeSplit
     try:
+        import gc
+        gc.collect()
+        rt.invalidate_weight_images()       # drops the entries of parameters earlier tests left behind
         ws = [torch.nn.Parameter(torch.randn(8, 8)) for _ in range(3)]
         before = len(rt._wlist)
         for _ in range(6):
@@ -262,7 +265,6 @@ def test_weight_image_registry_does_not_grow_with_steps():
             assert all(w._afft_split is None for w in ws)
         assert len(rt._wlist) - before == 3
         del ws, w, sp
-        import gc
         gc.collect()
         rt.invalidate_weight_images()
         assert len(rt._wlist) == before

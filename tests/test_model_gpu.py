@@ -368,6 +368,45 @@ def test_fused_optimizer_epilogue_equals_separate_update(name):
         assert (a == b) if isinstance(a, float) else torch.equal(a, b), what
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["t0_sa", "t2_flt", "t3_m5"])
+def test_last_block_on_token_rows_equals_all_rows(name, precision):
+    """runtime.skip_dead_rows (default on): the SA-Fuser's last block runs its MLP half on token 0 of every frame only -- the
+    rows models/fusion.py:362-365 keeps.  Against the reference's full row set (skip off): every output and the three losses agree
+    to rounding (the token-0 rows go through the same arithmetic; GEMM tile shapes differ) and so does every gradient, including
+    the last block's own MLP weights (the dropped rows contribute exact zeros).  The goldens themselves are checked with the
+    default (on) by test_model_matches_reference_golden."""
+    from afft_amd import runtime as rt
+    from afft_amd.common.runner import BasicLossAccuracy, Runner
+    c, state, data, tgt, sub = case_tensors(name)
+    dev = torch.device("cuda:0")
+    res = {}
+    for skip in (True, False):
+        rt.set_skip_dead_rows(skip)
+        model = build(c, precision)
+        model.load_state_dict(state)
+        model = model.cuda().eval()
+        rt.SINK.begin_step()
+        out, out_t = model({m: d.to(dev) for m, d in data.items()}, mixup_fn=None, target={"action": tgt.to(dev)},
+                           target_subclips={"action": sub.to(dev)}, target_subclips_ignore_index=None)
+        losses, _ = BasicLossAccuracy(False)(out, out_t["target"], out_t["target_subclips"])
+        total, _ = Runner._reduce_loss(losses, {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}, sync=False)
+        total.backward()
+        rt.SINK.finish_step(list(model.parameters()))
+        torch.cuda.synchronize()
+        res[skip] = (flatten_outputs(out), float(total), {k: p.grad.clone() for k, p in model.named_parameters()})
+    rt.set_skip_dead_rows(True)
+    import afft_amd
+    afft_amd.set_precision("bf16")
+    tol = 1e-5 if precision == "fp32" else 5e-3
+    (o1, l1, g1), (o0, l0, g0) = res[True], res[False]
+    assert abs(l1 - l0) <= tol * abs(l0)
+    for k in o0:
+        assert rel_l2(o1[k], o0[k]) <= tol, k
+    worst = max((rel_l2(g1[k], g0[k]), k) for k in g0 if float(g0[k].abs().max()) > 0)
+    assert worst[0] <= (1e-4 if precision == "fp32" else 2e-2), worst
+
+
 def test_fused_optimizer_audit_when_the_graph_changes_between_steps():
     """The fused set is learned on one step: a later step that routes a weight differently must not lose its
     update.  (1) A step that SKIPS a sub-layer (its weights get no gradient): the audit applies the regular update to them
