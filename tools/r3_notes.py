@@ -60,6 +60,11 @@ predictor's 128x128 launches 3.4 ms), the non-GEMM kernels to 2.7 ms, each withi
 5.8 TB/s, attention backward 42 us, optimizer epilogues 6.2 TB/s).  The two-stream step (15.4-15.6 ms) hides 1.6 ms of that sum.  What is left is
 the main loop of the 256x256 kernel (65 % of the power-limited MFMA rate; LDS array and matrix pipe both ~100 % booked by construction: 192 KiB of
 fragment reads + 64 KiB of LDS-DMA writes per 2048 MFMA cycles) -- see DESIGN.md section 4.
+
+== 7. 128x128 tiles for every GEMM with K < 2048 (the predictor's K = 1024 weight gradients, so that they can share a CU with the chain's 128x128
+workgroups; AFFT_PP_MIN_K experiment, removed again)
+{mink}
+-> noise (cfg2 +0.5 %, EK100 widths -0.6 %).
 """
 open(os.path.join(R, "profiles", "r03_experiments.txt"), "w").write(T.format(sweep=g("r3_sk_sweep2.txt"), diag=g("r3_sk_diag.txt"), ab=g("r3_pp_ab1.txt"),
-                                                                          wg=g("r3_wgrad_sgd.txt"), cap=g("r3_cap_sweep.txt")))
+                                                                          wg=g("r3_wgrad_sgd.txt"), cap=g("r3_cap_sweep.txt"), mink=g("r3_minK.txt")))
