@@ -34,6 +34,9 @@ def marginalize_scores(res_action: torch.Tensor, class_mappings: Dict[Tuple[str,
     return [out[0], out[1], res_action]
 
 
+EPIC100_VERSION = 0.2       # datasets/epic_kitchens.py: the dataset object's `version` for EPIC-KITCHENS-100
+
+
 def topk_accuracy(scores: np.ndarray, labels: np.ndarray, ks, selected_class=None):
     """common/utils.py:19-42: share of rows whose label is among the k best scores.  Ties rank as in the reference's
     `scores.argsort()[:, ::-1]`: among equal scores the HIGHER class index comes first."""
@@ -75,6 +78,10 @@ def compute_accuracies_epic(probs, dataset, compute_manyshot_unseen_tail: bool =
         res[f"{short}mt5r_ms"] = float("nan")
         if key in many and compute_manyshot_unseen_tail:
             res[f"{short}mt5r_ms"] = compute_accuracy(p, labels, classes=many[key])[2]
+    if compute_manyshot_unseen_tail and getattr(dataset, "version", None) == EPIC100_VERSION:
+        # challenge.py:190-191 adds {v,n,a}mt5r_{tail,unseen} from the dataset's participant / tail-class tables here
+        raise NotImplementedError("EPIC-100 unseen / tail metrics (challenge.py:109-158) need the RULSTM annotation tables and are not "
+                                  "mirrored: call with compute_manyshot_unseen_tail=False")
     return res
 
 
