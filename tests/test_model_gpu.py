@@ -429,7 +429,7 @@ def test_fused_optimizer_audit_when_the_graph_changes_between_steps():
         model = model.cuda().eval()
         tr = Trainer(model, wts, lr=1e-2, momentum=0.9, weight_decay=1e-4, bucket_elems=1 << 15)
         from afft_amd.models.transformerblock import Block
-        blk = [m for m in model.modules() if isinstance(m, Block)][-1]
+        blk = [m for m in model.modules() if isinstance(m, Block)][0]      # not the last block: that one runs forward_rows_first_token
         mlp_ids = {id(blk.mlp.mlp[0].weight), id(blk.mlp.mlp[2].weight)}
         orig = blk.forward_rows
 
