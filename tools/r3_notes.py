@@ -65,6 +65,11 @@ fragment reads + 64 KiB of LDS-DMA writes per 2048 MFMA cycles) -- see DESIGN.md
 workgroups; AFFT_PP_MIN_K experiment, removed again)
 {mink}
 -> noise (cfg2 +0.5 %, EK100 widths -0.6 %).
+
+== 8. Weight-gradient GEMMs cut along K into 2 / 3 sequential launches (so that their workgroups retire two / three times as often and the chain's
+kernels find CUs sooner; timing-only hack in sublayer.hip's wgrad(), removed) -- clips/s, ms/step
+{ksplit}
+-> slower: the extra epilogue pass over the fp32 gradient and the extra launch cost more than the shorter waits return.
 """
 open(os.path.join(R, "profiles", "r03_experiments.txt"), "w").write(T.format(sweep=g("r3_sk_sweep2.txt"), diag=g("r3_sk_diag.txt"), ab=g("r3_pp_ab1.txt"),
-                                                                          wg=g("r3_wgrad_sgd.txt"), cap=g("r3_cap_sweep.txt"), mink=g("r3_minK.txt")))
+                                                                          wg=g("r3_wgrad_sgd.txt"), cap=g("r3_cap_sweep.txt"), mink=g("r3_minK.txt"), ksplit=g("r3_ksplit.txt")))
