@@ -70,6 +70,12 @@ workgroups; AFFT_PP_MIN_K experiment, removed again)
 kernels find CUs sooner; timing-only hack in sublayer.hip's wgrad(), removed) -- clips/s, ms/step
 {ksplit}
 -> slower: the extra epilogue pass over the fp32 gradient and the extra launch cost more than the shorter waits return.
+
+== 9. No fused update for sub-layers of fewer than 2048 rows (the predictor's K = 1024 weight gradients become plain 52-us GEMMs, their update goes
+back to the per-bucket kernel; AFFT_FUSE_MIN_ROWS experiment, removed; three alternating repeats on one box) -- clips/s, ms/step, loss after 25 steps
+{fusemin}
+-> fused everywhere stays ahead (cfg2 15.10-15.26 vs 15.58-15.61 ms; EK100 widths mixed inside the box's noise).  The loss is identical: the
+step audit of round 3 (Trainer._audit_fused_step) moves the skipped weights back to the regular update on the first fused step.
 """
 open(os.path.join(R, "profiles", "r03_experiments.txt"), "w").write(T.format(sweep=g("r3_sk_sweep2.txt"), diag=g("r3_sk_diag.txt"), ab=g("r3_pp_ab1.txt"),
-                                                                          wg=g("r3_wgrad_sgd.txt"), cap=g("r3_cap_sweep.txt"), mink=g("r3_minK.txt"), ksplit=g("r3_ksplit.txt")))
+                                                                          wg=g("r3_wgrad_sgd.txt"), cap=g("r3_cap_sweep.txt"), mink=g("r3_minK.txt"), ksplit=g("r3_ksplit.txt"), fusemin=g("r3_fusemin.txt")))
