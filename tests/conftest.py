@@ -23,7 +23,7 @@ _GPU_TIERS = (
     ("test_marginalize_verb_noun_matches_reference_golden", "test_mixup_prologue_matches_oracle",
      "test_last_block_on_token_rows_equals_all_rows"),
     ("test_full_size_matches_reference_fixture",),
-    ("test_full_width_matches_oracle",),
+    ("test_full_width_matches_oracle", "test_bench_workload_matches_oracle_at_full_batch"),
     ("test_kernels_gpu.py",),
     ("test_rccl_path_single_rank", "test_bench_two_ranks_rehearsal_on_one_gpu", "test_bench_launches_itself"),
 )
