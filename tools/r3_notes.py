@@ -76,6 +76,19 @@ back to the per-bucket kernel; AFFT_FUSE_MIN_ROWS experiment, removed; three alt
 {fusemin}
 -> fused everywhere stays ahead (cfg2 15.10-15.26 vs 15.58-15.61 ms; EK100 widths mixed inside the box's noise).  The loss is identical: the
 step audit of round 3 (Trainer._audit_fused_step) moves the skipped weights back to the regular update on the first fused step.
+
+== 10. Weight gradients of the LATE layers inside the NEXT forward pass (timing prototype, removed)
+The forward pass is a serial chain with nothing beside it (q2 idle for 4.9 ms, 96 CUs idle in every N = 2048 GEMM) while the backward pass has both
+streams busy.  A layer that runs late in the forward pass (the predictor, the last fuser blocks) runs early in the backward pass, so its updated weights
+are not read again for most of the next forward pass: its composite backward skipped the weight-gradient half and the next forward pass handed the
+queue to the auxiliary stream when it started (newest first = the order in which that forward needs the weights); bench.py flushed inside the timed
+region.  Prototype WITHOUT the per-layer event waits a correct version needs (they could only add stalls; the losses below differ for that reason),
+two alternating repeats on one box -- clips/s, ms/step, loss; lazy = the predictor's sub-layers, fuser_blocks = how many trailing fuser blocks too:
+{lazy}
+-> slower in every setting (cfg2 14.80-15.01 ms plain vs 15.03-15.75 ms).  The work slows the forward chain by as much as it relieves the backward
+chain: the two-stream step is bound by what the kernels need in total (matrix pipe / LDS in the GEMMs, HBM in the optimizer epilogues and the
+LayerNorm / attention kernels), not by where the weight gradients are placed.  Together with sections 4, 5, 7, 8 and 9 this closes the schedule as
+a lever; what is left is the GEMM main loop itself (section 2 and DESIGN.md section 4).
 """
 open(os.path.join(R, "profiles", "r03_experiments.txt"), "w").write(T.format(sweep=g("r3_sk_sweep2.txt"), diag=g("r3_sk_diag.txt"), ab=g("r3_pp_ab1.txt"),
-                                                                          wg=g("r3_wgrad_sgd.txt"), cap=g("r3_cap_sweep.txt"), mink=g("r3_minK.txt"), ksplit=g("r3_ksplit.txt"), fusemin=g("r3_fusemin.txt")))
+                                                                          wg=g("r3_wgrad_sgd.txt"), cap=g("r3_cap_sweep.txt"), mink=g("r3_minK.txt"), ksplit=g("r3_ksplit.txt"), fusemin=g("r3_fusemin.txt"), lazy=g("r3_lazy_proto.txt")))
