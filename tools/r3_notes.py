@@ -33,6 +33,13 @@ MFMAs is free if the matrix pipe has queued work.  Measured (NT, us; base = same
 other wave of the SIMD.  The ping-pong split of work is right; a dedicated loader wave per SIMD is not possible (VGPR allocation is per kernel:
 three waves of 248 registers do not fit a SIMD).
 
+Re-sweep of the loop's knobs after the M0 change (tools/pp_ab.sh, NT; prio0 / prio2 = AFFT_PP_PRIO, lead5 / lead6 = AFFT_PP_LEAD, dmalast =
+AFFT_PP_DMA_FIRST=0; then "stag": half of a group's waves issue their LDS-DMA first while the other half reads fragments, then swap):
+{ab2}
+{ab3}
+-> everything within +-3 % of the defaults (no s_setprio reads 1-3 % faster alone on three shapes and nothing in the step: cfg2 15.12 / 15.51 /
+15.63 vs 15.41 / 15.25 / 15.65 ms over three alternating repeats); the staggered order loses 1-4 %.  Defaults unchanged.
+
 == 3. Weight-gradient GEMMs with the optimizer in the epilogue, per tile shape (tools/wgrad_sgd_bench.py; every launch its own p / momentum buffers)
 {wg}
 -> the fused update costs +38-40 us per 16.8 M-element weight = 235 MB more HBM traffic at 6.2 TB/s: the optimizer's traffic runs at the HBM
@@ -90,5 +97,5 @@ chain: the two-stream step is bound by what the kernels need in total (matrix pi
 LayerNorm / attention kernels), not by where the weight gradients are placed.  Together with sections 4, 5, 7, 8 and 9 this closes the schedule as
 a lever; what is left is the GEMM main loop itself (section 2 and DESIGN.md section 4).
 """
-open(os.path.join(R, "profiles", "r03_experiments.txt"), "w").write(T.format(sweep=g("r3_sk_sweep2.txt"), diag=g("r3_sk_diag.txt"), ab=g("r3_pp_ab1.txt"),
+open(os.path.join(R, "profiles", "r03_experiments.txt"), "w").write(T.format(sweep=g("r3_sk_sweep2.txt"), diag=g("r3_sk_diag.txt"), ab=g("r3_pp_ab1.txt"), ab2=g("r3_pp_ab2.txt"), ab3=g("r3_pp_ab3.txt"),
                                                                           wg=g("r3_wgrad_sgd.txt"), cap=g("r3_cap_sweep.txt"), mink=g("r3_minK.txt"), ksplit=g("r3_ksplit.txt"), fusemin=g("r3_fusemin.txt"), lazy=g("r3_lazy_proto.txt")))
