@@ -425,11 +425,23 @@ def main():
 
     # the instrumented step for the roofline object runs on EVERY rank (its gradient all-reduce is a collective);
     # only rank 0 keeps the timings
-    summ = None
+    summ = summ_alone = None
     if not args.no_roofline:
         with GemmTimer() as gt:      # the same kernel sequence as a timed step (fused optimizer epilogues included)
             trainer.step(feats, tgt, sub, optimize=not args.no_optimizer)
         summ = gt.summary()
+        # the same launches with NOTHING beside them (weight gradients on the main stream for one more instrumented step): what the
+        # dominant kernel does alone, to set beside what it does inside the two-stream step (kernel quality vs schedule)
+        summ_alone = None
+        if world == 1 and not captured and afft_amd.runtime.overlap_wgrad():
+            try:
+                afft_amd.runtime.set_overlap_wgrad(False)
+                trainer.step(feats, tgt, sub, optimize=not args.no_optimizer)
+                with GemmTimer() as gt2:
+                    trainer.step(feats, tgt, sub, optimize=not args.no_optimizer)
+                summ_alone = gt2.summary()
+            finally:
+                afft_amd.runtime.set_overlap_wgrad(True)
 
     if rank == 0:
         # forward latency, eval mode (BASELINE.json: "fwd p50 ms")
@@ -480,6 +492,11 @@ def main():
                                 f"(profiles/{traffic_src}); fabric-side: includes Infinity-Cache hits, which the L2's counters cannot tell from HBM "
                                 f"reads (profiles/r03_l2_hit_pmc.txt: 70-79 % L2 hits, ~2 TB/s of fabric reads while the kernel runs: not time-relevant)",
                 "fused_optimizer_epilogue": bool(d.get("fused_update_launches")),
+                # the same kernel symbol in a step whose weight gradients run on the main stream: every launch alone on the chip
+                "alone": (lambda a: {"achieved": round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 1),
+                                     "frac": round(a["flops"] / (a["ms"] * 1e-3) / 1e12 / dtype_peak, 4),
+                                     "avg_launch_ms": round(a["ms"] / a["launches"], 4), "launches": a["launches"]})(summ_alone[dom])
+                         if summ_alone and dom in summ_alone and summ_alone[dom]["ms"] > 0 else None,
                 "launches_per_step": d["launches"], "avg_launch_ms": round(avg_ms, 4),
                 "avg_algorithmic_gflop_per_launch": round(avg_fl / 1e9, 2),
                 "by_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
