@@ -72,6 +72,55 @@ __global__ __launch_bounds__(512, 2) void fill_kernel(const uint16_t* __restrict
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[i], 0, 0, 0);
     }
+    if (MODE & 16) {           // round 3: the GEMM's 24 fragment reads per wave and K-tile from a resident tile, NO fill; bit 3: + its 64 MFMAs
+      const char* t = smem + (kt & 1) * 65536;
+      const int gp = wave >> 2, wc = wave & 3;
+      auto frag = [&](const char* base, int row, int chunk) {
+        return *(const bf16x8*)(base + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+      };
+      bf16x8 bF[2][2][2];
+#pragma unroll
+      for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int sk = 0; sk < 2; ++sk)
+            bF[jh][j][sk] = frag(t + 32768, jh * 128 + wc * 32 + j * 16 + (lane & 15), sk * 4 + (lane >> 4));
+#pragma unroll
+      for (int ih = 0; ih < 2; ++ih) {
+        bf16x8 aF[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int sk = 0; sk < 2; ++sk) aF[i][sk] = frag(t, ih * 128 + gp * 64 + i * 16 + (lane & 15), sk * 4 + (lane >> 4));
+        if (MODE & 8) {
+#pragma unroll
+          for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                  acc2[ih][jh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bF[jh][j][sk], aF[i][sk], acc2[ih][jh][i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) keep ^= aF[i][sk];
+        }
+      }
+      if (!(MODE & 8)) {
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) keep ^= bF[jh][j][sk];
+      }
+      __builtin_amdgcn_s_barrier();
+      continue;
+    }
     if ((MODE & 12) == 12) {   // K-tile kt-1 (issued one iteration ago) has landed for every wave before anyone reads it
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -176,10 +225,13 @@ int main() {
         {"LDS-DMA + MFMA", run<5>(A, B, ld, nk, tiles_m, tiles_n, sink, 20), true},
         {"VGPR loads + MFMA", run<6>(A, B, ld, nk, tiles_m, tiles_n, sink, 20), true},
         {"LDS-DMA + LDS reads + MFMA", run<13>(A, B, ld, nk, tiles_m, tiles_n, sink, 20), true},
+        {"LDS reads only (no fill)", run<16>(A, B, ld, nk, tiles_m, tiles_n, sink, 20), false},
+        {"LDS reads + MFMA (no fill)", run<24>(A, B, ld, nk, tiles_m, tiles_n, sink, 20), true},
     };
     for (auto& r : res)
       printf("%-10d %-26s %10.4f %12.2f %12.1f\n", tiles_m * tiles_n, r.name, r.ms,
-             (r.name[0] == 'M' && r.name[1] == 'F') ? 0.0 : bytes / (r.ms * 1e-3) / 1e12, r.mfma ? flops / (r.ms * 1e-3) / 1e12 : 0.0);
+             (r.name[0] == 'M' && r.name[1] == 'F') ? 0.0 : (r.name[4] == 'r' ? 3.0 : 1.0) * bytes / (r.ms * 1e-3) / 1e12,   // "LDS reads": 192 KiB of fragment reads per K-tile
+             r.mfma ? flops / (r.ms * 1e-3) / 1e12 : 0.0);
   }
   return 0;
 }

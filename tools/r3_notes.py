@@ -40,6 +40,17 @@ AFFT_PP_DMA_FIRST=0; then "stag": half of a group's waves issue their LDS-DMA fi
 -> everything within +-3 % of the defaults (no s_setprio reads 1-3 % faster alone on three shapes and nothing in the step: cfg2 15.12 / 15.51 /
 15.63 vs 15.41 / 15.25 / 15.65 ms over three alternating repeats); the staggered order loses 1-4 %.  Defaults unchanged.
 
+The three legs of the loop, one at a time and together (tools/fill_bench.hip with two modes added in round 3: the GEMM's 24 fragment reads per wave
+and K-tile from a resident tile without any fill, alone and with its 64 MFMAs; "fill TB/s" of those two rows counts the 192 KiB of fragment reads):
+{fill}
+-> per 128 K-tiles on 256 CUs: MFMAs alone 0.126 ms (2180 TFLOP/s), fragment reads alone 0.076 ms (85 TB/s = ~145 B/clk per CU: ds_read_b128 is in
+the 128-B/clk class, so 192 KiB of reads + 64 KiB of LDS-DMA writes book the LDS array ~80 % of the MFMA time), LDS-DMA alone 0.086 ms (the texture
+path, ~48 B/clk per CU).  Reads + MFMAs without any fill already drop to 1731 TFLOP/s, and with the fill to 1379 (simple lock-step schedule) -- the
+ping-pong kernel's loop is at the same place (1270-1280 with its epilogue).  Each leg fits under the MFMA time on its own; what is lost is their
+serialisation inside a wave (a wave cannot prefetch fragments into the registers its own MFMAs are reading, and its partner on the SIMD needs
+reads + DMA issue + their latency -- ~360 cycles -- inside the 256 cycles of a 16-MFMA segment).  That is the number a next attempt has to beat:
+fewer fragment bytes per MFMA (a 128x128 wave tile) or fragment double-buffering (96 more VGPRs) -- neither fits two waves per SIMD.
+
 == 3. Weight-gradient GEMMs with the optimizer in the epilogue, per tile shape (tools/wgrad_sgd_bench.py; every launch its own p / momentum buffers)
 {wg}
 -> the fused update costs +38-40 us per 16.8 M-element weight = 235 MB more HBM traffic at 6.2 TB/s: the optimizer's traffic runs at the HBM
@@ -97,5 +108,5 @@ chain: the two-stream step is bound by what the kernels need in total (matrix pi
 LayerNorm / attention kernels), not by where the weight gradients are placed.  Together with sections 4, 5, 7, 8 and 9 this closes the schedule as
 a lever; what is left is the GEMM main loop itself (section 2 and DESIGN.md section 4).
 """
-open(os.path.join(R, "profiles", "r03_experiments.txt"), "w").write(T.format(sweep=g("r3_sk_sweep2.txt"), diag=g("r3_sk_diag.txt"), ab=g("r3_pp_ab1.txt"), ab2=g("r3_pp_ab2.txt"), ab3=g("r3_pp_ab3.txt"),
+open(os.path.join(R, "profiles", "r03_experiments.txt"), "w").write(T.format(sweep=g("r3_sk_sweep2.txt"), diag=g("r3_sk_diag.txt"), ab=g("r3_pp_ab1.txt"), ab2=g("r3_pp_ab2.txt"), ab3=g("r3_pp_ab3.txt"), fill=g("r3_fill_bench.txt"),
                                                                           wg=g("r3_wgrad_sgd.txt"), cap=g("r3_cap_sweep.txt"), mink=g("r3_minK.txt"), ksplit=g("r3_ksplit.txt"), fusemin=g("r3_fusemin.txt"), lazy=g("r3_lazy_proto.txt")))
