@@ -107,6 +107,11 @@ two alternating repeats on one box -- clips/s, ms/step, loss; lazy = the predict
 chain: the two-stream step is bound by what the kernels need in total (matrix pipe / LDS in the GEMMs, HBM in the optimizer epilogues and the
 LayerNorm / attention kernels), not by where the weight gradients are placed.  Together with sections 4, 5, 7, 8 and 9 this closes the schedule as
 a lever; what is left is the GEMM main loop itself (section 2 and DESIGN.md section 4).
+
+== 11. 128x128 tiles for EVERY weight-gradient GEMM (1024 short-lived workgroups, two per CU, instead of 256 that hold every CU for ~150 us, so that
+the chain's kernels find CUs sooner; AFFT_TN_VARIANT experiment, removed; two alternating repeats) -- clips/s, ms/step, loss
+{tnvar}
+-> slower on cfg2 (14.94 -> 15.73 ms: the small tile's 21 % longer weight gradients cost more than the shorter waits return), a wash at the EK100 widths.
 """
 open(os.path.join(R, "profiles", "r03_experiments.txt"), "w").write(T.format(sweep=g("r3_sk_sweep2.txt"), diag=g("r3_sk_diag.txt"), ab=g("r3_pp_ab1.txt"), ab2=g("r3_pp_ab2.txt"), ab3=g("r3_pp_ab3.txt"), fill=g("r3_fill_bench.txt"),
-                                                                          wg=g("r3_wgrad_sgd.txt"), cap=g("r3_cap_sweep.txt"), mink=g("r3_minK.txt"), ksplit=g("r3_ksplit.txt"), fusemin=g("r3_fusemin.txt"), lazy=g("r3_lazy_proto.txt")))
+                                                                          wg=g("r3_wgrad_sgd.txt"), cap=g("r3_cap_sweep.txt"), mink=g("r3_minK.txt"), ksplit=g("r3_ksplit.txt"), fusemin=g("r3_fusemin.txt"), lazy=g("r3_lazy_proto.txt"), tnvar=g("r3_tnvar.txt")))
