@@ -417,6 +417,25 @@ def main():
         "optimizer_path": "none" if args.no_optimizer else "fused-epilogue" if trainer._fused else "separate",
     }
 
+    # the same workload with the reference's full row set (the last SA-Fuser block's MLP on all M + 1 tokens of a frame), in the same
+    # process: what the dead-row elimination is worth, on the record beside the headline number
+    if world == 1 and not captured and afft_amd.runtime.skip_dead_rows() and c["fuser"] == "sa" and not args.no_parity_mode:
+        try:
+            afft_amd.runtime.set_skip_dead_rows(False)
+            for _ in range(3):
+                trainer.step(feats, tgt, sub, optimize=not args.no_optimizer)
+            sync_all()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                trainer.step(feats, tgt, sub, optimize=not args.no_optimizer)
+            sync_all()
+            dt = (time.perf_counter() - t1) / 10
+            result["reference_row_set"] = {"clips_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": 10,
+                                           "gflop_per_clip": round(gf_ref, 2),
+                                           "mfma_frac_whole_step": round(B / dt * gf_ref / 1e3 / PEAK_BF16_TFLOPS, 4)}
+        finally:
+            afft_amd.runtime.set_skip_dead_rows(True)
+
     if world > 1 and not args.no_comm_report:
         try:     # deterministic on every rank (same code path), so a failure cannot leave a collective half-entered
             result["comm"] = comm_report(args, trainer, feats, tgt, sub, world, rank, device, ms_per_step, rccl_log, sync_all)
