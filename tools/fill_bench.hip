@@ -186,15 +186,15 @@ __global__ __launch_bounds__(512, 2) void fill_kernel(const uint16_t* __restrict
 }
 
 template <int MODE>
-double run(const uint16_t* A, const uint16_t* B, int64_t ld, int nk, int tiles_m, int tiles_n, float* sink, int iters) {
+double run(const uint16_t* A, const uint16_t* B, int64_t ld, int nk, int tiles_m, int tiles_n, float* sink, int iters, int threads = 512) {
   auto kern = fill_kernel<MODE>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), 131072, 0, A, B, ld, nk, tiles_m, sink);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(threads), 131072, 0, A, B, ld, nk, tiles_m, sink);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), 131072, 0, A, B, ld, nk, tiles_m, sink);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(threads), 131072, 0, A, B, ld, nk, tiles_m, sink);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms;
@@ -227,6 +227,7 @@ int main() {
         {"LDS-DMA + LDS reads + MFMA", run<13>(A, B, ld, nk, tiles_m, tiles_n, sink, 20), true},
         {"LDS reads only (no fill)", run<16>(A, B, ld, nk, tiles_m, tiles_n, sink, 20), false},
         {"LDS reads + MFMA (no fill)", run<24>(A, B, ld, nk, tiles_m, tiles_n, sink, 20), true},
+        {"MFMA only, 4 waves (1/SIMD)", run<4>(A, B, ld, nk, tiles_m, tiles_n, sink, 20, 256), true},     // half the MFMAs of the 8-wave rows: TF/s column x 0.5
     };
     for (auto& r : res)
       printf("%-10d %-26s %10.4f %12.2f %12.1f\n", tiles_m * tiles_n, r.name, r.ms,

@@ -51,6 +51,19 @@ serialisation inside a wave (a wave cannot prefetch fragments into the registers
 reads + DMA issue + their latency -- ~360 cycles -- inside the 256 cycles of a 16-MFMA segment).  That is the number a next attempt has to beat:
 fewer fragment bytes per MFMA (a 128x128 wave tile) or fragment double-buffering (96 more VGPRs) -- neither fits two waves per SIMD.
 
+The four-wave kernels (gemm_w4.hip, EXPERIMENTAL=1) re-measured after the M0 change, with their diagnostic builds (tools/w4_variant.sh, tools/w4_ab.sh; us per
+launch, "w4" = variant 5, "pp" = the ping-pong kernel in the same library; d1 = no fragment reads, d2 = no LDS-DMA in the loop, d3 = neither, d11 = d3
+without the phase barriers -- wrong results, timing only):
+{w4diag}
+and with the four LDS-DMA instructions of a phase behind every second MFMA group, even / odd waves on even / odd groups ("stag"), or moved to groups
+0-3 / 4-7 ("at0" / "at4"):
+{w4stag}
+-> a single wave per SIMD does keep the matrix pipe full (fill_bench "MFMA only, 4 waves": the same time per MFMA as 8 waves), and the structure's
+floor without operands is 593 us for 8192^3 (vendor: 739 with everything).  Fragment reads cost +102 us, LDS-DMA +135 us, both together +306 us --
+more than their sum, and no placement of the DMA instructions changes it: the two legs collide in the LDS array, not at issue.  The four-wave kernel
+stays at the ping-pong kernel's time (890-900 vs 878-887 us); it needs an operand path that does not write LDS while fragments are read from it at
+this rate (or half the fragment traffic again), which neither staging form here provides.
+
 == 3. Weight-gradient GEMMs with the optimizer in the epilogue, per tile shape (tools/wgrad_sgd_bench.py; every launch its own p / momentum buffers)
 {wg}
 -> the fused update costs +38-40 us per 16.8 M-element weight = 235 MB more HBM traffic at 6.2 TB/s: the optimizer's traffic runs at the HBM
@@ -113,5 +126,5 @@ the chain's kernels find CUs sooner; AFFT_TN_VARIANT experiment, removed; two al
 {tnvar}
 -> slower on cfg2 (14.94 -> 15.73 ms: the small tile's 21 % longer weight gradients cost more than the shorter waits return), a wash at the EK100 widths.
 """
-open(os.path.join(R, "profiles", "r03_experiments.txt"), "w").write(T.format(sweep=g("r3_sk_sweep2.txt"), diag=g("r3_sk_diag.txt"), ab=g("r3_pp_ab1.txt"), ab2=g("r3_pp_ab2.txt"), ab3=g("r3_pp_ab3.txt"), fill=g("r3_fill_bench.txt"),
+open(os.path.join(R, "profiles", "r03_experiments.txt"), "w").write(T.format(sweep=g("r3_sk_sweep2.txt"), diag=g("r3_sk_diag.txt"), ab=g("r3_pp_ab1.txt"), ab2=g("r3_pp_ab2.txt"), ab3=g("r3_pp_ab3.txt"), fill=g("r3_fill_bench.txt"), w4diag=g("r3_w4_diag.txt"), w4stag=g("r3_w4_stag.txt"),
                                                                           wg=g("r3_wgrad_sgd.txt"), cap=g("r3_cap_sweep.txt"), mink=g("r3_minK.txt"), ksplit=g("r3_ksplit.txt"), fusemin=g("r3_fusemin.txt"), lazy=g("r3_lazy_proto.txt"), tnvar=g("r3_tnvar.txt")))
