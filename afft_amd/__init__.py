@@ -13,10 +13,17 @@ import sys as _sys
 from .runtime import precision, set_grad_mode, set_precision  # noqa: F401
 
 
-def install_as_models():
+def install_as_models(patch_ddp: bool = False):
     """Make ``import models.fusion`` / Hydra ``_target_: models.fusion.ModalTokenCMFuser`` resolve to this
-    package, so the reference's train.py / conf/ work unchanged."""
+    package, so the reference's train.py / conf/ work unchanged.
+    patch_ddp: also make ``torch.nn.parallel.DistributedDataParallel`` (train.py:364-368) construct
+    ``afft_amd.parallel.DistributedDataParallel`` -- the wrapper that works with the gradient sink and hands the all-reduce
+    to ``afft_amd.optim.SGD`` (Hydra: ``opt.optimizer._target_=afft_amd.optim.SGD``)."""
     import importlib
+    if patch_ddp:
+        import torch
+        from .parallel import DistributedDataParallel as _DDP
+        torch.nn.parallel.DistributedDataParallel = _DDP
     pkg = importlib.import_module("afft_amd.models")
     _sys.modules["models"] = pkg
     for name in ("base_model", "fusion", "transformerblock", "future_prediction", "feature_mapping"):

@@ -209,13 +209,15 @@ __device__ __forceinline__ float dgelu_tanh_fast(float x) {
 }
 constexpr int AFFT_ACT_FAST = 0x100;
 
-// ---- Nesterov-SGD update of one element, shared by the stand-alone update kernels and the fused GEMM epilogue: every
-//      rounding is pinned (explicit fma / mul), so both give bit-identical parameters
-__device__ __forceinline__ void sgd_update(float& p, float& buf, float g, float lr, float mom, float wd, float gscale, bool first) {
+// ---- momentum-SGD update of one element (torch.optim.SGD with dampening 0), shared by the stand-alone update kernels and the
+//      fused GEMM epilogue: every rounding is pinned (explicit fma / mul), so both give bit-identical parameters.
+//      flags: AFFT_SGD_FIRST_STEP (the momentum buffer starts as the gradient), AFFT_SGD_PLAIN_MOMENTUM (nesterov = False:
+//      p -= lr * buf instead of p -= lr * (g + mom * buf)); include/afft_hip.h.
+__device__ __forceinline__ void sgd_update(float& p, float& buf, float g, float lr, float mom, float wd, float gscale, int flags) {
   const float gg = __fmaf_rn(g, gscale, __fmul_rn(wd, p));
-  const float bb = first ? gg : __fmaf_rn(mom, buf, gg);
+  const float bb = (flags & AFFT_SGD_FIRST_STEP) ? gg : __fmaf_rn(mom, buf, gg);
   buf = bb;
-  p = __fmaf_rn(-lr, __fmaf_rn(mom, bb, gg), p);
+  p = __fmaf_rn(-lr, (flags & AFFT_SGD_PLAIN_MOMENTUM) ? bb : __fmaf_rn(mom, bb, gg), p);
 }
 struct SgdEpi { float* p; float* buf; bf16_t* p16; float lr, mom, wd, gscale; int first; };
 

@@ -281,19 +281,19 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const v
       float g4[4];
       load4(g_, i, g_dtype, g4);
       const float4 gv = make_float4(g4[0], g4[1], g4[2], g4[3]);
-      float4 bv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *(float4*)(buf + i);
+      float4 bv = (first & AFFT_SGD_FIRST_STEP) ? make_float4(0.f, 0.f, 0.f, 0.f) : *(float4*)(buf + i);
       float gg[4] = {gv.x, gv.y, gv.z, gv.w};
       float bb[4] = {bv.x, bv.y, bv.z, bv.w};
       float pp[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sgd_update(pp[r], bb[r], gg[r], lr, mom, wd, gscale, first != 0);
+      for (int r = 0; r < 4; ++r) sgd_update(pp[r], bb[r], gg[r], lr, mom, wd, gscale, first);
       *(float4*)(buf + i) = make_float4(bb[0], bb[1], bb[2], bb[3]);
       *(float4*)(p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
       if (p16) store4(p16, i, AFFT_BF16, pp);
     } else {
       for (int64_t j = i; j < n; ++j) {
-        float pj = p[j], bj = first ? 0.f : buf[j];
-        sgd_update(pj, bj, ld_any(g_, j, g_dtype), lr, mom, wd, gscale, first != 0);
+        float pj = p[j], bj = (first & AFFT_SGD_FIRST_STEP) ? 0.f : buf[j];
+        sgd_update(pj, bj, ld_any(g_, j, g_dtype), lr, mom, wd, gscale, first);
         buf[j] = bj;
         p[j] = pj;
         if (p16) p16[j] = f2bf(pj);
@@ -308,8 +308,8 @@ __global__ __launch_bounds__(256) void sgd_runs_kernel(float* __restrict__ p, co
                                                        float wd, float gscale, int first) {
   const int64_t s0 = runs[2 * blockIdx.x], len = runs[2 * blockIdx.x + 1];
   for (int64_t j = s0 + threadIdx.x; j < s0 + len; j += 256) {
-    float pj = p[j], bj = first ? 0.f : buf[j];
-    sgd_update(pj, bj, g[j], lr, mom, wd, gscale, first != 0);
+    float pj = p[j], bj = (first & AFFT_SGD_FIRST_STEP) ? 0.f : buf[j];
+    sgd_update(pj, bj, g[j], lr, mom, wd, gscale, first);
     buf[j] = bj;
     p[j] = pj;
     if (p16) p16[j] = f2bf(pj);

@@ -35,6 +35,7 @@ using namespace afft_gemm_detail;
 
 int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream, int x3, int max_wg);
 int afft_gemm_launch_w4(int a_ks, int b_ks, int reg_staged, afft_gemm_detail::GemmFast& g, hipStream_t stream);
+int afft_gemm_launch_bd(int rows160, int packed, afft_gemm_detail::GemmFast& g, hipStream_t stream);
 
 #ifndef AFFT_G128_EPI_UNROLL
 #define AFFT_G128_EPI_UNROLL 1   // 2 (what pays in gemm_pp.hip) measured 1-3 % slower on the EK100-width and cfg4 steps
@@ -389,6 +390,7 @@ int launch_layout_impl(GemmFast& g, hipStream_t stream, const afft_gemm_t* d) {
     if (variant == 3) sk_geometry(((g.e.M + 255) / 256) * ((g.e.N + 255) / 256), s, g.K / BK, &g.sk_tlmax, &g.sk_smax);
   }
   if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream, 0, d->max_workgroups);
+  if (variant >= 7 && variant <= 10) return afft_gemm_launch_bd(variant == 8 || variant == 10, variant >= 9, g, stream);
   if (variant == 4) return launch_fast<2, 2, 4, A_KS, B_KS, false>(g, stream);
 #ifdef AFFT_BUILD_EXPERIMENTAL
   if (variant == 5 || variant == 6) return afft_gemm_launch_w4(A_KS, B_KS, variant == 6, g, stream);
@@ -397,8 +399,12 @@ int launch_layout_impl(GemmFast& g, hipStream_t stream, const afft_gemm_t* d) {
   return launch_fast<2, 2, 2, A_KS, B_KS, false>(g, stream);
 }
 
+// B-direct kernels (gemm_bd.hip): k-contiguous operands only, whole 16-column blocks
+bool bd_ok(int N, bool A_KS, bool B_KS) { return !A_KS && !B_KS && N >= 16 && N % 16 == 0; }
+
 int choose_variant(int M, int N, int K, bool A_KS, bool B_KS) {
-  if (g_variant != 0) return g_variant;
+  if (g_variant >= 7 && g_variant <= 10) { if (bd_ok(N, A_KS, B_KS)) return g_variant; }
+  else if (g_variant != 0) return g_variant;
   // measured (profiles/r01_gemm_variants_bench2.txt): the 256x256 ping-pong kernel (1 workgroup/CU) wins once its
   // grid covers >= ~60 % of the CUs; below that (GPT-2's M = 1024 GEMMs, small weight gradients) two independent
   // 128x128 workgroups per CU win.  The 256x128 3-stage shape (variant 2) never wins and is kept for reference.
@@ -476,7 +482,7 @@ extern "C" int afft_set_gemm_variant(int v) {
 #else
   const bool w4 = false;   // gemm_w4.hip is only in `make EXPERIMENTAL=1` builds
 #endif
-  if (v != 0 && v != 1 && v != 3 && v != 4 && !w4) { afft_set_error("afft_set_gemm_variant: %d is not 0 (auto), 1 (128x128), 3 (256x256 ping-pong), 4 (128x128, 4 stages) [5 / 6 (256x256 four-wave): EXPERIMENTAL=1 builds only]", v); return 1; }
+  if (v != 0 && v != 1 && v != 3 && v != 4 && !(v >= 7 && v <= 10) && !w4) { afft_set_error("afft_set_gemm_variant: %d is not 0 (auto), 1 (128x128), 3 (256x256 ping-pong), 4 (128x128, 4 stages), 7 / 8 (B-direct 256x256 / 160x256, NT layouts; others as auto) [5 / 6 (256x256 four-wave): EXPERIMENTAL=1 builds only]", v); return 1; }
   g_variant = v;
   return 0;
 }

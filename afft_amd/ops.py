@@ -285,13 +285,14 @@ def reduce_rows_periodic(src: Tensor, period: int, out: Tensor):
     return out
 
 
-def sgd_nesterov(p: Tensor, g: Tensor, buf: Tensor, lr: float, mom: float, wd: float, gscale: float, first: bool,
+def sgd_nesterov(p: Tensor, g: Tensor, buf: Tensor, lr: float, mom: float, wd: float, gscale: float, first,
                  p_bf16: Optional[Tensor] = None, gscale_dev: Optional[Tensor] = None):
+    """first: bool (first step) or the AFFT_SGD_* flag word (1 = first step, 2 = plain momentum instead of Nesterov)"""
     assert p.is_contiguous() and g.is_contiguous() and buf.is_contiguous()
     if p_bf16 is not None:
         assert p_bf16.dtype == torch.bfloat16 and p_bf16.numel() == p.numel() and p_bf16.is_contiguous()
     L.check(L.lib().afft_sgd_nesterov(_p(p), _p(g), _dt(g), _p(buf), _p(p_bf16), p.numel(), lr, mom, wd, gscale,
-                                      _p(gscale_dev), 1 if first else 0, _stream()), "sgd_nesterov")
+                                      _p(gscale_dev), int(first), _stream()), "sgd_nesterov")
 
 
 def sgd_nesterov_runs(p: Tensor, g: Tensor, buf: Tensor, runs: Tensor, lr: float, mom: float, wd: float, gscale: float, first: bool,
@@ -300,7 +301,7 @@ def sgd_nesterov_runs(p: Tensor, g: Tensor, buf: Tensor, runs: Tensor, lr: float
     assert runs.dtype == torch.int64 and runs.dim() == 2 and runs.shape[1] == 2 and runs.is_contiguous()
     assert p.dtype == g.dtype == buf.dtype == torch.float32
     L.check(L.lib().afft_sgd_nesterov_runs(_p(p), _p(g), _p(buf), _p(p_bf16), _p(runs), runs.shape[0], lr, mom, wd, gscale,
-                                           1 if first else 0, _stream()), "sgd_nesterov_runs")
+                                           int(first), _stream()), "sgd_nesterov_runs")
 
 
 def sumsq(x: Tensor, out: Tensor, scale: float = 1.0):

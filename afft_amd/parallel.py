@@ -33,8 +33,16 @@ def _align(n: int, a: int = 64) -> int:
 class FlatParams:
     """Re-homes every trainable parameter of `model` (and its .grad) in contiguous fp32 buffers."""
 
-    def __init__(self, model: torch.nn.Module):
-        self.params: List[Tensor] = [p for p in model.parameters() if p.requires_grad]
+    def __init__(self, model):
+        """model: an nn.Module (its trainable parameters, in module order) or an iterable of parameters (the optimizer's
+        param_groups, flattened: afft_amd.optim.SGD)"""
+        src = model.parameters() if isinstance(model, torch.nn.Module) else model
+        self.params: List[Tensor] = []
+        seen = set()
+        for p in src:
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                self.params.append(p)
         assert self.params, "no trainable parameters"
         dev = self.params[0].device
         self.offsets: List[int] = []
@@ -136,6 +144,8 @@ class GradReducer:
         self.flat_g16 = (torch.empty(flat.total, dtype=torch.bfloat16, device=flat.flat_g.device)
                          if (comm_dtype == "bf16" and self.comm) else None)
         self.on_bucket: Optional[Callable[[int, int, Tensor, float], None]] = None
+        self.defer_all = False     # True: nothing is handed over during backward, finish_step launches every bucket (callers whose
+                                   # gradients only reach the flat buffer at the end of backward: DistributedDataParallel below)
 
     # ---- step protocol
     def begin_step(self):
@@ -152,7 +162,7 @@ class GradReducer:
             return
         b = self.bucket_of[i]
         self._count[b] += 1
-        if self.expected is not None and not self._launched[b] and self._count[b] == self.expected[b]:
+        if self.expected is not None and not self.defer_all and not self._launched[b] and self._count[b] == self.expected[b]:
             self._launch(b)
 
     def _grad_slice(self, s: int, e: int):
@@ -250,29 +260,107 @@ class GradReducer:
 
 
 class FusedSGD:
-    """Nesterov-momentum SGD over the flat buffers (conf/opt/optimizer/sgd.yaml + expts/01: lr 1e-3,
-    momentum 0.9, nesterov, wd 1e-6): one kernel launch per contiguous slice instead of 151 parameter groups;
-    the same kernel writes the bf16 weight images of the slice."""
+    """Momentum SGD over the flat buffers (conf/opt/optimizer/sgd.yaml + expts/01: lr 1e-3, momentum 0.9, nesterov, wd 1e-6):
+    one kernel launch per contiguous slice instead of 151 parameter groups; the same kernel writes the bf16 weight images of
+    the slice.  `hyper` (optional, one (lr, weight_decay) per parameter of `flat`, set_hyper) carries the per-module values
+    train.py:189-225 allows: parameters are then updated class by class, one launch per distinct (lr, wd) and bucket."""
 
-    def __init__(self, flat: FlatParams, lr: float = 1e-3, momentum: float = 0.9, weight_decay: float = 1e-6):
-        self.flat, self.lr, self.momentum, self.wd = flat, lr, momentum, weight_decay
+    def __init__(self, flat: FlatParams, lr: float = 1e-3, momentum: float = 0.9, weight_decay: float = 1e-6,
+                 nesterov: bool = True):
+        self.flat, self.lr, self.momentum, self.wd, self.nesterov = flat, lr, momentum, weight_decay, nesterov
         self.buf = torch.zeros_like(flat.flat_p)
         self.steps = 0
         self.runs: Optional[Dict[tuple, Tensor]] = None    # per bucket (s, e): the runs NOT updated in a GEMM epilogue
+        self.skip: set = set()                             # ids of the parameters updated in a GEMM epilogue (those runs exclude)
+        self.hyper: Optional[List[tuple]] = None           # per parameter (lr, wd); None = self.lr / self.wd for all
+        self._class_runs: Dict[tuple, Tensor] = {}
+
+    def flags(self) -> int:
+        """AFFT_SGD_* flag word of the update kernels (include/afft_hip.h)"""
+        return (1 if self.steps == 0 else 0) | (0 if self.nesterov else 2)
+
+    def set_hyper(self, hyper: Optional[List[tuple]]):
+        """one (lr, weight_decay) per parameter of the flat buffers, or None; collapses to the scalar form when all agree"""
+        if hyper is not None:
+            assert len(hyper) == len(self.flat.params)
+            first = hyper[0]
+            if all(h == first for h in hyper):
+                self.lr, self.wd = float(first[0]), float(first[1])
+                hyper = None
+        self.hyper = hyper
+
+    def hyper_of(self, i: int) -> tuple:
+        return self.hyper[i] if self.hyper is not None else (self.lr, self.wd)
+
+    def _runs_of(self, s: int, e: int, idx: tuple, skip_fused: bool) -> Tensor:
+        """{start, length} runs (<= 16 Ki elements each: one block of the runs kernel) covering the parameters `idx` of bucket
+        [s, e), without the ones updated in GEMM epilogues"""
+        key = (s, e, idx, skip_fused)
+        runs = self._class_runs.get(key)
+        if runs is None:
+            flat, CH = self.flat, 16384
+            segs, cur = [], None
+            for i in idx:
+                p, o = flat.params[i], flat.offsets[i]
+                if skip_fused and id(p) in self.skip:
+                    cur = None
+                    continue
+                n = _align(p.numel())
+                if cur is not None and cur[0] + cur[1] == o:
+                    cur[1] += n
+                else:
+                    cur = [o, n]
+                    segs.append(cur)
+            chunks = [(a + k, min(CH, n - k)) for a, n in segs for k in range(0, n, CH)]
+            runs = torch.tensor(chunks, dtype=torch.int64, device=flat.flat_p.device).reshape(-1, 2)
+            if len(self._class_runs) > 4096:
+                self._class_runs.clear()
+            self._class_runs[key] = runs
+        return runs
 
     def step_range(self, s: int, e: int, grad: Tensor, gscale: float, gscale_dev: Optional[Tensor] = None):
-        if self.runs is not None and gscale_dev is None and grad.dtype == torch.float32:
-            # the big weights of this bucket are updated in their weight-gradient epilogues (Trainer._enable_fused): one
-            # launch over what is left of the bucket -- LayerNorm weights, biases, tokens, multiply-used weights
-            runs = self.runs.get((s, e))
-            if runs is not None:
+        fused = self.runs is not None and gscale_dev is None and grad.dtype == torch.float32
+        if self.hyper is None:
+            if fused:
+                # the big weights of this bucket are updated in their weight-gradient epilogues (Trainer._enable_fused): one
+                # launch over what is left of the bucket -- LayerNorm weights, biases, tokens, multiply-used weights
+                runs = self.runs.get((s, e))
+                if runs is not None:
+                    if runs.shape[0]:
+                        ops.sgd_nesterov_runs(self.flat.flat_p, self.flat.flat_g, self.buf, runs, self.lr, self.momentum, self.wd,
+                                              gscale, self.flags(), p_bf16=self.flat.flat_p16)
+                    return
+            p16 = self.flat.flat_p16[s:e] if self.flat.flat_p16 is not None else None
+            ops.sgd_nesterov(self.flat.flat_p[s:e], grad, self.buf[s:e], self.lr, self.momentum, self.wd, gscale,
+                             self.flags(), p_bf16=p16, gscale_dev=gscale_dev)
+            self.flat.refresh_transposed(s, e)
+            return
+        # per-parameter (lr, wd): the parameters of the bucket class by class
+        flat = self.flat
+        classes: Dict[tuple, list] = {}
+        for i, o in enumerate(flat.offsets):
+            if s <= o < e:
+                classes.setdefault(self.hyper[i], []).append(i)
+        for (lr, wd), idx in classes.items():
+            if grad.dtype == torch.float32 and gscale_dev is None and grad.numel() == e - s:
+                runs = self._runs_of(s, e, tuple(idx), fused)
                 if runs.shape[0]:
-                    ops.sgd_nesterov_runs(self.flat.flat_p, self.flat.flat_g, self.buf, runs, self.lr, self.momentum, self.wd,
-                                          gscale, self.steps == 0, p_bf16=self.flat.flat_p16)
-                return
-        p16 = self.flat.flat_p16[s:e] if self.flat.flat_p16 is not None else None
-        ops.sgd_nesterov(self.flat.flat_p[s:e], grad, self.buf[s:e], self.lr, self.momentum, self.wd, gscale,
-                         self.steps == 0, p_bf16=p16, gscale_dev=gscale_dev)
+                    # the runs kernel addresses the whole flat buffers: hand it the gradient at its flat position
+                    g_full = flat.flat_g if grad.data_ptr() == flat.flat_g[s:e].data_ptr() else None
+                    if g_full is not None:
+                        ops.sgd_nesterov_runs(flat.flat_p, g_full, self.buf, runs, lr, self.momentum, wd, gscale, self.flags(),
+                                              p_bf16=flat.flat_p16)
+                        continue
+                elif fused:
+                    continue
+            for i in idx:       # bf16 / clipped gradients: one launch per parameter
+                p, o = flat.params[i], flat.offsets[i]
+                if fused and id(p) in self.skip:
+                    continue
+                n = _align(p.numel())
+                p16 = flat.flat_p16[o:o + n] if flat.flat_p16 is not None else None
+                ops.sgd_nesterov(flat.flat_p[o:o + n], grad[o - s:o - s + n], self.buf[o:o + n], lr, self.momentum, wd, gscale,
+                                 self.flags(), p_bf16=p16, gscale_dev=gscale_dev)
         self.flat.refresh_transposed(s, e)
 
     def end_step(self):
@@ -295,10 +383,120 @@ class FusedSGD:
         self.end_step()
 
 
-class Trainer:
+class _FusedEpilogue:
+    """The optimizer fused into the weight-gradient GEMM epilogues (single GPU), shared by Trainer and afft_amd.optim.SGD.
+    Needs: self.flat (FlatParams), self.opt (FusedSGD), self.reducer (GradReducer), self.grad_clip, self._fused (None until
+    learned), self._name_of(p)."""
+
+    _fused: Optional[Dict[int, object]] = None
+
+    def _name_of(self, p: Tensor) -> str:
+        return "?"
+
+    # ---- optimizer fused into the weight-gradient GEMM epilogues (single GPU)
+    def _can_fuse(self) -> bool:
+        return (rt.fused_sgd() and rt.composite() and rt.precision() == "bf16" and rt.grad_mode() == "sink"
+                and self.flat.flat_p.is_cuda and self.flat.flat_p16 is not None and self.flat.flat_pT16 is None
+                and not self.reducer.comm and self.grad_clip is None and not rt.CAPTURING)
+
+    def _enable_fused(self):
+        """After a step with the optimizer inside the backward pass: every GEMM weight that (a) went through a composite
+        backward, (b) received exactly ONE gradient contribution and (c) owns a bf16 image in the flat buffers is from now on
+        updated in the epilogue of its own weight-gradient GEMM (afft_sgd_fused_t): its gradient never goes to HBM and the
+        per-bucket update kernel only walks what is left of the bucket (`runs`).  N = 1 only: with more ranks the summed
+        gradient has to exist before the update."""
+        from . import _lib as L_
+        flat, fused = self.flat, {}
+        for p, o in zip(flat.params, flat.offsets):
+            img = getattr(p, "_afft_img", None)
+            if (p.dim() == 2 and id(p) in rt.SINK.composite_weights and rt.SINK.touch_count.get(id(p), 0) == 1
+                    and img is not None and img.external):
+                d = L_.SgdFused()
+                d.p, d.buf, d.p_bf16 = flat.flat_p.data_ptr() + 4 * o, self.opt.buf.data_ptr() + 4 * o, flat.flat_p16.data_ptr() + 2 * o
+                fused[id(p)] = d
+        self._fused = fused
+        self.opt.runs = self._runs_without(fused)
+
+    def _runs_without(self, fused) -> Dict[tuple, Tensor]:
+        """per bucket: the {start, length} runs of the flat buffers that are NOT updated in a GEMM epilogue"""
+        flat = self.flat
+        CH = 16384       # a run is one 256-thread block of the runs kernel: keep them short
+        self.opt.skip = set(fused)
+        self.opt._class_runs.clear()
+        runs = {}
+        for (s, e) in self.reducer.buckets:
+            segs, cur = [], None
+            for p, o in zip(flat.params, flat.offsets):
+                if not (s <= o < e):
+                    continue
+                n = _align(p.numel())
+                if id(p) in fused:
+                    cur = None
+                    continue
+                if cur is not None and cur[0] + cur[1] == o:
+                    cur[1] += n
+                else:
+                    cur = [o, n]
+                    segs.append(cur)
+            chunks = [(a + k, min(CH, n - k)) for a, n in segs for k in range(0, n, CH)]
+            runs[(s, e)] = torch.tensor(chunks, dtype=torch.int64, device=flat.flat_p.device).reshape(-1, 2)
+        return runs
+
+    def _audit_fused_step(self):
+        """The set of epilogue-updated weights was learned on ONE step; a later step may route a weight differently (a branch
+        that is skipped, a sub-layer shared by two call sites, the call-by-call path).  After every fused step, on the host:
+        each such weight must have been updated in an epilogue exactly once and have had no other gradient contribution.
+        * not updated in an epilogue this step: its whole gradient sits in the flat buffer (the first contribution
+          overwrites, finish_step zeroes an untouched one) and the bucket kernel skipped it -> the regular update is applied
+          to its range now (behind every bucket update: finish_step has joined the streams) and the weight leaves the set;
+        * updated in an epilogue AND given a second contribution: the update already used a partial gradient -> error."""
+        flat, sink, stale = self.flat, rt.SINK, []
+        for p, o in zip(flat.params, flat.offsets):
+            pid = id(p)
+            if pid not in self._fused:
+                continue
+            applied, touches = sink.fused_applied.get(pid, 0), sink.touch_count.get(pid, 0)
+            if applied == 1 and touches == 1:
+                continue
+            if applied != 0:
+                raise RuntimeError(f"fused optimizer: weight {self._name_of(p)} was updated in its gradient GEMM's epilogue and then "
+                                   f"received {touches - applied} more gradient contribution(s) in the same step (the graph changed "
+                                   "since the fused set was learned).  Its parameter, momentum and bf16 image -- and every other "
+                                   "bucket of this step -- HAVE ALREADY BEEN MODIFIED from a partial gradient: reload the last "
+                                   "checkpoint, then rebuild the Trainer / optimizer or disable runtime.set_fused_sgd")
+            n = _align(p.numel())
+            lr, wd = self.opt.hyper_of(self._index[pid])
+            ops.sgd_nesterov(flat.flat_p[o:o + n], flat.flat_g[o:o + n], self.opt.buf[o:o + n], lr, self.opt.momentum,
+                             wd, 1.0, self.opt.flags(), p_bf16=flat.flat_p16[o:o + n])
+            stale.append(pid)
+        if stale:
+            for pid in stale:
+                del self._fused[pid]
+            self.opt.runs = self._runs_without(self._fused)
+            return True
+        return False
+
+    @property
+    def _index(self) -> Dict[int, int]:
+        ix = getattr(self, "_index_cache", None)
+        if ix is None:
+            ix = self._index_cache = self.flat.index_of()
+        return ix
+
+    def _fused_desc(self, p: Tensor):
+        d = self._fused.get(id(p))
+        if d is not None:
+            lr, wd = self.opt.hyper_of(self._index[id(p)])
+            d.lr, d.mom, d.wd, d.gscale, d.first_step = lr, self.opt.momentum, wd, 1.0, self.opt.flags() & 2
+        return d
+
+class Trainer(_FusedEpilogue):
     """fwd + loss + bwd (+ overlapped gradient all-reduce) + fused SGD for a BaseModel.  With `overlap_optimizer`
     the update of a bucket runs on the side stream as soon as that bucket's gradient is final, under the
     backward GEMMs of the layers below it."""
+
+    def _name_of(self, p: Tensor) -> str:
+        return next((k for k, q in self.model.named_parameters() if q is p), "?")
 
     def __init__(self, model, loss_wts: Dict[str, float], lr=1e-3, momentum=0.9, weight_decay=1e-6,
                  comm_dtype: str = "fp32", bucket_elems: int = 32 * 1024 * 1024, group=None,
@@ -339,101 +537,27 @@ class Trainer:
                 dist.broadcast(t.data, src=root, group=group)
         self.flat.refresh_images()
 
-    # ---- optimizer fused into the weight-gradient GEMM epilogues (single GPU)
-    def _can_fuse(self) -> bool:
-        return (rt.fused_sgd() and rt.composite() and rt.precision() == "bf16" and rt.grad_mode() == "sink"
-                and self.flat.flat_p.is_cuda and self.flat.flat_p16 is not None and self.flat.flat_pT16 is None
-                and not self.reducer.comm and self.grad_clip is None and not rt.CAPTURING)
-
-    def _enable_fused(self):
-        """After a step with the optimizer inside the backward pass: every GEMM weight that (a) went through a composite
-        backward, (b) received exactly ONE gradient contribution and (c) owns a bf16 image in the flat buffers is from now on
-        updated in the epilogue of its own weight-gradient GEMM (afft_sgd_fused_t): its gradient never goes to HBM and the
-        per-bucket update kernel only walks what is left of the bucket (`runs`).  N = 1 only: with more ranks the summed
-        gradient has to exist before the update."""
-        from . import _lib as L_
-        flat, fused = self.flat, {}
-        for p, o in zip(flat.params, flat.offsets):
-            img = getattr(p, "_afft_img", None)
-            if (p.dim() == 2 and id(p) in rt.SINK.composite_weights and rt.SINK.touch_count.get(id(p), 0) == 1
-                    and img is not None and img.external):
-                d = L_.SgdFused()
-                d.p, d.buf, d.p_bf16 = flat.flat_p.data_ptr() + 4 * o, self.opt.buf.data_ptr() + 4 * o, flat.flat_p16.data_ptr() + 2 * o
-                fused[id(p)] = d
-        self._fused = fused
-        self.opt.runs = self._runs_without(fused)
-
-    def _runs_without(self, fused) -> Dict[tuple, Tensor]:
-        """per bucket: the {start, length} runs of the flat buffers that are NOT updated in a GEMM epilogue"""
-        flat = self.flat
-        CH = 16384       # a run is one 256-thread block of the runs kernel: keep them short
-        runs = {}
-        for (s, e) in self.reducer.buckets:
-            segs, cur = [], None
-            for p, o in zip(flat.params, flat.offsets):
-                if not (s <= o < e):
-                    continue
-                n = _align(p.numel())
-                if id(p) in fused:
-                    cur = None
-                    continue
-                if cur is not None and cur[0] + cur[1] == o:
-                    cur[1] += n
-                else:
-                    cur = [o, n]
-                    segs.append(cur)
-            chunks = [(a + k, min(CH, n - k)) for a, n in segs for k in range(0, n, CH)]
-            runs[(s, e)] = torch.tensor(chunks, dtype=torch.int64, device=flat.flat_p.device).reshape(-1, 2)
-        return runs
-
-    def _audit_fused_step(self):
-        """The set of epilogue-updated weights was learned on ONE step; a later step may route a weight differently (a branch
-        that is skipped, a sub-layer shared by two call sites, the call-by-call path).  After every fused step, on the host:
-        each such weight must have been updated in an epilogue exactly once and have had no other gradient contribution.
-        * not updated in an epilogue this step: its whole gradient sits in the flat buffer (the first contribution
-          overwrites, finish_step zeroes an untouched one) and the bucket kernel skipped it -> the regular update is applied
-          to its range now (behind every bucket update: finish_step has joined the streams) and the weight leaves the set;
-        * updated in an epilogue AND given a second contribution: the update already used a partial gradient -> error."""
-        flat, sink, stale = self.flat, rt.SINK, []
-        for p, o in zip(flat.params, flat.offsets):
-            pid = id(p)
-            if pid not in self._fused:
-                continue
-            applied, touches = sink.fused_applied.get(pid, 0), sink.touch_count.get(pid, 0)
-            if applied == 1 and touches == 1:
-                continue
-            if applied != 0:
-                name = next((k for k, q in self.model.named_parameters() if q is p), "?")
-                raise RuntimeError(f"fused optimizer: weight {name} was updated in its gradient GEMM's epilogue and then received "
-                                   f"{touches - applied} more gradient contribution(s) in the same step (the graph changed since "
-                                   "the fused set was learned); rebuild the Trainer or disable runtime.set_fused_sgd")
-            n = _align(p.numel())
-            ops.sgd_nesterov(flat.flat_p[o:o + n], flat.flat_g[o:o + n], self.opt.buf[o:o + n], self.opt.lr, self.opt.momentum,
-                             self.opt.wd, 1.0, self.opt.steps == 0, p_bf16=flat.flat_p16[o:o + n])
-            stale.append(pid)
-        if stale:
-            for pid in stale:
-                del self._fused[pid]
-            self.opt.runs = self._runs_without(self._fused)
-            return True
-        return False
-
-    def _fused_desc(self, p: Tensor):
-        d = self._fused.get(id(p))
-        if d is not None:
-            d.lr, d.mom, d.wd, d.gscale, d.first_step = self.opt.lr, self.opt.momentum, self.opt.wd, 1.0, 0
-        return d
-
-    def forward_backward(self, feats: Dict[str, Tensor], target, target_subclips, optimize_in_backward: bool = False):
+    def forward_backward(self, feats: Dict[str, Tensor], target, target_subclips, optimize_in_backward: bool = False,
+                         mixup_fn: Optional[Callable] = None, mixup_backbone: bool = True):
+        """mixup_fn / mixup_backbone: as in Runner.__call__ (common/runner.py:238-249; expts/01 trains with
+        train.use_mixup=true, train.mixup_backbone=true): MixUp inside BaseModel.forward after the backbones, or on the
+        features before the model; the losses then take soft targets and the ignore mask MixUp returns."""
         self.reducer.on_bucket = self.opt.step_range if optimize_in_backward else None
         fuse = optimize_in_backward and self._fused is not None and self._can_fuse()
         rt.SINK.fused = self._fused_desc if fuse else None
         saved_runs, self.opt.runs = self.opt.runs, (self.opt.runs if fuse else None)
         try:
             self.reducer.begin_step()
-            outputs, out_t = self.model(feats, mixup_fn=None, target=target, target_subclips=target_subclips,
-                                        target_subclips_ignore_index=None)
-            losses, _ = self.loss_fn(outputs, out_t['target'], out_t['target_subclips'])
+            kwargs = dict(mixup_fn=None, target=target, target_subclips=target_subclips, target_subclips_ignore_index=None)
+            if mixup_fn is not None:
+                if mixup_backbone:
+                    kwargs['mixup_fn'] = mixup_fn
+                else:
+                    feats, target, target_subclips, ign = mixup_fn(feats, target, target_subclips)
+                    kwargs.update(target=target, target_subclips=target_subclips, target_subclips_ignore_index=ign)
+            outputs, out_t = self.model(feats, **kwargs)
+            losses, _ = self.loss_fn(outputs, out_t['target'], out_t['target_subclips'], mixup_enable=mixup_fn is not None,
+                                     target_subclips_ignore_index=out_t['target_subclips_ignore_index'])
             loss, parts = self._reduce(losses, self.loss_wts, sync=False)
             loss.backward()
             self.reducer.finish_step()
@@ -493,20 +617,22 @@ class Trainer:
         self._graph_io = None
         self._graph_in = None
 
-    def _eager_step(self, feats, target, target_subclips):
+    def _eager_step(self, feats, target, target_subclips, mixup_fn=None, mixup_backbone=True):
         from . import dropout as D_
         D_.salt_step()
         if getattr(self, "_graph_single", False):
             was = rt.overlap_wgrad()
             rt.set_overlap_wgrad(False)
             try:
-                loss, parts = self.forward_backward(feats, target, target_subclips, optimize_in_backward=False)
+                loss, parts = self.forward_backward(feats, target, target_subclips, optimize_in_backward=False,
+                                                    mixup_fn=mixup_fn, mixup_backbone=mixup_backbone)
                 g, scale = self.reducer.grad_for_optimizer()
                 self.opt.step(g, scale, grad_clip=self.grad_clip)
             finally:
                 rt.set_overlap_wgrad(was)
             return loss, parts
-        return self.forward_backward(feats, target, target_subclips, optimize_in_backward=True)
+        return self.forward_backward(feats, target, target_subclips, optimize_in_backward=True, mixup_fn=mixup_fn,
+                                     mixup_backbone=mixup_backbone)
 
     def _feed_graph(self, feats, target, target_subclips) -> bool:
         """Copy a batch into the tensors the captured graph reads (no-op for the captured tensors themselves).  False when
@@ -530,14 +656,131 @@ class Trainer:
                 t.copy_(n, non_blocking=True)
         return True
 
-    def step(self, feats, target, target_subclips, optimize: bool = True):
+    def step(self, feats, target, target_subclips, optimize: bool = True, mixup_fn: Optional[Callable] = None,
+             mixup_backbone: bool = True):
         g = getattr(self, "_graph", None)
-        if g is not None and optimize and self._feed_graph(feats, target, target_subclips):
+        if g is not None and optimize and mixup_fn is None and self._feed_graph(feats, target, target_subclips):
             g.replay()
             return self._graph_io
         fused = optimize and self.overlap_optimizer
-        loss, parts = self.forward_backward(feats, target, target_subclips, optimize_in_backward=fused)
+        loss, parts = self.forward_backward(feats, target, target_subclips, optimize_in_backward=fused, mixup_fn=mixup_fn,
+                                            mixup_backbone=mixup_backbone)
         if optimize and not fused:
             g, scale = self.reducer.grad_for_optimizer()
             self.opt.step(g, scale, grad_clip=self.grad_clip)
         return loss, parts
+
+
+class DistributedDataParallel(torch.nn.Module):
+    """``torch.nn.parallel.DistributedDataParallel``-shaped wrapper for the reference's ``train.py:364-368``::
+
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[gpu], output_device=gpu)
+
+    (``afft_amd.install_as_models(patch_ddp=True)`` makes that very line construct this class.)  torch's wrapper learns about a
+    gradient from an autograd hook on the parameter; on the default "sink" path the weight-gradient GEMMs write (and, on one GPU,
+    consume) gradients without autograd ever seeing them, so torch DDP would wait for gradients that never arrive.  This wrapper
+    * broadcasts rank 0's parameters and buffers at construction (and, when the parameters belong to an ``afft_amd.optim.SGD``,
+      its momentum and step count; the bf16 weight images are re-derived) -- what torch DDP's constructor does;
+    * with an ``afft_amd.optim.SGD`` over the same parameters does nothing else: that optimizer's ``GradReducer`` already
+      all-reduces bucket by bucket during backward (RCCL, side stream) and applies 1 / world in its update;
+    * with any other optimizer (``torch.optim.SGD`` ...) owns a ``FlatParams`` + ``GradReducer`` itself: ``forward`` (training
+      mode) opens the step, a hook on the outputs queues an end-of-backward callback that completes the all-reduce, divides by
+      the world size and joins the streams, so ``optimizer.step()`` sees averaged gradients in ``p.grad`` as under torch DDP.
+    ``state_dict()`` keys carry the same ``module.`` prefix as torch DDP's."""
+
+    def __init__(self, module: torch.nn.Module, device_ids=None, output_device=None, dim: int = 0, broadcast_buffers: bool = True,
+                 process_group=None, bucket_cap_mb: Optional[float] = None, comm_dtype: str = "fp32", comm_algo: str = "allreduce",
+                 **unused):
+        super().__init__()
+        self.module = module
+        self.device_ids, self.output_device, self.dim = device_ids, output_device, dim
+        self.process_group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        from . import optim as _optim
+        self._engines = _optim.engines_for(module)
+        self._own = None
+        self._pending = False
+        if self.world > 1:
+            root = dist.get_global_rank(process_group, 0) if process_group is not None else 0
+            owned = set()
+            for e in self._engines:
+                e.sync_parameters(process_group)
+                owned |= {id(p) for p in e.flat.params}
+            with torch.no_grad():
+                for t in list(module.parameters()) + (list(module.buffers()) if broadcast_buffers else []):
+                    if id(t) not in owned:
+                        dist.broadcast(t.data, src=root, group=process_group)
+            rt.invalidate_weight_images()
+        if not self._engines and any(p.requires_grad for p in module.parameters()):
+            flat = FlatParams(module)
+            elems = 32 * 1024 * 1024 if bucket_cap_mb is None else max(1, int(bucket_cap_mb * 2 ** 20 / 4))
+            red = GradReducer(flat, group=process_group, bucket_elems=elems, comm_dtype=comm_dtype, comm_algo=comm_algo)
+            red.defer_all = True      # a foreign zero_grad(set_to_none=True) between forward and backward detaches p.grad from the
+            self._own = (flat, red)   # flat buffer: gradients are gathered into it when backward is over, then reduced
+
+    # ---- foreign optimizer: the wrapper brackets the backward pass itself
+    def _begin(self):
+        flat, red = self._own
+        for p, o in zip(flat.params, flat.offsets):      # a torch optimizer's zero_grad(set_to_none=True) dropped the views
+            if p.grad is None or p.grad.data_ptr() != flat.flat_g.data_ptr() + 4 * o:
+                if rt.grad_mode() != "sink":
+                    flat.flat_g[o:o + p.numel()].zero_()
+                p.grad = flat.flat_g[o:o + p.numel()].view(p.shape)
+        red.on_bucket = None
+        red.begin_step()
+        self._pending = True
+
+    def _finish(self):
+        if not self._pending:
+            return
+        self._pending = False
+        flat, red = self._own
+        if flat.flat_g.is_cuda and rt.overlap_wgrad():      # weight gradients were enqueued on the auxiliary stream
+            torch.cuda.current_stream().wait_stream(rt.aux_stream(flat.flat_g.device))
+        with torch.no_grad():
+            for p, o in zip(flat.params, flat.offsets):     # gradients produced into fresh tensors (p.grad was None): gather them
+                view = flat.flat_g[o:o + p.numel()].view(p.shape)
+                if p.grad is None:
+                    view.zero_()
+                elif p.grad.data_ptr() != view.data_ptr():
+                    view.copy_(p.grad)
+                rt.SINK.touched[id(p)] = True
+                p.grad = view
+        red.finish_step()
+        if red.comm:
+            g, scale = red.grad_for_optimizer()
+            if g is not flat.flat_g:                      # bf16 payload: back into the fp32 gradient buffer
+                flat.flat_g.copy_(g)
+            flat.flat_g.mul_(scale)
+
+    def _arm_outputs(self, out):
+        def visit(o):
+            if isinstance(o, torch.Tensor):
+                if o.requires_grad:
+                    o.register_hook(self._on_first_grad)
+            elif isinstance(o, dict):
+                for v in o.values():
+                    visit(v)
+            elif isinstance(o, (list, tuple)):
+                for v in o:
+                    visit(v)
+        visit(out)
+
+    def _on_first_grad(self, grad):
+        if self._pending and not getattr(self, "_queued", False):
+            self._queued = True
+
+            def _final():
+                self._queued = False
+                self._finish()
+            torch.autograd.Variable._execution_engine.queue_callback(_final)
+        return grad
+
+    def forward(self, *args, **kwargs):
+        bracket = self._own is not None and self.training and torch.is_grad_enabled()
+        if bracket:
+            self._begin()
+        out = self.module(*args, **kwargs)
+        if bracket:
+            self._arm_outputs(out)
+        return out

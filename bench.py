@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--full-rows", action="store_true",
                     help="run the SA-Fuser's last block on every token row as the reference does (default: its MLP half on token 0 only, "
                          "the only rows that reach an output; runtime.skip_dead_rows)")
+    ap.add_argument("--no-reference-loop", action="store_true",
+                    help="skip the side measurement of the reference's own loop (Runner + MixUp + optimizer over 151 groups + lr scheduler)")
     ap.add_argument("--wgrad-wgs", type=int, default=None, help="CU cap of the weight-gradient GEMMs on the auxiliary stream (default: runtime's)")
     return ap.parse_args()
 
@@ -217,6 +219,88 @@ def parity_side_measurements(args, device, feats, tgt, sub, c):
     ref = logits["fp32"]
     out["logits_rel_l2_vs_exact_fp32_mode"] = {m: float(((logits[m] - ref).norm() / ref.norm()).cpu()) for m in ("bf16", "bf16x3")}
     afft_amd.set_precision(args.precision)
+    return out
+
+
+def reference_loop_measurements(args, device, feats, tgt, sub, c, trainer_ms):
+    """What a user of the reference's UNCHANGED loop gets, on the bench workload, beside the headline number --
+    train.py:228-265 with the recipe of expts/01 (train.use_mixup=true, mixup_backbone=true, mixup_alpha 0.1, label smoothing
+    0.4, SGD momentum 0.9 nesterov over the 151 per-parameter groups of prepare_params, Warmup(CosineLR) stepped per iteration):
+
+        loss, metrics = Runner(model, device, wts)(batch, mixup_fn, True)       # host syncs as the reference has them
+        optimizer.zero_grad(); loss.backward(); optimizer.step(); lr_scheduler.step()
+
+    with (a) torch.optim.SGD and gradients through autograd (AFFT_GRAD_MODE=autograd: what works below torch's own DDP),
+    (b) torch.optim.SGD on the default gradient sink, (c) afft_amd.optim.SGD (Hydra: opt.optimizer._target_=afft_amd.optim.SGD)
+    with the reference's synchronous Runner and (d) the same with Runner(async_metrics=True); and Trainer.step with MixUp."""
+    import afft_amd
+    from afft_amd import dropout as D_
+    from afft_amd.common.mixup import MixUp
+    from afft_amd.common.runner import Runner
+    from afft_amd.common.scheduler import CosineLR, Warmup, prepare_params
+    from afft_amd.optim import SGD as AfftSGD
+    from afft_amd.parallel import Trainer
+    wts = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
+    B = args.batch
+    batch = ({"data_dict": feats, "target": tgt, "target_subclips": sub}, {})
+    n_warm, n_timed = 4, 10
+    out = {"steps": n_timed, "recipe": "expts/01: MixUp(alpha 0.1, label smoothing 0.4, mixup_backbone) + SGD(momentum 0.9, nesterov, lr 1e-3, "
+                                       "wd 1e-6) over prepare_params' per-parameter groups + Warmup(CosineLR) per iteration"}
+
+    def run(kind):
+        D_.manual_seed(42)
+        afft_amd.set_grad_mode("autograd" if kind == "torch_sgd_autograd" else "sink")
+        model, _ = build_model(args.config, device)
+        model.train(not args.eval_drop)
+        mix = MixUp(alpha=0.1, label_smoothing={"action": 0.4}, num_classes={"action": 3806})
+        if kind == "trainer_mixup":
+            tr = Trainer(model, wts, bucket_elems=args.bucket_melems * 1024 * 1024)
+            step = lambda: tr.step(feats, tgt, sub, mixup_fn=mix)      # noqa: E731
+            info = {}
+        else:
+            groups = prepare_params(model, None, 1e-3, 1e-6)
+            if kind.startswith("torch_sgd"):
+                opt = torch.optim.SGD(groups, lr=1e-3, momentum=0.9, nesterov=True)
+            else:
+                opt = AfftSGD(groups, lr=1e-3, momentum=0.9, nesterov=True, bucket_elems=args.bucket_melems * 1024 * 1024)
+            sched = Warmup(opt, CosineLR(opt, num_epochs=30, iters_per_epoch=1000, world_size=1, eta_min=1e-6), init_lr_ratio=0.01,
+                           num_epochs=20, iters_per_epoch=1000, world_size=1)
+            runner = Runner(model, device, wts, async_metrics=(kind == "afft_sgd_async"))
+            info = {"param_groups": len(opt.param_groups)}
+
+            def step():
+                loss, metrics = runner(batch, mix, True)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                sched.step()
+                return loss, metrics
+        for _ in range(n_warm):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_timed):
+            r = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n_timed
+        info.update({"clips_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3)})
+        if kind.startswith("afft_sgd"):
+            info["optimizer_path"] = "fused-epilogue" if opt._fused else "separate"
+            info["lr_seen_by_kernels"] = opt.opt.lr if opt.opt.hyper is None else "per-parameter"
+        del r
+        return info
+
+    try:
+        for kind in ("torch_sgd_autograd", "torch_sgd_sink", "afft_sgd", "afft_sgd_async", "trainer_mixup"):
+            try:
+                out[kind] = run(kind)
+            except Exception as ex:  # noqa: BLE001
+                out[kind] = {"error": repr(ex)}
+            torch.cuda.empty_cache()
+    finally:
+        afft_amd.set_grad_mode("sink")
+    if "ms_per_step" in out.get("afft_sgd", {}):
+        out["afft_sgd_vs_trainer_step"] = round(out["afft_sgd"]["ms_per_step"] / trainer_ms, 4)
     return out
 
 
@@ -527,6 +611,11 @@ def main():
                 result.update(parity_side_measurements(args, device, feats, tgt, sub, c))
             except Exception as ex:  # noqa: BLE001
                 result["parity_mode"] = {"error": repr(ex)}
+        if not args.no_reference_loop and world == 1 and args.precision == "bf16" and not args.no_optimizer:
+            try:
+                result["reference_loop"] = reference_loop_measurements(args, device, feats, tgt, sub, c, ms_per_step)
+            except Exception as ex:  # noqa: BLE001
+                result["reference_loop"] = {"error": repr(ex)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 result["cpu_baseline"] = cpu_baseline(args.config, args.cpu_batch)

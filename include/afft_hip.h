@@ -105,8 +105,13 @@ typedef struct {
  * kernels of the same step that still read p_bf16 (the data-gradient GEMM of the same layer). */
 typedef struct afft_sgd_fused {
   float* p; float* buf; void* p_bf16;
-  float lr, mom, wd, gscale; int32_t first_step;
+  float lr, mom, wd, gscale; int32_t first_step;   /* first_step: AFFT_SGD_* flags (below) */
 } afft_sgd_fused_t;
+/* `first_step` of every optimizer entry point is a flag word: AFFT_SGD_FIRST_STEP = the momentum buffer does not exist yet (it
+ * starts as the gradient: torch.optim.SGD's first step); AFFT_SGD_PLAIN_MOMENTUM = torch.optim.SGD(nesterov=False):
+ * p -= lr * buf instead of the Nesterov form p -= lr * (g' + mom * buf) (conf/opt/optimizer/sgd.yaml ships nesterov: false,
+ * every training recipe under expts/ sets opt.optimizer.nesterov=true). */
+enum { AFFT_SGD_FIRST_STEP = 1, AFFT_SGD_PLAIN_MOMENTUM = 2 };
 enum { AFFT_GEMM_WS_HEADER = 4096 };
 /* bytes of afft_gemm_t.workspace that let this problem use split-K under the current mode (0 = it would not split) */
 int64_t afft_gemm_workspace_bytes(int M, int N, int K, int a_kstrided, int b_kstrided);

@@ -264,12 +264,20 @@ def reduce_rows_periodic(src, period, out):
 def sgd_nesterov(p, g, buf, lr, mom, wd, gscale, first, p_bf16=None, gscale_dev=None):
     if gscale_dev is not None:
         gscale = gscale * float(gscale_dev)
+    flags = int(first)        # AFFT_SGD_* flag word: 1 = first step, 2 = plain momentum (nesterov=False)
     gg = g.float() * gscale + wd * p
-    bb = gg if first else mom * buf + gg
+    bb = gg if (flags & 1) else mom * buf + gg
     buf.copy_(bb)
-    p -= lr * (gg + mom * bb)
+    p -= lr * (bb if (flags & 2) else gg + mom * bb)
     if p_bf16 is not None:
         p_bf16.copy_(p)
+
+
+@torch.no_grad()
+def sgd_nesterov_runs(p, g, buf, runs, lr, mom, wd, gscale, first, p_bf16=None):
+    for a, n in runs.tolist():
+        sgd_nesterov(p[a:a + n], g[a:a + n], buf[a:a + n], lr, mom, wd, gscale, first,
+                     p_bf16=None if p_bf16 is None else p_bf16[a:a + n])
 
 
 @torch.no_grad()
@@ -351,7 +359,7 @@ def softmax_rows(x, y):
 
 
 _NAMES = ["Split", "gemm", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "softmax_ce", "mse", "cast",
-          "assemble_tokens", "colsum", "add_rows_periodic", "reduce_rows_periodic", "sgd_nesterov", "sumsq", "clip_coef",
+          "assemble_tokens", "colsum", "add_rows_periodic", "reduce_rows_periodic", "sgd_nesterov", "sgd_nesterov_runs", "sumsq", "clip_coef",
           "group_sum", "group_bcast", "act_bwd", "softmax_small_fwd", "softmax_small_bwd", "weighted_sum_fwd",
           "weighted_sum_bwd", "softmax_rows"]
 
