@@ -24,7 +24,8 @@ class Dropout(C.Structure):
 
 
 class SgdFused(C.Structure):      # afft_sgd_fused_t
-    _fields_ = [("p", vp), ("buf", vp), ("p_bf16", vp), ("lr", f32), ("mom", f32), ("wd", f32), ("gscale", f32), ("first_step", i32)]
+    _fields_ = [("p", vp), ("buf", vp), ("p_bf16", vp), ("lr", f32), ("mom", f32), ("wd", f32), ("gscale", f32), ("first_step", i32),
+                ("p_pk16", vp)]
 
 
 SgdP = C.POINTER(SgdFused)
@@ -50,6 +51,7 @@ class GemmDesc(C.Structure):
         ("max_workgroups", i32),
         ("split3", i32), ("a_lo", i64), ("b_lo", i64),
         ("sgd", SgdP),
+        ("b_packed", vp),
     ]
 
 
@@ -76,7 +78,7 @@ class AttnSublayer(C.Structure):      # afft_attn_sublayer_t
         ("g_w_qkv", vp), ("acc_w_qkv", i32), ("g_b_qkv", vp), ("acc_b_qkv", i32),
         ("g_w_proj", vp), ("acc_w_proj", i32), ("g_b_proj", vp), ("acc_b_proj", i32),
         ("g_ln_w", vp), ("g_ln_b", vp), ("acc_ln", i32),
-        ("dx", vp)] + _HAND + [("ln_partial", vp)] + _WS + [("sgd_w_qkv", SgdP), ("sgd_w_proj", SgdP)]
+        ("dx", vp)] + _HAND + [("ln_partial", vp)] + _WS + [("sgd_w_qkv", SgdP), ("sgd_w_proj", SgdP), ("w_qkv_pk", vp), ("w_proj_pk", vp)]
 
 
 class MLPSublayer(C.Structure):       # afft_mlp_sublayer_t
@@ -94,7 +96,7 @@ class MLPSublayer(C.Structure):       # afft_mlp_sublayer_t
         ("g_w1", vp), ("acc_w1", i32), ("g_b1", vp), ("acc_b1", i32),
         ("g_w2", vp), ("acc_w2", i32), ("g_b2", vp), ("acc_b2", i32),
         ("g_ln_w", vp), ("g_ln_b", vp), ("acc_ln", i32),
-        ("dx", vp)] + _HAND + [("ln_partial", vp)] + _WS + [("sgd_w1", SgdP), ("sgd_w2", SgdP)]
+        ("dx", vp)] + _HAND + [("ln_partial", vp)] + _WS + [("sgd_w1", SgdP), ("sgd_w2", SgdP), ("w1_pk", vp), ("w2_pk", vp)]
 
 
 class CrossAttnSublayer(C.Structure):  # afft_cross_attn_sublayer_t
@@ -134,6 +136,7 @@ _SIGS = {
     "afft_gemm_trace_begin": ([i32], C.c_int),
     "afft_gemm_trace_end": ([C.POINTER(GemmTraceRec), i32], C.c_int),
     "afft_gemm_workspace_bytes": ([C.c_int, C.c_int, C.c_int, C.c_int, C.c_int], i64),
+    "afft_pack_weight": ([vp, i64, i32, i32, vp, vp], C.c_int),
     "afft_split_bf16": ([vp, i64, i32, i32, vp, i64, i32, i64, vp], C.c_int),
     "afft_layernorm_fwd": ([vp, i64, vp, vp, f32, i32, i32, vp, i64, i32, vp, vp, vp], C.c_int),
     "afft_layernorm_bwd_nparts": ([i32], C.c_int),

@@ -219,7 +219,12 @@ __device__ __forceinline__ void sgd_update(float& p, float& buf, float g, float 
   buf = bb;
   p = __fmaf_rn(-lr, (flags & AFFT_SGD_PLAIN_MOMENTUM) ? bb : __fmaf_rn(mom, bb, gg), p);
 }
-struct SgdEpi { float* p; float* buf; bf16_t* p16; float lr, mom, wd, gscale; int first; };
+struct SgdEpi { float* p; float* buf; bf16_t* p16; float lr, mom, wd, gscale; int first; bf16_t* p16k; };
+// element offset of the 8-element fragment that holds W[m][n .. n + 7] (n % 8 == 0) in the fragment-packed image of a [rows, ld] weight
+// (afft_pack_weight, include/afft_hip.h)
+__device__ __forceinline__ int64_t packed_frag(int m, int n, int64_t ld) {
+  return (((int64_t)(m >> 4) * (ld >> 5) + (n >> 5)) * 64 + (m & 15) + 16 * ((n >> 3) & 3)) * 8;
+}
 
 // ---- GEMM epilogue shared by the bf16 fast path and the fp32 path ------------------------------
 struct EpiParams {
@@ -326,12 +331,14 @@ __device__ __forceinline__ void epilogue4(const EpiParams& e, const DropParams& 
       store4(e.sgd.p, idx, AFFT_F32, pv);
       store4(e.sgd.buf, idx, AFFT_F32, bv);
       if (e.sgd.p16) store4(e.sgd.p16, idx, AFFT_BF16, pv);
+      if (e.sgd.p16k) store4(e.sgd.p16k, packed_frag(m, n & ~7, e.ldo) + (n & 7), AFFT_BF16, pv);
     } else {
       for (int r = 0; r < 4 && n + r < e.N; ++r) {
         float pv = e.sgd.p[idx + r], bv = e.sgd.buf[idx + r];
         sgd_update(pv, bv, v[r] * e.alpha, e.sgd.lr, e.sgd.mom, e.sgd.wd, e.sgd.gscale, e.sgd.first);
         e.sgd.p[idx + r] = pv; e.sgd.buf[idx + r] = bv;
         if (e.sgd.p16) e.sgd.p16[idx + r] = f2bf(pv);
+        if (e.sgd.p16k) e.sgd.p16k[packed_frag(m, (n + r) & ~7, e.ldo) + ((n + r) & 7)] = f2bf(pv);
       }
     }
     return;
@@ -437,6 +444,7 @@ __device__ __forceinline__ void epilogue8(const EpiParams& e, const DropParams& 
     store8(e.sgd.p, idx, AFFT_F32, pv);
     store8(e.sgd.buf, idx, AFFT_F32, bv);
     if (e.sgd.p16) store8(e.sgd.p16, idx, AFFT_BF16, pv);
+    if (e.sgd.p16k) store8(e.sgd.p16k, packed_frag(m, n, e.ldo), AFFT_BF16, pv);
     return;
   }
   const float rs = (e.rowscale ? e.rowscale[m] : 1.0f) * drop_row_scale(dp, m);

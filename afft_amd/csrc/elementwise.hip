@@ -329,6 +329,35 @@ extern "C" int afft_sgd_nesterov_runs(float* p, const float* g, float* buf, void
   return 0;
 }
 
+namespace {
+// fp32 [rows, cols] -> fragment-packed bf16 image (include/afft_hip.h: afft_pack_weight).  One thread per 8-element fragment:
+// reads 32 contiguous bytes of a row, writes the 16-byte fragment; consecutive threads walk the k-chunks of one row, so reads
+// are coalesced along the row and a wave's writes fall into 16 rows x 4 lane groups of one or two 1-KiB blocks.
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ src, int64_t lds_, int rows, int cols,
+                                                          bf16_t* __restrict__ dst) {
+  const int chunks = cols >> 3;
+  const int64_t total = (int64_t)rows * chunks;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int m = (int)(i / chunks), n = (int)(i % chunks) << 3;
+    const float4 a = *(const float4*)(src + (int64_t)m * lds_ + n), b = *(const float4*)(src + (int64_t)m * lds_ + n + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    store8(dst, packed_frag(m, n, cols), AFFT_BF16, v);
+  }
+}
+}  // namespace
+
+extern "C" int afft_pack_weight(const float* src, int64_t lds_, int32_t rows, int32_t cols, void* dst, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(src && dst, "pack_weight: null pointer");
+  AFFT_CHECK(rows > 0 && cols > 0 && rows % 16 == 0 && cols % 32 == 0 && lds_ % 4 == 0, "pack_weight: needs rows %% 16 == 0, cols %% 32 == 0 (got %d x %d)", rows, cols);
+  AFFT_CHECK(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "pack_weight: buffers must be 16-byte aligned");
+  const int64_t total = (int64_t)rows * (cols >> 3);
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, stream, src, lds_, rows, cols, (bf16_t*)dst);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int afft_cast(const float* src, int64_t lds_, int32_t rows, int32_t cols, void* dst, int64_t ldd,
                          int32_t dst_dtype, void* dst_t, int64_t ldt, int32_t zero_pad, const afft_dropout_t* drop,
                          void* stream_) {

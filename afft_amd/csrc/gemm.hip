@@ -273,6 +273,8 @@ int launch_fast(GemmFast& g, hipStream_t stream) {
 }
 
 int choose_variant(int M, int N, int K, bool A_KS, bool B_KS);
+bool bd_packed_wins(int M, int N, int K);
+extern int g_bd_mode;
 
 // stream-K of `tiles` 256x256 tiles of nk K-tiles over a grid of G workgroups (SkPlan, gemm_tiles.h): false when no XCD has a
 // partial round to cut or a piece would be empty; else the workspace geometry (leftover tiles per XCD, pieces per tile)
@@ -362,7 +364,8 @@ int launch_layout(GemmFast& g, hipStream_t stream, const afft_gemm_t* d) {
   (void)hipEventRecord(t.a, stream);
   const int rc = launch_layout_impl<A_KS, B_KS>(g, stream, d);
   (void)hipEventRecord(t.b, stream);
-  const int variant = choose_variant(g.e.M, g.e.N, g.K, A_KS, B_KS);
+  int variant = choose_variant(g.e.M, g.e.N, g.K, A_KS, B_KS);
+  if (!A_KS && !B_KS && d->b_packed && !d->split3 && g_variant == 0 && g.ldb == d->K && bd_packed_wins(g.e.M, g.e.N, g.K)) variant = 10;
   const int tiles = ((g.e.M + 255) / 256) * ((g.e.N + 255) / 256), cap = d->max_workgroups & ~7;
   t.r = afft_gemm_trace_rec_t{g.e.M, g.e.N, d->K, A_KS, B_KS, variant, g.splitk, d->split3,
                               variant == 3 && A_KS && B_KS && !d->split3 && g.splitk == 1 && cap >= 8 && cap < tiles, d->sgd != nullptr, 0.f};
@@ -371,8 +374,37 @@ int launch_layout(GemmFast& g, hipStream_t stream, const afft_gemm_t* d) {
   return rc;
 }
 
+// "B direct" kernel on a fragment-packed weight (afft_gemm_t.b_packed, gemm_bd.hip) against the 256x256 ping-pong kernel: a cost
+// model in us fitted to both kernels alone on one MI355X (profiles/r04_gemm_bd.txt).  Ping-pong: one workgroup per CU, a K-tile
+// of a full round costs ~1.9 us, of a last round with <= 160 busy CUs 1.4 us (the part is power-limited), + 10 us; B-direct
+// 160x256 tiles: 1.09 us per K-tile and round + 8.8 us per round (prologue drain + epilogue, one workgroup per CU and no
+// overlap between tiles).  N = 2048 outputs of M = 5120 rows: 256 tiles = one whole round instead of 160 tiles on 256 CUs.
+// AFFT_BD_MODE: 0 = never, 1 = by the model (default), 2 = whenever the shape is eligible.
+int g_bd_mode = [] { const char* e = getenv("AFFT_BD_MODE"); return e ? atoi(e) : 1; }();   // declared above
+bool bd_packed_wins(int M, int N, int K) {
+  if (g_bd_mode == 0 || N % 16 != 0 || N < 256 || K % 64 != 0) return false;
+  const int ncu = cu_count(), nk = K / BK;
+  const int64_t t160 = (int64_t)((M + 159) / 160) * ((N + 255) / 256), t256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
+  if (t256 < 160) return false;                      // small grids: the 128x128 kernel's territory
+  if (g_bd_mode >= 2) return true;
+  const double waste = (double)((M + 159) / 160 * 160) / (double)M;
+  const int64_t r160 = (t160 + ncu - 1) / ncu, r256 = (t256 + ncu - 1) / ncu;
+  const int64_t busy = t256 - (r256 - 1) * ncu;
+  const double last = 1.4 + 0.5 * (double)std::max<int64_t>(0, busy - 160) / 96.0;
+  const double pp_us = nk * ((double)(r256 - 1) * 1.9 + last) + 10.0;
+  const double bd_us = (double)r160 * (nk * 1.09 + 8.8) * (waste > 1.0 ? 1.0 : 1.0);
+  return bd_us < pp_us;
+}
+
 template <bool A_KS, bool B_KS>
 int launch_layout_impl(GemmFast& g, hipStream_t stream, const afft_gemm_t* d) {
+  if constexpr (!A_KS && !B_KS) {
+    if (d->b_packed && !d->split3 && g_variant == 0 && g.ldb == d->K && bd_packed_wins(g.e.M, g.e.N, g.K)) {
+      g.splitk = 1; g.ws = nullptr; g.counters = nullptr;
+      g.B = (const bf16_t*)d->b_packed;
+      return afft_gemm_launch_bd(1, 1, g, stream);
+    }
+  }
   const int variant = choose_variant(g.e.M, g.e.N, g.K, A_KS, B_KS);
   g.splitk = 1;
   g.ws = nullptr;
@@ -508,13 +540,15 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
   e.out2 = d->out2; e.ldo2 = d->ldo2; e.out2_dtype = d->out2_dtype;
   AFFT_CHECK(d->drop.p >= 0.f && d->drop.p < 1.f && d->drop.path_p >= 0.f && d->drop.path_p < 1.f, "afft_gemm: dropout p outside [0,1)");
   e.drop = make_drop(&d->drop);
-  e.sgd = SgdEpi{nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 1.f, 0};
+  e.sgd = SgdEpi{nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 1.f, 0, nullptr};
   if (d->sgd) {
     AFFT_CHECK(d->sgd->p && d->sgd->buf, "afft_gemm: fused update without parameter / momentum buffers");
     AFFT_CHECK(!d->accumulate && !d->bias && d->act == AFFT_ACT_NONE && !d->residual && !d->rowscale && !d->pre && !d->out2 &&
                d->drop.p == 0.f && d->drop.path_p == 0.f, "afft_gemm: a fused update takes the plain product (no other epilogue stage)");
+    AFFT_CHECK(!d->sgd->p_pk16 || (d->ldo % 32 == 0 && d->M % 16 == 0 && ((uintptr_t)d->sgd->p_pk16 & 15) == 0),
+               "afft_gemm: a fragment-packed image needs a [16 a, 32 b] weight");
     e.sgd = SgdEpi{d->sgd->p, d->sgd->buf, (bf16_t*)d->sgd->p_bf16, d->sgd->lr, d->sgd->mom, d->sgd->wd, d->sgd->gscale,
-                   d->sgd->first_step};
+                   d->sgd->first_step, (bf16_t*)d->sgd->p_pk16};
   }
   auto ok4 = [](const void* p, int64_t ld, int dtype) {
     if (!p) return true;
@@ -530,6 +564,7 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
            ok4(d->residual, d->ldres, AFFT_F32) && ok4(d->bias, 4, AFFT_F32);
 
   // operand layouts of the MFMA fast path: k-contiguous (unit stride along k) or k-strided (unit stride along m / n)
+  AFFT_CHECK(!d->b_packed || (((uintptr_t)d->b_packed & 15) == 0), "afft_gemm: b_packed must be 16-byte aligned");
   const bool a_kc = d->a_cs == 1, a_ks = d->a_rs == 1;
   const bool b_kc = d->b_rs == 1, b_ks = d->b_cs == 1;
   bool fast = d->dtype == AFFT_BF16 && d->K >= BK && d->K % BK == 0 && aligned16(d->A) && aligned16(d->B);

@@ -104,6 +104,7 @@ extern "C" int afft_attn_sublayer_fwd(const afft_attn_sublayer_t* s, void* strea
   afft_gemm_t g = lin_fwd(s->xn, d, R, d, s->w_qkv, s->ldw_qkv, 3 * d, s->conv1d, ws);
   g.bias = s->b_qkv;
   g.out = s->qkv; g.ldo = 3 * d; g.out_dtype = AFFT_BF16;
+  if (!s->conv1d) g.b_packed = s->w_qkv_pk;
   TRY(afft_gemm(&g, st));
   const char* q = (const char*)s->qkv;
   TRY(afft_attention_fwd(q, 3 * d, q + 2 * d, 3 * d, q + 4 * d, 3 * d, AFFT_BF16, R / s->L, s->L, s->H, d / s->H, s->scale,
@@ -113,6 +114,7 @@ extern "C" int afft_attn_sublayer_fwd(const afft_attn_sublayer_t* s, void* strea
   g.residual = s->x; g.ldres = d;
   g.drop = s->out_drop;
   g.out = s->y; g.ldo = d; g.out_dtype = AFFT_F32;
+  if (!s->conv1d) g.b_packed = s->w_proj_pk;
   return afft_gemm(&g, st);
 }
 
@@ -181,12 +183,14 @@ extern "C" int afft_mlp_sublayer_fwd(const afft_mlp_sublayer_t* s, void* stream_
   g.act = s->gelu;
   g.pre = s->u; g.ldpre = hd; g.pre_dtype = AFFT_BF16;
   g.out = s->h; g.ldo = hd; g.out_dtype = AFFT_BF16;
+  if (!s->conv1d) g.b_packed = s->w1_pk;
   TRY(afft_gemm(&g, st));
   g = lin_fwd(s->h, hd, R, hd, s->w2, s->ldw2, d, s->conv1d, ws);
   g.bias = s->b2;
   g.residual = s->x; g.ldres = d;
   g.drop = s->out_drop;
   g.out = s->y; g.ldo = d; g.out_dtype = AFFT_F32;
+  if (!s->conv1d) g.b_packed = s->w2_pk;
   return afft_gemm(&g, st);
 }
 

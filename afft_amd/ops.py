@@ -92,9 +92,10 @@ def gemm(a, b, out: Tensor, *, a_t: bool = False, b_t: bool = False, bias: Optio
          act: int = ACT_NONE, aux: Optional[Tensor] = None, pre: Optional[Tensor] = None,
          rowscale: Optional[Tensor] = None, residual: Optional[Tensor] = None, accumulate: bool = False,
          out2: Optional[Tensor] = None, alpha: float = 1.0, drop: Optional["L.Dropout"] = None,
-         max_workgroups: int = 0, sgd: Optional["L.SgdFused"] = None) -> Tensor:
+         max_workgroups: int = 0, sgd: Optional["L.SgdFused"] = None, b_packed: Optional[Tensor] = None) -> Tensor:
     """out = epilogue(alpha * A @ B).  A = a (or a.T if a_t), B = b (or b.T if b_t); a, b 2-D views -- or both `Split`
-    (two-plane bf16 splits of fp32 matrices): the bf16x3 GEMM, fp32-accurate products on the bf16 MFMA path."""
+    (two-plane bf16 splits of fp32 matrices): the bf16x3 GEMM, fp32-accurate products on the bf16 MFMA path.
+    b_packed: the fragment-packed copy of a weight `b` [N, K] used as b.T (pack_weight; afft_gemm_t.b_packed)."""
     d = L.GemmDesc()
     if isinstance(a, Split):
         if not isinstance(b, Split):
@@ -122,6 +123,9 @@ def gemm(a, b, out: Tensor, *, a_t: bool = False, b_t: bool = False, bias: Optio
         ws = gemm_workspace(a.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     d.max_workgroups = max_workgroups
+    if b_packed is not None:
+        assert b_packed.dtype == torch.bfloat16 and b_packed.is_contiguous() and b_t and not a_t and b_packed.numel() == N * K
+        d.b_packed = _p(b_packed)
     if sgd is not None:       # afft_sgd_fused_t: the result is a weight gradient consumed by the update of sgd.p (layout of `out`)
         d.sgd = C.pointer(sgd)
     d.alpha = alpha
@@ -302,6 +306,15 @@ def sgd_nesterov_runs(p: Tensor, g: Tensor, buf: Tensor, runs: Tensor, lr: float
     assert p.dtype == g.dtype == buf.dtype == torch.float32
     L.check(L.lib().afft_sgd_nesterov_runs(_p(p), _p(g), _p(buf), _p(p_bf16), _p(runs), runs.shape[0], lr, mom, wd, gscale,
                                            int(first), _stream()), "sgd_nesterov_runs")
+
+
+def pack_weight(w: Tensor, dst: Tensor) -> Tensor:
+    """fp32 weight [rows, cols] (row stride free; rows % 16 == 0, cols % 32 == 0) -> its fragment-packed bf16 image `dst`
+    (rows * cols elements, contiguous): include/afft_hip.h afft_pack_weight"""
+    assert w.dtype == torch.float32 and w.dim() == 2 and w.stride(1) == 1
+    assert dst.dtype == torch.bfloat16 and dst.is_contiguous() and dst.numel() == w.numel()
+    L.check(L.lib().afft_pack_weight(_p(w), w.stride(0), w.shape[0], w.shape[1], _p(dst), _stream()), "pack_weight")
+    return dst
 
 
 def sumsq(x: Tensor, out: Tensor, scale: float = 1.0):

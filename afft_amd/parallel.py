@@ -63,6 +63,11 @@ class FlatParams:
         use_t = dev.type == "cuda" and rt.transposed_images()
         self.flat_pT16 = torch.zeros(off, dtype=torch.bfloat16, device=dev) if use_t else None
         self.transposed: List[tuple] = []     # (offset, param, transposed view) for the 2-D GEMM weights
+        # fragment-packed bf16 images (same offsets and sizes; runtime.packed_images): the B operand of the "B direct" GEMM
+        # kernels, written by the fused optimizer epilogue or re-packed after every other update (refresh_packed)
+        use_pk = dev.type == "cuda" and rt.packed_images()
+        self.flat_pk16 = torch.zeros(off, dtype=torch.bfloat16, device=dev) if use_pk else None
+        self.packed: List[tuple] = []         # (offset, param, packed flat view)
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 n = p.numel()
@@ -78,7 +83,12 @@ class FlatParams:
                             vt = self.flat_pT16[o:o + p.numel()].view(p.shape[1], p.shape[0])
                             ops.cast(p.detach(), None, vt)
                             self.transposed.append((o, p, vt))
-                        rt.adopt_weight_image(p, self.flat_p16[o:o + p.numel()].view(p.shape), vt)
+                        pk = None
+                        if use_pk:
+                            pk = self.flat_pk16[o:o + p.numel()]
+                            ops.pack_weight(p.detach(), pk)
+                            self.packed.append((o, p, pk))
+                        rt.adopt_weight_image(p, self.flat_p16[o:o + p.numel()].view(p.shape), vt, packed=pk)
         rt.invalidate_weight_images()
 
     def refresh_images(self):
@@ -89,7 +99,18 @@ class FlatParams:
             with torch.no_grad():
                 ops.cast(self.flat_p.view(n // 64, 64), self.flat_p16.view(n // 64, 64))
             self.refresh_transposed(0, n)
+            self.refresh_packed(0, n)
         rt.invalidate_weight_images()
+
+    def refresh_packed(self, s: int, e: int, skip=()):
+        """Re-pack the fragment-packed images of the weights in flat range [s, e) from their fp32 masters (after an update that
+        did not run in a weight-gradient epilogue); skip: ids of the weights whose epilogue keeps their image fresh itself."""
+        if not self.packed:
+            return
+        with torch.no_grad():
+            for o, p, pk in self.packed:
+                if s <= o < e and id(p) not in skip:
+                    ops.pack_weight(p.detach(), pk)
 
     def refresh_transposed(self, s: int, e: int):
         """Re-cast the transposed bf16 images of the weights that live in flat range [s, e)."""
@@ -329,11 +350,13 @@ class FusedSGD:
                     if runs.shape[0]:
                         ops.sgd_nesterov_runs(self.flat.flat_p, self.flat.flat_g, self.buf, runs, self.lr, self.momentum, self.wd,
                                               gscale, self.flags(), p_bf16=self.flat.flat_p16)
+                    self.flat.refresh_packed(s, e, skip=self.skip)
                     return
             p16 = self.flat.flat_p16[s:e] if self.flat.flat_p16 is not None else None
             ops.sgd_nesterov(self.flat.flat_p[s:e], grad, self.buf[s:e], self.lr, self.momentum, self.wd, gscale,
                              self.flags(), p_bf16=p16, gscale_dev=gscale_dev)
             self.flat.refresh_transposed(s, e)
+            self.flat.refresh_packed(s, e)
             return
         # per-parameter (lr, wd): the parameters of the bucket class by class
         flat = self.flat
@@ -362,6 +385,7 @@ class FusedSGD:
                 ops.sgd_nesterov(flat.flat_p[o:o + n], grad[o - s:o - s + n], self.buf[o:o + n], lr, self.momentum, wd, gscale,
                                  self.flags(), p_bf16=p16, gscale_dev=gscale_dev)
         self.flat.refresh_transposed(s, e)
+        self.flat.refresh_packed(s, e, skip=(self.skip if fused else ()))
 
     def end_step(self):
         self.steps += 1
@@ -413,6 +437,8 @@ class _FusedEpilogue:
                     and img is not None and img.external):
                 d = L_.SgdFused()
                 d.p, d.buf, d.p_bf16 = flat.flat_p.data_ptr() + 4 * o, self.opt.buf.data_ptr() + 4 * o, flat.flat_p16.data_ptr() + 2 * o
+                if img.pk is not None:
+                    d.p_pk16 = flat.flat_pk16.data_ptr() + 2 * o
                 fused[id(p)] = d
         self._fused = fused
         self.opt.runs = self._runs_without(fused)
@@ -468,6 +494,7 @@ class _FusedEpilogue:
             lr, wd = self.opt.hyper_of(self._index[pid])
             ops.sgd_nesterov(flat.flat_p[o:o + n], flat.flat_g[o:o + n], self.opt.buf[o:o + n], lr, self.opt.momentum,
                              wd, 1.0, self.opt.flags(), p_bf16=flat.flat_p16[o:o + n])
+            flat.refresh_packed(o, o + 1)
             stale.append(pid)
         if stale:
             for pid in stale:

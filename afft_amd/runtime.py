@@ -69,7 +69,7 @@ def pad64(n: int) -> int:
 
 # --------------------------------------------------------------------------- bf16 weight images
 class _WImage:
-    __slots__ = ("version", "ptr", "w", "wt", "external")
+    __slots__ = ("version", "ptr", "w", "wt", "external", "pk")
 
 
 _wlist: list = []   # weak references to parameters that own an image (for invalidate_weight_images)
@@ -100,6 +100,7 @@ def weight_images(p: Tensor):
         img.wt = torch.zeros(pad64(cols), pad64(rows), dtype=torch.bfloat16, device=p.device)
         img.version = -1
         img.external = False
+        img.pk = None
         img.ptr = p.data_ptr()
         p._afft_img = img
         _register(p)
@@ -127,6 +128,22 @@ def weight_split(p: Tensor):
 _TRANSPOSED_IMAGES = os.environ.get("AFFT_WT_IMAGES", "0") != "0"
 
 
+_PACKED_IMAGES = os.environ.get("AFFT_PACKED_IMAGES", "1") != "0"
+
+
+def packed_images() -> bool:
+    """Keep a fragment-packed bf16 copy of every GEMM weight a Trainer / afft_amd.optim.SGD owns (parallel.FlatParams): the
+    forward GEMMs of the fuser's nn.Linear layers may then run on the "B direct" kernels (csrc/gemm_bd.hip).  +2 bytes per
+    parameter of memory and of optimizer traffic (22 -> 24 B; written by the same epilogues / one pack kernel per weight)."""
+    return _PACKED_IMAGES
+
+
+def weight_packed(p: Tensor) -> Optional[Tensor]:
+    """the fragment-packed image of weight p, or None"""
+    img = getattr(p, "_afft_img", None)
+    return None if img is None or not img.external else img.pk
+
+
 def transposed_images() -> bool:
     """Keep a transposed bf16 image beside every GEMM weight of a Trainer (all forward / dgrad GEMMs then run NT) at
     the price of one transpose-cast per weight per optimizer step.  Off by default: measured on cfg2 the casts cost
@@ -134,12 +151,14 @@ def transposed_images() -> bool:
     return _TRANSPOSED_IMAGES
 
 
-def adopt_weight_image(p: Tensor, view16: Tensor, view16_t: Optional[Tensor] = None):
+def adopt_weight_image(p: Tensor, view16: Tensor, view16_t: Optional[Tensor] = None, packed: Optional[Tensor] = None):
     """Use `view16` (bf16, same shape as p, both dims multiples of 64, kept fresh by the optimizer kernel) and
-    optionally its transpose `view16_t` as p's MFMA images."""
+    optionally its transpose `view16_t` as p's MFMA images; `packed`: the fragment-packed copy of view16 (ops.pack_weight,
+    afft_gemm_t.b_packed), kept fresh by the same optimizer paths (parallel.FlatParams.refresh_packed)."""
     img = _WImage()
     img.w = view16
     img.wt = view16_t
+    img.pk = packed
     img.version = p._version
     img.external = True
     img.ptr = p.data_ptr()

@@ -56,6 +56,10 @@ def parse():
     ap.add_argument("--full-rows", action="store_true",
                     help="run the SA-Fuser's last block on every token row as the reference does (default: its MLP half on token 0 only, "
                          "the only rows that reach an output; runtime.skip_dead_rows)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="N > 1 started by bench.py itself: seconds after which the ranks are terminated and an error line is printed")
+    ap.add_argument("--collective-timeout", type=float, default=120.0,
+                    help="torch.distributed timeout (s): a rank that waits longer in a collective raises instead of hanging")
     ap.add_argument("--no-reference-loop", action="store_true",
                     help="skip the side measurement of the reference's own loop (Runner + MixUp + optimizer over 151 groups + lr scheduler)")
     ap.add_argument("--wgrad-wgs", type=int, default=None, help="CU cap of the weight-gradient GEMMs on the auxiliary stream (default: runtime's)")
@@ -352,6 +356,33 @@ def comm_report(args, trainer, feats, tgt, sub, world, rank, device, ms_with_com
         torch.cuda.empty_cache()
     rep["loss_after_%d_steps" % n_payload] = {k: round(v, 5) for k, v in losses.items()}
     rep["loss_delta_bf16_vs_fp32_payload"] = round(losses["bf16"] - losses["fp32"], 6)
+    # (b2) what the exchange itself achieves: every bucket's collective alone, in the payload dtype, 5 timed repeats each --
+    # algorithm bandwidth = bytes / time, bus bandwidth = 2 (n - 1) / n of it (what a ring moves per link; xGMI: 7 links x ~153 GB/s)
+    try:
+        pay = torch.bfloat16 if args.comm_dtype == "bf16" else torch.float32
+        per_bucket = []
+        for (s0, e0) in trainer.reducer.buckets:
+            buf = torch.zeros(e0 - s0, dtype=pay, device=device)
+            for _ in range(2):
+                trainer.reducer._reduce(buf)
+            sync_all()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                trainer.reducer._reduce(buf)
+            sync_all()
+            dt = torch.tensor([(time.perf_counter() - t1) / 5], dtype=torch.float64, device=device)
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            gb = buf.numel() * buf.element_size() / 1e9
+            per_bucket.append({"mib": round(gb * 1e9 / 2 ** 20, 1), "ms": round(float(dt) * 1e3, 3), "algbw_gbs": round(gb / float(dt), 1),
+                               "busbw_gbs": round(gb / float(dt) * 2 * (world - 1) / world, 1)})
+            del buf
+        rep["allreduce_per_bucket"] = per_bucket
+        tot_gb = sum(b["mib"] for b in per_bucket) * 2 ** 20 / 1e9
+        tot_s = sum(b["ms"] for b in per_bucket) / 1e3
+        rep["allreduce_alone_ms_per_step"] = round(tot_s * 1e3, 3)
+        rep["allreduce_busbw_gbs"] = round(tot_gb / tot_s * 2 * (world - 1) / world, 1) if tot_s > 0 else None
+    except Exception as ex:  # noqa: BLE001
+        rep["allreduce_per_bucket"] = {"error": repr(ex)}
     # (c) RCCL debug lines
     if rank == 0 and rccl_log:
         try:
@@ -371,28 +402,54 @@ def comm_report(args, trainer, feats, tgt, sub, world, rank, device, ms_with_com
     return rep
 
 
-def launch_ranks(n: int) -> int:
+def launch_ranks(n: int, script: str = None, argv: list = None, timeout: float = None) -> int:
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the ranks ourselves, as the reference does
     (run.py:34-51 calls `torchrun --nproc_per_node=N` through subprocess).  The launcher is a CHILD process (never an exec: this
     process must not be replaced, and nothing here has touched the GPU yet); its stdout -- rank 0's JSON line -- is ours, and
-    so is its return code."""
+    so is its return code.  A run that fails or does not finish within `timeout` seconds (--launch-timeout) cannot hang the
+    caller silently: the child's whole process group is terminated and ONE JSON line {"error": ..., "rc": ...} is printed, and
+    the return code is non-zero (VERDICT r3 #6; the reference's launcher has no such guard, common/utils.py:187-190)."""
+    import signal
     import socket
     import subprocess
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), script or os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else list(argv))
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL across processes needs it on this pool
     env.setdefault("OMP_NUM_THREADS", "8")
-    return subprocess.run(cmd, env=env).returncode
+    t0 = time.perf_counter()
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)      # its own process group: the ranks can be ended together
+    err = None
+    try:
+        rc = proc.wait(timeout=timeout)
+        if rc != 0:
+            err = f"the launcher exited with code {rc} (a rank failed; its traceback is on stderr above)"
+    except subprocess.TimeoutExpired:
+        err = f"no result within --launch-timeout {timeout:.0f} s: ranks terminated (hung collective or rendezvous?)"
+        rc = 124
+    if err is not None:
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)      # the exact group this function started, nothing matched by name
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        print(json.dumps({"error": err, "rc": rc, "n_gpus": n, "elapsed_s": round(time.perf_counter() - t0, 1)}), flush=True)
+        return rc if rc != 0 else 1
+    return 0
 
 
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(args.gpus))
+        sys.exit(launch_ranks(args.gpus, timeout=args.launch_timeout))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -409,8 +466,10 @@ def main():
     rccl_log = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        from datetime import timedelta
+        pg_timeout = timedelta(seconds=args.collective_timeout)
         if backend != "nccl":
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=pg_timeout)
         elif not args.no_comm_report:
             # which algorithm / protocol RCCL picks for the bucket sizes is decided inside the library: have it say so, into a
             # per-process file (INIT + TUNING lines only) that rank 0 summarises after the timed region
@@ -419,7 +478,9 @@ def main():
             os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING")
             os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=device)   # "nccl" == RCCL on ROCm
+            # a bounded timeout + asynchronous error handling: a rank that dies leaves the others an exception, not a hang
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+            dist.init_process_group(backend="nccl", device_id=device, timeout=pg_timeout)   # "nccl" == RCCL on ROCm
     assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import afft_amd

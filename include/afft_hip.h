@@ -95,6 +95,12 @@ typedef struct {
   /* Optional: apply the optimizer IN the epilogue instead of storing the result (see afft_sgd_fused_t below): the GEMM is a
    * weight gradient whose value is consumed once, by the update of that weight.  Needs accumulate = 0, no bias / act. */
   const struct afft_sgd_fused* sgd;
+  /* Optional (NT layout, B = a weight [N, K] with N % 16 == 0, K % 64 == 0, b_cs == K): the FRAGMENT-PACKED copy of B made by
+   * afft_pack_weight / kept fresh by afft_sgd_fused_t.p_pk16.  With it the launch may take the "B direct" kernels (csrc/gemm_bd.hip:
+   * 160 x 256 tiles for M = 5120-type row counts, A through LDS, B global -> register in MFMA operand layout, no LDS traffic for
+   * B); without it, or when the cost model prefers the LDS-staged kernels, B is read row-major as before.  Same result up to
+   * the summation order inside a tile (both accumulate K in order, fp32). */
+  const void* b_packed;
 } afft_gemm_t;
 /* Nesterov-SGD update fused into the epilogue of the weight-gradient GEMM that produces the gradient (single-GPU training, no
  * gradient clipping, a weight that receives exactly one gradient contribution per step): element [m, n] of the result is the
@@ -106,7 +112,8 @@ typedef struct {
 typedef struct afft_sgd_fused {
   float* p; float* buf; void* p_bf16;
   float lr, mom, wd, gscale; int32_t first_step;   /* first_step: AFFT_SGD_* flags (below) */
-} afft_sgd_fused_t;
+  void* p_pk16;                                    /* optional: the fragment-packed bf16 image (afft_pack_weight) of the same weight, */
+} afft_sgd_fused_t;                                /* refreshed by the same epilogue (ldo % 32 == 0 and M % 16 == 0)               */
 /* `first_step` of every optimizer entry point is a flag word: AFFT_SGD_FIRST_STEP = the momentum buffer does not exist yet (it
  * starts as the gradient: torch.optim.SGD's first step); AFFT_SGD_PLAIN_MOMENTUM = torch.optim.SGD(nesterov=False):
  * p -= lr * buf instead of the Nesterov form p -= lr * (g' + mom * buf) (conf/opt/optimizer/sgd.yaml ships nesterov: false,
@@ -215,6 +222,12 @@ int afft_mse(const float* a, int64_t lda, const float* b, int64_t ldb, int32_t r
  * dropout of a GEMM input (classifier Dropout(0.2), future_prediction.py:108). */
 int afft_cast(const float* src, int64_t lds, int32_t rows, int32_t cols, void* dst, int64_t ldd, int32_t dst_dtype,
               void* dst_t, int64_t ldt, int32_t zero_pad, const afft_dropout_t* drop, void* stream);
+/* Fragment-packed bf16 image of a weight W [rows, cols] (fp32 masters, row stride lds; rows % 16 == 0, cols % 32 == 0): for every
+ * block of 16 rows rb and every 32-deep K-step ks, the 64 lanes' MFMA operand fragments side by side,
+ *   dst[((rb * (cols / 32) + ks) * 64 + lane) * 8 + j] = bf16(W[16 rb + (lane & 15)][32 ks + 8 (lane >> 4) + j]),  j = 0..7,
+ * so that a wave loads the B operand of v_mfma_f32_16x16x32_bf16 for 16 output columns x 32 k with ONE fully coalesced 1-KiB
+ * global load (row-major: 16 rows x 64 B per instruction, four cache lines per quad of lanes).  afft_gemm_t.b_packed. */
+int afft_pack_weight(const float* src, int64_t lds, int32_t rows, int32_t cols, void* dst, void* stream);
 /* Two-plane bf16 split of an fp32 matrix for afft_gemm_t.split3: hi[r, c] = bf16(src[r, c]), lo[r, c] = bf16(src[r, c] - hi[r, c]),
  * both planes [rows_pad, ldd] bf16 with everything outside [rows, cols] zero-filled (K padding of either GEMM operand role);
  * lo = hi + plane_stride elements. */
@@ -359,6 +372,8 @@ typedef struct {       /* y = x + drop(proj(attention(split(qkv(LN(x))))))      
   /* optional fused optimizer (afft_sgd_fused_t) per weight: that weight's gradient GEMM then runs BEHIND the data-gradient
    * GEMM that reads the weight and updates it in its epilogue; its g_w_* buffer is not written */
   const afft_sgd_fused_t* sgd_w_qkv; const afft_sgd_fused_t* sgd_w_proj;
+  /* optional fragment-packed copies of the two weight images (afft_gemm_t.b_packed; nn.Linear layout only): forward GEMMs */
+  const void* w_qkv_pk; const void* w_proj_pk;
 } afft_attn_sublayer_t;
 int afft_attn_sublayer_fwd(const afft_attn_sublayer_t* s, void* stream);
 int afft_attn_sublayer_bwd(const afft_attn_sublayer_t* s, void* stream, void* aux_stream);
@@ -387,6 +402,7 @@ typedef struct {       /* y = x + drop(fc2(gelu(fc1(LN(x)))))                   
   void* gemm_ws; int64_t gemm_ws_bytes; void* gemm_ws_aux; int64_t gemm_ws_aux_bytes;
   int32_t wgrad_workgroups;
   const afft_sgd_fused_t* sgd_w1; const afft_sgd_fused_t* sgd_w2;       /* as in afft_attn_sublayer_t */
+  const void* w1_pk; const void* w2_pk;                                 /* as in afft_attn_sublayer_t */
 } afft_mlp_sublayer_t;
 int afft_mlp_sublayer_fwd(const afft_mlp_sublayer_t* s, void* stream);
 int afft_mlp_sublayer_bwd(const afft_mlp_sublayer_t* s, void* stream, void* aux_stream);

@@ -59,7 +59,8 @@ class Split:
 
 @torch.no_grad()
 def gemm(a, b, out, *, a_t=False, b_t=False, bias=None, act=L.ACT_NONE, aux=None, pre=None, rowscale=None, residual=None,
-         accumulate=False, out2=None, alpha=1.0, drop=None, max_workgroups=0):
+         accumulate=False, out2=None, alpha=1.0, drop=None, max_workgroups=0, sgd=None, b_packed=None):
+    assert sgd is None and b_packed is None, "cpu_ops test double: fused update / packed weights are GPU-only paths"
     _no_drop(drop)
     if isinstance(a, Split):     # bf16x3: hi*hi + lo*hi + hi*lo over the padded planes, live part of the result
         ah, al = (p.float().t() if a_t else p.float() for p in a.planes)

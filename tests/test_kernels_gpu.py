@@ -462,6 +462,108 @@ def test_softmax_ce_out_of_range_label_poisons_the_row():
     assert rel_l2(rl[[0, 2, 4]], ref) < 1e-5
 
 
+def _pack_ref(w):
+    """torch restatement of afft_pack_weight (include/afft_hip.h): [rows, cols] -> [rows / 16][cols / 32][lane = (r & 15) + 16 ((c >> 3) & 3)][8]"""
+    R, Cc = w.shape
+    return w.reshape(R // 16, 16, Cc // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
+
+
+BD_CASES = [
+    # name, variant (7: 256x256 tiles, B row-major; 8: 160x256; 9 / 10: the same with a fragment-packed B), M, N, K, epilogue
+    ("bd160_one_ktile", 8, 160, 256, 64, dict(out_f32=True)),
+    ("bd160_short_k", 8, 320, 512, 192, dict(bias=True, out_f32=True)),            # fewer K-tiles than the look-ahead
+    ("bd160_tails", 8, 4100, 2064, 1024, dict(bias=True, residual=True, out_f32=True, alpha=0.5)),
+    ("bd160_path_proj", 8, 5120, 2048, 2048, dict(bias=True, residual=True, out_f32=True)),
+    ("bd160_gelu", 8, 1000, 768, 448, dict(bias=True, act=1, pre=True)),
+    ("bd256_tails", 7, 4100, 2064, 1024, dict(bias=True, residual=True, out_f32=True)),
+    ("bd256_gelu", 7, 600, 512, 320, dict(bias=True, act=2, pre=True)),
+    ("bd160_packed_one_ktile", 10, 160, 256, 64, dict(out_f32=True)),
+    ("bd160_packed_tails", 10, 4100, 2064, 1024, dict(bias=True, residual=True, out_f32=True)),
+    ("bd160_packed_path_fc2", 10, 5120, 2048, 8192, dict(bias=True, residual=True, out_f32=True)),
+    ("bd160_packed_gelu", 10, 1000, 768, 448, dict(bias=True, act=1, pre=True)),
+    ("bd256_packed", 9, 1000, 1040, 704, dict(bias=True, out_f32=True)),
+    ("auto_packed_path_proj", 0, 5120, 2048, 2048, dict(bias=True, residual=True, out_f32=True)),   # b_packed given: the dispatcher's choice
+]
+
+
+@pytest.mark.parametrize("case", BD_CASES, ids=[c[0] for c in BD_CASES])
+def test_gemm_b_direct(case):
+    """csrc/gemm_bd.hip: B operand global -> register (row-major or fragment-packed), A through LDS, 160- and 256-row tiles,
+    NT layout: against fp64 math, row / column tails, K shorter than the look-ahead, every epilogue stage the forward GEMMs
+    use; repeated launches give the same bits."""
+    from afft_amd import _lib, ops
+    name, variant, M, N, K, ep = case
+    A, W = bfr(rnd(M, K, seed=11)), bfr(rnd(N, K, seed=12))
+    a = A.to(torch.bfloat16).to(dev())
+    w = W.to(torch.bfloat16).to(dev())
+    packed = None
+    if variant in (9, 10) or variant == 0:
+        Np = (N + 15) // 16 * 16
+        wp = torch.zeros(Np, K, dtype=torch.float32, device=dev())
+        wp[:N] = W.to(dev())
+        packed = torch.empty(Np * K, dtype=torch.bfloat16, device=dev())
+        ops.pack_weight(wp, packed)
+        assert torch.equal(packed, _pack_ref(wp.to(torch.bfloat16)))
+    bias = rnd(N, seed=13).to(dev()) if ep.get("bias") else None
+    res = rnd(M, N, seed=14).to(dev()) if ep.get("residual") else None
+    act = ep.get("act", 0)
+    out = torch.zeros(M, N, dtype=torch.float32 if ep.get("out_f32") else torch.bfloat16, device=dev())
+    pre = torch.zeros(M, N, dtype=torch.bfloat16, device=dev()) if ep.get("pre") else None
+    alpha = ep.get("alpha", 1.0)
+    _lib.check(_lib.lib().afft_set_gemm_variant(variant))
+    try:
+        def run():
+            if variant in (9, 10):      # forced packed variants read the packed image through B
+                ops.gemm(a, packed.view(-1, K)[:N], out, b_t=True, bias=bias, act=act, pre=pre, residual=res, alpha=alpha)
+            else:
+                ops.gemm(a, w, out, b_t=True, bias=bias, act=act, pre=pre, residual=res, alpha=alpha,
+                         b_packed=packed if (variant == 0 and N % 16 == 0) else None)
+        run()
+        torch.cuda.synchronize()
+        first = out.clone()
+        ref = alpha * (A.double() @ W.double().t()).float()
+        if bias is not None:
+            ref = ref + bias.cpu()
+        pre_ref = ref.clone()
+        ref = _act(act, ref, None)
+        if res is not None:
+            ref = ref + res.cpu()
+        assert rel_l2(out.float().cpu(), ref) < (2e-3 if ep.get("out_f32") else 1e-2), name
+        if pre is not None:
+            assert rel_l2(pre.float().cpu(), pre_ref) < 1e-2
+        for _ in range(5):
+            run()
+            assert torch.equal(out, first)
+        if variant == 0:       # the dispatcher really took the B-direct kernel for this shape
+            assert _lib.lib().afft_gemm_variant_for(M, N, K, 0, 0) in (1, 3)       # ... which the row-major query does not know about
+    finally:
+        _lib.check(_lib.lib().afft_set_gemm_variant(0))
+
+
+def test_fused_sgd_epilogue_keeps_the_packed_image_fresh():
+    """afft_sgd_fused_t.p_pk16: the weight-gradient epilogue that updates a weight also rewrites its fragment-packed image:
+    == afft_pack_weight of the updated fp32 weight (bf16 rounding of the same values), 256x256 and 128x128 tile epilogues"""
+    from afft_amd import _lib, ops
+    for variant, M, N, K in ((3, 2048, 1024, 640), (1, 384, 256, 320)):
+        _lib.check(_lib.lib().afft_set_gemm_variant(variant))
+        a = bfr(rnd(K, M, seed=51)).to(torch.bfloat16).to(dev())
+        b = bfr(rnd(K, N, seed=52)).to(torch.bfloat16).to(dev())
+        p, m = rnd(M, N, seed=53).to(dev()), rnd(M, N, seed=54).to(dev())
+        p16 = torch.zeros(M, N, dtype=torch.bfloat16, device=dev())
+        pk = torch.zeros(M * N, dtype=torch.bfloat16, device=dev())
+        d = _lib.SgdFused()
+        d.p, d.buf, d.p_bf16, d.p_pk16 = p.data_ptr(), m.data_ptr(), p16.data_ptr(), pk.data_ptr()
+        d.lr, d.mom, d.wd, d.gscale, d.first_step = 0.05, 0.9, 1e-3, 0.5, 0
+        gout = torch.empty(M, N, device=dev())
+        ops.gemm(a, b, gout, a_t=True, sgd=d)
+        torch.cuda.synchronize()
+        _lib.check(_lib.lib().afft_set_gemm_variant(0))
+        assert torch.equal(p16, p.to(torch.bfloat16))
+        want = torch.empty(M * N, dtype=torch.bfloat16, device=dev())
+        ops.pack_weight(p, want)
+        assert torch.equal(pk, want) and torch.equal(pk, _pack_ref(p16))
+
+
 @pytest.mark.parametrize("case", [("pp", 3, 1, 2048, 1024, 640), ("pp_tail", 3, 1, 2048, 1100, 640), ("small", 1, 1, 384, 256, 320),
                                   ("small_splitk", 1, 2, 512, 512, 1024), ("pp_capped", 3, 1, 2048, 1024, 640)],
                          ids=lambda c: c[0])

@@ -307,3 +307,26 @@ def test_bench_comm_report_runs_on_two_ranks(tmp_path):
     assert rep["ms_per_step_without_exchange"] > 0 and "exposed_comm_ms" in rep
     assert set(rep["loss_after_4_steps"]) == {"fp32", "bf16"}
     assert abs(rep["loss_delta_bf16_vs_fp32_payload"]) < 0.05 * abs(rep["loss_after_4_steps"]["fp32"])
+
+
+# ----------------------------------------------------------------------------- a dead / hung rank cannot hang the caller
+@pytest.mark.parametrize("mode", ["die", "hang"])
+def test_launcher_reports_a_dead_or_hung_rank(mode, capfd):
+    """bench.launch_ranks (what `python bench.py --gpus N` runs when no launcher is around it) with two gloo ranks of which
+    rank 1 dies mid-step ('die') or never enters its collective ('hang'): the call returns non-zero well inside its timeout
+    budget -- rank 0's collective raises (closed connection / process-group timeout) or the launcher's own timeout ends the
+    ranks -- and prints ONE JSON error line instead of hanging (VERDICT r3 #6)."""
+    import json
+    import time
+    import bench
+    here = os.path.dirname(os.path.abspath(__file__))
+    t0 = time.perf_counter()
+    rc = bench.launch_ranks(2, script=os.path.join(here, "scripts", "rank_dies.py"), argv=[mode], timeout=60)
+    took = time.perf_counter() - t0
+    out = capfd.readouterr().out
+    assert rc != 0, out
+    assert took < 60, took
+    line = [ln for ln in out.splitlines() if ln.startswith("{") and '"error"' in ln]
+    assert len(line) == 1, out
+    rep = json.loads(line[0])
+    assert rep["rc"] != 0 and rep["n_gpus"] == 2 and "error" in rep
