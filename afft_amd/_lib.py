@@ -126,6 +126,12 @@ class GemmTraceRec(C.Structure):   # afft_gemm_trace_rec_t
                 ("split3", i32), ("capped", i32), ("fused_update", i32), ("ms", f32)]
 
 
+class KernelTraceRec(C.Structure):   # afft_kernel_trace_rec_t
+    _fields_ = [("kind", i32), ("rows", i32), ("width", i32), ("reserved", i32), ("bytes", i64), ("flops", i64), ("ms", f32)]
+
+
+K_ATTN_FWD, K_ATTN_BWD, K_LN_FWD, K_LN_BWD = 1, 2, 3, 4
+
 _SIGS = {
     "afft_version": ([], C.c_int),
     "afft_gemm": ([C.POINTER(GemmDesc), vp], C.c_int),
@@ -135,6 +141,8 @@ _SIGS = {
     "afft_gemm_splitk_for": ([C.c_int, C.c_int, C.c_int, C.c_int, C.c_int], C.c_int),
     "afft_gemm_trace_begin": ([i32], C.c_int),
     "afft_gemm_trace_end": ([C.POINTER(GemmTraceRec), i32], C.c_int),
+    "afft_kernel_trace_begin": ([i32], C.c_int),
+    "afft_kernel_trace_end": ([C.POINTER(KernelTraceRec), i32], C.c_int),
     "afft_gemm_workspace_bytes": ([C.c_int, C.c_int, C.c_int, C.c_int, C.c_int], i64),
     "afft_pack_weight": ([vp, i64, i32, i32, vp, vp], C.c_int),
     "afft_split_bf16": ([vp, i64, i32, i32, vp, i64, i32, i64, vp], C.c_int),

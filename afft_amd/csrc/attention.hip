@@ -250,6 +250,8 @@ extern "C" int afft_attention_fwd(const void* q, int64_t ldq, const void* k, int
   AFFT_CHECK(drop_p >= 0.f && drop_p < 1.f, "attention_fwd: dropout p outside [0,1)");
   AFFT_CHECK(hd >= 1 && hd <= 1024, "attention_fwd: head dimension %d outside 1..1024", hd);
   if (nseq == 0) return 0;
+  const int64_t es_ = dtype == AFFT_F32 ? 4 : 2, rw_ = (int64_t)nseq * L * H * hd, pb_ = probs ? (int64_t)nseq * H * L * L * 4 : 0;
+  AfftKernelScope ktrace(AFFT_K_ATTN_FWD, nseq * L, H * hd, 4 * es_ * rw_ + pb_, 4 * (int64_t)nseq * H * L * L * hd, stream);
   if (dtype == AFFT_BF16 && use_mfma_attention()) {
     const int rc = afft_attention_mfma(false, nullptr, 0, q, ldq, k, ldk, v, ldv, probs, nseq, L, H, hd, scale,
                                        mask | (mask == AFFT_MASK_BLOCKCAUSAL ? mask_period << 8 : 0),
@@ -280,6 +282,8 @@ extern "C" int afft_attention_bwd(const void* dout, int64_t lddo, const void* q,
   AFFT_CHECK(drop_p >= 0.f && drop_p < 1.f, "attention_bwd: dropout p outside [0,1)");
   AFFT_CHECK(hd >= 1 && hd <= 1024, "attention_bwd: head dimension %d outside 1..1024", hd);
   if (nseq == 0) return 0;
+  const int64_t es_ = dtype == AFFT_F32 ? 4 : 2, rw_ = (int64_t)nseq * L * H * hd, pb_ = (int64_t)nseq * H * L * L * 4;
+  AfftKernelScope ktrace(AFFT_K_ATTN_BWD, nseq * L, H * hd, 7 * es_ * rw_ + pb_, 8 * (int64_t)nseq * H * L * L * hd, stream);
   if (dtype == AFFT_BF16 && use_mfma_attention()) {
     const int rc = afft_attention_mfma(true, dout, lddo, q, ldq, k, ldk, v, ldv, const_cast<float*>(probs), nseq, L, H, hd,
                                        scale, 0, drop_p, drop_key, nullptr, 0, dq, lddq, dk, lddk, dv, lddv, stream);

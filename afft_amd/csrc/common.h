@@ -30,6 +30,26 @@ void afft_set_error(const char* fmt, ...);
 #include <atomic>
 int afft_ensure_dynamic_lds(const void* kern, size_t bytes, std::atomic<uint64_t>* done);
 
+// measurement hook for the non-GEMM kernels (afft_kernel_trace_begin / _end, elementwise.hip): a scope object in an entry point
+// brackets everything the call enqueues on `stream` with an event pair while a trace is open; free otherwise (one relaxed load)
+extern std::atomic<int> g_afft_ktrace_open;
+void afft_ktrace_push(int kind, int rows, int width, int64_t bytes, int64_t flops, hipStream_t stream, hipEvent_t a, hipEvent_t b);
+struct AfftKernelScope {
+  hipEvent_t a = nullptr, b = nullptr;
+  hipStream_t st; int kind, rows, width; int64_t bytes, flops;
+  AfftKernelScope(int kind_, int rows_, int width_, int64_t bytes_, int64_t flops_, hipStream_t s)
+      : st(s), kind(kind_), rows(rows_), width(width_), bytes(bytes_), flops(flops_) {
+    if (!g_afft_ktrace_open.load(std::memory_order_relaxed)) return;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { (void)hipGetLastError(); a = b = nullptr; return; }
+    (void)hipEventRecord(a, st);
+  }
+  ~AfftKernelScope() {
+    if (!a) return;
+    (void)hipEventRecord(b, st);
+    afft_ktrace_push(kind, rows, width, bytes, flops, st, a, b);
+  }
+};
+
 #define AFFT_LAUNCH_CHECK()                                                     \
   do {                                                                          \
     hipError_t e_ = hipGetLastError();                                          \

@@ -3,6 +3,9 @@
 #include <stdarg.h>
 
 #include <cstdlib>
+#include <mutex>
+#include <vector>
+
 #include "common.h"
 
 // ---- error plumbing shared by every translation unit
@@ -32,6 +35,53 @@ int afft_ensure_dynamic_lds(const void* kern, size_t bytes, std::atomic<uint64_t
   return 0;
 }
 extern "C" int afft_version(void) { return 1; }
+
+// ---- kernel trace (include/afft_hip.h: afft_kernel_trace_begin / _end)
+std::atomic<int> g_afft_ktrace_open{0};
+namespace {
+struct KTraceRec { afft_kernel_trace_rec_t r; hipEvent_t a, b; };
+std::mutex g_ktrace_mu;
+std::vector<KTraceRec>* g_ktrace = nullptr;
+size_t g_ktrace_cap = 0;
+}  // namespace
+void afft_ktrace_push(int kind, int rows, int width, int64_t bytes, int64_t flops, hipStream_t, hipEvent_t a, hipEvent_t b) {
+  std::lock_guard<std::mutex> lk(g_ktrace_mu);
+  if (!g_ktrace || g_ktrace->size() >= g_ktrace_cap) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); return; }
+  g_ktrace->push_back(KTraceRec{afft_kernel_trace_rec_t{kind, rows, width, 0, bytes, flops, 0.f}, a, b});
+}
+extern "C" int afft_kernel_trace_begin(int32_t capacity) {
+  std::lock_guard<std::mutex> lk(g_ktrace_mu);
+  AFFT_CHECK(!g_ktrace, "afft_kernel_trace_begin: a trace is already open");
+  AFFT_CHECK(capacity > 0, "afft_kernel_trace_begin: capacity must be positive");
+  g_ktrace = new std::vector<KTraceRec>();
+  g_ktrace->reserve(capacity);
+  g_ktrace_cap = (size_t)capacity;
+  g_afft_ktrace_open.store(1);
+  return 0;
+}
+extern "C" int afft_kernel_trace_end(afft_kernel_trace_rec_t* out, int32_t capacity) {
+  std::vector<KTraceRec>* tr;
+  {
+    std::lock_guard<std::mutex> lk(g_ktrace_mu);
+    g_afft_ktrace_open.store(0);
+    tr = g_ktrace;
+    g_ktrace = nullptr;
+  }
+  if (!tr) { afft_set_error("afft_kernel_trace_end: no trace is open"); return -1; }
+  int n = 0;
+  for (KTraceRec& t : *tr) {
+    float ms = 0.f;
+    if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess && out && n < capacity) {
+      t.r.ms = ms;
+      out[n++] = t.r;
+    }
+    (void)hipEventDestroy(t.a);
+    (void)hipEventDestroy(t.b);
+  }
+  (void)hipGetLastError();
+  delete tr;
+  return n;
+}
 
 namespace {
 

@@ -34,7 +34,6 @@
 using namespace afft_gemm_detail;
 
 int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream, int x3, int max_wg);
-int afft_gemm_launch_w4(int a_ks, int b_ks, int reg_staged, afft_gemm_detail::GemmFast& g, hipStream_t stream);
 int afft_gemm_launch_bd(int rows160, int packed, afft_gemm_detail::GemmFast& g, hipStream_t stream);
 
 #ifndef AFFT_G128_EPI_UNROLL
@@ -226,7 +225,7 @@ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 int g_splitk_mode = 1;   // 0 off, 1 auto, 2 / 4: force that many slices wherever the shape allows (tests, tuning)
 // stream-K of the 256x256 kernel (choose_splitk): on when the plain grid's utilisation is below AFFT_SK_MAX_EFF and every
 // workgroup gets at least AFFT_SK_MIN_ITERS K-iterations.  Default 0 = never: measured on the path's shapes (profiles/
-// r03_streamk.txt) the balanced launch is 8-12 % SLOWER than the plain partial round -- a K-iteration takes 1.36 us with 160
+// r03_experiments.txt section 1) the balanced launch is 8-12 % SLOWER than the plain partial round -- a K-iteration takes 1.36 us with 160
 // CUs busy and 1.82 us with 256 (the part is power-limited: +60 % CUs buy +10-20 % throughput), and the hand-over of the parked
 // tiles costs 35 us of the rest.  Forced by afft_set_gemm_splitk(2 / 4) in the tests.
 double g_sk_max_eff = [] { const char* e = getenv("AFFT_SK_MAX_EFF"); return e ? atof(e) : 0.0; }();
@@ -378,7 +377,10 @@ int launch_layout(GemmFast& g, hipStream_t stream, const afft_gemm_t* d) {
 // model in us fitted to both kernels alone on one MI355X (profiles/r04_gemm_bd.txt).  Ping-pong: one workgroup per CU, a K-tile
 // of a full round costs ~1.9 us, of a last round with <= 160 busy CUs 1.4 us (the part is power-limited), + 10 us; B-direct
 // 160x256 tiles: 1.09 us per K-tile and round + 8.8 us per round (prologue drain + epilogue, one workgroup per CU and no
-// overlap between tiles).  N = 2048 outputs of M = 5120 rows: 256 tiles = one whole round instead of 160 tiles on 256 CUs.
+// overlap between tiles).  Taken only when its grid is ONE round (N = 2048 outputs of M = 5120 rows: 256 tiles on 256 CUs where
+// 256-row tiles give 160): inside the model's forward pass the multi-round shapes measured slower than the ping-pong kernel
+// (fc1 with its GELU epilogue 229 vs 201 us: four rounds of epilogues with nothing beside them), the one-round shapes faster
+// (fc2 162 vs 184 us, projection 64 vs 67 us; profiles/r04_gemm_bd.txt "in the step").
 // AFFT_BD_MODE: 0 = never, 1 = by the model (default), 2 = whenever the shape is eligible.
 int g_bd_mode = [] { const char* e = getenv("AFFT_BD_MODE"); return e ? atoi(e) : 1; }();   // declared above
 bool bd_packed_wins(int M, int N, int K) {
@@ -387,12 +389,12 @@ bool bd_packed_wins(int M, int N, int K) {
   const int64_t t160 = (int64_t)((M + 159) / 160) * ((N + 255) / 256), t256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
   if (t256 < 160) return false;                      // small grids: the 128x128 kernel's territory
   if (g_bd_mode >= 2) return true;
-  const double waste = (double)((M + 159) / 160 * 160) / (double)M;
   const int64_t r160 = (t160 + ncu - 1) / ncu, r256 = (t256 + ncu - 1) / ncu;
+  if (r160 != 1) return false;
   const int64_t busy = t256 - (r256 - 1) * ncu;
   const double last = 1.4 + 0.5 * (double)std::max<int64_t>(0, busy - 160) / 96.0;
   const double pp_us = nk * ((double)(r256 - 1) * 1.9 + last) + 10.0;
-  const double bd_us = (double)r160 * (nk * 1.09 + 8.8) * (waste > 1.0 ? 1.0 : 1.0);
+  const double bd_us = (double)r160 * (nk * 1.09 + 8.8);
   return bd_us < pp_us;
 }
 
@@ -424,9 +426,6 @@ int launch_layout_impl(GemmFast& g, hipStream_t stream, const afft_gemm_t* d) {
   if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream, 0, d->max_workgroups);
   if (variant >= 7 && variant <= 10) return afft_gemm_launch_bd(variant == 8 || variant == 10, variant >= 9, g, stream);
   if (variant == 4) return launch_fast<2, 2, 4, A_KS, B_KS, false>(g, stream);
-#ifdef AFFT_BUILD_EXPERIMENTAL
-  if (variant == 5 || variant == 6) return afft_gemm_launch_w4(A_KS, B_KS, variant == 6, g, stream);
-#endif
   if (g.splitk > 1) return launch_fast<2, 2, 2, A_KS, B_KS, true>(g, stream);
   return launch_fast<2, 2, 2, A_KS, B_KS, false>(g, stream);
 }
@@ -509,12 +508,7 @@ extern "C" int afft_set_gemm_splitk(int mode) {
 }
 
 extern "C" int afft_set_gemm_variant(int v) {
-#ifdef AFFT_BUILD_EXPERIMENTAL
-  const bool w4 = v == 5 || v == 6;
-#else
-  const bool w4 = false;   // gemm_w4.hip is only in `make EXPERIMENTAL=1` builds
-#endif
-  if (v != 0 && v != 1 && v != 3 && v != 4 && !(v >= 7 && v <= 10) && !w4) { afft_set_error("afft_set_gemm_variant: %d is not 0 (auto), 1 (128x128), 3 (256x256 ping-pong), 4 (128x128, 4 stages), 7 / 8 (B-direct 256x256 / 160x256, NT layouts; others as auto) [5 / 6 (256x256 four-wave): EXPERIMENTAL=1 builds only]", v); return 1; }
+  if (v != 0 && v != 1 && v != 3 && v != 4 && !(v >= 7 && v <= 10)) { afft_set_error("afft_set_gemm_variant: %d is not 0 (auto), 1 (128x128), 3 (256x256 ping-pong), 4 (128x128, 4 stages), 7 / 8 (B-direct 256x256 / 160x256 tiles on NT layouts, B row-major; other layouts as auto), 9 / 10 (the same, B points at a fragment-packed image)", v); return 1; }
   g_variant = v;
   return 0;
 }

@@ -68,6 +68,7 @@ __device__ __forceinline__ GemmFast reload_kernel_args() {
   typedef const __attribute__((address_space(4))) unsigned* KArgs;
   KArgs p = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(p));
+  // the kernarg segment starts with the kernel's FIRST parameter: gemm_bf16_pp_kernel(const GemmFast g, ...) -- keep it first
   struct Raw { unsigned w[sizeof(GemmFast) / 4]; } raw;
   static_assert(sizeof(GemmFast) % 4 == 0, "argument block is copied dword by dword");
 #pragma unroll

@@ -29,7 +29,7 @@ struct GemmFast {
   int tiles_m, tiles_n;
   int splitk;   // 128x128 kernel: K is cut into `splitk` slices along gridDim.y; 256x256 kernel: > 1 = stream-K over a grid of
                 // `splitk` workgroups (gemm_pp.hip); 1 = off
-  float* ws;    // split-K: fp32 partial tiles [tile][slice][128*128]; stream-K: [workgroup][2][256*256]
+  float* ws;    // split-K: fp32 partial tiles [tile][slice][128*128]; stream-K: parked tiles [xcd][sk_tlmax][sk_smax][256*256] (below)
   int* counters;  // split-K / stream-K: arrivals per tile (zero between launches)
   int sk_tlmax, sk_smax;   // stream-K workspace geometry: parked tiles [xcd][sk_tlmax leftover tiles][sk_smax pieces][256*256]
   // bf16x3 (X3 instantiations): K counts the K-tiles of all three segments, nk_seg of them per segment; segment 0 reads

@@ -225,6 +225,7 @@ extern "C" int afft_layernorm_fwd(const float* x, int64_t ldx, const float* w, c
   const int nv = pick_nv(d);
   AFFT_CHECK(nv != 0, "layernorm_fwd: d=%d exceeds 4096", d);
   if (rows == 0) return 0;
+  AfftKernelScope ktrace(AFFT_K_LN_FWD, rows, d, (int64_t)rows * d * (4 + (y_dtype == AFFT_F32 ? 4 : 2)) + (int64_t)rows * 8, 0, stream);
   const int grid = (rows + LN_WAVES - 1) / LN_WAVES;
 #define LN_FWD(NV) hipLaunchKernelGGL(ln_fwd_kernel<NV>, dim3(grid), dim3(256), 0, stream, x, ldx, w, b, eps, rows, d, y, ldy, y_dtype, mean, rstd)
   switch (nv) { case 1: LN_FWD(1); break; case 2: LN_FWD(2); break; case 4: LN_FWD(4); break; case 8: LN_FWD(8); break; default: LN_FWD(16); }
@@ -243,6 +244,8 @@ extern "C" int afft_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype
   AFFT_CHECK(d > 0 && d % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "layernorm_bwd: d/ld must be multiples of 4");
   AFFT_CHECK(d <= 4096, "layernorm_bwd: d=%d exceeds 4096", d);
   if (rows == 0) return 0;
+  AfftKernelScope ktrace(AFFT_K_LN_BWD, rows, d,
+                         (int64_t)rows * d * ((dy_dtype == AFFT_F32 ? 4 : 2) + 4 + (dx_in ? 4 : 0) + 4 + (dx_bf16 ? 2 : 0)) + (int64_t)rows * 8, 0, stream);
   const int qs = (d / 4 + LNB_CS - 1) / LNB_CS;
   const int nv = qs <= 64 ? 1 : qs <= 128 ? 2 : 4;
   const int grid = afft_layernorm_bwd_nparts(rows);

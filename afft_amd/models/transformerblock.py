@@ -192,7 +192,11 @@ class Block(nn.Module):
     def forward_rows_first_token(self, x2: Tensor, L: int, mask: str):
         """forward_rows for a caller that only uses token 0 of every sequence afterwards (the SA-Fuser's last block,
         models/fusion.py:362-365): attention over all L tokens, the MLP half on the nseq token-0 rows only.
-        Returns (rows [nseq, dim], probs [nseq, H, L, L]) -- the same numbers as forward_rows(...)[0][::L]."""
+        Returns (rows [nseq, dim], probs [nseq, H, L, L]) -- the same numbers as forward_rows(...)[0][::L] whenever the MLP's
+        element dropout is off (eval mode, p = 0: the goldens and the on / off test).  In training the dropout mask of an element
+        is a function of (key, element index), and token 0 of frame r is row r * L in the full-row run but row r here: the two
+        runs draw different (equally distributed) masks for the MLP output, so they agree in distribution, not bit for bit; the
+        DropPath group index is the same in both."""
         a = self.attn
         dp = _dp_rate(self.drop_path)
         x2, probs = F_.AttnSublayer.apply(x2, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias,

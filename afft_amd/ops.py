@@ -48,8 +48,9 @@ def _rowmajor(t: Tensor, what: str):
 
 
 _WS: dict = {}      # (device index, raw stream) -> split-K scratch of that stream (afft_gemm_t.workspace), never shared
-_WS_BYTES = (132 << 20)   # header + stream-K of the 256x256 kernel (256 workgroups x 2 parked tiles x 256 KiB = 128 MiB); also covers every
-                          # split-K problem of the 128x128 kernel the automatic mode picks (<= 128 tiles x 4 slices x 64 KiB)
+_WS_BYTES = (132 << 20)   # header + every split-K problem of the 128x128 kernel the automatic mode picks (<= 256 tiles x 4 slices x 64 KiB = 64 MiB) and the
+                          # stream-K layouts the tests force ([8 XCDs][leftover tiles][pieces] x 256 KiB, gemm.hip: sk_geometry; stream-K itself is off by
+                          # default).  A launch whose problem needs more than this runs unsplit (afft_gemm_workspace_bytes tells how much it wants).
 
 
 def set_workspace_bytes(n: int):
@@ -58,6 +59,8 @@ def set_workspace_bytes(n: int):
     global _WS_BYTES
     if n != _WS_BYTES:
         _WS_BYTES = int(n)
+        if _WS and torch.cuda.is_available():
+            torch.cuda.synchronize()      # kernels on other streams may still be using the scratch that is about to be freed
         _WS.clear()
 
 

@@ -213,6 +213,11 @@ class GradSink:
 
     def grad_buffer(self, p: Tensor):
         """(grad tensor, accumulate?)"""
+        if self.fused_applied.get(id(p), 0) > 0:
+            raise RuntimeError("fused optimizer: a weight that was already UPDATED in its gradient GEMM's epilogue in this step is "
+                               "receiving another gradient contribution (the graph changed since the fused set was learned).  Its "
+                               "parameter, momentum and bf16 image have been modified from a partial gradient: reload the last "
+                               "checkpoint, then rebuild the Trainer / optimizer or call runtime.set_fused_sgd(False)")
         self.touch_count[id(p)] = self.touch_count.get(id(p), 0) + 1
         if p.grad is None:
             p.grad = torch.zeros_like(p)
@@ -285,7 +290,10 @@ _SKIP_DEAD_ROWS = os.environ.get("AFFT_SKIP_DEAD_ROWS", "1") != "0"
 def skip_dead_rows() -> bool:
     """The SA-Fuser returns token 0 of its last block only (models/fusion.py:362-365): with this on (default) that block's
     MLP half runs on the token-0 rows alone instead of all M + 1 tokens of a frame -- rows the reference computes and throws
-    away.  Outputs and gradients are unchanged; AFFT_SKIP_DEAD_ROWS=0 runs the reference's full row set (bench.py --full-rows)."""
+    away.  Outputs and gradients are unchanged with dropout off (eval, p = 0); with the MLP's element dropout on, the compact rows
+    draw their masks at other element indices than the same rows of the full-row run (transformerblock.Block.forward_rows_first_token):
+    the training trajectory is equivalent in distribution, not bitwise.  AFFT_SKIP_DEAD_ROWS=0 runs the reference's full row set
+    (bench.py --full-rows)."""
     return _SKIP_DEAD_ROWS
 
 

@@ -115,6 +115,8 @@ class GemmTimer:
         b = lambda x: "true" if x else "false"    # noqa: E731
         if r.variant == 3:
             return f"gemm_bf16_pp_kernel<{b(r.a_kstrided)}, {b(r.b_kstrided)}, {b(r.splitk > 1)}, {b(r.split3)}, {b(r.capped)}>"
+        if r.variant in (7, 8, 9, 10):       # B-direct kernels (csrc/gemm_bd.hip): <16-row blocks per tile, A look-ahead, B look-ahead, packed B>
+            return f"gemm_bf16_bd_kernel<{10 if r.variant in (8, 10) else 16}, 3, {2 if r.variant in (8, 10) else 1}, {b(r.variant >= 9)}>"
         return f"gemm_bf16_kernel<2, 2, 2, {b(r.a_kstrided)}, {b(r.b_kstrided)}, {b(r.splitk > 1)}, {b(r.split3)}>"
 
     def summary(self):
@@ -130,6 +132,102 @@ class GemmTimer:
             d["ms"] += r.ms
             d["fused_update_launches"] += r.fused_update
         return out
+
+
+class KernelTimer:
+    """The same hook for the HBM-bound kernels (afft_kernel_trace_begin / _end): attention and LayerNorm calls of one
+    instrumented step, each bracketed by a HIP event pair on its stream, with the call's algorithmic bytes and FLOPs."""
+    CAP = 4096
+    NAMES = {1: "attn_fwd", 2: "attn_bwd", 3: "ln_fwd", 4: "ln_bwd"}
+
+    def __enter__(self):
+        from afft_amd import _lib
+        self.lib = _lib
+        _lib.check(_lib.lib().afft_kernel_trace_begin(self.CAP), "kernel_trace_begin")
+        self.records = None
+        return self
+
+    def __exit__(self, *exc):
+        torch.cuda.synchronize()
+        buf = (self.lib.KernelTraceRec * self.CAP)()
+        n = self.lib.lib().afft_kernel_trace_end(buf, self.CAP)
+        if n < 0:
+            raise RuntimeError("afft_kernel_trace_end failed: " + self.lib.lib().afft_last_error().decode())
+        self.records = [buf[i] for i in range(n)]
+
+    def summary(self):
+        out = {}
+        for r in self.records:
+            d = out.setdefault(self.NAMES.get(r.kind, str(r.kind)), {"launches": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0, "by_rows": {}})
+            d["launches"] += 1
+            d["ms"] += r.ms
+            d["bytes"] += r.bytes
+            d["flops"] += r.flops
+            e = d["by_rows"].setdefault(r.rows, [0, 0.0])
+            e[0] += 1
+            e[1] += r.ms
+        return out
+
+
+def hbm_kernel_report(in_step, alone):
+    """achieved HBM GB/s of the attention / LayerNorm kernels (algorithmic bytes / HIP-event time of the call), inside the
+    two-stream step and with every kernel alone on the chip, against the 8 TB/s peak of the guide"""
+    rep = {}
+    for name, d in in_step.items():
+        a = (alone or {}).get(name)
+        gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else None
+        rep[name] = {"launches_per_step": d["launches"], "avg_us_in_step": round(d["ms"] / d["launches"] * 1e3, 1),
+                     "gbs_in_step": round(gbs, 0) if gbs else None, "frac_of_hbm_peak_in_step": round(gbs / PEAK_HBM_GBS, 3) if gbs else None,
+                     "avg_us_alone": round(a["ms"] / a["launches"] * 1e3, 1) if a and a["launches"] else None,
+                     "gbs_alone": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 0) if a and a["ms"] > 0 else None,
+                     "algorithmic_mb_per_launch": round(d["bytes"] / d["launches"] / 1e6, 1)}
+        if d["flops"]:
+            rep[name]["tflops_in_step"] = round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 1)
+    return rep
+
+
+def sublayer_report(gemm_records, kern, c, B):
+    """The north-star's "fused-attention kernel" is a REGION here -- LN -> QKV GEMM -> packed-frame attention -> projection +
+    bias + dropout + residual, one composite C-ABI call, 4 kernels -- so its MFMA utilisation is reported for the region:
+    FLOPs of its GEMMs and of the attention MFMAs over the summed HIP-event durations of its kernels inside the instrumented
+    step, forward and backward (data-gradient chain; the weight gradients run on the auxiliary stream and are listed apart),
+    for the fuser's full-row blocks (R = B * T * S rows).  Same for the MLP sub-layer."""
+    T, d = c["T"], c["common_dim"]
+    S = len(c["modal_dims"]) + 1
+    R = B * T * S
+
+    def gemm(layout, M, N, K):
+        a_ks, b_ks = {"nt": (0, 0), "nn": (0, 1), "tn": (1, 1)}[layout]
+        rs = [r for r in gemm_records if (r.M, r.N, r.K, r.a_kstrided, r.b_kstrided) == (M, N, K, a_ks, b_ks)]
+        if not rs:
+            return None
+        return sum(r.ms for r in rs) / len(rs), 2.0 * M * N * K, len(rs)
+
+    def kern_avg(name, rows):
+        e = kern.get(name, {}).get("by_rows", {}).get(rows)
+        if not e:
+            return None
+        fl = kern[name]["flops"] / kern[name]["launches"] if kern[name]["launches"] else 0.0
+        return e[1] / e[0], fl, e[0]
+
+    def region(parts):
+        if any(p is None for p in parts):
+            return None
+        ms, fl = sum(p[0] for p in parts), sum(p[1] for p in parts)
+        return {"us": round(ms * 1e3, 1), "gflop": round(fl / 1e9, 1), "tflops": round(fl / (ms * 1e-3) / 1e12, 1),
+                "frac_of_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+
+    rep = {"rows": R, "d": d,
+           "attention_fwd": region([kern_avg("ln_fwd", R), gemm("nt", R, 3 * d, d), kern_avg("attn_fwd", R), gemm("nt", R, d, d)]),
+           "attention_bwd_chain": region([gemm("nn", R, d, d), kern_avg("attn_bwd", R), gemm("nn", R, d, 3 * d), kern_avg("ln_bwd", R)]),
+           "attention_wgrads_aux_stream": region([gemm("tn", d, d, R), gemm("tn", 3 * d, d, R)]),
+           "mlp_fwd": region([kern_avg("ln_fwd", R), gemm("nt", R, 4 * d, d), gemm("nt", R, d, 4 * d)]),
+           "mlp_bwd_chain": region([gemm("nn", R, 4 * d, d), gemm("nn", R, d, 4 * d), kern_avg("ln_bwd", R)]),
+           "mlp_wgrads_aux_stream": region([gemm("tn", d, 4 * d, R), gemm("tn", 4 * d, d, R)]),
+           "note": "kernel-time based (sum of HIP-event durations of the region's launches inside the instrumented two-stream step); "
+                   "LN rows = the region's own LayerNorm; backward chains exclude the weight-gradient GEMMs, which overlap them on the "
+                   "auxiliary stream with the optimizer in their epilogues"}
+    return rep
 
 
 def _cpu_steps(name, B, steps):
@@ -590,10 +688,12 @@ def main():
     # the instrumented step for the roofline object runs on EVERY rank (its gradient all-reduce is a collective);
     # only rank 0 keeps the timings
     summ = summ_alone = None
+    ksumm = ksumm_alone = gemm_recs = None
     if not args.no_roofline:
-        with GemmTimer() as gt:      # the same kernel sequence as a timed step (fused optimizer epilogues included)
+        with GemmTimer() as gt, KernelTimer() as kt:      # the same kernel sequence as a timed step (fused optimizer epilogues included)
             trainer.step(feats, tgt, sub, optimize=not args.no_optimizer)
         summ = gt.summary()
+        ksumm, gemm_recs = kt.summary(), gt.records
         # the same launches with NOTHING beside them (weight gradients on the main stream for one more instrumented step): what the
         # dominant kernel does alone, to set beside what it does inside the two-stream step (kernel quality vs schedule)
         summ_alone = None
@@ -601,9 +701,10 @@ def main():
             try:
                 afft_amd.runtime.set_overlap_wgrad(False)
                 trainer.step(feats, tgt, sub, optimize=not args.no_optimizer)
-                with GemmTimer() as gt2:
+                with GemmTimer() as gt2, KernelTimer() as kt2:
                     trainer.step(feats, tgt, sub, optimize=not args.no_optimizer)
                 summ_alone = gt2.summary()
+                ksumm_alone = kt2.summary()
             finally:
                 afft_amd.runtime.set_overlap_wgrad(True)
 
@@ -667,6 +768,11 @@ def main():
                                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else None}
                               for k, v in summ.items()},
             }
+            try:
+                result["roofline"]["sublayers"] = sublayer_report(gemm_recs, ksumm, c, B)
+                result["hbm_kernels"] = hbm_kernel_report(ksumm, ksumm_alone)
+            except Exception as ex:  # noqa: BLE001
+                result["hbm_kernels"] = {"error": repr(ex)}
         if not args.no_parity_mode and world == 1 and args.precision == "bf16":
             try:
                 result.update(parity_side_measurements(args, device, feats, tgt, sub, c))

@@ -124,7 +124,8 @@ enum { AFFT_GEMM_WS_HEADER = 4096 };
 int64_t afft_gemm_workspace_bytes(int M, int N, int K, int a_kstrided, int b_kstrided);
 int afft_gemm(const afft_gemm_t* g, void* stream);
 /* Tuning / test hook: force the bf16 kernel (0 = auto, 1 = 128x128x64 2-stage, 3 = 256x256x64 ping-pong, 4 = 128x128x64 4-stage,
- * 5 / 6 = experimental 256x256x64 four-wave kernels with LDS-DMA / register-staged operands). */
+ * 7 / 8 = "B direct" 256x256 / 160x256 tiles on NT layouts with a row-major B (other layouts: as auto), 9 / 10 = the same with B
+ * pointing at a fragment-packed image -- what the dispatcher takes by itself when afft_gemm_t.b_packed is given). */
 int afft_set_gemm_variant(int variant);
 /* Split-K for small grids of the 128x128 kernel (<= 128 tiles with K >= 2048, <= 256 tiles with K >= 4096): K is cut into 2 or 4 slices, every slice
  * parks its fp32 partial tile in the caller's workspace (afft_gemm_t.workspace) and the slice that arrives last adds them up in slice order
@@ -138,13 +139,26 @@ int afft_gemm_splitk_for(int M, int N, int K, int a_kstrided, int b_kstrided);
 /* Measurement hook (bench.py's roofline object): while a trace is open, every afft_gemm launch of the bf16 fast path --
  * from any entry point, the composite ones included -- is bracketed by a HIP event pair ON THE STREAM IT IS LAUNCHED ON.
  * afft_gemm_trace_end synchronises those events and returns the records (at most `capacity`; return value = count, < 0 on
- * error).  One trace at a time, process-wide.  variant: 1 = 128x128 tile, 3 = 256x256 ping-pong (4-6: experiments). */
+ * error).  One trace at a time, process-wide.  variant: 1 = 128x128 tile, 3 = 256x256 ping-pong, 10 = B-direct 160x256 (4, 7-9: tests). */
 typedef struct {
   int32_t M, N, K, a_kstrided, b_kstrided, variant, splitk, split3, capped, fused_update;
   float ms;
 } afft_gemm_trace_rec_t;
 int afft_gemm_trace_begin(int32_t capacity);
 int afft_gemm_trace_end(afft_gemm_trace_rec_t* out, int32_t capacity);
+
+/* The same hook for the HBM-bound kernels of the path (bench.py's `hbm_kernels` / `roofline.sublayers`): while a kernel trace is
+ * open every afft_attention_fwd / _bwd and afft_layernorm_fwd / _bwd call -- from any entry point, the composite ones included --
+ * is bracketed by a HIP event pair on its stream.  bytes = the algorithmic HBM bytes of the call (every operand read once, every
+ * result written once), flops = its MFMA-shaped work (attention only).  One trace at a time, process-wide. */
+enum { AFFT_K_ATTN_FWD = 1, AFFT_K_ATTN_BWD = 2, AFFT_K_LN_FWD = 3, AFFT_K_LN_BWD = 4 };
+typedef struct {
+  int32_t kind, rows, width, reserved;
+  int64_t bytes, flops;
+  float ms;
+} afft_kernel_trace_rec_t;
+int afft_kernel_trace_begin(int32_t capacity);
+int afft_kernel_trace_end(afft_kernel_trace_rec_t* out, int32_t capacity);
 
 /* ------------------------------------------------------------------ LayerNorm
  * nn.LayerNorm(eps) fwd/bwd: models/fusion.py:281,362 ; transformerblock.py:122,127,150-152 ;

@@ -71,18 +71,6 @@ GEMM_CASES = [
     ("tn_bf16_pp_splitk3_sk48_acc", 2048, 1536, 1088, "bf16", "tn", dict(out_f32=True, accumulate=True)),
     ("nt_bf16_pp_splitk3_sk640", 5120, 8192, 512, "bf16", "nt", dict(bias=True, act=1, pre=True)),
     ("nt_bf16_pp_splitk3_sk160", 5120, 2048, 1024, "bf16", "nt", dict(bias=True, residual=True, out_f32=True)),   # the fuser's 160-tile grid
-    # 256x256 four-wave kernel (accumulators in AGPRs) forced: every layout, row / column tails, odd and even K-tile counts
-    ("nt_bf16_w4", 300, 520, 192, "bf16", "nt", dict(bias=True, act=2, out2=True)),
-    ("nt_bf16_w4_long", 512, 768, 1024, "bf16", "nt", dict(bias=True, act=1, pre=True)),
-    ("nn_bf16_w4", 300, 512, 640, "bf16", "nn", dict(bias=True, residual=True, out_f32=True)),
-    ("tn_bf16_w4", 512, 264, 704, "bf16", "tn", dict(out_f32=True)),
-    ("tn_bf16_w4_acc", 1000, 520, 64, "bf16", "tn", dict(out_f32=True, accumulate=True, lda_pad=1024, ldb_pad=528)),
-    # the same kernel with register-staged operands (global -> VGPR -> ds_write)
-    ("nt_bf16_w4r", 300, 520, 192, "bf16", "nt", dict(bias=True, act=2, out2=True)),
-    ("nt_bf16_w4r_long", 512, 768, 1024, "bf16", "nt", dict(bias=True, act=1, pre=True)),
-    ("nn_bf16_w4r", 300, 512, 640, "bf16", "nn", dict(bias=True, residual=True, out_f32=True)),
-    ("tn_bf16_w4r", 512, 264, 704, "bf16", "tn", dict(out_f32=True)),
-    ("tn_bf16_w4r_acc", 1000, 520, 64, "bf16", "tn", dict(out_f32=True, accumulate=True, lda_pad=1024, ldb_pad=528)),
     ("nt_f32", 150, 130, 100, "f32", "nt", dict(bias=True, act=1, pre=True)),
     ("nn_f32", 96, 200, 77, "f32", "nn", dict(bias=True, residual=True, out_f32=True)),
     ("tn_f32", 66, 70, 130, "f32", "tn", dict(accumulate=True, out_f32=True)),
@@ -91,10 +79,6 @@ GEMM_CASES = [
 ]
 
 
-# the four-wave kernels live in `make EXPERIMENTAL=1` builds only (never dispatched): their cases run with AFFT_TEST_EXPERIMENTAL=1
-if __import__("os").environ.get("AFFT_TEST_EXPERIMENTAL") != "1":
-    GEMM_CASES = [c for c in GEMM_CASES if "_w4" not in c[0]]
-
 
 @pytest.mark.parametrize("case", GEMM_CASES, ids=[c[0] for c in GEMM_CASES])
 def test_gemm(case):
@@ -102,10 +86,7 @@ def test_gemm(case):
     name, M, N, K, dt, layout, ep = case
     from afft_amd import _lib
     _lib.check(_lib.lib().afft_set_gemm_splitk(0 if "nosplit" in name else 4 if "pp_splitk3" in name else 1))   # 1 = auto (default)
-    want = 3 if "_pp" in name else 6 if "_w4r" in name else 5 if "_w4" in name else 0
-    if _lib.lib().afft_set_gemm_variant(want) != 0:
-        assert want in (5, 6)
-        pytest.skip("four-wave kernels are in EXPERIMENTAL=1 builds only")
+    _lib.check(_lib.lib().afft_set_gemm_variant(3 if "_pp" in name else 0))
     tdt = torch.bfloat16 if dt == "bf16" else torch.float32
     a_t, b_t = layout[0] == "t", layout[1] == "t"
     lda_pad, ldb_pad = ep.get("lda_pad"), ep.get("ldb_pad")
@@ -658,7 +639,8 @@ def test_splitk_handoff_stress(variant, M, N, K, mode):
     side = torch.cuda.Stream()
     _lib.check(_lib.lib().afft_set_gemm_variant(variant))
     _lib.check(_lib.lib().afft_set_gemm_splitk(mode))
-    ops.set_workspace_bytes(128 << 20)
+    old_ws = ops._WS_BYTES
+    ops.set_workspace_bytes(max(old_ws, 128 << 20))
     try:
         ops.gemm(a, b, out, a_t=True)
         first = out.clone()
@@ -674,7 +656,8 @@ def test_splitk_handoff_stress(variant, M, N, K, mode):
         torch.cuda.synchronize()
         assert int(bad) == 0, f"{int(bad)} elements differed over 400 launches"
     finally:
-        ops.set_workspace_bytes(48 << 20)
+        torch.cuda.synchronize()
+        ops.set_workspace_bytes(old_ws)      # whatever the default is: later tests must not run with a smaller scratch
         _lib.check(_lib.lib().afft_set_gemm_splitk(1))
         _lib.check(_lib.lib().afft_set_gemm_variant(0))
 

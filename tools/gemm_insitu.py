@@ -46,5 +46,5 @@ for k, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     lay, M, N, K, var, sk, fu = k
     avg = ms / n
     tot += ms / 5
-    print(f"{lay:6} {M:6d} {N:6d} {K:6d} {('256' if var == 3 else '128'):>5} {sk:6d} {fu:8d} {n / 5:6.1f} {avg * 1e3:8.1f} {2.0 * M * N * K / avg / 1e9:8.1f}")
+    print(f"{lay:6} {M:6d} {N:6d} {K:6d} {({3: '256', 10: 'bd160', 9: 'bd256', 8: 'bd160', 7: 'bd256'}.get(var, '128')):>5} {sk:6d} {fu:8d} {n / 5:6.1f} {avg * 1e3:8.1f} {2.0 * M * N * K / avg / 1e9:8.1f}")
 print(f"sum of GEMM launch durations per step: {tot:.2f} ms")
