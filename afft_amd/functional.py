@@ -555,7 +555,7 @@ def _fill_ws(s, dev, main_raw, aux_raw):
     if aux_raw is not None:
         wa = ops.gemm_workspace(dev, aux_raw)
         s.gemm_ws_aux, s.gemm_ws_aux_bytes = wa.data_ptr(), wa.numel()
-    s.wgrad_workgroups = rt.wgrad_workgroups() if aux_raw is not None else 0
+    s.wgrad_workgroups = rt.wgrad_workgroups_for(int(s.rows)) if aux_raw is not None else 0
 
 
 def _keep_for_aux(aux, *tensors):

@@ -315,6 +315,24 @@ def set_wgrad_workgroups(n: int):
     _WGRAD_WGS = max(0, int(n))
 
 
+_WGRAD_WGS_SMALL = int(os.environ.get("AFFT_WGRAD_WGS_SMALL", "0"))
+_WGRAD_SMALL_ROWS = int(os.environ.get("AFFT_WGRAD_SMALL_ROWS", "2048"))
+
+
+def wgrad_workgroups_for(rows: int) -> int:
+    """CU cap of a sub-layer's weight-gradient GEMMs by its row count: sub-layers with at most AFFT_WGRAD_SMALL_ROWS rows (the
+    predictor's M = B*T rows: its data-gradient GEMMs are 128-tile grids that fill half the chip, its weight gradients are bound
+    by the optimizer epilogue's HBM traffic, not by CUs) take AFFT_WGRAD_WGS_SMALL (0 = no cap), the others wgrad_workgroups()."""
+    if _WGRAD_WGS_SMALL > 0 and rows <= _WGRAD_SMALL_ROWS:
+        return _WGRAD_WGS_SMALL
+    return _WGRAD_WGS
+
+
+def set_wgrad_workgroups_small(n: int, rows: int = 2048):
+    global _WGRAD_WGS_SMALL, _WGRAD_SMALL_ROWS
+    _WGRAD_WGS_SMALL, _WGRAD_SMALL_ROWS = max(0, int(n)), int(rows)
+
+
 _SIDE_MIN_ROWS = int(os.environ.get("AFFT_SIDE_MIN_ROWS", "0"))
 
 

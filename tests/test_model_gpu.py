@@ -1204,3 +1204,175 @@ def test_forward_under_no_grad_equals_forward_with_grad():
     assert fa["logits/action/all-fused"].requires_grad and not fb["logits/action/all-fused"].requires_grad
     for k in fa:
         assert torch.equal(fa[k].detach(), fb[k]), k
+
+
+# ----------------------------------------------------------------------------- round 4: the reference's own loop on the fast path
+def _reference_loop(model, opt, sched, feats, tgt, sub, steps, mixup_fn=None, async_metrics=False):
+    """train.py:241-265: runner -> zero_grad -> backward -> step -> scheduler.step"""
+    from afft_amd.common.runner import Runner
+    wts = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
+    runner = Runner(model, torch.device("cuda:0"), wts, compute_metrics=False, async_metrics=async_metrics)
+    batch = ({"data_dict": feats, "target": {"action": tgt}, "target_subclips": {"action": sub}}, {})
+    for _ in range(steps):
+        loss, _ = runner(batch, mixup_fn, True)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if sched is not None:
+            sched.step()
+    return loss
+
+
+@pytest.mark.parametrize("name", ["t3_m5", "t0_sa"])
+def test_reference_loop_with_dropin_sgd_equals_trainer_bitwise(name):
+    """the reference-shaped loop (Runner + afft_amd.optim.SGD over prepare_params' per-parameter groups, with
+    dropout on) == Trainer.step, bit for bit, after 4 steps -- parameters, momentum, bf16 images -- and the optimizer took the
+    fused-epilogue path; a Warmup(CosineLR) scheduler on both sides (Trainer's lr set by hand) keeps them equal."""
+    from afft_amd import dropout as D_, runtime as rt
+    from afft_amd.common.scheduler import CosineLR, Warmup, prepare_params
+    from afft_amd.optim import SGD
+    from afft_amd.parallel import Trainer
+    c, state, data, tgt, sub = case_tensors(name)
+    dev = torch.device("cuda:0")
+    wts = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
+    feats = {m: d.to(dev) for m, d in data.items()}
+    tgt, sub = tgt.to(dev), sub.to(dev)
+
+    def fresh():
+        D_.manual_seed(5)
+        model = build(c, "bf16")
+        model.load_state_dict(state)
+        return model.cuda().train()
+
+    # (a) Trainer, lr driven by the same schedule by hand
+    model = fresh()
+    tr = Trainer(model, wts, lr=1e-2, momentum=0.9, weight_decay=1e-4, bucket_elems=1 << 15)
+    dummy = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-2)
+    sch = Warmup(dummy, CosineLR(dummy, num_epochs=2, iters_per_epoch=2, world_size=1, eta_min=1e-6), init_lr_ratio=0.1,
+                 num_epochs=1, iters_per_epoch=2, world_size=1)
+    for _ in range(4):
+        tr.opt.lr = dummy.param_groups[0]["lr"]
+        tr.step(feats, {"action": tgt}, {"action": sub})
+        dummy.step()
+        sch.step()
+    torch.cuda.synchronize()
+    want = (tr.flat.flat_p.clone(), tr.opt.buf.clone(), tr.flat.flat_p16.clone())
+    assert tr._fused and len(tr._fused) >= 8
+    # (b) the reference's loop with the drop-in optimizer
+    model = fresh()
+    opt = SGD(prepare_params(model, None, 1e-2, 1e-4), lr=1e-2, momentum=0.9, nesterov=True, bucket_elems=1 << 15)
+    sched = Warmup(opt, CosineLR(opt, num_epochs=2, iters_per_epoch=2, world_size=1, eta_min=1e-6), init_lr_ratio=0.1,
+                   num_epochs=1, iters_per_epoch=2, world_size=1)
+    _reference_loop(model, opt, sched, feats, tgt, sub, 4)
+    torch.cuda.synchronize()
+    assert opt._fused and len(opt._fused) == len(tr._fused)
+    assert opt.in_backward and len(opt.param_groups) == len(list(model.parameters()))
+    for a, b, what in zip((opt.flat.flat_p, opt.opt.buf, opt.flat.flat_p16), want, ("parameters", "momentum", "bf16 images")):
+        assert torch.equal(a, b), what
+    # the momentum buffers are torch-shaped state
+    p0 = next(iter(model.parameters()))
+    assert opt.state[p0]["momentum_buffer"].data_ptr() == opt.opt.buf.data_ptr()
+
+
+def test_dropin_sgd_matches_torch_sgd_on_the_gpu_and_with_mixup():
+    """afft_amd.optim.SGD vs torch.optim.SGD on the same groups (both through the gradient sink), MixUp on as in expts/01,
+    dropout off (so the two runs see the same network): parameters agree to the bf16 path's tolerance after 3 steps; a
+    grad_clip run (in_backward off) clips on the device and matches clip_grad_norm_ + torch.optim.SGD."""
+    from afft_amd import dropout as D_
+    from afft_amd.common.mixup import MixUp
+    from afft_amd.common.scheduler import prepare_params
+    from afft_amd.optim import SGD
+    c, state, data, tgt, sub = case_tensors("t0_sa")
+    dev = torch.device("cuda:0")
+    feats = {m: d.to(dev) for m, d in data.items()}
+    tgt, sub = tgt.to(dev), sub.to(dev)
+    sub = sub.clamp(min=0)          # no ignored frames: every sample takes part in MixUp
+
+    class FixedLam(MixUp):          # MixUp with the Beta draw pinned, so both runs mix alike
+        def __init__(self):
+            super().__init__(alpha=0.1, label_smoothing={"action": 0.4}, num_classes={"action": c["num_classes"]})
+            self.mixup_beta_sampler = type("S", (), {"sample": staticmethod(lambda: torch.tensor(0.7))})()
+
+    def run(kind, clip=None):
+        D_.manual_seed(5)
+        model = build(c, "bf16")
+        model.load_state_dict(state)
+        model = model.cuda().eval()
+        groups = prepare_params(model, None, 1e-2, 1e-4)
+        if kind == "afft":
+            opt = SGD(groups, lr=1e-2, momentum=0.9, nesterov=True, bucket_elems=1 << 15, grad_clip=clip)
+            assert opt.in_backward == (clip is None)
+            _reference_loop(model, opt, None, feats, tgt, sub, 3, mixup_fn=FixedLam())
+        else:
+            opt = torch.optim.SGD(groups, lr=1e-2, momentum=0.9, nesterov=True)
+            from afft_amd.common.runner import Runner
+            runner = Runner(model, dev, {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}, compute_metrics=False)
+            batch = ({"data_dict": feats, "target": {"action": tgt}, "target_subclips": {"action": sub}}, {})
+            for _ in range(3):
+                loss, _ = runner(batch, FixedLam(), True)
+                opt.zero_grad()
+                loss.backward()
+                if clip is not None:
+                    torch.nn.utils.clip_grad_norm_([p for g in opt.param_groups for p in g["params"]], clip)
+                opt.step()
+        torch.cuda.synchronize()
+        return torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+
+    for clip in (None, 0.05):
+        a, b = run("afft", clip), run("torch", clip)
+        assert rel_l2(a, b) < 2e-6, (clip, rel_l2(a, b))
+
+
+def test_packed_weight_images_stay_coherent_and_feed_the_forward():
+    """Fragment-packed weight images (FlatParams.flat_pk16): at the bench's cfg2 widths with 64 clips the fuser's projection / fc2
+    forward GEMMs run on the B-direct kernel from them.  After fused-epilogue steps AND after separate-update steps every packed
+    image equals afft_pack_weight of its fp32 master; the logits with the B-direct forward agree with the ping-pong forward to the
+    bf16 path's rounding (same products, another summation order inside a tile)."""
+    import bench as B
+    from afft_amd import _lib, dropout as D_, ops, runtime as rt
+    from afft_amd.parallel import Trainer
+    dev = torch.device("cuda:0")
+    D_.manual_seed(7)
+    model, c = B.build_model("cfg2", dev)
+    feats, tgt, sub = B.make_inputs(c, 64, c["T"], 0, dev)
+    wts = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
+    tr = Trainer(model, wts)
+    assert tr.flat.flat_pk16 is not None and len(tr.flat.packed) >= 24
+    model.train()
+
+    def coherent():
+        torch.cuda.synchronize()
+        for o, p, pk in tr.flat.packed[:6] + tr.flat.packed[-6:]:
+            want = torch.empty_like(pk)
+            ops.pack_weight(p.detach(), want)
+            assert torch.equal(pk, want), o
+    for _ in range(3):
+        tr.step(feats, tgt, sub)          # step 1 separate (learns the fused set), then fused epilogues
+    assert tr._fused and all(d.p_pk16 for d in tr._fused.values())
+    coherent()
+    rt.set_fused_sgd(False)
+    try:
+        tr2_steps = 2
+        tr._fused = None
+        tr.opt.runs = None
+        for _ in range(tr2_steps):
+            tr.step(feats, tgt, sub)      # per-bucket update kernels + re-pack
+        coherent()
+    finally:
+        rt.set_fused_sgd(True)
+    # forward: B-direct (default dispatch) against ping-pong everywhere
+    model.eval()
+    with torch.no_grad():
+        with B.GemmTimer() as gt:
+            o1, _ = model(feats, mixup_fn=None, target=tgt, target_subclips=sub, target_subclips_ignore_index=None)
+        assert sum(1 for r in gt.records if r.variant == 10) >= 10, "the B-direct kernel was not dispatched"
+        lib = _lib.lib()
+        saved = [rt.weight_packed]
+        rt.weight_packed = lambda p: None          # no packed copies handed to the GEMMs: the ping-pong forward
+        try:
+            o2, _ = model(feats, mixup_fn=None, target=tgt, target_subclips=sub, target_subclips_ignore_index=None)
+        finally:
+            rt.weight_packed = saved[0]
+    a, b = o1["logits/action"]["all-fused"].float(), o2["logits/action"]["all-fused"].float()
+    assert rel_l2(a, b) < 2e-3, rel_l2(a, b)
+    del lib

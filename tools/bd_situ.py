@@ -46,4 +46,8 @@ for (M, N, K) in [(5120, 2048, 8192), (5120, 2048, 2048), (5120, 8192, 2048)]:
             row.append(one(lambda: ops.gemm(a, bb, o16, b_t=True), cold))
             row.append(one(lambda: ops.gemm(a, bb, o32, b_t=True, bias=bias, residual=res), cold))
         print(f"{M}x{N}x{K} v{v}: warm bf16-out {row[0]:6.1f} | warm bias+res+f32 {row[1]:6.1f} | cold bf16-out {row[2]:6.1f} | cold bias+res+f32 {row[3]:6.1f} us", flush=True)
-_lib.check(_lib.lib().afft_set_gemm_variant(0))
+    _lib.check(_lib.lib().afft_set_gemm_variant(0))
+    bt = b.t()
+    o32b = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    row = [one(lambda: torch.mm(a, bt, out=o16), False), one(lambda: torch.mm(a, bt, out=o16), True)]
+    print(f"{M}x{N}x{K} vendor (torch.mm, bf16 out; a yard-stick only): warm {row[0]:6.1f} | cold {row[1]:6.1f} us", flush=True)
