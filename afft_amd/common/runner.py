@@ -65,10 +65,11 @@ class MultiDimCrossEntropy(nn.Module):
 class BasicLossAccuracy(nn.Module):
     """acc1 / acc5 / mt5r inputs and the three loss terms."""
 
-    def __init__(self, compute_metrics: bool = True):
+    def __init__(self, compute_metrics: bool = True, lazy_host: bool = False):
         super().__init__()
         self.cls_criterion = MultiDimCrossEntropy(ignore_index=-1, reduction='none')
         self.compute_metrics = compute_metrics
+        self.lazy_host = lazy_host        # host copies of the logits / labels as LazyHostArray instead of a blocking .cpu()
 
     @staticmethod
     def reg_criterion(a, b):
@@ -94,8 +95,12 @@ class BasicLossAccuracy(nn.Module):
             labels = tgt_val.clone()
         if len(labels.shape) == 1:
             labels = labels.unsqueeze(dim=-1)
-        metrics[mt5r_key + key_suffix] = {'logits': preds[:, sequence_index, :].cpu().numpy(),
-                                          'labels': labels[:, sequence_index].cpu().numpy()}
+        if self.lazy_host and preds.is_cuda:
+            metrics[mt5r_key + key_suffix] = {'logits': LazyHostArray(preds[:, sequence_index, :].contiguous()),
+                                              'labels': LazyHostArray(labels[:, sequence_index].contiguous())}
+        else:
+            metrics[mt5r_key + key_suffix] = {'logits': preds[:, sequence_index, :].cpu().numpy(),
+                                              'labels': labels[:, sequence_index].cpu().numpy()}
         acc1, acc5 = accuracy(preds, labels, topk=(1, min(5, preds.size(-1))))
         metrics[acc1_key + key_suffix] = acc1
         metrics[acc5_key + key_suffix] = acc5
@@ -143,6 +148,135 @@ def get_loss_wts(loss_wts: Dict, key: str) -> float:
     raise ValueError(f'{key} not contained in predefined loss_wts: {loss_wts}')
 
 
+class _Pending:
+    """one non-blocking device-to-host copy into pinned memory + the event that says it has landed"""
+
+    def __init__(self, dev_tensor: torch.Tensor):
+        t = dev_tensor.detach()
+        if t.is_cuda:
+            self.host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            self.host.copy_(t, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+        else:
+            self.host, self.event = t.clone(), None
+
+    def wait(self) -> torch.Tensor:
+        if self.event is not None:
+            self.event.synchronize()
+            self.event = None
+        return self.host
+
+
+class LazyHostArray:
+    """A numpy array that is still on its way from the GPU: what `tensor.cpu().numpy()` returns in the reference
+    (common/runner.py:82-85, the (B, 3806) logits of the mean-top-5-recall meter), without the host waiting for the GPU inside
+    the forward call.  The first numpy use (np.asarray / np.argsort / an attribute / an operator: metric_tracking.py:23-29)
+    waits for the copy's event only."""
+
+    def __init__(self, dev_tensor: torch.Tensor):
+        self._p = _Pending(dev_tensor)
+        self._a = None
+
+    def _arr(self):
+        if self._a is None:
+            self._a = self._p.wait().numpy()
+        return self._a
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._arr()
+        return a if dtype is None else a.astype(dtype)
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self._arr(), name)
+
+    def __getitem__(self, i):
+        return self._arr()[i]
+
+    def __len__(self):
+        return len(self._arr())
+
+    def __eq__(self, o):
+        return self._arr() == o
+
+    def __ne__(self, o):
+        return self._arr() != o
+
+    __hash__ = None
+
+
+class LazyScalar:
+    """A loss value that is still on its way from the GPU: what `tensor.item()` returns in the reference
+    (common/runner.py:211-212), usable wherever the training loop uses that float (AverageMeter.update: val * n, += ;
+    formatting; comparisons) -- the first such use waits for the copy and raises the reference's 'The loss is NaN!' then."""
+
+    def __init__(self, pending: _Pending, index: int):
+        self._p, self._i, self._v = pending, index, None
+
+    def _val(self) -> float:
+        if self._v is None:
+            self._v = float(self._p.wait()[self._i])
+            if self._v != self._v:
+                raise ValueError('The loss is NaN!')
+        return self._v
+
+    def __float__(self):
+        return self._val()
+
+    def item(self):
+        return self._val()
+
+    def __repr__(self):
+        return repr(self._val())
+
+    def __format__(self, spec):
+        return format(self._val(), spec)
+
+    def __mul__(self, o):
+        return self._val() * o
+
+    __rmul__ = __mul__
+
+    def __add__(self, o):
+        return self._val() + o
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return self._val() - o
+
+    def __rsub__(self, o):
+        return o - self._val()
+
+    def __truediv__(self, o):
+        return self._val() / o
+
+    def __rtruediv__(self, o):
+        return o / self._val()
+
+    def __neg__(self):
+        return -self._val()
+
+    def __lt__(self, o):
+        return self._val() < float(o)
+
+    def __le__(self, o):
+        return self._val() <= float(o)
+
+    def __gt__(self, o):
+        return self._val() > float(o)
+
+    def __ge__(self, o):
+        return self._val() >= float(o)
+
+    def __eq__(self, o):
+        return self._val() == float(o)
+
+    __hash__ = None
+
+
 class PendingScalars:
     """Loss values on their way to the host: ONE pinned, non-blocking device-to-host copy of all scalars of a step and an
     event, instead of one blocking .item() per loss term (common/runner.py:211-212 syncs the GPU every step).
@@ -172,13 +306,23 @@ class PendingScalars:
 
 
 class Runner:
-    """wrapper class of BasicLossAccuracy, runs on each batch, returns all metrics.
-    async_metrics=True: the step never waits for the GPU -- metrics['losses'] is a PendingScalars."""
+    """wrapper class of BasicLossAccuracy, runs on each batch, returns all metrics (common/runner.py:178-270; the reference
+    constructs it as Runner(model, device, loss_wts=...), train.py:371).
+    async_metrics: what happens to the values the reference fetches with blocking copies inside this call (the .item() of every
+    loss term, :211-212; the .cpu().numpy() of the logits for the recall meter, :82-85), i.e. BEFORE backward is enqueued:
+      "lazy" (default; AFFT_RUNNER_SYNC=1 turns it off): the SAME keys hold LazyScalar / LazyHostArray values -- non-blocking
+          pinned copies that wait for their event at their first use (metric_tracker.update at the end of the iteration,
+          train.py:278), so the unchanged loop enqueues forward, backward and the update without the host ever waiting;
+      False: the reference's blocking fetches, value for value;
+      True: metrics['losses'] is ONE PendingScalars for all terms."""
 
-    def __init__(self, model, device, loss_wts, compute_metrics: bool = True, async_metrics: bool = False):
+    def __init__(self, model, device, loss_wts, compute_metrics: bool = True, async_metrics=None):
+        import os
+        if async_metrics is None:
+            async_metrics = False if os.environ.get("AFFT_RUNNER_SYNC", "0") == "1" else "lazy"
         self.model = model
         self.device = device
-        self.loss_acc_fn = BasicLossAccuracy(compute_metrics)
+        self.loss_acc_fn = BasicLossAccuracy(compute_metrics, lazy_host=(async_metrics == "lazy"))
         self.loss_wts = loss_wts
         self.async_metrics = async_metrics
 
@@ -218,7 +362,13 @@ class Runner:
         losses, metrics = self.loss_acc_fn(outputs, out_t['target'], out_t['target_subclips'],
                                            mixup_enable=(mixup_fn is not None),
                                            target_subclips_ignore_index=out_t['target_subclips_ignore_index'])
-        if self.async_metrics:
+        if self.async_metrics == "lazy":
+            loss, dev_losses = self._reduce_loss(losses, self.loss_wts, sync=False)
+            dev_losses['total_loss'] = loss.detach()
+            keys = list(dev_losses)
+            pend = _Pending(torch.stack([dev_losses[k].detach().float().reshape(()) for k in keys]))
+            metrics.update({k: LazyScalar(pend, i) for i, k in enumerate(keys)})
+        elif self.async_metrics:
             loss, dev_losses = self._reduce_loss(losses, self.loss_wts, sync=False)
             dev_losses['total_loss'] = loss.detach()
             metrics['losses'] = PendingScalars(dev_losses)

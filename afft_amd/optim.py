@@ -156,6 +156,7 @@ class SGD(torch.optim.Optimizer, _FusedEpilogue):
 
     def _disarm(self):
         rt.SINK.fused = None
+        rt.SINK.fused_applied.clear()      # ids are only meaningful inside the step that recorded them
         rt.SINK.on_grad_ready = None
         self.opt.runs = self._saved_runs
         self._armed = False

@@ -592,6 +592,7 @@ class Trainer(_FusedEpilogue):
                 saved_runs = self.opt.runs      # the set shrank: keep the rebuilt runs
         finally:
             rt.SINK.fused = None
+            rt.SINK.fused_applied.clear()      # ids are only meaningful inside the step that recorded them
             self.opt.runs = saved_runs
         if optimize_in_backward:
             self.opt.end_step()

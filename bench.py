@@ -367,7 +367,9 @@ def reference_loop_measurements(args, device, feats, tgt, sub, c, trainer_ms):
                 opt = AfftSGD(groups, lr=1e-3, momentum=0.9, nesterov=True, bucket_elems=args.bucket_melems * 1024 * 1024)
             sched = Warmup(opt, CosineLR(opt, num_epochs=30, iters_per_epoch=1000, world_size=1, eta_min=1e-6), init_lr_ratio=0.01,
                            num_epochs=20, iters_per_epoch=1000, world_size=1)
-            runner = Runner(model, device, wts, async_metrics=(kind == "afft_sgd_async"))
+            # torch_sgd_*: the reference's blocking fetches inside the runner call; afft_sgd: our Runner's default (lazy host values:
+            # the same keys, waited for at their first use); afft_sgd_async: one PendingScalars object
+            runner = Runner(model, device, wts, async_metrics=(True if kind == "afft_sgd_async" else False if kind.startswith("torch_sgd") else None))
             info = {"param_groups": len(opt.param_groups)}
 
             def step():
@@ -376,6 +378,15 @@ def reference_loop_measurements(args, device, feats, tgt, sub, c, trainer_ms):
                 loss.backward()
                 opt.step()
                 sched.step()
+                # train.py:278 metric_tracker.update(metrics, ...): every value is consumed on the host at the end of the iteration
+                for k, v in metrics.items():
+                    if isinstance(v, dict):
+                        for a in v.values():
+                            float(__import__("numpy").asarray(a).reshape(-1)[0])
+                    elif hasattr(v, "result"):
+                        v.result()
+                    else:
+                        float(v)
                 return loss, metrics
         for _ in range(n_warm):
             step()

@@ -257,3 +257,35 @@ def test_two_rank_reference_loop_with_ddp_wrapper(tmp_path, kind):
     assert err < 1e-6, err
     import afft_amd
     afft_amd.set_precision("bf16")
+
+
+def test_runner_lazy_metrics_are_the_references_values():
+    """Runner's default ("lazy") returns, under the reference's own keys, values that wait for their device-to-host copy at first
+    use: consumed the way metric_tracking.py consumes them (val * n, np.argsort, labels == l) they are the blocking Runner's values"""
+    import numpy as np
+    import cpu_ops
+    from afft_amd.common.runner import LazyHostArray, LazyScalar, Runner
+    c, state, data, tgt, sub = _afft_case()
+    with cpu_ops.installed():
+        model = _afft_model(c, state, "fp32")
+        lazy = Runner(model, torch.device("cpu"), WTS)
+        sync = Runner(model, torch.device("cpu"), WTS, async_metrics=False)
+        assert lazy.async_metrics == "lazy"
+        l1, m1 = lazy(_batch(data, tgt, sub), None, True)
+        l2, m2 = sync(_batch(data, tgt, sub), None, True)
+    assert float(l1.detach()) == float(l2.detach())
+    assert set(m1) == set(m2)
+    for k, v in m2.items():
+        if isinstance(v, float):
+            assert isinstance(m1[k], LazyScalar) and m1[k] * 3 == v * 3 and 0.0 + m1[k] == v and f"{m1[k]:.4f}" == f"{v:.4f}"
+        elif isinstance(v, dict):
+            assert np.array_equal(np.argsort(m1[k]["logits"], axis=1), np.argsort(v["logits"], axis=1))
+            lab = m1[k]["labels"]
+            assert np.array_equal(lab.reshape(-1, 1), v["labels"].reshape(-1, 1)) and np.array_equal(lab == v["labels"][0], v["labels"] == v["labels"][0])
+    # on the GPU path the holders are the lazy classes; a NaN loss raises the reference's error at first use
+    from afft_amd.common.runner import _Pending
+    bad = LazyScalar(_Pending(torch.tensor([float("nan")])), 0)
+    with pytest.raises(ValueError, match="NaN"):
+        float(bad)
+    arr = LazyHostArray(torch.arange(6.0).reshape(2, 3))
+    assert arr.shape == (2, 3) and np.asarray(arr).sum() == 15.0
