@@ -155,6 +155,8 @@ _SIGS = {
     "afft_attention_bwd": ([vp, i64, vp, i64, vp, i64, vp, i64, i32, vp, i32, i32, i32, i32, f32, f32, C.c_uint32,
                             vp, i64, vp, i64, vp, i64, vp], C.c_int),
     "afft_softmax_ce": ([vp, i64, i32, i32, vp, vp, i64, vp, f32, vp, vp, vp, i64, i32, vp, vp], C.c_int),
+    "afft_loss_reduce": ([C.POINTER(vp), C.POINTER(i64), C.POINTER(f32), i32, vp, vp, vp], C.c_int),
+    "afft_loss_reduce_bwd": ([C.POINTER(vp), C.POINTER(i64), C.POINTER(f32), i32, vp, vp], C.c_int),
     "afft_mse": ([vp, i64, vp, i64, i32, i32, f32, vp, f32, vp, vp, i64, vp, i64, vp, i64, vp], C.c_int),
     "afft_cast": ([vp, i64, i32, i32, vp, i64, i32, vp, i64, i32, C.POINTER(Dropout), vp], C.c_int),
     "afft_assemble_tokens": ([C.POINTER(vp), C.POINTER(i64), i32, vp, i64, vp, i32, i32, i32, vp, vp], C.c_int),

@@ -72,9 +72,15 @@ class BasicLossAccuracy(nn.Module):
         self.lazy_host = lazy_host        # host copies of the logits / labels as LazyHostArray instead of a blocking .cpu()
 
     @staticmethod
-    def reg_criterion(a, b):
+    def reg_criterion(a, b, skip: int = 0):
+        """MSELoss(a[:, skip:], b[:, skip:]) (common/runner.py:164-166 slices [:, 1:] first): frames that are contiguous C-vectors
+        are walked in place (F_.MSE with a frame range); anything else takes the copying path."""
         B, T, C = a.shape
-        return F_.MSE.apply(a.reshape(B * T, C).contiguous(), b.reshape(B * T, C).contiguous())
+        if (a.dtype == b.dtype == torch.float32 and a.stride(2) == 1 and b.stride(2) == 1 and a.stride(1) == C and b.stride(1) == C
+                and T - skip > 0):
+            return F_.MSE.apply(a, b, skip, skip, T - skip)
+        a, b = a[:, skip:], b[:, skip:]
+        return F_.MSE.apply(a.reshape(-1, C).contiguous(), b.reshape(-1, C).contiguous())
 
     def forward_future_action(self, logits, tgt_val, mixup_enable, losses, metrics, acc1_key, acc5_key, mt5r_key,
                               loss_key, key_suffix=''):
@@ -137,7 +143,7 @@ class BasicLossAccuracy(nn.Module):
                 for modk, upd in outputs['past_futures'].items():
                     if modk not in outputs['orig_past']:
                         continue
-                    losses[f'past_reg_{modk}'] = self.reg_criterion(upd[:, 1:], outputs['orig_past'][modk][:, 1:])
+                    losses[f'past_reg_{modk}'] = self.reg_criterion(upd, outputs['orig_past'][modk], skip=1)
         return losses, metrics
 
 
@@ -328,13 +334,14 @@ class Runner:
 
     @staticmethod
     def _reduce_loss(losses, loss_wts, sync: bool = True):
-        losses = {key: torch.mean(val) for key, val in losses.items()}
-        losses_wtd = []
-        for key, val in losses.items():
-            w = get_loss_wts(loss_wts, key)
-            if w > 0:
-                losses_wtd.append(w * val)
-        loss = torch.sum(torch.stack(losses_wtd))
+        keys = list(losses)
+        wts = [max(float(get_loss_wts(loss_wts, k)), 0.0) for k in keys]      # a weight <= 0 drops the term from the total (runner.py:205-207)
+        if 1 <= len(keys) <= 8:
+            loss, means = F_.ReduceLosses.apply(tuple(wts), *[losses[k] for k in keys])      # one launch each way
+            losses = {k: means[i] for i, k in enumerate(keys)}
+        else:
+            losses = {key: torch.mean(val) for key, val in losses.items()}
+            loss = torch.sum(torch.stack([w * losses[k] for k, w in zip(keys, wts) if w > 0]))
         if not sync:
             return loss, {k: v.detach() for k, v in losses.items()}
         if torch.isnan(loss):

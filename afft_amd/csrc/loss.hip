@@ -101,7 +101,60 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, i
   }
 }
 
+// Runner._reduce_loss in one launch: term i = n[i] floats at x[i]; means[i] = their mean (lane-strided partial sums, then a fixed
+// tree: the same bits on every run), total = sum_i w[i] * means[i].  One workgroup (the terms are a few thousand values).
+struct LossTerms { const float* x[8]; float* g[8]; int64_t n[8]; float w[8]; int nterms; };
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const LossTerms t, float* __restrict__ means, float* __restrict__ total) {
+  __shared__ float sh[4];
+  float tot = 0.f;
+  for (int i = 0; i < t.nterms; ++i) {
+    float s = 0.f;
+    for (int64_t j = threadIdx.x; j < t.n[i]; j += 256) s += t.x[i][j];
+    s = block_reduce(s, sh, false);
+    const float m = t.n[i] > 0 ? s / (float)t.n[i] : 0.f;
+    if (threadIdx.x == 0 && means) means[i] = m;
+    tot += t.w[i] * m;
+  }
+  if (threadIdx.x == 0) *total = tot;
+}
+// its backward: g[i][:] = g_total * w[i] / n[i]
+__global__ __launch_bounds__(256) void loss_reduce_bwd_kernel(const LossTerms t, const float* __restrict__ g_total) {
+  const float go = g_total ? g_total[0] : 1.f;
+  const int i = blockIdx.y;
+  if (!t.g[i] || t.n[i] <= 0) return;
+  const float v = go * t.w[i] / (float)t.n[i];
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < t.n[i]; j += (int64_t)gridDim.x * 256) t.g[i][j] = v;
+}
+
 }  // namespace
+
+extern "C" int afft_loss_reduce(const float* const* x, const int64_t* n, const float* w, int32_t nterms, float* means, float* total,
+                                void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(x && n && w && total, "loss_reduce: null pointer");
+  AFFT_CHECK(nterms >= 1 && nterms <= 8, "loss_reduce: 1..8 terms (got %d)", nterms);
+  LossTerms t = {};
+  t.nterms = nterms;
+  for (int i = 0; i < nterms; ++i) { AFFT_CHECK(x[i] || n[i] == 0, "loss_reduce: null term"); t.x[i] = x[i]; t.n[i] = n[i]; t.w[i] = w[i]; }
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, stream, t, means, total);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int afft_loss_reduce_bwd(float* const* g, const int64_t* n, const float* w, int32_t nterms, const float* g_total,
+                                    void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(g && n && w, "loss_reduce_bwd: null pointer");
+  AFFT_CHECK(nterms >= 1 && nterms <= 8, "loss_reduce_bwd: 1..8 terms (got %d)", nterms);
+  LossTerms t = {};
+  t.nterms = nterms;
+  int64_t nmax = 1;
+  for (int i = 0; i < nterms; ++i) { t.g[i] = g[i]; t.n[i] = n[i]; t.w[i] = w[i]; nmax = n[i] > nmax ? n[i] : nmax; }
+  const int gx = (int)((nmax + 255) / 256 > 64 ? 64 : (nmax + 255) / 256);
+  hipLaunchKernelGGL(loss_reduce_bwd_kernel, dim3(gx, nterms), dim3(256), 0, stream, t, g_total);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int afft_softmax_ce(const float* logits, int64_t ldl, int32_t rows, int32_t C, const int64_t* labels,
                                const float* soft, int64_t lds, const uint8_t* keep, float gscale, const float* row_g,

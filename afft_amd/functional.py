@@ -1541,22 +1541,98 @@ class SoftmaxCE(torch.autograd.Function):
 
 
 class MSE(torch.autograd.Function):
-    """mean((a-b)^2), gradient to both sides (common/runner.py:164-166)."""
+    """mean((a-b)^2), gradient to both sides (common/runner.py:164-166).
+    a, b: 2-D [rows, d], or -- `a_lo` given -- 3-D (B, Ta, C) / (B, Tb, C) of which the frames a[:, a_lo : a_lo + nt] and
+    b[:, b_lo : b_lo + nt] are compared (the reference slices `[:, 1:]` before the loss, runner.py:164: here the kernel walks
+    the slices in place through its row strides -- B rows of nt * C values -- and the gradients come back as FULL tensors of the
+    inputs' shapes, zeros outside the slices: no slice copies forward, no slice-backward fill + copy per side)."""
 
     @staticmethod
-    def forward(ctx, a, b):
-        rows, d = a.shape
+    def forward(ctx, a, b, a_lo=None, b_lo=0, nt=0):
+        ctx.rng = None
+        if a_lo is not None:
+            assert a.dim() == 3 and b.dim() == 3 and a.shape[0] == b.shape[0] and a.shape[2] == b.shape[2]
+            assert a.stride(2) == 1 and b.stride(2) == 1 and a.stride(1) == a.shape[2] and b.stride(1) == b.shape[2]
+            B, _, C = a.shape
+            ctx.rng = (a_lo, b_lo, nt)
+            av = torch.as_strided(a, (B, nt * C), (a.stride(0), 1), a.storage_offset() + a_lo * C)
+            bv = torch.as_strided(b, (B, nt * C), (b.stride(0), 1), b.storage_offset() + b_lo * C)
+        else:
+            av, bv = a, b
+        rows, d = av.shape
         out = torch.zeros((), dtype=torch.float32, device=a.device)
-        ops.mse(a, b, 1.0, out, None, None, lscale=1.0 / (rows * d))
+        ops.mse(av, bv, 1.0, out, None, None, lscale=1.0 / (rows * d))
         ctx.save_for_backward(a, b)
         return out
 
     @staticmethod
     def backward(ctx, g):
         a, b = ctx.saved_tensors
-        rows, d = a.shape
-        da = torch.zeros(rows, d, dtype=torch.float32, device=a.device)
-        db = torch.zeros(rows, d, dtype=torch.float32, device=a.device)
-        ops.mse(a, b, 1.0 / (rows * d), None, da, db, g_dev=g.contiguous())
+        if ctx.rng is None:
+            rows, d = a.shape
+            da = torch.zeros(rows, d, dtype=torch.float32, device=a.device)
+            db = torch.zeros(rows, d, dtype=torch.float32, device=a.device)
+            ops.mse(a, b, 1.0 / (rows * d), None, da, db, g_dev=g.contiguous())
+            flush_ready()
+            return da, db
+        a_lo, b_lo, nt = ctx.rng
+        B, _, C = a.shape
+        da = torch.zeros(a.shape, dtype=torch.float32, device=a.device)
+        db = torch.zeros(b.shape, dtype=torch.float32, device=a.device)
+        av = torch.as_strided(a, (B, nt * C), (a.stride(0), 1), a.storage_offset() + a_lo * C)
+        bv = torch.as_strided(b, (B, nt * C), (b.stride(0), 1), b.storage_offset() + b_lo * C)
+        dav = torch.as_strided(da, (B, nt * C), (da.stride(0), 1), a_lo * C)
+        dbv = torch.as_strided(db, (B, nt * C), (db.stride(0), 1), b_lo * C)
+        ops.mse(av, bv, 1.0 / (B * nt * C), None, dav, dbv, g_dev=g.contiguous())
         flush_ready()
-        return da, db
+        return da, db, None, None, None
+
+
+class ReduceLosses(torch.autograd.Function):
+    """Runner._reduce_loss (common/runner.py:198-213) in one launch each way: total = sum_i w_i * mean(v_i) over the per-row
+    loss tensors v_i (scalars count as one row), and the means for the log.  Backward hands every producer its upstream
+    gradient g * w_i / n_i as one filled buffer (the softmax-CE kernel's row_g, the MSE kernel's g_dev) -- instead of
+    mean / mul / stack / sum forward and div / mul / expand / copy backward per term (15 torch kernels per step at three terms)."""
+
+    @staticmethod
+    def forward(ctx, weights, *vals):
+        flat = [v.reshape(-1).float().contiguous() for v in vals]
+        dev = flat[0].device
+        means = torch.empty(len(flat), dtype=torch.float32, device=dev)
+        total = torch.empty((), dtype=torch.float32, device=dev)
+        ops.loss_reduce(flat, weights, means, total)
+        ctx.weights, ctx.shapes = tuple(weights), [v.shape for v in vals]
+        ctx.needs = list(ctx.needs_input_grad[1:])
+        ctx.mark_non_differentiable(means)
+        return total, means
+
+    @staticmethod
+    def backward(ctx, g_total, _g_means):
+        grads = [torch.empty(shp, dtype=torch.float32, device=g_total.device) if need else None
+                 for shp, need in zip(ctx.shapes, ctx.needs)]
+        ops.loss_reduce_bwd(grads, ctx.weights, g_total.contiguous())
+        return (None, *grads)
+
+
+class SplitRows(torch.autograd.Function):
+    """(x[:, :n], x[:, n:]) of x (B, L, C) as two views whose gradients are written side by side into ONE buffer: autograd's own
+    slicing would zero-fill a full-size gradient per slice, copy into it and add the two (5 kernels on the (B, T + 1, 3806) logits
+    of the merged classifier heads; here 2 copies)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n, ctx.shape = n, x.shape
+        return x[:, :n], x[:, n:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        dx = torch.empty(ctx.shape, dtype=ga.dtype if ga is not None else gb.dtype, device=(ga if ga is not None else gb).device)
+        if ga is not None:
+            dx[:, :ctx.n].copy_(ga)
+        else:
+            dx[:, :ctx.n].zero_()
+        if gb is not None:
+            dx[:, ctx.n:].copy_(gb)
+        else:
+            dx[:, ctx.n:].zero_()
+        return dx, None

@@ -283,23 +283,31 @@ class CrossModalFusionPrediction(nn.Module, metaclass=abc.ABCMeta):
         other observed ones); future = z_hat_{T+1}.. ; all-fused = the fused feature from frame T on."""
         T = next(iter(z.values())).shape[1]
         cut = T - 1
-        return {'orig_past': z,
-                'future': {m: zh[:, cut:] for m, zh in z_hat.items()},
-                'all-fused': {m: f[:, cut:] for m, f in fusions.items()},
-                'past_futures': {m: torch.cat([z[m][:, :1], zh[:, :cut]], dim=1) for m, zh in z_hat.items()}}
+        # [z_1, z_hat_2 .. z_hat_{T+k}] ONCE per modality: past_futures and future are its two ends (views) -- and the merged
+        # classifier heads (_with_logits) take it whole, instead of a second concatenation of the same rows
+        seen_then_predicted = {m: torch.cat([z[m][:, :1], zh], dim=1) for m, zh in z_hat.items()}
+        out = {'orig_past': z,
+               'future': {m: sp[:, T:] for m, sp in seen_then_predicted.items()},
+               'all-fused': {m: f[:, cut:] for m, f in fusions.items()},
+               'past_futures': {m: sp[:, :T] for m, sp in seen_then_predicted.items()}}
+        out['_seen_then_predicted'] = seen_then_predicted
+        return out
 
     def _with_logits(self, out: dict) -> dict:
         """past_logits/* from past_futures and logits/* from future (future_prediction.py:283-285 applies the SAME heads to both):
         one GEMM per head over the rows of both -- the future is 1-3 frames per clip, a GEMM of its own would be all launch and
         tail -- and two views of its output."""
         past, fut = out['past_futures'], out['future']
+        whole = out.pop('_seen_then_predicted', None)
         if rt.merge_heads() and past.keys() == fut.keys():
             T = next(iter(past.values())).shape[1]
-            both = self.apply_classifier({m: torch.cat([past[m], fut[m]], dim=1) for m in past})
+            if whole is None:
+                whole = {m: torch.cat([past[m], fut[m]], dim=1) for m in past}
+            both = self.apply_classifier(whole)
             for key, per_mod in both.items():
-                out[PAST_LOGITS_PREFIX + key] = {m: v[:, :T] for m, v in per_mod.items()}
-            for key, per_mod in both.items():
-                out[key] = {m: v[:, T:] for m, v in per_mod.items()}
+                halves = {m: F_.SplitRows.apply(v, T) for m, v in per_mod.items()}
+                out[PAST_LOGITS_PREFIX + key] = {m: h[0] for m, h in halves.items()}
+                out[key] = {m: h[1] for m, h in halves.items()}
             return out
         out.update(self.apply_classifier(past, outputs_prefix=PAST_LOGITS_PREFIX))
         out.update(self.apply_classifier(fut))

@@ -228,6 +228,25 @@ def softmax_ce(logits: Tensor, C_: int, *, labels: Optional[Tensor] = None, soft
                                     _dt(dlogits) if dlogits is not None else 0, _p(row_loss), _stream()), "softmax_ce")
 
 
+def loss_reduce(vals, weights, means: Optional[Tensor], total: Tensor):
+    """means[i] = mean(vals[i]), total[0] = sum_i weights[i] * means[i]: Runner._reduce_loss in one launch (afft_loss_reduce)"""
+    n = len(vals)
+    assert 1 <= n <= 8 and all(v.dtype == torch.float32 and v.is_contiguous() for v in vals)
+    ptrs = (C.c_void_p * n)(*[v.data_ptr() for v in vals])
+    cnts = (C.c_int64 * n)(*[v.numel() for v in vals])
+    ws = (C.c_float * n)(*[float(w) for w in weights])
+    L.check(L.lib().afft_loss_reduce(ptrs, cnts, ws, n, _p(means), _p(total), _stream()), "loss_reduce")
+
+
+def loss_reduce_bwd(grads, weights, g_total: Optional[Tensor]):
+    """grads[i][:] = g_total * weights[i] / grads[i].numel() (None entries are skipped)"""
+    n = len(grads)
+    ptrs = (C.c_void_p * n)(*[None if g is None else g.data_ptr() for g in grads])
+    cnts = (C.c_int64 * n)(*[0 if g is None else g.numel() for g in grads])
+    ws = (C.c_float * n)(*[float(w) for w in weights])
+    L.check(L.lib().afft_loss_reduce_bwd(ptrs, cnts, ws, n, _p(g_total), _stream()), "loss_reduce_bwd")
+
+
 def mse(a: Tensor, b: Tensor, gscale: float, loss_sum: Optional[Tensor], da: Optional[Tensor], db: Optional[Tensor],
         g_dev: Optional[Tensor] = None, lscale: float = 1.0):
     """loss_sum[0] += lscale * sum (a - b)^2 (ordered sum through the current stream's scratch: no float atomics), da / db +=

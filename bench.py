@@ -749,7 +749,7 @@ def main():
             ach = avg_fl / (avg_ms * 1e-3) / 1e12
             dtype_peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3
             traffic, traffic_src = None, None
-            for fn in ("r03c_gemm_hbm_traffic_pmc.json", "r03b_gemm_hbm_traffic_pmc.json", "r03a_gemm_hbm_traffic_pmc.json", "r02i_gemm_hbm_traffic_pmc.json", "r02h_gemm_hbm_traffic_pmc.json", "r02g_gemm_hbm_traffic_pmc.json", "r02_gemm_hbm_traffic_pmc.json", "r01_gemm_hbm_traffic_pmc.json"):
+            for fn in ("r04b_gemm_hbm_traffic_pmc.json", "r04a_gemm_hbm_traffic_pmc.json", "r03c_gemm_hbm_traffic_pmc.json", "r03b_gemm_hbm_traffic_pmc.json", "r03a_gemm_hbm_traffic_pmc.json", "r02i_gemm_hbm_traffic_pmc.json", "r02h_gemm_hbm_traffic_pmc.json", "r02g_gemm_hbm_traffic_pmc.json", "r02_gemm_hbm_traffic_pmc.json", "r01_gemm_hbm_traffic_pmc.json"):
                 try:   # HBM-side bytes per launch from separate rocprofv3 --pmc passes (tools/traffic_summary.py), committed
                     tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
                     hit = [v for k, v in tj.items() if isinstance(v, dict) and (k == dom or dom.startswith(k.rstrip(">")))]
@@ -766,7 +766,7 @@ def main():
                 "algorithmic_bytes_per_launch": int(d["bytes"] / d["launches"]),
                 "traffic_note": f"bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate --pmc passes of this command "
                                 f"(profiles/{traffic_src}); fabric-side: includes Infinity-Cache hits, which the L2's counters cannot tell from HBM "
-                                f"reads (profiles/r03_l2_hit_pmc.txt: 70-79 % L2 hits, ~2 TB/s of fabric reads while the kernel runs: not time-relevant)",
+                                f"reads (profiles/r03_l2_hit_pmc.txt: 70-79 % L2 hits, ~2 TB/s of fabric reads while the kernel runs: not time-relevant); read from the committed profile of this command, not measured in this run",
                 "fused_optimizer_epilogue": bool(d.get("fused_update_launches")),
                 # the same kernel symbol in a step whose weight gradients run on the main stream: every launch alone on the chip
                 "alone": (lambda a: {"achieved": round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 1),

@@ -215,6 +215,12 @@ int afft_attention_bwd(const void* dout, int64_t lddo, const void* q, int64_t ld
 int afft_softmax_ce(const float* logits, int64_t ldl, int32_t rows, int32_t C, const int64_t* labels,
                     const float* soft, int64_t lds, const uint8_t* keep, float gscale, const float* row_g,
                     float* loss_sum, void* dlogits, int64_t ldd, int32_t d_dtype, float* row_loss, void* stream);
+/* Runner._reduce_loss (common/runner.py:198-213) in one launch: term i = n[i] fp32 per-row losses at x[i] (HOST arrays of nterms <= 8
+ * device pointers / counts / weights); means[i] = mean(x[i]) (may be NULL), total[0] = sum_i w[i] * means[i], in a fixed order (bit-stable).
+ * afft_loss_reduce_bwd: g[i][0 .. n[i]) = g_total[0] * w[i] / n[i] (g_total NULL = 1; g[i] NULL skips a term): the upstream
+ * gradients of the per-row losses, ready for afft_softmax_ce's row_g / afft_mse's g_dev. */
+int afft_loss_reduce(const float* const* x, const int64_t* n, const float* w, int32_t nterms, float* means, float* total, void* stream);
+int afft_loss_reduce_bwd(float* const* g, const int64_t* n, const float* w, int32_t nterms, const float* g_total, void* stream);
 /* Scalar reductions (the MSE loss, the gradient norm) are ORDERED: every workgroup writes one partial sum into the
  * caller-provided per-stream workspace (the same buffer as afft_gemm_t.workspace / afft_colsum: the partials sit behind its
  * AFFT_GEMM_WS_HEADER bytes of counters; at most AFFT_REDUCE_PARTIALS floats) and a second one-workgroup kernel adds them up

@@ -282,6 +282,25 @@ def sgd_nesterov_runs(p, g, buf, runs, lr, mom, wd, gscale, first, p_bf16=None):
 
 
 @torch.no_grad()
+def loss_reduce(vals, weights, means, total):
+    tot = torch.zeros((), dtype=torch.float32)
+    for i, (v, w) in enumerate(zip(vals, weights)):
+        m = v.float().mean() if v.numel() else torch.zeros(())
+        if means is not None:
+            means[i] = m
+        tot = tot + w * m
+    total.copy_(tot)
+
+
+@torch.no_grad()
+def loss_reduce_bwd(grads, weights, g_total):
+    go = 1.0 if g_total is None else float(g_total)
+    for g, w in zip(grads, weights):
+        if g is not None and g.numel():
+            g.fill_(go * w / g.numel())
+
+
+@torch.no_grad()
 def sumsq(x, out, scale=1.0):
     out += scale * (x.float() ** 2).sum()
     return out
@@ -360,7 +379,7 @@ def softmax_rows(x, y):
 
 
 _NAMES = ["Split", "gemm", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "softmax_ce", "mse", "cast",
-          "assemble_tokens", "colsum", "add_rows_periodic", "reduce_rows_periodic", "sgd_nesterov", "sgd_nesterov_runs", "sumsq", "clip_coef",
+          "assemble_tokens", "colsum", "add_rows_periodic", "reduce_rows_periodic", "sgd_nesterov", "sgd_nesterov_runs", "loss_reduce", "loss_reduce_bwd", "sumsq", "clip_coef",
           "group_sum", "group_bcast", "act_bwd", "softmax_small_fwd", "softmax_small_bwd", "weighted_sum_fwd",
           "weighted_sum_bwd", "softmax_rows"]
 

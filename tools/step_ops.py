@@ -24,7 +24,8 @@ for _ in range(4):
     tr.step(feats, tgt, sub)
 torch.cuda.synchronize()
 N = 3
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+             experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     for _ in range(N):
         tr.step(feats, tgt, sub)
     torch.cuda.synchronize()
@@ -36,14 +37,14 @@ for ev in prof.events():
     dev_us = sum(k.duration for k in ev.kernels) if ev.kernels else 0.0
     if not ev.kernels:
         continue
-    site = next((s for s in (ev.stack or []) if root in s and "tools/" not in s), "?")
-    site = site.replace(root + "/", "")
+    stack = [s for s in (ev.stack or []) if ("afft_amd/" in s or "bench.py" in s) and "tools/" not in s]
+    site = " <- ".join(x.split("afft_amd/")[-1] for x in stack[:2]) if stack else "?"
     agg[(ev.name, site)][0] += len(ev.kernels)
     agg[(ev.name, site)][1] += dev_us
 print(f"{name} B={batch}: torch-native ops that launch kernels, per step (over {N} steps)")
 tot_n = tot_us = 0
 for (op, site), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    print(f"{n / N:6.1f} launches {us / N:8.1f} us  {op:28} {site[:110]}")
+    print(f"{n / N:6.1f} launches {us / N:8.1f} us  {op:16} {site[:150]}")
     tot_n += n / N
     tot_us += us / N
 print(f"total: {tot_n:.1f} launches, {tot_us:.1f} us of device time per step")
