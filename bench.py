@@ -385,7 +385,7 @@ def reference_loop_measurements(args, device, feats, tgt, sub, c, trainer_ms):
                             float(__import__("numpy").asarray(a).reshape(-1)[0])
                     elif hasattr(v, "result"):
                         v.result()
-                    else:
+                    elif not isinstance(v, torch.Tensor):      # accuracies stay device tensors in the reference's meters too (val * n, +=)
                         float(v)
                 return loss, metrics
         for _ in range(n_warm):
