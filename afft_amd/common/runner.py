@@ -94,7 +94,9 @@ class BasicLossAccuracy(nn.Module):
             seq = torch.full_like(rows, sequence_index)
             preds = logits.detach().clone()
             preds[rows, seq, inds[:, 0]] += preds[rows, seq, inds[:, 1]]
-            preds[rows, seq, inds[:, 1]] = 0.0
+            # a device-resident zero: a Python scalar on the right-hand side is staged through pageable host memory, and that
+            # copy waits for everything queued in front of it (the whole forward pass)
+            preds.index_put_((rows, seq, inds[:, 1]), torch.zeros((), dtype=preds.dtype, device=preds.device))
             labels = inds[:, 0]
         else:
             preds = logits.detach()
