@@ -322,7 +322,7 @@ class Runner:
           pinned copies that wait for their event at their first use (metric_tracker.update at the end of the iteration,
           train.py:278), so the unchanged loop enqueues forward, backward and the update without the host ever waiting;
       False: the reference's blocking fetches, value for value;
-      True: metrics['losses'] is ONE PendingScalars for all terms."""
+      True: metrics['losses'] is ONE PendingScalars for all terms; the recall meter's arrays are lazy as above."""
 
     def __init__(self, model, device, loss_wts, compute_metrics: bool = True, async_metrics=None):
         import os
@@ -330,7 +330,7 @@ class Runner:
             async_metrics = False if os.environ.get("AFFT_RUNNER_SYNC", "0") == "1" else "lazy"
         self.model = model
         self.device = device
-        self.loss_acc_fn = BasicLossAccuracy(compute_metrics, lazy_host=(async_metrics == "lazy"))
+        self.loss_acc_fn = BasicLossAccuracy(compute_metrics, lazy_host=bool(async_metrics))
         self.loss_wts = loss_wts
         self.async_metrics = async_metrics
 

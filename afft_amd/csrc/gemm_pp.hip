@@ -39,8 +39,8 @@ namespace {
 // apart: while one group issues its 16 MFMAs of a phase, the other reads the next phase's fragments from LDS and
 // issues LDS-DMA.  Per K-tile (64 deep) a wave runs 4 phases = the 4 quadrants of its 128x64 output, and its rows /
 // columns are interleaved over the two 128-row halves of the A and B tiles, so a K-tile is consumed half-tile by
-// half-tile (A0,B0 | B1 | A1 | B0 of the next K-tile) and staged half-tile by half-tile, LEAD = 7 half-tiles (14 LDS-DMA
-// instructions per wave) ahead, behind a counted s_waitcnt vmcnt(8) that is the same in every phase: past the end of K
+// half-tile (A0,B0 | B1 | A1 | B0 of the next K-tile) and staged half-tile by half-tile, LEAD = 6 half-tiles (12 LDS-DMA
+// instructions per wave) ahead, behind a counted s_waitcnt vmcnt(6) that is the same in every phase: past the end of K
 // the stream goes on with 256-byte dummy transfers (AFFT_PP_CLAMP), so no phase needs a run-time choice of the wait.
 // What bounds it (tools/fill_bench.hip): not the fill -- LDS-DMA sustains 15 TB/s beside 1.9 PFLOP/s of
 // register-operand MFMAs -- but the LDS -> register leg (the MFMAs wait for their ds_read fragments; a bare loop with the
@@ -52,7 +52,13 @@ namespace {
 //   n + 3 has landed (this wave's pieces), s_barrier;  C(n): 16 MFMAs, s_barrier.
 //   slot 2n:   group 0 runs L(n),  group 1 runs C(n-1)      slot 2n+1: group 0 runs C(n),  group 1 runs L(n)
 //   RAW: half-tile m is first read in L(m - (m&3 ? 1 : 0) ...) >= two slots after every wave's wait for it;
-//   WAR: half-tile m overwrites m - 8, whose last reader (group 1) finished >= 3 slots earlier (LEAD <= 7).
+//   WAR: half-tile m overwrites m - 8.  Half-tile h is read in L(h) (q = 0), L(h-1) (q = 2, 3) or L(h-2) (q = 1), and a wave only
+//   waits for those LDS reads at the head of its next C segment -- group 1 holds h's data in registers when the barrier that
+//   ends slot 2h+2 falls (q = 0; earlier for the others).  The overwriting transfer is issued in L(h + 8 - LEAD), by group 0 in
+//   slot 2(h + 8 - LEAD): LEAD = 6 -> slot 2h+4, two barriers later.  LEAD = 7 (rounds 2-3) put it in slot 2h+2, the very slot
+//   in which group 1 is still waiting for its reads of A rows 0-127: ordered by latency alone, and once in a few thousand
+//   launches inside the training step (LDS busy with a co-resident kernel of the other stream) the transfer won -- a few rows
+//   of one tile came out with one K-tile of the wrong operand (profiles/r04_pp_war_race.txt).  LEAD = 6 is also as fast or faster.
 #ifdef AFFT_PP_STAMP   // diagnostic build only: per-segment cycle sums of workgroup 0 (see tools/pp_stamp.py)
 unsigned long long* g_pp_stamp = nullptr;
 #define STAMP(var) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); } while (0)
@@ -94,9 +100,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
 ) {
   constexpr int HB = 128 * BK * 2;   // half-tile bytes (16 KiB)
 #ifndef AFFT_PP_LEAD
-#define AFFT_PP_LEAD 7
+#define AFFT_PP_LEAD 6
 #endif
-  constexpr int LEAD = AFFT_PP_LEAD;             // half-tiles of look-ahead of the LDS-DMA stream (<= 7)
+  constexpr int LEAD = AFFT_PP_LEAD;             // half-tiles of look-ahead of the LDS-DMA stream
+#ifndef AFFT_PP_ALLOW_RACY_LEAD                  // (diagnostic builds reproduce the round-3 schedule with -DAFFT_PP_LEAD=7 -DAFFT_PP_ALLOW_RACY_LEAD)
+  static_assert(LEAD >= 3 && LEAD <= 6, "LEAD = 7 refills a ring slot in the slot in which its last reader still waits for its LDS reads (see WAR above)");
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -284,6 +284,26 @@ def flush_ready(all_threads: bool = False):
         pending.clear()
 
 
+def settle_joins(device=None, drop_pending: bool = False):
+    """After backward() has returned (or was abandoned by an exception): a join of the auxiliary stream that join_side queued for
+    the end of the backward pass but that never ran -- the engine drops its callbacks when a Function raises -- is carried out
+    now, and the flag that says "a join is queued" is cleared on every thread.  Without this the flag outlives the failed pass
+    and every later backward pass on that thread would skip its join (the next forward pass would then read weights the
+    auxiliary stream is still updating)."""
+    stuck = False
+    with _ALL_LOCK:
+        for _, d in _ALL_STATES:
+            if d.get("join_queued"):
+                d["join_queued"] = False
+                stuck = True
+            if drop_pending:      # a step is about to start: readiness notes left over from an abandoned pass belong to nobody
+                d["pending_ready"].clear()
+    if stuck and torch.cuda.is_available() and rt.overlap_wgrad():
+        dev = device if device is not None and device.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
+        torch.cuda.current_stream(dev).wait_stream(rt.aux_stream(dev))
+    return stuck
+
+
 # --------------------------------------------------------------------------- gradient hand-over between sub-layers
 # The residual-stream gradient dx a sub-layer's backward returns is the dy of the sub-layer that ran before it in the
 # forward pass, whose first two steps are "cast dy to bf16 with my output-dropout mask replayed" and "column-sum that
@@ -583,6 +603,9 @@ def _fuse_updates(s, weights) -> list:
     return keep
 
 
+_TAP = None      # diagnostics (tools/repro_diag.py): called with (kind, tensors) right after a composite backward has been enqueued
+
+
 def _ln_partial(rows: int, d: int, dev) -> Tensor:
     return torch.empty(L_.lib().afft_layernorm_bwd_nparts(rows) * 3 * d, dtype=torch.float32, device=dev)
 
@@ -677,7 +700,11 @@ def _attn_bwd_c(ctx, dy):
     partial = _ln_partial(R, d, dev)
     s.ln_partial = partial.data_ptr()
     _fill_ws(s, dev, main_raw, aux_raw)
+    if _TAP is not None:
+        _TAP("attn_bwd_pre", dict(R=R, d=d, w_qkv=w_qkv, w_proj=w_proj))
     L_.check(L_.lib().afft_attn_sublayer_bwd(C.byref(s), main_raw, aux_raw), "attn_sublayer_bwd")
+    if _TAP is not None:
+        _TAP("attn_bwd", dict(scratch=scratch, dy=dy, dx=dx, R=R, d=d, w_qkv=w_qkv, w_proj=w_proj, saved=saved, shadow=sh, partial=partial, x=x))
     _keep_for_aux(aux, saved, scratch, dy, sh.act.buf if sh is not None else None, *fresh)
     _publish_handover(ho, ctx.up, dx)
     if rt.grad_mode() == "sink":
@@ -775,6 +802,8 @@ def _mlp_bwd_c(ctx, dy):
     s.ln_partial = partial.data_ptr()
     _fill_ws(s, dev, main_raw, aux_raw)
     L_.check(L_.lib().afft_mlp_sublayer_bwd(C.byref(s), main_raw, aux_raw), "mlp_sublayer_bwd")
+    if _TAP is not None:
+        _TAP("mlp_bwd", dict(scratch=scratch, dy=dy, dx=dx, R=R, d=d, hidden=hidden, w1=w1, w2=w2, saved=saved, shadow=sh, partial=partial, x=x))
     _keep_for_aux(aux, saved, scratch, dy, sh.act.buf if sh is not None else None, *fresh)
     _publish_handover(ho, ctx.up, dx)
     if rt.grad_mode() == "sink":

@@ -170,6 +170,8 @@ class GradReducer:
 
     # ---- step protocol
     def begin_step(self):
+        from . import functional as F_
+        F_.settle_joins(self.flat.flat_g.device, drop_pending=True)      # a previous backward pass that raised left its end-of-pass join undone
         self._count = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._handles = []
@@ -240,6 +242,7 @@ class GradReducer:
         """Call after backward: zero untouched grads, hand over whatever is still pending, join the side stream."""
         from . import functional as F_
         F_.flush_ready(all_threads=True)       # a notification whose Function did not flush must not leak into the next step's counts
+        F_.settle_joins(self.flat.flat_g.device)
         rt.SINK.on_grad_ready = None
         rt.SINK.finish_step(self.flat.params)
         if not self.comm and self.on_bucket is None:

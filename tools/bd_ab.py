@@ -26,13 +26,18 @@ def load(path):
     return lib
 
 
+LAYOUT = os.environ.get("LAYOUT", "NT")      # NT: A [M,K], B [N,K] (forward) | NN: B [K,N] (data gradient) | TN: A [K,M], B [K,N] (weight gradient)
+
+
 def desc(a, b, out):
     d = _lib.GemmDesc()
-    M, K = a.shape
-    N = b.shape[0]
+    M, N = out.shape
+    K = a.shape[0] if LAYOUT == "TN" else a.shape[1]
     d.M, d.N, d.K, d.dtype = M, N, K, _lib.BF16
-    d.A, d.a_rs, d.a_cs = a.data_ptr(), a.stride(0), 1
-    d.B, d.b_rs, d.b_cs = b.data_ptr(), 1, b.stride(0)
+    d.A = a.data_ptr()
+    d.a_rs, d.a_cs = (1, a.stride(0)) if LAYOUT == "TN" else (a.stride(0), 1)
+    d.B = b.data_ptr()
+    d.b_rs, d.b_cs = (1, b.stride(0)) if LAYOUT == "NT" else (b.stride(0), 1)
     d.alpha = 1.0
     d.out, d.ldo, d.out_dtype = out.data_ptr(), out.stride(0), _lib.BF16
     return d
@@ -49,11 +54,11 @@ def main():
     cold = os.environ.get("COLD") == "1"       # COLD=1: one launch at a time, a 1-GiB fill in front of it (weights and activations from HBM)
     flush = torch.empty(1 << 28, dtype=torch.float32, device=DEV) if cold else None
     for (M, N, K) in SHAPES:
-        a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
-        b = torch.randn(N, K, generator=g).to(torch.bfloat16).to(DEV)
+        a = torch.randn(*((K, M) if LAYOUT == "TN" else (M, K)), generator=g).to(torch.bfloat16).to(DEV)
+        b = torch.randn(*((N, K) if LAYOUT == "NT" else (K, N)), generator=g).to(torch.bfloat16).to(DEV)
         out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
         from tools.bd_check import pack_b
-        bp = pack_b(b)
+        bp = pack_b(b) if LAYOUT == "NT" else b
         d0, dp = desc(a, b, out), desc(a, bp, out)
         res = {}
         for rnd in range(rounds):
