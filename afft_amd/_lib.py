@@ -144,6 +144,7 @@ _SIGS = {
     "afft_kernel_trace_begin": ([i32], C.c_int),
     "afft_kernel_trace_end": ([C.POINTER(KernelTraceRec), i32], C.c_int),
     "afft_gemm_workspace_bytes": ([C.c_int, C.c_int, C.c_int, C.c_int, C.c_int], i64),
+    "afft_gemm_packed_wanted": ([C.c_int, C.c_int, C.c_int], C.c_int),
     "afft_pack_weight": ([vp, i64, i32, i32, vp, vp], C.c_int),
     "afft_split_bf16": ([vp, i64, i32, i32, vp, i64, i32, i64, vp], C.c_int),
     "afft_layernorm_fwd": ([vp, i64, vp, vp, f32, i32, i32, vp, i64, i32, vp, vp, vp], C.c_int),

@@ -267,6 +267,18 @@ class LazyScalar:
     def __neg__(self):
         return -self._val()
 
+    def __abs__(self):
+        return abs(self._val())
+
+    def __pow__(self, o):
+        return self._val() ** o
+
+    def __round__(self, n=None):
+        return round(self._val(), n)
+
+    def __bool__(self):
+        return bool(self._val())
+
     def __lt__(self, o):
         return self._val() < float(o)
 

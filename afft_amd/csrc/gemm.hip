@@ -457,6 +457,10 @@ extern "C" int afft_gemm_variant_for(int M, int N, int K, int a_kstrided, int b_
   return choose_variant(M, N, K, a_kstrided != 0, b_kstrided != 0);
 }
 
+extern "C" int afft_gemm_packed_wanted(int M, int N, int K) {
+  return (g_variant == 0 && bd_packed_wins(M, N, K)) ? 1 : 0;
+}
+
 extern "C" int64_t afft_gemm_workspace_bytes(int M, int N, int K, int a_kstrided, int b_kstrided) {
   const int v = choose_variant(M, N, K, a_kstrided != 0, b_kstrided != 0);
   const int64_t b = splitk_bytes(v, M, N, K, nullptr);

@@ -93,7 +93,7 @@ def _lin_fwd(x: Act, W: Tensor, conv1d: bool, out: Tensor, **ep) -> Tensor:
     if rt.precision() == "bf16":
         w16, wt16 = rt.weight_images(W)      # [pad(rows), pad(cols)] and its transpose
         if not conv1d:                       # W [out, in] is B stored [N, K]: "NT"
-            pk = rt.weight_packed(W) if x.k.shape[1] == W.shape[1] else None
+            pk = rt.weight_packed(W, x.k.shape[0]) if x.k.shape[1] == W.shape[1] else None
             return ops.gemm(x.k, w16[:W.shape[0]], out, b_t=True, b_packed=pk, **ep)
         if wt16 is not None:                 # W^T [out, in]: "NT"
             return ops.gemm(x.k, wt16[:W.shape[1]], out, b_t=True, **ep)
@@ -496,11 +496,11 @@ def _img(W: Tensor):
     return w16.data_ptr(), w16.stride(0)
 
 
-def _pk(W: Tensor, conv1d: bool):
-    """pointer of the fragment-packed copy of an nn.Linear weight's image (afft_gemm_t.b_packed), or None"""
+def _pk(W: Tensor, conv1d: bool, rows: int):
+    """pointer of the fragment-packed copy of an nn.Linear weight's image (afft_gemm_t.b_packed) for a GEMM over `rows` rows, or None"""
     if conv1d:
         return None
-    pk = rt.weight_packed(W)
+    pk = rt.weight_packed(W, rows)
     return None if pk is None else pk.data_ptr()
 
 
@@ -627,7 +627,7 @@ def _attn_fwd_c(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, ep
     s.x, s.ln_w, s.ln_b = x.data_ptr(), _ptr(ln_w), _ptr(ln_b)
     s.w_qkv, s.ldw_qkv = _img(w_qkv)
     s.w_proj, s.ldw_proj = _img(w_proj)
-    s.w_qkv_pk, s.w_proj_pk = _pk(w_qkv, conv1d), _pk(w_proj, conv1d)
+    s.w_qkv_pk, s.w_proj_pk = _pk(w_qkv, conv1d, R), _pk(w_proj, conv1d, R)
     s.b_qkv, s.b_proj = _ptr(b_qkv), _ptr(b_proj)
     s.p_attn, s.k_attn = _attn_drop(drop)
     od = _out_drop(drop)
@@ -732,7 +732,7 @@ def _mlp_fwd_c(ctx, x, ln_w, ln_b, w1, b1, w2, b2, eps, gelu, conv1d, hidden, dr
     s.x, s.ln_w, s.ln_b = x.data_ptr(), _ptr(ln_w), _ptr(ln_b)
     s.w1, s.ldw1 = _img(w1)
     s.w2, s.ldw2 = _img(w2)
-    s.w1_pk, s.w2_pk = _pk(w1, conv1d), _pk(w2, conv1d)
+    s.w1_pk, s.w2_pk = _pk(w1, conv1d, R), _pk(w2, conv1d, R)
     s.b1, s.b2 = _ptr(b1), _ptr(b2)
     od = _out_drop(drop)
     if od is not None:

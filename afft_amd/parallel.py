@@ -64,7 +64,8 @@ class FlatParams:
         self.flat_pT16 = torch.zeros(off, dtype=torch.bfloat16, device=dev) if use_t else None
         self.transposed: List[tuple] = []     # (offset, param, transposed view) for the 2-D GEMM weights
         # fragment-packed bf16 images (same offsets and sizes; runtime.packed_images): the B operand of the "B direct" GEMM
-        # kernels, written by the fused optimizer epilogue or re-packed after every other update (refresh_packed)
+        # kernels.  A slot per GEMM weight; an image goes live when a forward GEMM first wants it (runtime.weight_packed) and is
+        # from then on written by the fused optimizer epilogue or re-packed after every other update (refresh_packed)
         use_pk = dev.type == "cuda" and rt.packed_images()
         self.flat_pk16 = torch.zeros(off, dtype=torch.bfloat16, device=dev) if use_pk else None
         self.packed: List[tuple] = []         # (offset, param, packed flat view)
@@ -86,7 +87,6 @@ class FlatParams:
                         pk = None
                         if use_pk:
                             pk = self.flat_pk16[o:o + p.numel()]
-                            ops.pack_weight(p.detach(), pk)
                             self.packed.append((o, p, pk))
                         rt.adopt_weight_image(p, self.flat_p16[o:o + p.numel()].view(p.shape), vt, packed=pk)
         rt.invalidate_weight_images()
@@ -109,7 +109,7 @@ class FlatParams:
             return
         with torch.no_grad():
             for o, p, pk in self.packed:
-                if s <= o < e and id(p) not in skip:
+                if s <= o < e and id(p) not in skip and rt.packed_live(p):
                     ops.pack_weight(p.detach(), pk)
 
     def refresh_transposed(self, s: int, e: int):
@@ -440,8 +440,6 @@ class _FusedEpilogue:
                     and img is not None and img.external):
                 d = L_.SgdFused()
                 d.p, d.buf, d.p_bf16 = flat.flat_p.data_ptr() + 4 * o, self.opt.buf.data_ptr() + 4 * o, flat.flat_p16.data_ptr() + 2 * o
-                if img.pk is not None:
-                    d.p_pk16 = flat.flat_pk16.data_ptr() + 2 * o
                 fused[id(p)] = d
         self._fused = fused
         self.opt.runs = self._runs_without(fused)
@@ -517,6 +515,7 @@ class _FusedEpilogue:
         d = self._fused.get(id(p))
         if d is not None:
             lr, wd = self.opt.hyper_of(self._index[id(p)])
+            d.p_pk16 = p._afft_img.pk.data_ptr() if rt.packed_live(p) else None      # only images a forward GEMM uses are kept fresh
             d.lr, d.mom, d.wd, d.gscale, d.first_step = lr, self.opt.momentum, wd, 1.0, self.opt.flags() & 2
         return d
 

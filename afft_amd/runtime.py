@@ -69,7 +69,7 @@ def pad64(n: int) -> int:
 
 # --------------------------------------------------------------------------- bf16 weight images
 class _WImage:
-    __slots__ = ("version", "ptr", "w", "wt", "external", "pk")
+    __slots__ = ("version", "ptr", "w", "wt", "external", "pk", "pk_live")
 
 
 _wlist: list = []   # weak references to parameters that own an image (for invalidate_weight_images)
@@ -101,6 +101,7 @@ def weight_images(p: Tensor):
         img.version = -1
         img.external = False
         img.pk = None
+        img.pk_live = False
         img.ptr = p.data_ptr()
         p._afft_img = img
         _register(p)
@@ -138,10 +139,30 @@ def packed_images() -> bool:
     return _PACKED_IMAGES
 
 
-def weight_packed(p: Tensor) -> Optional[Tensor]:
-    """the fragment-packed image of weight p, or None"""
+def weight_packed(p: Tensor, rows: Optional[int] = None) -> Optional[Tensor]:
+    """The fragment-packed image of nn.Linear weight p [out, in] for a forward GEMM over `rows` rows, or None.
+    Images come to life on demand: the slot exists for every weight the flat buffers own (parallel.FlatParams), but it is
+    filled -- and from then on kept fresh by the optimizer paths, at 2 bytes per parameter and step -- only once the GEMM
+    dispatcher says it would use it for a problem of this size (afft_gemm_packed_wanted: at cfg2 the fuser's projection and fc2
+    weights, a fifth of the parameters).  rows = None: only report a live image."""
     img = getattr(p, "_afft_img", None)
-    return None if img is None or not img.external else img.pk
+    if img is None or not img.external or img.pk is None:
+        return None
+    if not img.pk_live:
+        if rows is None or p.dim() != 2:
+            return None
+        from . import _lib as L_, ops
+        if not L_.lib().afft_gemm_packed_wanted(int(rows), int(p.shape[0]), int(p.shape[1])):
+            return None
+        with torch.no_grad():
+            ops.pack_weight(p.detach(), img.pk)      # forward pass, current stream: the parameter is at rest
+        img.pk_live = True
+    return img.pk
+
+
+def packed_live(p: Tensor) -> bool:
+    img = getattr(p, "_afft_img", None)
+    return bool(img is not None and img.external and img.pk is not None and img.pk_live)
 
 
 def transposed_images() -> bool:
@@ -159,6 +180,7 @@ def adopt_weight_image(p: Tensor, view16: Tensor, view16_t: Optional[Tensor] = N
     img.w = view16
     img.wt = view16_t
     img.pk = packed
+    img.pk_live = False
     img.version = p._version
     img.external = True
     img.ptr = p.data_ptr()

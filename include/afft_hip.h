@@ -120,6 +120,11 @@ typedef struct afft_sgd_fused {
  * every training recipe under expts/ sets opt.optimizer.nesterov=true). */
 enum { AFFT_SGD_FIRST_STEP = 1, AFFT_SGD_PLAIN_MOMENTUM = 2 };
 enum { AFFT_GEMM_WS_HEADER = 4096 };
+/* 1 when afft_gemm would run an NT problem of this size on the B-direct kernel if it were handed a fragment-packed B
+ * (afft_gemm_t.b_packed), 0 when it would ignore the packed copy: callers keep packed images only of the weights that use them
+ * (every image costs 2 bytes per parameter of optimizer traffic per step). */
+int afft_gemm_packed_wanted(int M, int N, int K);
+
 /* bytes of afft_gemm_t.workspace that let this problem use split-K under the current mode (0 = it would not split) */
 int64_t afft_gemm_workspace_bytes(int M, int N, int K, int a_kstrided, int b_kstrided);
 int afft_gemm(const afft_gemm_t* g, void* stream);

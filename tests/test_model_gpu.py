@@ -456,6 +456,11 @@ def test_fused_optimizer_audit_when_the_graph_changes_between_steps():
             with pytest.raises(RuntimeError, match="fused optimizer"):
                 tr.step(feats, {"action": tgt.to(dev)}, {"action": sub.to(dev)})
             torch.cuda.synchronize()
+            # the backward pass that raised had queued its end-of-pass join of the auxiliary stream; the engine dropped the
+            # callback: the next step must not inherit the "already queued" flag (every later backward would skip its join)
+            tr.reducer.begin_step()
+            assert not any(d.get("join_queued") for _, d in F_._ALL_STATES)
+            assert not any(d.get("pending_ready") for _, d in F_._ALL_STATES)
     rt.set_fused_sgd(True)
     rt.SINK.fused = None
     for a, b, what in zip(res[True], res[False], ("parameters", "momentum", "bf16 images")):
@@ -623,7 +628,11 @@ def test_runner_async_metrics_equal_synchronous():
     batch = ({"data_dict": data, "target": {"action": tgt}, "target_subclips": {"action": sub}}, {})
     wts = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
     rt.SINK.begin_step()
-    loss_s, m_s = Runner(model, dev, wts, compute_metrics=False)(batch)
+    loss_s, m_s = Runner(model, dev, wts, compute_metrics=False, async_metrics=False)(batch)       # the reference's blocking .item() fetches
+    rt.SINK.begin_step()
+    loss_l, m_l = Runner(model, dev, wts, compute_metrics=False)(batch)                            # default: lazy values under the same keys
+    for k, v in m_s.items():
+        assert abs(m_l[k] - v) < 1e-6 * max(1.0, abs(v)), k
     rt.SINK.begin_step()
     loss_a, m_a = Runner(model, dev, wts, compute_metrics=False, async_metrics=True)(batch)
     pend = m_a["losses"]
@@ -1338,18 +1347,27 @@ def test_packed_weight_images_stay_coherent_and_feed_the_forward():
     wts = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
     tr = Trainer(model, wts)
     assert tr.flat.flat_pk16 is not None and len(tr.flat.packed) >= 24
+    assert not any(rt.packed_live(p) for _, p, _ in tr.flat.packed), "images come to life on demand (the first forward GEMM that wants one)"
     model.train()
 
     def coherent():
         torch.cuda.synchronize()
-        for o, p, pk in tr.flat.packed[:6] + tr.flat.packed[-6:]:
+        live = [(o, p, pk) for o, p, pk in tr.flat.packed if rt.packed_live(p)]
+        assert len(live) >= 11      # the fuser's 6 projection + 5 fc2 weights (one-round grids at 5120 rows; the last block's MLP runs on 1024 rows)
+        for o, p, pk in live:
             want = torch.empty_like(pk)
             ops.pack_weight(p.detach(), want)
             assert torch.equal(pk, want), o
+        return live
     for _ in range(3):
         tr.step(feats, tgt, sub)          # step 1 separate (learns the fused set), then fused epilogues
-    assert tr._fused and all(d.p_pk16 for d in tr._fused.values())
-    coherent()
+    live = coherent()
+    assert len(live) < len(tr.flat.packed) // 2, "only the weights the dispatcher runs on the B-direct kernel pay for an image"
+    ids = {id(p) for _, p, _ in live}
+    for p in tr.flat.params:              # the epilogue writes the image of exactly those
+        d = tr._fused_desc(p) if id(p) in tr._fused else None
+        if d is not None:
+            assert bool(d.p_pk16) == (id(p) in ids)
     rt.set_fused_sgd(False)
     try:
         tr2_steps = 2
@@ -1368,7 +1386,7 @@ def test_packed_weight_images_stay_coherent_and_feed_the_forward():
         assert sum(1 for r in gt.records if r.variant == 10) >= 10, "the B-direct kernel was not dispatched"
         lib = _lib.lib()
         saved = [rt.weight_packed]
-        rt.weight_packed = lambda p: None          # no packed copies handed to the GEMMs: the ping-pong forward
+        rt.weight_packed = lambda p, rows=None: None          # no packed copies handed to the GEMMs: the ping-pong forward
         try:
             o2, _ = model(feats, mixup_fn=None, target=tgt, target_subclips=sub, target_subclips_ignore_index=None)
         finally:
