@@ -147,6 +147,7 @@ _SIGS = {
     "afft_gemm_packed_wanted": ([C.c_int, C.c_int, C.c_int], C.c_int),
     "afft_pack_weight": ([vp, i64, i32, i32, vp, vp], C.c_int),
     "afft_split_bf16": ([vp, i64, i32, i32, vp, i64, i32, i64, vp], C.c_int),
+    "afft_split_f16": ([vp, i64, i32, i32, vp, i64, i32, i64, vp], C.c_int),
     "afft_layernorm_fwd": ([vp, i64, vp, vp, f32, i32, i32, vp, i64, i32, vp, vp, vp], C.c_int),
     "afft_layernorm_bwd_nparts": ([i32], C.c_int),
     "afft_layernorm_bwd": ([vp, i64, i32, vp, i64, vp, vp, vp, i32, i32, vp, vp, i64, vp, C.POINTER(Dropout), vp, vp, i32,

@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256) void cast_rows4_kernel(const float* __restrict
 
 // two-plane bf16 split x = hi + lo of an fp32 matrix (bf16x3 GEMM operands), zero-filled out to [rows_pad, ldd];
 // 8 columns per thread: two 16-byte loads when the source allows, one 16-byte store per plane
+template <bool F16>   // F16: fp16 planes (hi = fp16(x), lo = fp16(x - hi)) for the fp16 two-pass GEMM mode
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ src, int64_t lds_, int rows, int cols,
                                                          bf16_t* __restrict__ hi, int64_t ldd, int rows_pad,
                                                          int64_t plane_stride, int src_vec) {
@@ -150,11 +151,20 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 #pragma unroll
         for (int k = 0; k < 8; ++k) if (c + k < cols) v[k] = p[k];
     }
-    float h[8], l[8];
+    if constexpr (F16) {
+      typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+      h8 hv, lv;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { h[k] = bf2f(f2bf(v[k])); l[k] = v[k] - h[k]; }
-    store8(hi, (int64_t)r * ldd + c, AFFT_BF16, h);
-    store8(hi + plane_stride, (int64_t)r * ldd + c, AFFT_BF16, l);
+      for (int k = 0; k < 8; ++k) { hv[k] = (_Float16)v[k]; lv[k] = (_Float16)(v[k] - (float)hv[k]); }
+      *(h8*)(hi + (int64_t)r * ldd + c) = hv;
+      *(h8*)(hi + plane_stride + (int64_t)r * ldd + c) = lv;
+    } else {
+      float h[8], l[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { h[k] = bf2f(f2bf(v[k])); l[k] = v[k] - h[k]; }
+      store8(hi, (int64_t)r * ldd + c, AFFT_BF16, h);
+      store8(hi + plane_stride, (int64_t)r * ldd + c, AFFT_BF16, l);
+    }
   }
 }
 
@@ -434,8 +444,8 @@ extern "C" int afft_cast(const float* src, int64_t lds_, int32_t rows, int32_t c
   return 0;
 }
 
-extern "C" int afft_split_bf16(const float* src, int64_t lds_, int32_t rows, int32_t cols, void* hi, int64_t ldd,
-                               int32_t rows_pad, int64_t plane_stride, void* stream_) {
+static int split_planes(bool f16, const float* src, int64_t lds_, int32_t rows, int32_t cols, void* hi, int64_t ldd,
+                        int32_t rows_pad, int64_t plane_stride, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(src && hi, "split_bf16: null pointer");
   AFFT_CHECK(rows >= 0 && cols >= 0 && rows_pad >= rows && ldd >= cols, "split_bf16: bad sizes");
@@ -445,10 +455,22 @@ extern "C" int afft_split_bf16(const float* src, int64_t lds_, int32_t rows, int
   const int src_vec = lds_ % 4 == 0 && (((uintptr_t)src) & 15) == 0;
   int64_t blocks = ((int64_t)rows_pad * (ldd / 8) + 255) / 256;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(split_bf16_kernel, dim3((int)blocks), dim3(256), 0, stream, src, lds_, rows, cols, (bf16_t*)hi, ldd,
-                     rows_pad, plane_stride, src_vec);
+  if (f16) hipLaunchKernelGGL(split_bf16_kernel<true>, dim3((int)blocks), dim3(256), 0, stream, src, lds_, rows, cols, (bf16_t*)hi, ldd,
+                              rows_pad, plane_stride, src_vec);
+  else hipLaunchKernelGGL(split_bf16_kernel<false>, dim3((int)blocks), dim3(256), 0, stream, src, lds_, rows, cols, (bf16_t*)hi, ldd,
+                          rows_pad, plane_stride, src_vec);
   AFFT_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int afft_split_bf16(const float* src, int64_t lds_, int32_t rows, int32_t cols, void* hi, int64_t ldd,
+                               int32_t rows_pad, int64_t plane_stride, void* stream_) {
+  return split_planes(false, src, lds_, rows, cols, hi, ldd, rows_pad, plane_stride, stream_);
+}
+
+extern "C" int afft_split_f16(const float* src, int64_t lds_, int32_t rows, int32_t cols, void* hi, int64_t ldd,
+                              int32_t rows_pad, int64_t plane_stride, void* stream_) {
+  return split_planes(true, src, lds_, rows, cols, hi, ldd, rows_pad, plane_stride, stream_);
 }
 
 extern "C" int afft_assemble_tokens(const float* const* feats, const int64_t* ldf, int32_t n_mod, const float* token,

@@ -42,7 +42,7 @@ int afft_gemm_launch_bd(int rows160, int packed, afft_gemm_detail::GemmFast& g, 
 
 namespace {
 
-template <int WM, int WN, int STAGES, bool A_KS, bool B_KS, bool SPLITK, bool X3 = false>
+template <int WM, int WN, int STAGES, bool A_KS, bool B_KS, bool SPLITK, int X3 = 0>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf16_kernel(const GemmFast g) {
   constexpr int NW = WM * WN;
   constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf1
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<X3>(bfr[j], af[i], acc[i][j]);
     }
     if (kt + 1 < nk) {
       // tile kt+1 must have landed; tiles kt+2 .. min(kt+D, nk-1) may stay in flight across the barrier
@@ -256,7 +256,7 @@ size_t g_trace_cap = 0;
 
 int g_variant = 0;  // 0 auto, 1 = 128x128 tile, 2 = 256x128 tile, 3 = 256x256 ping-pong (tuning / tests)
 
-template <int WM, int WN, int STAGES, bool A_KS, bool B_KS, bool SPLITK, bool X3 = false>
+template <int WM, int WN, int STAGES, bool A_KS, bool B_KS, bool SPLITK, int X3 = 0>
 int launch_fast(GemmFast& g, hipStream_t stream) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr size_t ring = (size_t)STAGES * (BM + BN) * BK * 2, epi = (size_t)BM * (BN * 4 + 16);
@@ -411,9 +411,18 @@ int launch_layout_impl(GemmFast& g, hipStream_t stream, const afft_gemm_t* d) {
   g.splitk = 1;
   g.ws = nullptr;
   g.counters = nullptr;
+  if (d->split3 == 2) {     // fp16 two-pass (forward layouts only): same tile choice as bf16x3
+    if constexpr (!A_KS) {
+      if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream, 2, 0);
+      return launch_fast<2, 2, 2, A_KS, B_KS, false, 2>(g, stream);
+    } else {
+      afft_set_error("afft_gemm: the fp16 two-pass mode (split3 = 2) is built for the forward layouts only (A k-contiguous)");
+      return 1;
+    }
+  }
   if (d->split3) {     // bf16x3: 256x256 tiles once the grid fills the chip, else 128x128; no split-K
     if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream, 1, 0);
-    return launch_fast<2, 2, 2, A_KS, B_KS, false, true>(g, stream);
+    return launch_fast<2, 2, 2, A_KS, B_KS, false, 1>(g, stream);
   }
   int s = 1;
   const int64_t need = splitk_bytes(variant, g.e.M, g.e.N, g.K, &s);
@@ -570,12 +579,13 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
   fast = fast && (a_kc || a_ks) && (b_kc || b_ks) && lda % 8 == 0 && ldb % 8 == 0 && lda >= 8 && ldb >= 8;
   fast = fast && !(a_ks && !a_kc && b_kc && !b_ks);   // (A k-strided, B k-contiguous) does not occur on the path
 
-  AFFT_CHECK(!d->split3 || fast, "afft_gemm: split3 needs bf16 planes in a fast-path layout (K %% 64 == 0, 16-byte aligned rows)");
+  AFFT_CHECK(d->split3 >= 0 && d->split3 <= 2, "afft_gemm: split3 is 0, 1 (bf16x3) or 2 (fp16 two-pass)");
+  AFFT_CHECK(!d->split3 || fast, "afft_gemm: split3 needs 16-bit planes in a fast-path layout (K %% 64 == 0, 16-byte aligned rows)");
   if (fast) {
     GemmFast g;
     g.A = (const bf16_t*)d->A; g.B = (const bf16_t*)d->B;
     g.lda = lda; g.ldb = ldb;
-    g.K = d->split3 ? 3 * d->K : d->K;
+    g.K = d->split3 == 2 ? 2 * d->K : d->split3 ? 3 * d->K : d->K;
     g.nk_seg = d->K / BK;
     g.a_lo = d->a_lo; g.b_lo = d->b_lo;
     g.e = e;

@@ -82,7 +82,7 @@ __device__ __forceinline__ GemmFast reload_kernel_args() {
   return __builtin_bit_cast(GemmFast, raw);
 }
 
-// X3: bf16x3 operand planes (gemm_tiles.h: seg_operands).  PERSIST: the grid is capped (a multiple of 8 workgroups, one per
+// X3: 1 = bf16x3 operand planes, 2 = fp16 planes, two passes (gemm_tiles.h: seg_operands, mfma16).  PERSIST: the grid is capped (a multiple of 8 workgroups, one per
 // CU) and every workgroup walks the tiles bid, bid + gridDim.x, ... -- the launch then holds that many CUs and no more,
 // which is how the weight-gradient GEMMs leave the rest of the chip to the data-gradient chain of the other stream.
 //
@@ -92,7 +92,7 @@ __device__ __forceinline__ GemmFast reload_kernel_args() {
 // every workgroup gets the same number of K-iterations (SkPlan, gemm_tiles.h).  A piece of a tile parks its accumulators in
 // the workspace and the LAST piece of a tile to arrive adds them up in K order and runs the epilogue (handoff_combine:
 // nobody waits, bitwise reproducible).  5120x2048x8192: 80 K-iterations on each of 256 CUs instead of 128 on 160.
-template <bool A_KS, bool B_KS, bool SPLITK, bool X3 = false, bool PERSIST = false>
+template <bool A_KS, bool B_KS, bool SPLITK, int X3 = 0, bool PERSIST = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
 #ifdef AFFT_PP_STAMP
     , unsigned long long* stamp_out
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
             issue(dma_m, dma_q);
             __builtin_amdgcn_sched_barrier(0);
           }
-          acc[ih][jh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bF[slot][j][s], aF[i][s], acc[ih][jh][i][j], 0, 0, 0);
+          acc[ih][jh][i][j] = mfma16<X3>(bF[slot][j][s], aF[i][s], acc[ih][jh][i][j]);
         }
     if (AFFT_PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
   } while (SPLITK ? sk_more : vb < g.tiles_m * g.tiles_n);
 }
 
-template <bool A_KS, bool B_KS, bool SPLITK, bool X3 = false, bool PERSIST = false>
+template <bool A_KS, bool B_KS, bool SPLITK, int X3 = 0, bool PERSIST = false>
 int launch_pp(GemmFast& g, hipStream_t stream, int grid_cap = 0) {
   constexpr size_t lds = 128 * 1040;          // ring: 2 K-tiles x 4 half-tiles x 16 KiB = 128 KiB; epilogue image: 130 KiB
   g.tiles_m = (g.e.M + 255) / 256;
@@ -443,9 +443,15 @@ int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipSt
 #ifndef AFFT_PP_NT_ONLY   // development switch: build only the plain NT instantiation (compile time)
   if (x3) {    // bf16x3 operand planes; never combined with split-K or a capped grid
     if (sk) { afft_set_error("afft_gemm: split3 with split-K"); return 1; }
-    if (!a_ks && !b_ks) return launch_pp<false, false, false, true>(g, stream);
-    if (!a_ks && b_ks) return launch_pp<false, true, false, true>(g, stream);
-    if (a_ks && b_ks) return launch_pp<true, true, false, true>(g, stream);
+    if (x3 == 2) {   // fp16x2: forward GEMMs only (NT, and NN for [in, out] weights)
+      if (!a_ks && !b_ks) return launch_pp<false, false, false, 2>(g, stream);
+      if (!a_ks && b_ks) return launch_pp<false, true, false, 2>(g, stream);
+      afft_set_error("afft_gemm: the fp16 two-pass mode is built for the forward layouts only");
+      return 1;
+    }
+    if (!a_ks && !b_ks) return launch_pp<false, false, false, 1>(g, stream);
+    if (!a_ks && b_ks) return launch_pp<false, true, false, 1>(g, stream);
+    if (a_ks && b_ks) return launch_pp<true, true, false, 1>(g, stream);
   }
   // capped grid: built for the weight-gradient layout only (the GEMMs that run beside another stream's chain)
   const int cap = max_wg & ~7, tiles = ((g.e.M + 255) / 256) * ((g.e.N + 255) / 256);

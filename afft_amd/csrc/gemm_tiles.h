@@ -32,15 +32,24 @@ struct GemmFast {
   float* ws;    // split-K: fp32 partial tiles [tile][slice][128*128]; stream-K: parked tiles [xcd][sk_tlmax][sk_smax][256*256] (below)
   int* counters;  // split-K / stream-K: arrivals per tile (zero between launches)
   int sk_tlmax, sk_smax;   // stream-K workspace geometry: parked tiles [xcd][sk_tlmax leftover tiles][sk_smax pieces][256*256]
-  // bf16x3 (X3 instantiations): K counts the K-tiles of all three segments, nk_seg of them per segment; segment 0 reads
-  // (A hi, B hi), 1 (A lo, B hi), 2 (A hi, B lo); the lo planes sit a_lo / b_lo elements behind A / B
+  // bf16x3 (X3 = 1 instantiations): K counts the K-tiles of all three segments, nk_seg of them per segment; segment 0 reads
+  // (A hi, B hi), 1 (A lo, B hi), 2 (A hi, B lo); the lo planes sit a_lo / b_lo elements behind A / B.
+  // fp16x2 (X3 = 2): fp16 planes, the first TWO segments only (A = hi + lo, B rounded once), v_mfma_f32_16x16x32_f16
   int nk_seg;
   int64_t a_lo, b_lo;
   EpiParams e;
 };
 
 // global K-tile index -> K offset inside the segment and the operand planes of that segment (wave-uniform SALU work)
-template <bool X3>
+// the MFMA of every bf16-path kernel: 16-bit operands by the instantiation's plane format (X3 = 2: fp16, else bf16)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+template <int X3>
+__device__ __forceinline__ f32x4 mfma16(bf16x8 b, bf16x8 a, f32x4 c) {
+  if constexpr (X3 == 2) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, b), __builtin_bit_cast(f16x8_t, a), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c, 0, 0, 0);
+}
+
+template <int X3>
 __device__ __forceinline__ void seg_operands(const GemmFast& g, int kt, int& k0, const bf16_t*& A, const bf16_t*& B) {
   A = g.A; B = g.B;
   if constexpr (X3) {

@@ -66,8 +66,9 @@ class Act:
     def split(self) -> "ops.Split":
         """bf16x3 mode: the two-plane bf16 split of this (fp32) buffer, made once and used by every GEMM that reads it
         (forward / dgrad as the k-contiguous operand, wgrad as the k-strided one)."""
-        if self._split is None:
-            self._split = ops.Split(self.live)
+        f16 = rt.split_mode() == "f16"      # fp16x2: fp16 planes (forward only)
+        if self._split is None or self._split.f16 != f16:
+            self._split = ops.Split(self.live, f16=f16)
         return self._split
 
 
@@ -98,9 +99,15 @@ def _lin_fwd(x: Act, W: Tensor, conv1d: bool, out: Tensor, **ep) -> Tensor:
         if wt16 is not None:                 # W^T [out, in]: "NT"
             return ops.gemm(x.k, wt16[:W.shape[1]], out, b_t=True, **ep)
         return ops.gemm(x.k, w16[:, :W.shape[1]], out, **ep)             # W [in, out] = [K, N]: "NN"
-    if rt.precision() == "bf16x3":
+    if rt.split_mode() is not None:          # bf16x3: three bf16 passes; fp16x2: x = hi + lo in fp16, W rounded once to fp16
         return ops.gemm(x.split(), rt.weight_split(W), out, b_t=not conv1d, **ep)
     return ops.gemm(x.live, W, out, b_t=not conv1d, **ep)
+
+
+def _forward_only_check():
+    if rt.precision() == "fp16x2":
+        raise RuntimeError("afft_amd: precision 'fp16x2' is an evaluation (forward-only) mode -- gradients of 1e-6..1e-4 sit in "
+                           "fp16's subnormal range; train in 'bf16' (or 'bf16x3' / 'fp32' for parity-grade gradients)")
 
 
 def _lin_dgrad(dy: Act, W: Tensor, conv1d: bool, out: Tensor, **ep) -> Tensor:
@@ -112,6 +119,7 @@ def _lin_dgrad(dy: Act, W: Tensor, conv1d: bool, out: Tensor, **ep) -> Tensor:
         if wt16 is not None:                 # dx = dy W, W^T [in, out] is B stored [N, K]: "NT"
             return ops.gemm(dy.k, wt16[:W.shape[1]], out, b_t=True, **ep)
         return ops.gemm(dy.k, w16[:, :W.shape[1]], out, **ep)            # W [out, in] = [K, N]: "NN"
+    _forward_only_check()
     if rt.precision() == "bf16x3":
         return ops.gemm(dy.split(), rt.weight_split(W), out, b_t=conv1d, **ep)
     return ops.gemm(dy.live, W, out, b_t=conv1d, **ep)
@@ -168,6 +176,7 @@ def _split_for_side(act: Act):
 def _wgrad(dy: Act, x: Act, W: Tensor, conv1d: bool) -> Optional[Tensor]:
     """dW = dy^T x (nn.Linear) or x^T dy (Conv1D); accumulated into W.grad (sink mode) or returned."""
     a, b = (x, dy) if conv1d else (dy, x)
+    _forward_only_check()
     if rt.precision() == "bf16x3":
         at, bt = _split_for_side(a), _split_for_side(b)
         _on_side(at.planes)

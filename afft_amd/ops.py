@@ -77,18 +77,19 @@ def gemm_workspace(device, raw_stream: Optional[int] = None) -> Tensor:
 
 
 class Split(object):
-    """fp32 matrix [rows, cols] as two bf16 planes hi + lo (afft_split_bf16), each [pad64(rows), pad64(cols)] with zero
-    tails: the operand of a bf16x3 GEMM in either role (k-contiguous rows or k-strided columns)."""
-    __slots__ = ("planes", "rows", "cols")
+    """fp32 matrix [rows, cols] as two 16-bit planes hi + lo, each [pad64(rows), pad64(cols)] with zero tails: the operand of a
+    bf16x3 GEMM (bf16 planes, afft_split_bf16) in either role (k-contiguous rows or k-strided columns), or -- f16 = True -- of
+    the fp16 two-pass forward GEMM (fp16 planes, afft_split_f16; afft_gemm_t.split3 = 2)."""
+    __slots__ = ("planes", "rows", "cols", "f16")
 
-    def __init__(self, x: Tensor):
+    def __init__(self, x: Tensor, f16: bool = False):
         assert x.dtype == torch.float32 and x.dim() == 2
         rows, cols = x.shape
         pr, pc = (rows + 63) // 64 * 64, (cols + 63) // 64 * 64
-        self.rows, self.cols = rows, cols
-        self.planes = torch.empty(2, pr, pc, dtype=torch.bfloat16, device=x.device)
-        L.check(L.lib().afft_split_bf16(_p(x), _rowmajor(x, "x"), rows, cols, _p(self.planes), pc, pr, pr * pc, _stream()),
-                "split_bf16")
+        self.rows, self.cols, self.f16 = rows, cols, bool(f16)
+        self.planes = torch.empty(2, pr, pc, dtype=torch.float16 if f16 else torch.bfloat16, device=x.device)
+        fn = L.lib().afft_split_f16 if f16 else L.lib().afft_split_bf16
+        L.check(fn(_p(x), _rowmajor(x, "x"), rows, cols, _p(self.planes), pc, pr, pr * pc, _stream()), "split")
 
 
 def gemm(a, b, out: Tensor, *, a_t: bool = False, b_t: bool = False, bias: Optional[Tensor] = None,
@@ -107,7 +108,9 @@ def gemm(a, b, out: Tensor, *, a_t: bool = False, b_t: bool = False, bias: Optio
         a, b = sa.planes[0], sb.planes[0]
         M, K = (sa.cols, a.shape[0]) if a_t else (sa.rows, a.shape[1])
         Kb, N = (b.shape[1], sb.rows) if b_t else (b.shape[0], sb.cols)
-        d.split3, d.a_lo, d.b_lo = 1, a.numel(), b.numel()
+        if sa.f16 != sb.f16:
+            raise TypeError("afft_amd.gemm: one operand is split into fp16 planes, the other into bf16 planes")
+        d.split3, d.a_lo, d.b_lo = (2 if sa.f16 else 1), a.numel(), b.numel()
     else:
         M, K = (a.shape[1], a.shape[0]) if a_t else (a.shape[0], a.shape[1])
         Kb, N = (b.shape[1], b.shape[0]) if b_t else (b.shape[0], b.shape[1])
@@ -117,7 +120,7 @@ def gemm(a, b, out: Tensor, *, a_t: bool = False, b_t: bool = False, bias: Optio
         raise TypeError("afft_amd.gemm: operand dtypes differ")
     if out.shape[0] != M or out.shape[1] != N:
         raise ValueError(f"afft_amd.gemm: out is {tuple(out.shape)}, expected ({M},{N})")
-    d.M, d.N, d.K, d.dtype = M, N, K, _dt(a)
+    d.M, d.N, d.K, d.dtype = M, N, K, (L.BF16 if d.split3 else _dt(a))      # split planes: 16-bit elements either way
     d.A = _p(a)
     d.a_rs, d.a_cs = (a.stride(1), a.stride(0)) if a_t else (a.stride(0), a.stride(1))
     d.B = _p(b)

@@ -29,10 +29,13 @@ _PRECISION = os.environ.get("AFFT_PRECISION", "bf16")
 _GRAD_MODE = os.environ.get("AFFT_GRAD_MODE", "sink")  # 'sink' | 'autograd'
 
 
+PRECISIONS = ("bf16", "fp32", "bf16x3", "fp16x2")
+
+
 def set_precision(p: str):
     global _PRECISION
-    if p not in ("bf16", "fp32", "bf16x3"):
-        raise ValueError("precision must be 'bf16', 'fp32' or 'bf16x3'")
+    if p not in PRECISIONS:
+        raise ValueError("precision must be one of " + ", ".join(repr(x) for x in PRECISIONS))
     _PRECISION = p
 
 
@@ -45,8 +48,13 @@ def act_dtype() -> torch.dtype:
 
 
 def fp32_acts() -> bool:
-    """activations are kept in fp32 (the parity modes 'fp32' and 'bf16x3')"""
+    """activations are kept in fp32 (the parity modes 'fp32', 'bf16x3' and 'fp16x2')"""
     return _PRECISION != "bf16"
+
+
+def split_mode() -> Optional[str]:
+    """how the GEMM operands of the current precision are split into 16-bit planes: None, 'bf16' (bf16x3) or 'f16' (fp16x2)"""
+    return {"bf16x3": "bf16", "fp16x2": "f16"}.get(_PRECISION)
 
 
 def set_grad_mode(m: str):
@@ -117,9 +125,10 @@ def weight_split(p: Tensor):
     (version counter / storage) or invalidate_weight_images() is called (the fused SGD kernel writes through raw
     pointers, so the Trainer invalidates after every step)."""
     ent = getattr(p, "_afft_split", None)
-    if ent is None or ent[0] != p._version or ent[1] != p.data_ptr():
+    f16 = split_mode() == "f16"
+    if ent is None or ent[0] != p._version or ent[1] != p.data_ptr() or ent[2].f16 != f16:
         with torch.no_grad():
-            sp = ops.Split(p.detach())
+            sp = ops.Split(p.detach(), f16=f16)
         _register(p)
         ent = (p._version, p.data_ptr(), sp)
         p._afft_split = ent

@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2", help="cfg2 (default) | ek100 | cfg1 | cfg4 | cfg5 | cfg2_cm | cfg2_tsa")
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "fp16x2"])
     ap.add_argument("--comm-dtype", default="bf16", choices=["bf16", "fp32"], help="gradient all-reduce payload")
     ap.add_argument("--comm-algo", default="allreduce", choices=["allreduce", "rs_ag"],
                     help="gradient exchange per bucket: one all-reduce, or reduce-scatter + all-gather (fallback)")
@@ -288,13 +288,24 @@ def parity_side_measurements(args, device, feats, tgt, sub, c):
     small = {m: f[:8].contiguous() for m, f in feats.items()}
     ts, ss = {"action": tgt["action"][:8].contiguous()}, {"action": sub["action"][:8].contiguous()}
     logits = {}
-    for mode in ("fp32", "bf16x3", "bf16"):
+    fwd_ms = {}
+    for mode in ("fp32", "bf16x3", "fp16x2", "bf16"):
         afft_amd.set_precision(mode)
         model, _ = build_model(args.config, device)
         model.eval()
         with torch.no_grad():
             o, _ = model(small, mixup_fn=None, target=ts, target_subclips=ss, target_subclips_ignore_index=None)
-        logits[mode] = o["logits/action"]["all-fused"].double()
+            logits[mode] = o["logits/action"]["all-fused"].double()
+            if mode != "fp32":       # the evaluation forward of the full batch: what a parity-grade test / validation pass costs
+                for _ in range(2):
+                    model(feats, mixup_fn=None, target=tgt, target_subclips=sub, target_subclips_ignore_index=None)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    model(feats, mixup_fn=None, target=tgt, target_subclips=sub, target_subclips_ignore_index=None)
+                torch.cuda.synchronize()
+                fwd_ms[mode] = round((time.perf_counter() - t0) / 5 * 1e3, 2)
+        del o
         if mode == "bf16x3":
             model.train(not args.eval_drop)
             tr = Trainer(model, wts, bucket_elems=args.bucket_melems * 1024 * 1024)
@@ -319,7 +330,9 @@ def parity_side_measurements(args, device, feats, tgt, sub, c):
         del model
         torch.cuda.empty_cache()
     ref = logits["fp32"]
-    out["logits_rel_l2_vs_exact_fp32_mode"] = {m: float(((logits[m] - ref).norm() / ref.norm()).cpu()) for m in ("bf16", "bf16x3")}
+    out["logits_rel_l2_vs_exact_fp32_mode"] = {m: float(((logits[m] - ref).norm() / ref.norm()).cpu()) for m in ("bf16", "bf16x3", "fp16x2")}
+    # fp16x2 = evaluation-only parity mode: activations hi + lo in fp16, weights rounded once to fp16, two MFMA passes
+    out["eval_forward_ms"] = {"batch": args.batch, **fwd_ms}
     afft_amd.set_precision(args.precision)
     return out
 

@@ -90,7 +90,11 @@ typedef struct {
   /* "bf16x3": fp32-accurate products from bf16 MFMAs.  A and B each point at the HI plane of a two-plane split
    * x = hi + lo (afft_split_bf16: hi = bf16(x), lo = bf16(x - hi)); the lo plane sits a_lo / b_lo ELEMENTS behind it.
    * The kernel accumulates A_hi*B_hi + A_lo*B_hi + A_hi*B_lo in one pass over a 3x longer K (fp32 accumulate):
-   * products exact to ~2^-17 relative, the precision mode whose logits meet the 1e-3 tolerance at MFMA speed. */
+   * products exact to ~2^-17 relative, the precision mode whose logits meet the 1e-3 tolerance at MFMA speed.
+   * split3 = 2, "fp16x2" (forward layouts only: A k-contiguous): the planes are FP16 (afft_split_f16) and only the first two
+   * segments run, A_hi*B_hi + A_lo*B_hi on v_mfma_f32_16x16x32_f16 -- A exact to ~2^-22, B rounded once to fp16 (2^-11): the
+   * evaluation forward at 2/3 of the bf16x3 MFMA work (operands must stay inside fp16's range: weights and activations do,
+   * gradients do not, hence no backward). */
   int32_t split3; int64_t a_lo, b_lo;
   /* Optional: apply the optimizer IN the epilogue instead of storing the result (see afft_sgd_fused_t below): the GEMM is a
    * weight gradient whose value is consumed once, by the update of that weight.  Needs accumulate = 0, no bias / act. */
@@ -258,6 +262,9 @@ int afft_pack_weight(const float* src, int64_t lds, int32_t rows, int32_t cols, 
  * lo = hi + plane_stride elements. */
 int afft_split_bf16(const float* src, int64_t lds, int32_t rows, int32_t cols, void* hi, int64_t ldd, int32_t rows_pad,
                     int64_t plane_stride, void* stream);
+/* The same with fp16 planes (hi = fp16(x), lo = fp16(x - hi)): operands of afft_gemm_t.split3 = 2. */
+int afft_split_f16(const float* src, int64_t lds, int32_t rows, int32_t cols, void* hi, int64_t ldd, int32_t rows_pad,
+                   int64_t plane_stride, void* stream);
 /* ModalTokenCMFuser token assembly (models/fusion.py:338-352): X[(b*T+t), s, :] for s=0 the modal token
  * (token + (t)*tok_stride_t; stride 0 = one universal token), s>=1 modality s-1 at feats[s-1] + (b*T+t)*ldf[s-1];
  * + modality_embedding[s,:] if given.  feats / ldf are HOST arrays of n_mod (<= 8) device pointers / strides. */

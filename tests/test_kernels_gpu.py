@@ -232,6 +232,58 @@ def test_gemm_bf16x3(case):
         assert rel_l2(pre.cpu(), pre_ref) < 1e-5
 
 
+F16X2_CASES = [
+    ("nt_f16x2", 300, 520, 200, "nt", 0, dict(bias=True, act=1, pre=True)),
+    ("nn_f16x2", 130, 256, 320, "nn", 0, dict(bias=True, residual=True)),
+    ("nt_f16x2_pp", 300, 520, 200, "nt", 3, dict(bias=True, act=2)),
+    ("nn_f16x2_pp", 512, 300, 320, "nn", 3, dict(residual=True)),
+    ("nt_f16x2_big", 1100, 3806, 2048, "nt", 0, dict(bias=True)),
+]
+
+
+@pytest.mark.parametrize("case", F16X2_CASES, ids=[c[0] for c in F16X2_CASES])
+def test_gemm_fp16x2(case):
+    """fp16 two-pass forward GEMM (afft_gemm_t.split3 = 2): A = hi + lo in fp16 (exact to 2^-22), B rounded ONCE to fp16, two
+    segments A_hi B + A_lo B on v_mfma_f32_16x16x32_f16.  Against float64 with B rounded to fp16 the result is fp32-grade; against
+    the exact product the error is B's rounding, 2^-11 / sqrt(3) per element ~ 2e-4 relative -- 20x below the bf16 GEMM's."""
+    from afft_amd import _lib, ops
+    name, M, N, K, layout, variant, ep = case
+    _lib.check(_lib.lib().afft_set_gemm_variant(variant))
+    A, Bm = rnd(M, K, seed=31), rnd(K, N, seed=32)
+    b_t = layout[1] == "t"
+    sa = ops.Split(A.to(dev()), f16=True)
+    sb = ops.Split((Bm.t().contiguous() if b_t else Bm).to(dev()), f16=True)
+    assert sa.planes.dtype == torch.float16
+    torch.cuda.synchronize()
+    assert torch.equal(sa.planes[0][:M, :K].cpu(), A.half())
+    assert float((sa.planes[0].float() + sa.planes[1].float())[:M, :K].cpu().sub(A).abs().max()) <= float(A.abs().max()) * 2.0 ** -21
+    bias = rnd(N, seed=3) if ep.get("bias") else None
+    act = ep.get("act", 0)
+    res = rnd(M, N, seed=5) if ep.get("residual") else None
+    out = torch.zeros(M, N, device=dev())
+    pre = torch.zeros(M, N, device=dev()) if ep.get("pre") else None
+    ops.gemm(sa, sb, out, b_t=b_t, bias=None if bias is None else bias.to(dev()), act=act, pre=pre,
+             residual=None if res is None else res.to(dev()))
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().afft_set_gemm_variant(0))
+
+    def finish(prod):
+        r = prod.float()
+        if bias is not None:
+            r = r + bias
+        r = _act(act, r, None)
+        return r + res if res is not None else r
+    rounded, exact = finish(A.double() @ Bm.half().double()), finish(A.double() @ Bm.double())
+    assert rel_l2(out.cpu(), rounded) < 1e-5, (name, rel_l2(out.cpu(), rounded))
+    e = rel_l2(out.cpu(), exact)
+    assert 2e-5 < e < 4e-4, (name, e)
+    # backward layouts are not built for this mode: a clear error, not a wrong kernel
+    with pytest.raises(RuntimeError, match="forward layouts only|fast-path layout"):
+        ops.gemm(ops.Split(A.t().contiguous().to(dev()), f16=True), sb, out, a_t=True, b_t=b_t)
+    with pytest.raises(TypeError, match="fp16 planes"):
+        ops.gemm(sa, ops.Split((Bm.t().contiguous() if b_t else Bm).to(dev())), out, b_t=b_t)
+
+
 @pytest.mark.parametrize("cap", [8, 24, 1000])
 def test_gemm_weight_gradient_capped_grid(cap):
     """max_workgroups: the 256x256 weight-gradient kernel with a capped grid (every workgroup walks several tiles) gives

@@ -38,6 +38,68 @@ def build(c, precision):
     return model
 
 
+@pytest.mark.parametrize("name", list(CASES))
+def test_fp16x2_forward_matches_reference_golden(name):
+    """precision 'fp16x2' (evaluation forward: activations hi + lo in fp16, weights rounded once to fp16, two MFMA passes): every
+    output of every small golden within the north-star 1e-3 of the reference; the backward pass refuses to run."""
+    from afft_amd import runtime as rt
+    import afft_amd
+    z, shapes = load_golden(name)
+    c, state, data, tgt, sub = case_tensors(name)
+    if c.get("soft"):
+        pytest.skip("the MixUp golden is a training-mode case")
+    model = build(c, "fp16x2")
+    model.load_state_dict(state, strict=True)
+    model = model.cuda().eval()
+    dev = torch.device("cuda:0")
+    try:
+        rt.SINK.begin_step()
+        out, out_t = model({m: d.to(dev) for m, d in data.items()}, mixup_fn=None, target={"action": tgt.to(dev)},
+                           target_subclips={"action": sub.to(dev)}, target_subclips_ignore_index=None)
+        flat = flatten_outputs(out)
+        worst, checked = 0.0, 0
+        for k in z.files:
+            if not k.startswith("out:") or (k[4:] == "attentions/modality_attns" and c["fuser"] == "ca"):
+                continue
+            e = rel_l2(flat[k[4:]].detach().float().cpu(), torch.from_numpy(z[k]))
+            worst = max(worst, e)
+            assert e < 1e-3, (k, e)
+            checked += 1
+        assert checked >= 6
+        print(f"[{name}/fp16x2] worst output error {worst:.2e}")
+        logits = next(v for k, v in flat.items() if k.startswith("logits/"))
+        with pytest.raises(RuntimeError, match="forward-only"):
+            logits.float().sum().backward()
+    finally:
+        afft_amd.set_precision("bf16")
+
+
+@pytest.mark.parametrize("name", ["f_cfg2", "f_ek100"])
+def test_fp16x2_forward_full_size(name):
+    """the same at the bench's widths and at the EK100 widths of expts/01, against the reference's own outputs
+    (tests/golden/f_*.npz): within 8e-4 (measured 5.7e-4 / see the printed line)"""
+    import afft_amd
+    from afft_amd import runtime as rt
+    c, z, state, data, tgt, sub = full_case_tensors(name)
+    model = build(c, "fp16x2")
+    model.load_state_dict(state, strict=True)
+    dev = torch.device("cuda:0")
+    model = model.to(dev).eval()
+    try:
+        with torch.no_grad():
+            out, _ = model({m: d.to(dev) for m, d in data.items()}, mixup_fn=None, target={"action": tgt.to(dev)},
+                           target_subclips={"action": sub.to(dev)}, target_subclips_ignore_index=None)
+        flat = flatten_outputs(out)
+        keys = sorted({k.split(":")[1] for k in z.files if k.startswith("out:")})
+        worst = max(compact_error(flat[key].float(), z, "out:" + key) for key in keys)
+        print(f"[{name}/fp16x2] worst output error {worst:.2e}")
+        assert worst < 8e-4, worst
+    finally:
+        afft_amd.set_precision("bf16")
+        del model
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("name", list(CASES))
 def test_model_matches_reference_golden(name, precision):
