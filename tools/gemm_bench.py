@@ -10,15 +10,30 @@ from afft_amd import _lib, ops  # noqa: E402
 
 def bench(layout, M, N, K, variant, iters=20):
     """variant: 1 / 3 (tile shape) with automatic split-K; 10 = 128x128 tile without split-K; 12 / 14 = 128x128, split-K 2 / 4 forced;
-    30 = 256x256 tile without split-K; 32 / 33 = 256x256, split-K 2 / 3 forced"""
+    30 = 256x256 tile without split-K; 32 / 33 = 256x256, split-K 2 / 3 forced; 100 = the library's own choice when the weight
+    comes with a fragment-packed image (NT only: what the model's forward GEMMs get); 110 / 109 = B-direct 160x256 / 256x256 tiles
+    on the packed image, forced"""
     dev = "cuda:0"
+    packed = variant in (100, 109, 110)
+    if packed and layout != "nt":
+        variant = 0
+        packed = False
+    forced = {100: 0, 109: 9, 110: 10}.get(variant)
     _lib.check(_lib.lib().afft_set_gemm_splitk({10: 0, 12: 2, 14: 4, 30: 0, 32: 2, 33: 4}.get(variant, 1)))
-    variant = 3 if variant >= 30 else 1 if variant >= 10 else variant      # 0 = the library's own choice
+    variant = forced if forced is not None else 3 if variant >= 30 else 1 if variant >= 10 else variant      # 0 = the library's own choice
     _lib.check(_lib.lib().afft_set_gemm_variant(variant))
     g = torch.Generator().manual_seed(0)
     if layout == "nt":
         a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev); b = torch.randn(N, K, generator=g).to(torch.bfloat16).to(dev)
         kw = dict(b_t=True)
+        if packed:
+            pk = torch.empty(N * K, dtype=torch.bfloat16, device=dev)
+            ops.pack_weight(b.float(), pk)
+            if variant in (9, 10):       # forced: B itself is the packed image
+                kw = dict(b_t=True, b_packed=pk)
+                b = pk.view(N, K)
+            else:
+                kw = dict(b_t=True, b_packed=pk)
     elif layout == "nn":
         a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev); b = torch.randn(K, N, generator=g).to(torch.bfloat16).to(dev)
         kw = dict()
@@ -36,6 +51,7 @@ def bench(layout, M, N, K, variant, iters=20):
     e.record()
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / iters
+    _lib.check(_lib.lib().afft_set_gemm_variant(0))
     return ms, 2.0 * M * N * K / ms / 1e9
 
 
