@@ -114,10 +114,10 @@ class GemmTimer:
     def symbol(r) -> str:
         b = lambda x: "true" if x else "false"    # noqa: E731
         if r.variant == 3:
-            return f"gemm_bf16_pp_kernel<{b(r.a_kstrided)}, {b(r.b_kstrided)}, {b(r.splitk > 1)}, {b(r.split3)}, {b(r.capped)}>"
+            return f"gemm_bf16_pp_kernel<{b(r.a_kstrided)}, {b(r.b_kstrided)}, {b(r.splitk > 1)}, {int(r.split3)}, {b(r.capped)}>"
         if r.variant in (7, 8, 9, 10):       # B-direct kernels (csrc/gemm_bd.hip): <16-row blocks per tile, A look-ahead, B look-ahead, packed B>
             return f"gemm_bf16_bd_kernel<{10 if r.variant in (8, 10) else 16}, 3, {2 if r.variant in (8, 10) else 1}, {b(r.variant >= 9)}>"
-        return f"gemm_bf16_kernel<2, 2, 2, {b(r.a_kstrided)}, {b(r.b_kstrided)}, {b(r.splitk > 1)}, {b(r.split3)}>"
+        return f"gemm_bf16_kernel<2, 2, 2, {b(r.a_kstrided)}, {b(r.b_kstrided)}, {b(r.splitk > 1)}, {int(r.split3)}>"
 
     def summary(self):
         out = {}
@@ -762,7 +762,7 @@ def main():
             ach = avg_fl / (avg_ms * 1e-3) / 1e12
             dtype_peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3
             traffic, traffic_src = None, None
-            for fn in ("r04b_gemm_hbm_traffic_pmc.json", "r04a_gemm_hbm_traffic_pmc.json", "r03c_gemm_hbm_traffic_pmc.json", "r03b_gemm_hbm_traffic_pmc.json", "r03a_gemm_hbm_traffic_pmc.json", "r02i_gemm_hbm_traffic_pmc.json", "r02h_gemm_hbm_traffic_pmc.json", "r02g_gemm_hbm_traffic_pmc.json", "r02_gemm_hbm_traffic_pmc.json", "r01_gemm_hbm_traffic_pmc.json"):
+            for fn in ("r04b_gemm_hbm_traffic_pmc.json", "r03c_gemm_hbm_traffic_pmc.json", "r03b_gemm_hbm_traffic_pmc.json", "r03a_gemm_hbm_traffic_pmc.json", "r02i_gemm_hbm_traffic_pmc.json", "r02h_gemm_hbm_traffic_pmc.json", "r02g_gemm_hbm_traffic_pmc.json", "r02_gemm_hbm_traffic_pmc.json", "r01_gemm_hbm_traffic_pmc.json"):
                 try:   # HBM-side bytes per launch from separate rocprofv3 --pmc passes (tools/traffic_summary.py), committed
                     tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
                     hit = [v for k, v in tj.items() if isinstance(v, dict) and (k == dom or dom.startswith(k.rstrip(">")))]
@@ -772,7 +772,7 @@ def main():
                 except Exception:  # noqa: BLE001
                     pass
             result["roofline"] = {
-                "kernel": dom + " (bf16 MFMA GEMM, v_mfma_f32_16x16x32_bf16; template <A k-strided, B k-strided, split-K, bf16x3, capped "
+                "kernel": dom + " (bf16 MFMA GEMM, v_mfma_f32_16x16x32_bf16; template <A k-strided, B k-strided, split-K, operand planes (0 = plain bf16, 1 = bf16x3, 2 = fp16x2), capped "
                           "grid>: A,B = false,false NT forward / false,true NN data gradient / true,true TN weight gradient)",
                 "bound": "mfma", "achieved": round(ach, 1), "peak": dtype_peak, "unit": "TFLOP/s",
                 "frac": round(ach / dtype_peak, 4), "traffic": traffic,
