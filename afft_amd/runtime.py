@@ -142,9 +142,10 @@ _PACKED_IMAGES = os.environ.get("AFFT_PACKED_IMAGES", "1") != "0"
 
 
 def packed_images() -> bool:
-    """Keep a fragment-packed bf16 copy of every GEMM weight a Trainer / afft_amd.optim.SGD owns (parallel.FlatParams): the
-    forward GEMMs of the fuser's nn.Linear layers may then run on the "B direct" kernels (csrc/gemm_bd.hip).  +2 bytes per
-    parameter of memory and of optimizer traffic (22 -> 24 B; written by the same epilogues / one pack kernel per weight)."""
+    """Reserve a fragment-packed bf16 slot beside every GEMM weight a Trainer / afft_amd.optim.SGD owns (parallel.FlatParams): the
+    forward GEMMs of nn.Linear layers may then run on the "B direct" kernels (csrc/gemm_bd.hip).  +2 bytes per parameter of
+    memory; optimizer traffic (+2 B per parameter and step, written by the same epilogues / one pack kernel per weight) only for
+    the images that went live (weight_packed)."""
     return _PACKED_IMAGES
 
 
