@@ -45,16 +45,17 @@ def _act(act, v, aux):
 
 
 class Split:
-    """ops.Split: x = hi + lo in two zero-padded bf16 planes"""
+    """ops.Split: x = hi + lo in two zero-padded 16-bit planes (bf16, or fp16 for the fp16x2 forward mode)"""
 
-    def __init__(self, x):
+    def __init__(self, x, f16=False):
         rows, cols = x.shape
         pr, pc = (rows + 63) // 64 * 64, (cols + 63) // 64 * 64
-        self.rows, self.cols = rows, cols
-        self.planes = torch.zeros(2, pr, pc, dtype=torch.bfloat16)
-        hi = x.detach().to(torch.bfloat16)
+        self.rows, self.cols, self.f16 = rows, cols, bool(f16)
+        dt = torch.float16 if f16 else torch.bfloat16
+        self.planes = torch.zeros(2, pr, pc, dtype=dt)
+        hi = x.detach().to(dt)
         self.planes[0, :rows, :cols] = hi
-        self.planes[1, :rows, :cols] = (x.detach() - hi.float()).to(torch.bfloat16)
+        self.planes[1, :rows, :cols] = (x.detach() - hi.float()).to(dt)
 
 
 @torch.no_grad()
@@ -65,7 +66,10 @@ def gemm(a, b, out, *, a_t=False, b_t=False, bias=None, act=L.ACT_NONE, aux=None
     if isinstance(a, Split):     # bf16x3: hi*hi + lo*hi + hi*lo over the padded planes, live part of the result
         ah, al = (p.float().t() if a_t else p.float() for p in a.planes)
         bh, bl = (p.float().t() if b_t else p.float() for p in b.planes)
-        v = alpha * (ah @ bh + al @ bh + ah @ bl)[:out.shape[0], :out.shape[1]]
+        if a.f16:     # fp16x2: the first two segments only (A = hi + lo, B rounded once)
+            v = alpha * (ah @ bh + al @ bh)[:out.shape[0], :out.shape[1]]
+        else:
+            v = alpha * (ah @ bh + al @ bh + ah @ bl)[:out.shape[0], :out.shape[1]]
     else:
         A = (a.t() if a_t else a).float()
         B = (b.t() if b_t else b).float()

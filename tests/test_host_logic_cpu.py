@@ -72,6 +72,30 @@ def test_host_wiring_reproduces_reference_golden(name, precision):
     assert n >= 5
 
 
+def test_fp16x2_is_a_forward_only_precision():
+    """precision 'fp16x2': the forward GEMMs take fp16 hi + lo activation planes and weights rounded once to fp16 (two segments);
+    outputs within 1e-3 of the reference golden; any backward GEMM refuses to run (host wiring; the kernels: GPU tests)."""
+    import afft_amd
+    z, _ = load_golden("t0_sa")
+    c, state, data, tgt, sub = case_tensors("t0_sa")
+    try:
+        with cpu_ops.installed():
+            model = _build(c, "fp16x2")
+            model.load_state_dict(state, strict=True)
+            model.eval()
+            out, _ = model(data, mixup_fn=None, target={"action": tgt}, target_subclips={"action": sub},
+                           target_subclips_ignore_index=None)
+            flat = flatten_outputs(out)
+            for k in z.files:
+                if k.startswith("out:") and not k.endswith("modality_attns"):
+                    assert rel_l2(flat[k[4:]].float(), torch.from_numpy(z[k])) < 1e-3, k
+            logits = next(v for k, v in flat.items() if k.startswith("logits/"))
+            with pytest.raises(RuntimeError, match="forward-only"):
+                logits.sum().backward()
+    finally:
+        afft_amd.set_precision("bf16")
+
+
 def _grads(model):
     return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
 
@@ -247,8 +271,8 @@ def test_weight_image_registry_does_not_grow_with_steps():
     from afft_amd import ops, runtime as rt
 
     class FakeSplit:
-        def __init__(self, x):
-            self.planes, self.rows, self.cols = x.clone(), x.shape[0], x.shape[1]
+        def __init__(self, x, f16=False):
+            self.planes, self.rows, self.cols, self.f16 = x.clone(), x.shape[0], x.shape[1], f16
 
     saved, ops.Split = ops.Split, FakeSplit
     try:
