@@ -10,7 +10,7 @@ three-term anticipation loss, forward and backward -- behind the reference's own
 """
 import sys as _sys
 
-from .runtime import precision, set_grad_mode, set_precision  # noqa: F401
+from .runtime import precision, precision_scope, set_grad_mode, set_precision  # noqa: F401
 
 
 def install_as_models(patch_ddp: bool = False):

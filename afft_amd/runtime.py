@@ -43,6 +43,24 @@ def precision() -> str:
     return _PRECISION
 
 
+class precision_scope:
+    """`with precision_scope("fp16x2"):` -- run a block in another precision and come back (None: leave it as it is)"""
+
+    def __init__(self, p: Optional[str]):
+        self.p, self.saved = p, None
+
+    def __enter__(self):
+        if self.p is not None:
+            self.saved = _PRECISION
+            set_precision(self.p)
+        return self
+
+    def __exit__(self, *exc):
+        if self.saved is not None:
+            set_precision(self.saved)
+        return False
+
+
 def act_dtype() -> torch.dtype:
     return torch.bfloat16 if _PRECISION == "bf16" else torch.float32
 

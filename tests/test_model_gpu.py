@@ -957,6 +957,13 @@ def test_evaluate_loop_scores_and_logit_store(tmp_path):
     assert rel_l2(torch.from_numpy(sc["verb"]), (p @ maps[("verb", "action")].double()).float()) < 2e-5
     assert rel_l2(torch.from_numpy(sc["noun"]), (p @ maps[("noun", "action")].double()).float()) < 2e-5
     assert np.array_equal(sc["action"], logits.cpu().numpy())
+    # the evaluation loops in the evaluation-forward precision: within 1e-3 of the fp32 logits, and the mode is restored
+    import afft_amd
+    key2, lg2 = E.collect_logits(model, loader, dev, precision="fp16x2")
+    assert key2 == key and afft_amd.runtime.precision() == "fp32"
+    assert 1e-6 < rel_l2(lg2, logits) < 1e-3, rel_l2(lg2, logits)
+    sc2 = E.evaluate_scores(model, maps, loader, dev, precision="fp16x2")
+    assert rel_l2(torch.from_numpy(sc2["verb"]), torch.from_numpy(sc["verb"])) < 1e-3
     path = E.save_logits(model, loader, dev, save_dir=str(tmp_path), save_file_name="run1")
     path = E.save_logits(model, loader, dev, save_dir=str(tmp_path), save_file_name="run1")    # appends
     with open(path, "rb") as fh:
