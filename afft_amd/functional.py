@@ -619,7 +619,7 @@ def _ln_partial(rows: int, d: int, dev) -> Tensor:
     return torch.empty(L_.lib().afft_layernorm_bwd_nparts(rows) * 3 * d, dtype=torch.float32, device=dev)
 
 
-def _attn_fwd_c(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, eps, conv1d, scale, drop):
+def _attn_fwd_c(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, eps, conv1d, scale, drop, probs_out=None):
     R, d = x.shape
     dev = x.device
     nseq, pr = R // L, rt.pad64(R)
@@ -627,7 +627,7 @@ def _attn_fwd_c(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, ep
     saved = torch.empty(pr * 5 * d, dtype=torch.bfloat16, device=dev)
     xn, qkv, ao = Act.carve(saved, 0, R, d), Act.carve(saved, pr * d, R, 3 * d), Act.carve(saved, pr * 4 * d, R, d)
     stats = torch.empty(2, R, dtype=torch.float32, device=dev)
-    probs = torch.empty(nseq, H, L, L, dtype=torch.float32, device=dev)
+    probs = probs_out if probs_out is not None else torch.empty(nseq, H, L, L, dtype=torch.float32, device=dev)
     y = torch.empty(R, d, dtype=torch.float32, device=dev)
     scale = float(scale) if scale else float(d // H) ** -0.5
     mk, per = _mask_args(mask)
@@ -724,7 +724,7 @@ def _attn_bwd_c(ctx, dy):
     join_side(dev)
     ctx.acts = None
     flush_ready()
-    return dx, g_lw, g_lb, g_wq, g_bq, g_wp, g_bp, None, None, None, None, None, None, None, None
+    return dx, g_lw, g_lb, g_wq, g_bq, g_wp, g_bp, None, None, None, None, None, None, None, None, None
 
 
 def _mlp_fwd_c(ctx, x, ln_w, ln_b, w1, b1, w2, b2, eps, gelu, conv1d, hidden, drop):
@@ -947,16 +947,20 @@ class AttnSublayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, eps, conv1d, pre_ln=True, scale=None,
-                drop=None):
+                drop=None, probs_out=None):
+        """probs_out: fp32 [nseq, H, L, L] to write the attention maps into (the caller's slice of ONE buffer for all its blocks:
+        the SA-Fuser returns the stacked maps, models/fusion.py:144 -- no torch.stack copy of every block's maps per forward)"""
         R, d = x.shape
         nseq, hd = R // L, d // H
         dev = x.device
         ctx.composite = False
+        if probs_out is not None:
+            assert probs_out.shape == (nseq, H, L, L) and probs_out.dtype == torch.float32 and probs_out.is_contiguous()
         # probs is returned for the caller's attention maps and takes no gradient: without this autograd hands backward a
         # freshly ZERO-FILLED tensor of its shape for it on every call (a fill kernel per attention sub-layer and step)
         ctx.set_materialize_grads(False)
         if _composite_ok(x, pre_ln, d):
-            return _attn_fwd_c(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, eps, conv1d, scale, drop)
+            return _attn_fwd_c(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, eps, conv1d, scale, drop, probs_out)
         ctx.up = _upstream_of(x) if pre_ln else None
         mean, rstd = _stats(R if pre_ln else 0, dev)
         if pre_ln:
@@ -967,7 +971,7 @@ class AttnSublayer(torch.autograd.Function):
         qkv = Act(R, 3 * d, dev)
         _lin_fwd(xn, w_qkv, conv1d, qkv.live, bias=b_qkv)
         ao = Act(R, d, dev)
-        probs = torch.empty(nseq, H, L, L, dtype=torch.float32, device=dev)
+        probs = probs_out if probs_out is not None else torch.empty(nseq, H, L, L, dtype=torch.float32, device=dev)
         scale = float(scale) if scale else float(hd) ** -0.5
         mk, per = _mask_args(mask)
         ops.attention_fwd(qkv.cols(0, d), qkv.cols(d, 2 * d), qkv.cols(2 * d, 3 * d), nseq, L, H, hd, scale,
@@ -986,7 +990,7 @@ class AttnSublayer(torch.autograd.Function):
         if dy is None:          # (set_materialize_grads(False)) nobody used y
             _drop_shadow()      # a hand-over meant for this backward and queued notifications must not outlive it
             flush_ready()
-            return (None,) * 15
+            return (None,) * 16
         if ctx.composite:
             return _attn_bwd_c(ctx, dy)
         x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, mean, rstd, probs = ctx.saved_tensors
@@ -1021,7 +1025,7 @@ class AttnSublayer(torch.autograd.Function):
         join_side(dev)
         ctx.acts = None
         flush_ready()
-        return dx, g_lw, g_lb, g_wq, g_bq, g_wp, g_bp, None, None, None, None, None, None, None, None
+        return dx, g_lw, g_lb, g_wq, g_bq, g_wp, g_bp, None, None, None, None, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------- pre-LN MLP sub-layer

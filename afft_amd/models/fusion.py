@@ -128,20 +128,27 @@ class ModalTokenCMFuser(nn.Module):
         if self.training and self.embd_drop.p > 0:
             X = F_.ElementDropout.apply(X, D_.elementwise(self.embd_drop.p))
         mask = "diag" if self.cross_attn else "none"
+        # the attention maps of all blocks in ONE buffer (the reference stacks the per-block tensors, models/fusion.py:366): every
+        # block's kernel writes its slice, the stacked result is a view
+        depth = len(self.blocks)
+        maps = (torch.empty(depth, BT, self.blocks[0].attn.num_heads, S, S, dtype=torch.float32, device=X.device)
+                if depth and X.is_cuda else None)      # (CPU test doubles write with in-place torch ops: version counters)
         attn_weights = []
         # Only token 0 of the last block's output is used (models/fusion.py:362-365): that block runs its MLP half on the
         # token-0 rows alone (Block.forward_rows_first_token) -- 4/5 of one block's MLP, 7 % of the step's FLOPs at M = 4,
         # that the reference computes and discards; every output and every gradient is unchanged.
         dead_rows = rt.skip_dead_rows()
         for i, blk in enumerate(self.blocks):
+            po = maps[i] if maps is not None else None
             if dead_rows and i + 1 == len(self.blocks):
-                X, probs = blk.forward_rows_first_token(X, S, mask)                # X [BT, C]
+                X, probs = blk.forward_rows_first_token(X, S, mask, po)            # X [BT, C]
             else:
-                X, probs = blk.forward_rows(X, S, mask)                            # probs [BT, H, S, S]
+                X, probs = blk.forward_rows(X, S, mask, po)                        # probs [BT, H, S, S]
             attn_weights.append(probs.view(B, T, *probs.shape[1:]))
         z = F_.LayerNormRows.apply(X, self.norm.weight, self.norm.bias, self.norm.eps,
                                    1 if dead_rows and len(self.blocks) > 0 else S)  # token 0 of each frame
-        return z.view(B, T, C), torch.stack(attn_weights).transpose(0, 1)
+        stacked = maps.view(depth, B, T, *maps.shape[2:]) if maps is not None else torch.stack(attn_weights)
+        return z.view(B, T, C), stacked.transpose(0, 1)
 
 
 class CMFuser(nn.Module):

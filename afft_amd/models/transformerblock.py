@@ -176,20 +176,20 @@ class Block(nn.Module):
         mlp_hidden_dim = int(dim * mlp_ratio)
         self.mlp = MLP(in_features=dim, hidden_features=mlp_hidden_dim, act_layer=act_layer, drop=drop)
 
-    def forward_rows(self, x2: Tensor, L: int, mask: str):
-        """x2: fp32 [nseq*L, dim] rows. Returns (rows, probs [nseq, H, L, L])."""
+    def forward_rows(self, x2: Tensor, L: int, mask: str, probs_out: Optional[Tensor] = None):
+        """x2: fp32 [nseq*L, dim] rows. Returns (rows, probs [nseq, H, L, L]); probs_out: where to write the attention maps."""
         a = self.attn
         dp = _dp_rate(self.drop_path)
         x2, probs = F_.AttnSublayer.apply(x2, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias,
                                           a.proj.weight, a.proj.bias, L, a.num_heads, mask, self.norm1.eps, False,
-                                          True, a.scale, D_.with_path(a.drop_cfg(), dp, L))
+                                          True, a.scale, D_.with_path(a.drop_cfg(), dp, L), probs_out)
         m = self.mlp.mlp
         x2 = F_.MLPSublayer.apply(x2, self.norm2.weight, self.norm2.bias, m[0].weight, m[0].bias, m[2].weight,
                                   m[2].bias, self.norm2.eps, "erf", False, True,
                                   D_.with_path(self.mlp.drop_cfg(), dp, L))
         return x2, probs
 
-    def forward_rows_first_token(self, x2: Tensor, L: int, mask: str):
+    def forward_rows_first_token(self, x2: Tensor, L: int, mask: str, probs_out: Optional[Tensor] = None):
         """forward_rows for a caller that only uses token 0 of every sequence afterwards (the SA-Fuser's last block,
         models/fusion.py:362-365): attention over all L tokens, the MLP half on the nseq token-0 rows only.
         Returns (rows [nseq, dim], probs [nseq, H, L, L]) -- the same numbers as forward_rows(...)[0][::L] whenever the MLP's
@@ -201,7 +201,7 @@ class Block(nn.Module):
         dp = _dp_rate(self.drop_path)
         x2, probs = F_.AttnSublayer.apply(x2, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias,
                                           a.proj.weight, a.proj.bias, L, a.num_heads, mask, self.norm1.eps, False,
-                                          True, a.scale, D_.with_path(a.drop_cfg(), dp, L))
+                                          True, a.scale, D_.with_path(a.drop_cfg(), dp, L), probs_out)
         x0 = F_.TakeRows.apply(x2, L)
         m = self.mlp.mlp
         x0 = F_.MLPSublayer.apply(x0, self.norm2.weight, self.norm2.bias, m[0].weight, m[0].bias, m[2].weight,

@@ -495,10 +495,10 @@ def test_fused_optimizer_audit_when_the_graph_changes_between_steps():
         mlp_ids = {id(blk.mlp.mlp[0].weight), id(blk.mlp.mlp[2].weight)}
         orig = blk.forward_rows
 
-        def attention_only(self, x2, L, mask):
+        def attention_only(self, x2, L, mask, probs_out=None):
             a = self.attn
             return F_.AttnSublayer.apply(x2, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight,
-                                         a.proj.bias, L, a.num_heads, mask, self.norm1.eps, False, True, a.scale, None)
+                                         a.proj.bias, L, a.num_heads, mask, self.norm1.eps, False, True, a.scale, None, probs_out)
         for step in range(5):
             if step == 2:
                 if fused:
@@ -512,8 +512,8 @@ def test_fused_optimizer_audit_when_the_graph_changes_between_steps():
         torch.cuda.synchronize()
         res[fused] = (tr.flat.flat_p.clone(), tr.opt.buf.clone(), tr.flat.flat_p16.clone())
         if fused:       # (2) a second gradient contribution to weights already updated in an epilogue
-            def twice(self, x2, L, mask):
-                return orig(orig(x2, L, mask)[0], L, mask)
+            def twice(self, x2, L, mask, probs_out=None):
+                return orig(orig(x2, L, mask)[0], L, mask, probs_out)
             blk.forward_rows = types.MethodType(twice, blk)
             with pytest.raises(RuntimeError, match="fused optimizer"):
                 tr.step(feats, {"action": tgt.to(dev)}, {"action": sub.to(dev)})
