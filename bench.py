@@ -276,6 +276,53 @@ def cpu_baseline(name, B, steps=3):
             "cfg1_B4_clips_s": round(cfg1, 3), "thread_sweep_cfg1_clips_s": {str(k): v for k, v in sweep.items()}}
 
 
+def power_report(step_fn, seconds=2.5):
+    """Package power and graphics clock while the training step loops (rocm-smi polled from a thread, after the timed region:
+    the timing above is not perturbed).  The GEMM loops of this path run at the package power limit (profiles/r04_power.txt), so
+    the line says at which clock and power the number above was made.  None when rocm-smi is not there."""
+    import subprocess
+    import threading
+
+    def smi():
+        out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=10).stdout
+        card = next(iter(json.loads(out[out.index("{"):]).values()))
+        pw = next((float(v) for k, v in card.items() if "Power" in k and "(W)" in k), None)
+        clk = next((int(v.strip("()Mhz")) for k, v in card.items() if k.startswith("sclk") and "speed" in k), None)
+        return pw, clk
+    try:
+        smi()
+    except Exception as ex:  # noqa: BLE001
+        return {"error": repr(ex)[:120]}
+    stop, samples = threading.Event(), []
+
+    def poll():
+        while not stop.is_set():
+            try:
+                samples.append(smi())
+            except Exception:  # noqa: BLE001
+                pass
+            time.sleep(0.05)
+    th = threading.Thread(target=poll)
+    th.start()
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        step_fn()
+        n += 1
+        if n % 4 == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    stop.set()
+    th.join()
+    pw = sorted(s[0] for s in samples if s[0] is not None)
+    ck = sorted(s[1] for s in samples if s[1] is not None)
+    if not pw or not ck:
+        return {"error": "no samples"}
+    return {"samples": len(pw), "package_power_w_avg": round(sum(pw) / len(pw), 1), "package_power_w_max": pw[-1],
+            "sclk_mhz_median": ck[len(ck) // 2], "sclk_mhz_max_of_part": 2400, "ms_per_step_while_polled": round(dt * 1e3, 3),
+            "note": "rocm-smi every 50 ms over a separate loop of the same step; GEMM loops alone sit at ~1375 W (profiles/r04_power.txt)"}
+
+
 def parity_side_measurements(args, device, feats, tgt, sub, c):
     """What the precision of the headline number costs, on the record: throughput of the 1e-3-accurate mode
     (bf16x3: fp32-grade GEMMs from three bf16 MFMA passes) on the same workload and step definition, and the relative L2
@@ -731,6 +778,12 @@ def main():
                 ksumm_alone = kt2.summary()
             finally:
                 afft_amd.runtime.set_overlap_wgrad(True)
+
+    if rank == 0 and world == 1 and not captured and not args.no_roofline:
+        try:
+            result["power"] = power_report(lambda: trainer.step(feats, tgt, sub, optimize=not args.no_optimizer))
+        except Exception as ex:  # noqa: BLE001
+            result["power"] = {"error": repr(ex)[:120]}
 
     if rank == 0:
         # forward latency, eval mode (BASELINE.json: "fwd p50 ms")
