@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AFFT_LIB") or os.path.join(_HERE, "lib", "libafft_hip.so")   # AFFT_LIB: kernel-tuning builds
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2      # F16: fp16 planes / images of the "fp16x2" precision (outputs and copies; never a GEMM operand dtype)
 GEMM_WS_HEADER = 4096
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_DGELU_ERF, ACT_DGELU_TANH, ACT_RELU, ACT_SIGMOID_GATE = 0, 1, 2, 3, 4, 5, 6
 MASK_NONE, MASK_DIAG, MASK_CAUSAL, MASK_BLOCKCAUSAL = 0, 1, 2, 3
@@ -25,7 +25,7 @@ class Dropout(C.Structure):
 
 class SgdFused(C.Structure):      # afft_sgd_fused_t
     _fields_ = [("p", vp), ("buf", vp), ("p_bf16", vp), ("lr", f32), ("mom", f32), ("wd", f32), ("gscale", f32), ("first_step", i32),
-                ("p_pk16", vp)]
+                ("p_pk16", vp), ("p_f16", vp)]
 
 
 SgdP = C.POINTER(SgdFused)
@@ -52,6 +52,7 @@ class GemmDesc(C.Structure):
         ("split3", i32), ("a_lo", i64), ("b_lo", i64),
         ("sgd", SgdP),
         ("b_packed", vp),
+        ("out_lo", i64),
     ]
 
 
@@ -78,7 +79,8 @@ class AttnSublayer(C.Structure):      # afft_attn_sublayer_t
         ("g_w_qkv", vp), ("acc_w_qkv", i32), ("g_b_qkv", vp), ("acc_b_qkv", i32),
         ("g_w_proj", vp), ("acc_w_proj", i32), ("g_b_proj", vp), ("acc_b_proj", i32),
         ("g_ln_w", vp), ("g_ln_b", vp), ("acc_ln", i32),
-        ("dx", vp)] + _HAND + [("ln_partial", vp)] + _WS + [("sgd_w_qkv", SgdP), ("sgd_w_proj", SgdP), ("w_qkv_pk", vp), ("w_proj_pk", vp)]
+        ("dx", vp)] + _HAND + [("ln_partial", vp)] + _WS + [("sgd_w_qkv", SgdP), ("sgd_w_proj", SgdP), ("w_qkv_pk", vp), ("w_proj_pk", vp),
+                                                       ("f16x2", i32), ("xn_b", vp), ("qkv_b", vp), ("ao_b", vp)]
 
 
 class MLPSublayer(C.Structure):       # afft_mlp_sublayer_t
@@ -96,7 +98,8 @@ class MLPSublayer(C.Structure):       # afft_mlp_sublayer_t
         ("g_w1", vp), ("acc_w1", i32), ("g_b1", vp), ("acc_b1", i32),
         ("g_w2", vp), ("acc_w2", i32), ("g_b2", vp), ("acc_b2", i32),
         ("g_ln_w", vp), ("g_ln_b", vp), ("acc_ln", i32),
-        ("dx", vp)] + _HAND + [("ln_partial", vp)] + _WS + [("sgd_w1", SgdP), ("sgd_w2", SgdP), ("w1_pk", vp), ("w2_pk", vp)]
+        ("dx", vp)] + _HAND + [("ln_partial", vp)] + _WS + [("sgd_w1", SgdP), ("sgd_w2", SgdP), ("w1_pk", vp), ("w2_pk", vp),
+                                                       ("f16x2", i32), ("xn_b", vp), ("h_b", vp)]
 
 
 class CrossAttnSublayer(C.Structure):  # afft_cross_attn_sublayer_t
@@ -149,11 +152,14 @@ _SIGS = {
     "afft_split_bf16": ([vp, i64, i32, i32, vp, i64, i32, i64, vp], C.c_int),
     "afft_split_f16": ([vp, i64, i32, i32, vp, i64, i32, i64, vp], C.c_int),
     "afft_layernorm_fwd": ([vp, i64, vp, vp, f32, i32, i32, vp, i64, i32, vp, vp, vp], C.c_int),
+    "afft_layernorm_fwd_split": ([vp, i64, vp, vp, f32, i32, i32, vp, i64, i64, vp, i64, vp, vp, vp], C.c_int),
     "afft_layernorm_bwd_nparts": ([i32], C.c_int),
     "afft_layernorm_bwd": ([vp, i64, i32, vp, i64, vp, vp, vp, i32, i32, vp, vp, i64, vp, C.POINTER(Dropout), vp, vp, i32,
                             vp, i32, vp, vp], C.c_int),
     "afft_attention_fwd": ([vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, i32, i32, f32, C.c_uint32,
                             vp, i64, vp, vp], C.c_int),
+    "afft_attention_fwd_split": ([vp, i64, vp, i64, vp, i64, i64, i32, i32, i32, i32, f32, i32, i32, f32, C.c_uint32,
+                                  vp, i64, i64, vp, i64, vp, vp], C.c_int),
     "afft_attention_bwd": ([vp, i64, vp, i64, vp, i64, vp, i64, i32, vp, i32, i32, i32, i32, f32, f32, C.c_uint32,
                             vp, i64, vp, i64, vp, i64, vp], C.c_int),
     "afft_softmax_ce": ([vp, i64, i32, i32, vp, vp, i64, vp, f32, vp, vp, vp, i64, i32, vp, vp], C.c_int),
@@ -167,6 +173,8 @@ _SIGS = {
     "afft_reduce_rows_periodic": ([vp, i64, i32, i32, i32, vp, i64, vp], C.c_int),
     "afft_sgd_nesterov": ([vp, vp, i32, vp, vp, i64, f32, f32, f32, f32, vp, i32, vp], C.c_int),
     "afft_sgd_nesterov_runs": ([vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, i32, vp], C.c_int),
+    "afft_sgd_nesterov2": ([vp, vp, i32, vp, vp, vp, i64, f32, f32, f32, f32, vp, i32, vp], C.c_int),
+    "afft_sgd_nesterov_runs2": ([vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, i32, vp], C.c_int),
     "afft_sumsq": ([vp, i32, i64, f32, vp, vp, i64, vp], C.c_int),
     "afft_group_sum": ([vp, i32, i32, i64, f32, vp, vp], C.c_int),
     "afft_set_dropout_salt": ([vp], C.c_int),

@@ -36,6 +36,10 @@ struct AttnArgs {
   unsigned dthresh, dkey;
   float dinv;
   const unsigned* salt;   // device word XOR-ed into dkey (afft_set_dropout_salt) or NULL
+  // fp16x2 forward (PL instantiations): q / k / v / out are the HI planes of two-plane fp16 splits
+  int64_t in_lo, out_lo;  // elements from a hi plane to its lo plane (inputs; output)
+  bf16_t* out_b;          // optional bf16 copy of the output (what the bf16 backward reads)
+  int64_t ldob;
 };
 
 __device__ __forceinline__ bool pair_valid(int mask, int period, int L, int rows_valid, int qi, int kj) {
@@ -92,17 +96,32 @@ __device__ __forceinline__ void store_o4(bf16_t* dst, const f32x4& a) {
   *(uint2*)dst = u;
 }
 
-template <int NT>
+typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+__device__ __forceinline__ f32x4 mfma32_h(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16_h(bf16x4 a, h4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, a), b, c, 0, 0, 0);
+}
+
+// PL ("planes", the fp16x2 forward): q, k, v arrive as two-plane fp16 splits x = hi + lo and every product is accumulated from
+// hi*hi + lo*hi + hi*lo on the fp16 MFMAs (exact to ~2^-21: the attention core adds no operand rounding of its own to a forward
+// pass whose GEMMs carry their activations as hi + lo); the probabilities are split the same way in registers, and the output is
+// written as planes again (+ the bf16 copy the backward pass reads).
+template <int NT, bool PL>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned dkey = a.dkey ^ (a.salt ? *a.salt : 0u);
   constexpr int R = 16 * NT;
+  constexpr int NP = PL ? 2 : 1;       // planes per operand tile
   const int hd = a.hd, hc = a.hc, L = a.L, H = a.H;
   const int rb = hc * 2;               // bytes per LDS row: one head-dimension chunk
   const int nch = hd / hc;
-  char* Qs = smem;
-  char* Ks = Qs + R * rb;
-  char* Vs = nch == 1 ? Ks + R * rb : smem;     // chunked: V chunks reuse the Q/K space after the scores are done
+  const int tb = R * rb;               // bytes of one tile
+  char* Qs = smem;                     // [NP planes][R][hc]
+  char* Ks = Qs + NP * tb;
+  char* Vs = nch == 1 ? Ks + NP * tb : smem;     // chunked: V chunks reuse the Q/K space after the scores are done
   const int grp = blockIdx.x / H, h = blockIdx.x % H;
   const int seq0 = grp * a.G;
   const int nsq = min(a.G, a.nseq - seq0);
@@ -118,27 +137,43 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
     for (int qt = 0; qt < NT; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int c = 0; c < nch; ++c) {
     if (c) __syncthreads();            // the previous chunk has been consumed by every wave
-    load_tile(a.q + (int64_t)h * hd + c * hc, a.ldq, row0, rows_valid, R, hc, Qs);
-    load_tile(a.k + (int64_t)h * hd + c * hc, a.ldk, row0, rows_valid, R, hc, Ks);
-    if (nch == 1) load_tile(a.v + (int64_t)h * hd, a.ldv, row0, rows_valid, R, hc, Vs);
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+      load_tile(a.q + pl * a.in_lo + (int64_t)h * hd + c * hc, a.ldq, row0, rows_valid, R, hc, Qs + pl * tb);
+      load_tile(a.k + pl * a.in_lo + (int64_t)h * hd + c * hc, a.ldk, row0, rows_valid, R, hc, Ks + pl * tb);
+      if (nch == 1) load_tile(a.v + pl * a.in_lo + (int64_t)h * hd, a.ldv, row0, rows_valid, R, hc, Vs + pl * tb);
+    }
     __syncthreads();
     for (int ks = 0; ks < hc / 32; ++ks) {
       const int ch = ks * 4 + (lane >> 4);
-      bf16x8 kf[NT], qf[NT];
+      bf16x8 kf[NT], qf[NT], kl[NT], ql[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         kf[t] = row_frag(Ks, t * 16 + (lane & 15), ch, rb);
         qf[t] = row_frag(Qs, t * 16 + (lane & 15), ch, rb);
+        if constexpr (PL) {
+          kl[t] = row_frag(Ks + tb, t * 16 + (lane & 15), ch, rb);
+          ql[t] = row_frag(Qs + tb, t * 16 + (lane & 15), ch, rb);
+        }
       }
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-        for (int qt = 0; qt < NT; ++qt)
-          s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], s[kt][qt], 0, 0, 0);
+        for (int qt = 0; qt < NT; ++qt) {
+          if constexpr (PL) {
+            s[kt][qt] = mfma32_h(kl[kt], qf[qt], s[kt][qt]);       // small terms first
+            s[kt][qt] = mfma32_h(kf[kt], ql[qt], s[kt][qt]);
+            s[kt][qt] = mfma32_h(kf[kt], qf[qt], s[kt][qt]);
+          } else {
+            s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], s[kt][qt], 0, 0, 0);
+          }
+        }
     }
   }
   // masked softmax over keys, per query column
   bf16x4 pb[NT][NT];
+  h4 ph[NT][NT], pq[NT][NT];       // PL: the probabilities as hi + lo fp16
+  (void)pb; (void)ph; (void)pq;
 #pragma unroll
   for (int qt = 0; qt < NT; ++qt) {
     const int qi = qt * 16 + (lane & 15);
@@ -183,7 +218,12 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
           if (a.dthresh) pv[r] = drop_keep(dkey, (unsigned)pidx, a.dthresh) ? p * a.dinv : 0.f;
         }
       }
-      pb[kt][qt] = pack4(pv);
+      if constexpr (PL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ph[kt][qt][r] = (_Float16)pv[r]; pq[kt][qt][r] = (_Float16)(pv[r] - (float)ph[kt][qt][r]); }
+      } else {
+        pb[kt][qt] = pack4(pv);
+      }
     }
     // masked (but same-sequence) pairs must read as exactly 0 in probs: write them too
     if (wave == 0 && a.probs && qi < rows_valid) {
@@ -201,7 +241,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
   for (int c = 0; c < nch; ++c) {
     if (nch > 1) {
       __syncthreads();                 // scores / previous V chunk done by every wave
-      load_tile(a.v + (int64_t)h * hd + c * hc, a.ldv, row0, rows_valid, R, hc, Vs);
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl)
+        load_tile(a.v + pl * a.in_lo + (int64_t)h * hd + c * hc, a.ldv, row0, rows_valid, R, hc, Vs + pl * tb);
       __syncthreads();
     }
     for (int cb = wave; cb < hc / 16; cb += 4) {
@@ -211,14 +253,33 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
         const bf16x4 vt = tr_frag(Vs, kt * 16, cb, lane, rb);
+        if constexpr (PL) {
+          const bf16x4 vl = tr_frag(Vs + tb, kt * 16, cb, lane, rb);
 #pragma unroll
-        for (int qt = 0; qt < NT; ++qt) o[qt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt, pb[kt][qt], o[qt], 0, 0, 0);
+          for (int qt = 0; qt < NT; ++qt) {
+            o[qt] = mfma16_h(vl, ph[kt][qt], o[qt]);
+            o[qt] = mfma16_h(vt, pq[kt][qt], o[qt]);
+            o[qt] = mfma16_h(vt, ph[kt][qt], o[qt]);
+          }
+        } else {
+#pragma unroll
+          for (int qt = 0; qt < NT; ++qt) o[qt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt, pb[kt][qt], o[qt], 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int qt = 0; qt < NT; ++qt) {
         const int qi = qt * 16 + (lane & 15);
-        if (qi < rows_valid)
-          store_o4(a.out + (row0 + qi) * a.ldo + (int64_t)h * hd + c * hc + cb * 16 + 4 * (lane >> 4), o[qt]);
+        if (qi < rows_valid) {
+          const int64_t col = (int64_t)h * hd + c * hc + cb * 16 + 4 * (lane >> 4);
+          if constexpr (PL) {
+            const float ov[4] = {o[qt][0], o[qt][1], o[qt][2], o[qt][3]};
+            if (a.out_lo) store_split<4>(a.out, (row0 + qi) * a.ldo + col, a.out_lo, ov);
+            else store4(a.out, (row0 + qi) * a.ldo + col, AFFT_F16, ov);
+            if (a.out_b) store_o4(a.out_b + (row0 + qi) * a.ldob + col, o[qt]);
+          } else {
+            store_o4(a.out + (row0 + qi) * a.ldo + col, o[qt]);
+          }
+        }
       }
     }
   }
@@ -403,8 +464,10 @@ bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 int afft_attention_mfma(bool backward, const void* dout, int64_t lddo, const void* q, int64_t ldq, const void* k,
                         int64_t ldk, const void* v, int64_t ldv, float* probs, int nseq, int L, int H, int hd,
                         float scale, int mask, float drop_p, unsigned drop_key, void* out, int64_t ldo, void* dq,
-                        int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, hipStream_t stream) {
+                        int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, hipStream_t stream,
+                        int planes, int64_t in_lo, int64_t out_lo, void* out_b, int64_t ldob) {
   if (L > 64 || hd % 64 != 0 || hd > 1024) return -1;
+  if (planes && (backward || in_lo % 8 || out_lo % 4 || ldob % 4 || (((uintptr_t)out_b) & 7))) return -1;
   if (ldq % 8 || ldk % 8 || ldv % 8 || !al16(q) || !al16(k) || !al16(v)) return -1;
   if (!backward && (ldo % 4 || (((uintptr_t)out) & 7))) return -1;
   if (backward && (lddo % 8 || !al16(dout) || lddq % 4 || lddk % 4 || lddv % 4 || (((uintptr_t)dq) & 7) ||
@@ -413,13 +476,14 @@ int afft_attention_mfma(bool backward, const void* dout, int64_t lddo, const voi
   // the whole head dimension in LDS when it fits (3 tiles forward, 4 backward); else chunks of the head dimension,
   // the scores / dP accumulate over the chunks and the operand tiles are re-staged (2 tiles forward, 3 backward)
   int hc = hd;
-  size_t lds = (size_t)(backward ? 4 : 3) * 16 * NT * hd * 2;
+  const int np = planes ? 2 : 1;       // fp16x2 forward: every operand tile is two planes
+  size_t lds = (size_t)(backward ? 4 : 3) * np * 16 * NT * hd * 2;
   if (lds > 160 * 1024) {
     hc = 0;
     for (int cand = hd / 2; cand >= 64; cand /= 2)
-      if (hd % cand == 0 && cand % 64 == 0 && (size_t)(backward ? 3 : 2) * 16 * NT * cand * 2 <= 160 * 1024) { hc = cand; break; }
+      if (hd % cand == 0 && cand % 64 == 0 && (size_t)(backward ? 3 : 2) * np * 16 * NT * cand * 2 <= 160 * 1024) { hc = cand; break; }
     if (!hc) return -1;
-    lds = (size_t)(backward ? 3 : 2) * 16 * NT * hc * 2;
+    lds = (size_t)(backward ? 3 : 2) * np * 16 * NT * hc * 2;
   }
   // experiment: AFFT_ATTN_BWD_HC / AFFT_ATTN_FWD_HC force the chunked path with that chunk width (a smaller LDS footprint per
   // workgroup -> more workgroups per CU, for one more staging pass of dO)
@@ -428,7 +492,7 @@ int afft_attention_mfma(bool backward, const void* dout, int64_t lddo, const voi
   const int force = backward ? force_bwd : force_fwd;
   if (force >= 64 && force < hd && hd % force == 0 && force % 64 == 0) {
     hc = force;
-    lds = (size_t)(backward ? 3 : 2) * 16 * NT * hc * 2;
+    lds = (size_t)(backward ? 3 : 2) * np * 16 * NT * hc * 2;
   }
   AttnArgs a;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.dout = (const bf16_t*)dout;
@@ -436,6 +500,7 @@ int afft_attention_mfma(bool backward, const void* dout, int64_t lddo, const voi
   a.out = (bf16_t*)out; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
   a.ldo = ldo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.probs = probs;
+  a.in_lo = in_lo; a.out_lo = out_lo; a.out_b = (bf16_t*)out_b; a.ldob = ldob;
   a.nseq = nseq; a.L = L; a.H = H; a.hd = hd; a.G = (16 * NT) / L; a.hc = hc;
   a.scale = scale; a.mask = mask & 0xff; a.period = mask >> 8;   // block-causal period rides in the upper bits
   afft_dropout_t dd = {drop_p, drop_key, 0.f, 0u, 1};
@@ -449,10 +514,14 @@ int afft_attention_mfma(bool backward, const void* dout, int64_t lddo, const voi
     if (afft_ensure_dynamic_lds(reinterpret_cast<const void*>(KERN), 160 * 1024, &attr_done)) return -1;    \
     hipLaunchKernelGGL(KERN, grid, block, lds, stream, a);                                                  \
   } while (0)
-  if (!backward) {
-    if (NT == 1) AFFT_ATTN_LAUNCH(attn_fwd_mfma_kernel<1>);
-    else if (NT == 2) AFFT_ATTN_LAUNCH(attn_fwd_mfma_kernel<2>);
-    else AFFT_ATTN_LAUNCH(attn_fwd_mfma_kernel<4>);
+  if (!backward && planes) {
+    if (NT == 1) AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<1, true>));
+    else if (NT == 2) AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<2, true>));
+    else AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<4, true>));
+  } else if (!backward) {
+    if (NT == 1) AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<1, false>));
+    else if (NT == 2) AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<2, false>));
+    else AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<4, false>));
   } else {
     if (NT == 1) AFFT_ATTN_LAUNCH(attn_bwd_mfma_kernel<1>);
     else if (NT == 2) AFFT_ATTN_LAUNCH(attn_bwd_mfma_kernel<2>);

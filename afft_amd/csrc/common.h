@@ -65,6 +65,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return __builtin_bit_cast(unsigned short, (__bf16)f);
 }
 
+// fp16 planes of the "fp16x2" precision (AFFT_F16): raw fp16 bits in memory, RNE conversion (v_cvt_f16_f32)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_v;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_v;
+__device__ __forceinline__ unsigned short f2h(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+__device__ __forceinline__ float h2f(unsigned short v) { return (float)__builtin_bit_cast(_Float16, v); }
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static __device__ __forceinline__ float ld(const float* p) { return *p; }
@@ -76,10 +82,10 @@ template <> struct Elem<bf16_t> {
 };
 
 __device__ __forceinline__ float ld_any(const void* p, int64_t idx, int dtype) {
-  return dtype == AFFT_F32 ? ((const float*)p)[idx] : bf2f(((const bf16_t*)p)[idx]);
+  return dtype == AFFT_F32 ? ((const float*)p)[idx] : dtype == AFFT_F16 ? h2f(((const bf16_t*)p)[idx]) : bf2f(((const bf16_t*)p)[idx]);
 }
 __device__ __forceinline__ void st_any(void* p, int64_t idx, int dtype, float v) {
-  if (dtype == AFFT_F32) ((float*)p)[idx] = v; else ((bf16_t*)p)[idx] = f2bf(v);
+  if (dtype == AFFT_F32) ((float*)p)[idx] = v; else if (dtype == AFFT_F16) ((bf16_t*)p)[idx] = f2h(v); else ((bf16_t*)p)[idx] = f2bf(v);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -239,7 +245,7 @@ __device__ __forceinline__ void sgd_update(float& p, float& buf, float g, float 
   buf = bb;
   p = __fmaf_rn(-lr, (flags & AFFT_SGD_PLAIN_MOMENTUM) ? bb : __fmaf_rn(mom, bb, gg), p);
 }
-struct SgdEpi { float* p; float* buf; bf16_t* p16; float lr, mom, wd, gscale; int first; bf16_t* p16k; };
+struct SgdEpi { float* p; float* buf; bf16_t* p16; float lr, mom, wd, gscale; int first; bf16_t* p16k; bf16_t* p16h; };   // p16h: fp16 image (row-major, like p16)
 // element offset of the 8-element fragment that holds W[m][n .. n + 7] (n % 8 == 0) in the fragment-packed image of a [rows, ld] weight
 // (afft_pack_weight, include/afft_hip.h)
 __device__ __forceinline__ int64_t packed_frag(int m, int n, int64_t ld) {
@@ -258,6 +264,7 @@ struct EpiParams {
   const float* residual; int64_t ldres;
   int accumulate;
   void* out; int64_t ldo; int out_dtype;
+  int64_t out_lo;   // != 0 (out_dtype AFFT_F16): out is the HI plane of a two-plane fp16 split, the lo plane sits out_lo elements behind it
   void* out2; int64_t ldo2; int out2_dtype;
   int vec4;  // host-verified: every ld % 4 == 0 and bases 16-byte aligned -> 4-wide accesses legal
   int vec8;  // host-verified: every ld % 8 == 0 and bases 16-byte aligned -> 8-wide accesses legal (16-B bf16 stores)
@@ -268,6 +275,11 @@ struct EpiParams {
 __device__ __forceinline__ void store4(void* base, int64_t idx, int dtype, const float (&v)[4]) {
   if (dtype == AFFT_F32) {
     *(float4*)((float*)base + idx) = make_float4(v[0], v[1], v[2], v[3]);
+  } else if (dtype == AFFT_F16) {
+    f16x4_v h;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[r] = (_Float16)v[r];
+    *(f16x4_v*)((bf16_t*)base + idx) = h;
   } else {
     uint2 u;
     u.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
@@ -279,11 +291,27 @@ __device__ __forceinline__ void load4(const void* base, int64_t idx, int dtype, 
   if (dtype == AFFT_F32) {
     float4 t = *(const float4*)((const float*)base + idx);
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else if (dtype == AFFT_F16) {
+    const f16x4_v h = *(const f16x4_v*)((const bf16_t*)base + idx);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (float)h[r];
   } else {
     uint2 u = *(const uint2*)((const bf16_t*)base + idx);
     v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
     v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
   }
+}
+
+// two-plane fp16 split of N values: hi = fp16(v) at idx, lo = fp16(v - hi) lo_off elements behind it (the A operand of the
+// fp16 two-pass GEMM, afft_gemm_t.split3 = 2, written by the producing kernel instead of a separate split pass)
+template <int N>
+__device__ __forceinline__ void store_split(void* base, int64_t idx, int64_t lo_off, const float (&v)[N]) {
+  typedef __attribute__((ext_vector_type(N))) _Float16 hN;
+  hN h, l;
+#pragma unroll
+  for (int r = 0; r < N; ++r) { h[r] = (_Float16)v[r]; l[r] = (_Float16)(v[r] - (float)h[r]); }
+  *(hN*)((bf16_t*)base + idx) = h;
+  *(hN*)((bf16_t*)base + idx + lo_off) = l;
 }
 
 __host__ __device__ __forceinline__ bool act_needs_aux(int act) {
@@ -351,6 +379,7 @@ __device__ __forceinline__ void epilogue4(const EpiParams& e, const DropParams& 
       store4(e.sgd.p, idx, AFFT_F32, pv);
       store4(e.sgd.buf, idx, AFFT_F32, bv);
       if (e.sgd.p16) store4(e.sgd.p16, idx, AFFT_BF16, pv);
+      if (e.sgd.p16h) store4(e.sgd.p16h, idx, AFFT_F16, pv);
       if (e.sgd.p16k) store4(e.sgd.p16k, packed_frag(m, n & ~7, e.ldo) + (n & 7), AFFT_BF16, pv);
     } else {
       for (int r = 0; r < 4 && n + r < e.N; ++r) {
@@ -358,6 +387,7 @@ __device__ __forceinline__ void epilogue4(const EpiParams& e, const DropParams& 
         sgd_update(pv, bv, v[r] * e.alpha, e.sgd.lr, e.sgd.mom, e.sgd.wd, e.sgd.gscale, e.sgd.first);
         e.sgd.p[idx + r] = pv; e.sgd.buf[idx + r] = bv;
         if (e.sgd.p16) e.sgd.p16[idx + r] = f2bf(pv);
+        if (e.sgd.p16h) e.sgd.p16h[idx + r] = f2h(pv);
         if (e.sgd.p16k) e.sgd.p16k[packed_frag(m, (n + r) & ~7, e.ldo) + ((n + r) & 7)] = f2bf(pv);
       }
     }
@@ -394,7 +424,8 @@ __device__ __forceinline__ void epilogue4(const EpiParams& e, const DropParams& 
       float4 t = *(const float4*)((const float*)e.out + (int64_t)m * e.ldo + n);
       v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
     }
-    store4(e.out, (int64_t)m * e.ldo + n, e.out_dtype, v);
+    if (e.out_lo) store_split<4>(e.out, (int64_t)m * e.ldo + n, e.out_lo, v);
+    else store4(e.out, (int64_t)m * e.ldo + n, e.out_dtype, v);
     if (e.out2) store4(e.out2, (int64_t)m * e.ldo2 + n, e.out2_dtype, v);
   } else {
 #pragma unroll
@@ -412,6 +443,7 @@ __device__ __forceinline__ void epilogue4(const EpiParams& e, const DropParams& 
       if (e.residual) x += e.residual[(int64_t)m * e.ldres + nn];
       if (e.accumulate) x += ((const float*)e.out)[(int64_t)m * e.ldo + nn];
       st_any(e.out, (int64_t)m * e.ldo + nn, e.out_dtype, x);
+      if (e.out_lo) ((bf16_t*)e.out)[(int64_t)m * e.ldo + nn + e.out_lo] = f2h(x - h2f(f2h(x)));
       if (e.out2) st_any(e.out2, (int64_t)m * e.ldo2 + nn, e.out2_dtype, x);
     }
   }
@@ -423,6 +455,11 @@ __device__ __forceinline__ void store8(void* base, int64_t idx, int dtype, const
   if (dtype == AFFT_F32) {
     *(float4*)((float*)base + idx) = make_float4(v[0], v[1], v[2], v[3]);
     *(float4*)((float*)base + idx + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  } else if (dtype == AFFT_F16) {
+    f16x8_v h;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) h[r] = (_Float16)v[r];
+    *(f16x8_v*)((bf16_t*)base + idx) = h;
   } else {
     uint4 u;
     u.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
@@ -436,6 +473,10 @@ __device__ __forceinline__ void load8(const void* base, int64_t idx, int dtype, 
   if (dtype == AFFT_F32) {
     const float4 a = *(const float4*)((const float*)base + idx), b = *(const float4*)((const float*)base + idx + 4);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else if (dtype == AFFT_F16) {
+    const f16x8_v h = *(const f16x8_v*)((const bf16_t*)base + idx);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = (float)h[r];
   } else {
     const uint4 u = *(const uint4*)((const bf16_t*)base + idx);
     v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
@@ -464,6 +505,7 @@ __device__ __forceinline__ void epilogue8(const EpiParams& e, const DropParams& 
     store8(e.sgd.p, idx, AFFT_F32, pv);
     store8(e.sgd.buf, idx, AFFT_F32, bv);
     if (e.sgd.p16) store8(e.sgd.p16, idx, AFFT_BF16, pv);
+    if (e.sgd.p16h) store8(e.sgd.p16h, idx, AFFT_F16, pv);
     if (e.sgd.p16k) store8(e.sgd.p16k, packed_frag(m, n, e.ldo), AFFT_BF16, pv);
     return;
   }
@@ -503,6 +545,7 @@ __device__ __forceinline__ void epilogue8(const EpiParams& e, const DropParams& 
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] += t[r];
   }
-  store8(e.out, (int64_t)m * e.ldo + n, e.out_dtype, v);
+  if (e.out_lo) store_split<8>(e.out, (int64_t)m * e.ldo + n, e.out_lo, v);
+  else store8(e.out, (int64_t)m * e.ldo + n, e.out_dtype, v);
   if (e.out2) store8(e.out2, (int64_t)m * e.ldo2 + n, e.out2_dtype, v);
 }

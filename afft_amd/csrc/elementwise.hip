@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void reduce_rows_periodic_kernel(const float* 
 }
 
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const void* __restrict__ g_, int g_dtype,
-                                                  float* __restrict__ buf, bf16_t* __restrict__ p16, int64_t n, float lr,
+                                                  float* __restrict__ buf, bf16_t* __restrict__ p16, bf16_t* __restrict__ p16h, int64_t n, float lr,
                                                   float mom, float wd, float gscale, const float* __restrict__ gscale_dev,
                                                   int first) {
   if (gscale_dev) gscale *= *gscale_dev;   // clip coefficient computed on the device (afft_clip_coef)
@@ -350,6 +350,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const v
       *(float4*)(buf + i) = make_float4(bb[0], bb[1], bb[2], bb[3]);
       *(float4*)(p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
       if (p16) store4(p16, i, AFFT_BF16, pp);
+      if (p16h) store4(p16h, i, AFFT_F16, pp);
     } else {
       for (int64_t j = i; j < n; ++j) {
         float pj = p[j], bj = (first & AFFT_SGD_FIRST_STEP) ? 0.f : buf[j];
@@ -357,6 +358,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const v
         buf[j] = bj;
         p[j] = pj;
         if (p16) p16[j] = f2bf(pj);
+        if (p16h) p16h[j] = f2h(pj);
       }
     }
   }
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const v
 
 // the same update over a table of runs {start, length}: block b owns run b (runs are short: biases, LayerNorm weights)
 __global__ __launch_bounds__(256) void sgd_runs_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
-                                                       bf16_t* __restrict__ p16, const int64_t* __restrict__ runs, float lr, float mom,
+                                                       bf16_t* __restrict__ p16, bf16_t* __restrict__ p16h, const int64_t* __restrict__ runs, float lr, float mom,
                                                        float wd, float gscale, int first) {
   const int64_t s0 = runs[2 * blockIdx.x], len = runs[2 * blockIdx.x + 1];
   for (int64_t j = s0 + threadIdx.x; j < s0 + len; j += 256) {
@@ -373,20 +375,25 @@ __global__ __launch_bounds__(256) void sgd_runs_kernel(float* __restrict__ p, co
     buf[j] = bj;
     p[j] = pj;
     if (p16) p16[j] = f2bf(pj);
+    if (p16h) p16h[j] = f2h(pj);
   }
 }
 
 }  // namespace
 
-extern "C" int afft_sgd_nesterov_runs(float* p, const float* g, float* buf, void* p_bf16, const int64_t* runs, int32_t nruns,
-                                      float lr, float mom, float wd, float gscale, int32_t first_step, void* stream_) {
+extern "C" int afft_sgd_nesterov_runs2(float* p, const float* g, float* buf, void* p_bf16, void* p_f16, const int64_t* runs, int32_t nruns,
+                                       float lr, float mom, float wd, float gscale, int32_t first_step, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(p && g && buf && (runs || nruns == 0), "sgd_runs: null pointer");
   if (nruns <= 0) return 0;
-  hipLaunchKernelGGL(sgd_runs_kernel, dim3(nruns), dim3(256), 0, stream, p, g, buf, (bf16_t*)p_bf16, runs, lr, mom, wd, gscale,
+  hipLaunchKernelGGL(sgd_runs_kernel, dim3(nruns), dim3(256), 0, stream, p, g, buf, (bf16_t*)p_bf16, (bf16_t*)p_f16, runs, lr, mom, wd, gscale,
                      first_step);
   AFFT_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int afft_sgd_nesterov_runs(float* p, const float* g, float* buf, void* p_bf16, const int64_t* runs, int32_t nruns,
+                                      float lr, float mom, float wd, float gscale, int32_t first_step, void* stream_) {
+  return afft_sgd_nesterov_runs2(p, g, buf, p_bf16, nullptr, runs, nruns, lr, mom, wd, gscale, first_step, stream_);
 }
 
 namespace {
@@ -973,9 +980,8 @@ extern "C" int afft_clip_coef(const float* sumsq, float max_norm, float* coef, f
   return 0;
 }
 
-extern "C" int afft_sgd_nesterov(float* p, const void* g, int32_t g_dtype, float* buf, void* p_bf16, int64_t n, float lr,
-                                 float mom, float wd, float gscale, const float* gscale_dev, int32_t first_step,
-                                 void* stream_) {
+extern "C" int afft_sgd_nesterov2(float* p, const void* g, int32_t g_dtype, float* buf, void* p_bf16, void* p_f16, int64_t n, float lr,
+                                  float mom, float wd, float gscale, const float* gscale_dev, int32_t first_step, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(p && g && buf, "sgd: null pointer");
   AFFT_CHECK(((uintptr_t)p & 15) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)buf & 15) == 0, "sgd: buffers must be 16-byte aligned");
@@ -991,8 +997,12 @@ extern "C" int afft_sgd_nesterov(float* p, const void* g, int32_t g_dtype, float
     return (int64_t)(v > 0 ? v : 256);
   }();
   if (blocks > max_blocks) blocks = max_blocks;
-  hipLaunchKernelGGL(sgd_kernel, dim3((int)blocks), dim3(256), 0, stream, p, g, g_dtype, buf, (bf16_t*)p_bf16, n, lr, mom, wd,
+  hipLaunchKernelGGL(sgd_kernel, dim3((int)blocks), dim3(256), 0, stream, p, g, g_dtype, buf, (bf16_t*)p_bf16, (bf16_t*)p_f16, n, lr, mom, wd,
                      gscale, gscale_dev, first_step);
   AFFT_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int afft_sgd_nesterov(float* p, const void* g, int32_t g_dtype, float* buf, void* p_bf16, int64_t n, float lr, float mom,
+                                 float wd, float gscale, const float* gscale_dev, int32_t first_step, void* stream_) {
+  return afft_sgd_nesterov2(p, g, g_dtype, buf, p_bf16, nullptr, n, lr, mom, wd, gscale, gscale_dev, first_step, stream_);
 }

@@ -544,10 +544,14 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
   e.rowscale = d->rowscale; e.residual = d->residual; e.ldres = d->ldres;
   e.accumulate = d->accumulate;
   e.out = d->out; e.ldo = d->ldo; e.out_dtype = d->out_dtype;
+  AFFT_CHECK(d->out_dtype >= AFFT_F32 && d->out_dtype <= AFFT_F16, "afft_gemm: bad out_dtype %d", d->out_dtype);
+  AFFT_CHECK(!d->out_lo || (d->out_dtype == AFFT_F16 && !d->accumulate && d->out_lo % 8 == 0),
+             "afft_gemm: out_lo (two-plane fp16 output) needs out_dtype AFFT_F16, no accumulate, and a 16-byte aligned plane offset");
+  e.out_lo = d->out_lo;
   e.out2 = d->out2; e.ldo2 = d->ldo2; e.out2_dtype = d->out2_dtype;
   AFFT_CHECK(d->drop.p >= 0.f && d->drop.p < 1.f && d->drop.path_p >= 0.f && d->drop.path_p < 1.f, "afft_gemm: dropout p outside [0,1)");
   e.drop = make_drop(&d->drop);
-  e.sgd = SgdEpi{nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 1.f, 0, nullptr};
+  e.sgd = SgdEpi{nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 1.f, 0, nullptr, nullptr};
   if (d->sgd) {
     AFFT_CHECK(d->sgd->p && d->sgd->buf, "afft_gemm: fused update without parameter / momentum buffers");
     AFFT_CHECK(!d->accumulate && !d->bias && d->act == AFFT_ACT_NONE && !d->residual && !d->rowscale && !d->pre && !d->out2 &&
@@ -555,7 +559,7 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
     AFFT_CHECK(!d->sgd->p_pk16 || (d->ldo % 32 == 0 && d->M % 16 == 0 && ((uintptr_t)d->sgd->p_pk16 & 15) == 0),
                "afft_gemm: a fragment-packed image needs a [16 a, 32 b] weight");
     e.sgd = SgdEpi{d->sgd->p, d->sgd->buf, (bf16_t*)d->sgd->p_bf16, d->sgd->lr, d->sgd->mom, d->sgd->wd, d->sgd->gscale,
-                   d->sgd->first_step, (bf16_t*)d->sgd->p_pk16};
+                   d->sgd->first_step, (bf16_t*)d->sgd->p_pk16, (bf16_t*)d->sgd->p_f16};
   }
   auto ok4 = [](const void* p, int64_t ld, int dtype) {
     if (!p) return true;
@@ -564,8 +568,8 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
   };
   auto ok8 = [](const void* p, int64_t ld) { return !p || ((ld % 8 == 0) && ((((uintptr_t)p) & 15) == 0)); };
   e.vec8 = ok8(d->out, d->ldo) && ok8(d->out2, d->ldo2) && ok8(d->pre, d->ldpre) && ok8(d->aux, d->ldaux) &&
-           ok8(d->residual, d->ldres) && ok8(d->bias, 8) && ok8(e.sgd.p, d->ldo) && ok8(e.sgd.buf, d->ldo) && ok8(e.sgd.p16, d->ldo);
-  e.vec4 = ok4(e.sgd.p, d->ldo, AFFT_F32) && ok4(e.sgd.buf, d->ldo, AFFT_F32) && ok4(e.sgd.p16, d->ldo, AFFT_BF16) &&
+           ok8(d->residual, d->ldres) && ok8(d->bias, 8) && ok8(e.sgd.p, d->ldo) && ok8(e.sgd.buf, d->ldo) && ok8(e.sgd.p16, d->ldo) && ok8(e.sgd.p16h, d->ldo);
+  e.vec4 = ok4(e.sgd.p, d->ldo, AFFT_F32) && ok4(e.sgd.buf, d->ldo, AFFT_F32) && ok4(e.sgd.p16, d->ldo, AFFT_BF16) && ok4(e.sgd.p16h, d->ldo, AFFT_BF16) &&
            ok4(d->out, d->ldo, d->out_dtype) && ok4(d->out2, d->ldo2, d->out2_dtype) &&
            ok4(d->pre, d->ldpre, d->pre_dtype) && ok4(d->aux, d->ldaux, d->aux_dtype) &&
            ok4(d->residual, d->ldres, AFFT_F32) && ok4(d->bias, 4, AFFT_F32);

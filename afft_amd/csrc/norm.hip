@@ -11,7 +11,8 @@ template <int NV>  // float4 chunks per lane: d <= 256*NV
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ w, const float* __restrict__ b,
                                                      float eps, int rows, int d, void* __restrict__ y, int64_t ldy,
-                                                     int y_dtype, float* __restrict__ mean, float* __restrict__ rstd) {
+                                                     int y_dtype, float* __restrict__ mean, float* __restrict__ rstd,
+                                                     int64_t y_lo, bf16_t* __restrict__ y2, int64_t ldy2) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * LN_WAVES + wave;
   if (row >= rows) return;
@@ -53,7 +54,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         const float4 bb = *(const float4*)(b + 4 * q);
         o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w;
       }
-      store4(y, (int64_t)row * ldy + 4 * q, y_dtype, o);
+      if (y_lo) store_split<4>(y, (int64_t)row * ldy + 4 * q, y_lo, o);     // fp16x2 operand planes (afft_layernorm_fwd_split)
+      else store4(y, (int64_t)row * ldy + 4 * q, y_dtype, o);
+      if (y2) store4(y2, (int64_t)row * ldy2 + 4 * q, AFFT_BF16, o);
     }
   }
 }
@@ -216,22 +219,35 @@ extern "C" int afft_layernorm_bwd_nparts(int32_t rows) {
   return n < 1 ? 1 : (n > 256 ? 256 : n);           // one workgroup (16 waves) per CU at most
 }
 
-extern "C" int afft_layernorm_fwd(const float* x, int64_t ldx, const float* w, const float* b, float eps,
-                                  int32_t rows, int32_t d, void* y, int64_t ldy, int32_t y_dtype, float* mean,
-                                  float* rstd, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int ln_fwd_launch(const float* x, int64_t ldx, const float* w, const float* b, float eps, int32_t rows, int32_t d, void* y,
+                         int64_t ldy, int32_t y_dtype, int64_t y_lo, void* y2, int64_t ldy2, float* mean, float* rstd, hipStream_t stream) {
   AFFT_CHECK(x && y, "layernorm_fwd: null pointer");
-  AFFT_CHECK(d > 0 && d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "layernorm_fwd: d/ld must be multiples of 4 (d=%d)", d);
+  AFFT_CHECK(d > 0 && d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldy2 % 4 == 0 && y_lo % 4 == 0,
+             "layernorm_fwd: d/ld must be multiples of 4 (d=%d)", d);
+  AFFT_CHECK(y_dtype >= AFFT_F32 && y_dtype <= AFFT_F16, "layernorm_fwd: bad y_dtype %d", y_dtype);
   const int nv = pick_nv(d);
   AFFT_CHECK(nv != 0, "layernorm_fwd: d=%d exceeds 4096", d);
   if (rows == 0) return 0;
-  AfftKernelScope ktrace(AFFT_K_LN_FWD, rows, d, (int64_t)rows * d * (4 + (y_dtype == AFFT_F32 ? 4 : 2)) + (int64_t)rows * 8, 0, stream);
+  AfftKernelScope ktrace(AFFT_K_LN_FWD, rows, d,
+                         (int64_t)rows * d * (4 + (y_dtype == AFFT_F32 ? 4 : 2) + (y_lo ? 2 : 0) + (y2 ? 2 : 0)) + (int64_t)rows * 8, 0, stream);
   const int grid = (rows + LN_WAVES - 1) / LN_WAVES;
-#define LN_FWD(NV) hipLaunchKernelGGL(ln_fwd_kernel<NV>, dim3(grid), dim3(256), 0, stream, x, ldx, w, b, eps, rows, d, y, ldy, y_dtype, mean, rstd)
+#define LN_FWD(NV) hipLaunchKernelGGL(ln_fwd_kernel<NV>, dim3(grid), dim3(256), 0, stream, x, ldx, w, b, eps, rows, d, y, ldy, y_dtype, mean, rstd, y_lo, (bf16_t*)y2, ldy2)
   switch (nv) { case 1: LN_FWD(1); break; case 2: LN_FWD(2); break; case 4: LN_FWD(4); break; case 8: LN_FWD(8); break; default: LN_FWD(16); }
 #undef LN_FWD
   AFFT_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int afft_layernorm_fwd(const float* x, int64_t ldx, const float* w, const float* b, float eps,
+                                  int32_t rows, int32_t d, void* y, int64_t ldy, int32_t y_dtype, float* mean,
+                                  float* rstd, void* stream_) {
+  return ln_fwd_launch(x, ldx, w, b, eps, rows, d, y, ldy, y_dtype, 0, nullptr, 0, mean, rstd, (hipStream_t)stream_);
+}
+
+extern "C" int afft_layernorm_fwd_split(const float* x, int64_t ldx, const float* w, const float* b, float eps, int32_t rows, int32_t d,
+                                        void* y_hi, int64_t ldy, int64_t y_lo, void* y_bf16, int64_t ldyb, float* mean, float* rstd,
+                                        void* stream_) {
+  return ln_fwd_launch(x, ldx, w, b, eps, rows, d, y_hi, ldy, AFFT_F16, y_lo, y_bf16, ldyb, mean, rstd, (hipStream_t)stream_);
 }
 
 extern "C" int afft_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx,

@@ -86,6 +86,9 @@ int zero_row_tail(void* buf, int rows, int64_t width, hipStream_t st) {
 
 bool has_drop(const afft_dropout_t& d) { return d.p > 0.f || d.path_p > 0.f; }
 
+// "fp16x2" forward: A is a two-plane fp16 split (lo plane a_lo elements behind the hi plane), the weight an FP16 image
+void as_f16x2(afft_gemm_t& g, int64_t a_lo) { g.split3 = 2; g.a_lo = a_lo; g.b_lo = 0; g.workspace = nullptr; g.workspace_bytes = 0; g.b_packed = nullptr; }
+
 }  // namespace
 
 // ======================================================================================= self-attention sub-layer
@@ -97,6 +100,32 @@ extern "C" int afft_attn_sublayer_fwd(const afft_attn_sublayer_t* s, void* strea
              "attn_sublayer_fwd: bad geometry (rows %d, L %d, d %d, H %d)", s->rows, s->L, s->d, s->H);
   const int R = s->rows, d = s->d;
   const Ws ws = {s->gemm_ws, s->gemm_ws_bytes};
+  if (s->f16x2) {
+    // fp16 two-pass forward: every activation a GEMM reads is carried as hi + lo fp16 planes written by its producer (LayerNorm,
+    // the qkv epilogue, the attention kernel); the bf16 copies (xn_b / qkv_b / ao_b) are what the bf16 backward reads
+    const int pr = pad64(R);
+    const int64_t lo1 = (int64_t)pr * d, lo3 = (int64_t)pr * 3 * d;
+    if (s->xn_b) TRY(zero_row_tail(s->xn_b, R, d, st));
+    if (s->qkv_b) TRY(zero_row_tail(s->qkv_b, R, 3 * d, st));
+    if (s->ao_b) TRY(zero_row_tail(s->ao_b, R, d, st));
+    TRY(afft_layernorm_fwd_split(s->x, d, s->ln_w, s->ln_b, s->eps, R, d, s->xn, d, lo1, s->xn_b, d, s->mean, s->rstd, st));
+    afft_gemm_t g = lin_fwd(s->xn, d, R, d, s->w_qkv, s->ldw_qkv, 3 * d, s->conv1d, ws);
+    as_f16x2(g, lo1);
+    g.bias = s->b_qkv;
+    g.out = s->qkv; g.ldo = 3 * d; g.out_dtype = AFFT_F16; g.out_lo = lo3;
+    g.out2 = s->qkv_b; g.ldo2 = 3 * d; g.out2_dtype = AFFT_BF16;
+    TRY(afft_gemm(&g, st));
+    const char* q = (const char*)s->qkv;
+    TRY(afft_attention_fwd_split(q, 3 * d, q + 2 * d, 3 * d, q + 4 * d, 3 * d, lo3, R / s->L, s->L, s->H, d / s->H, s->scale, s->mask,
+                                 s->mask_period, s->p_attn, s->k_attn, s->ao, d, lo1, s->ao_b, d, s->probs, st));
+    g = lin_fwd(s->ao, d, R, d, s->w_proj, s->ldw_proj, d, s->conv1d, ws);
+    as_f16x2(g, lo1);
+    g.bias = s->b_proj;
+    g.residual = s->x; g.ldres = d;
+    g.drop = s->out_drop;
+    g.out = s->y; g.ldo = d; g.out_dtype = AFFT_F32;
+    return afft_gemm(&g, st);
+  }
   TRY(zero_row_tail(s->xn, R, d, st));
   TRY(zero_row_tail(s->qkv, R, 3 * d, st));
   TRY(zero_row_tail(s->ao, R, d, st));
@@ -174,6 +203,29 @@ extern "C" int afft_mlp_sublayer_fwd(const afft_mlp_sublayer_t* s, void* stream_
   AFFT_CHECK(s->gelu == AFFT_ACT_GELU_ERF || s->gelu == AFFT_ACT_GELU_TANH, "mlp_sublayer_fwd: gelu must be GELU_ERF or GELU_TANH");
   const int R = s->rows, d = s->d, hd = s->hidden;
   const Ws ws = {s->gemm_ws, s->gemm_ws_bytes};
+  if (s->f16x2) {      // see afft_attn_sublayer_fwd
+    const int pr = pad64(R);
+    const int64_t lo1 = (int64_t)pr * d, loh = (int64_t)pr * hd;
+    if (s->xn_b) TRY(zero_row_tail(s->xn_b, R, d, st));
+    if (s->h_b) TRY(zero_row_tail(s->h_b, R, hd, st));
+    if (s->u) TRY(zero_row_tail(s->u, R, hd, st));
+    TRY(afft_layernorm_fwd_split(s->x, d, s->ln_w, s->ln_b, s->eps, R, d, s->xn, d, lo1, s->xn_b, d, s->mean, s->rstd, st));
+    afft_gemm_t g = lin_fwd(s->xn, d, R, d, s->w1, s->ldw1, hd, s->conv1d, ws);
+    as_f16x2(g, lo1);
+    g.bias = s->b1;
+    g.act = s->gelu;
+    g.pre = s->u; g.ldpre = hd; g.pre_dtype = AFFT_BF16;
+    g.out = s->h; g.ldo = hd; g.out_dtype = AFFT_F16; g.out_lo = loh;
+    g.out2 = s->h_b; g.ldo2 = hd; g.out2_dtype = AFFT_BF16;
+    TRY(afft_gemm(&g, st));
+    g = lin_fwd(s->h, hd, R, hd, s->w2, s->ldw2, d, s->conv1d, ws);
+    as_f16x2(g, loh);
+    g.bias = s->b2;
+    g.residual = s->x; g.ldres = d;
+    g.drop = s->out_drop;
+    g.out = s->y; g.ldo = d; g.out_dtype = AFFT_F32;
+    return afft_gemm(&g, st);
+  }
   TRY(zero_row_tail(s->xn, R, d, st));
   if (s->u) TRY(zero_row_tail(s->u, R, hd, st));
   TRY(zero_row_tail(s->h, R, hd, st));

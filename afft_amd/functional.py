@@ -27,12 +27,13 @@ class Act:
     """A GEMM operand/result buffer [rows, width] in the activation dtype. In bf16 mode it is allocated
     [pad64(rows), pad64(width)] with zero tails so it can be the k-contiguous operand of the next GEMM
     (K = pad64(width)) and the k-strided operand of a wgrad GEMM (K = pad64(rows))."""
-    __slots__ = ("buf", "rows", "width", "_split")
+    __slots__ = ("buf", "rows", "width", "_split", "_b16")
 
     def __init__(self, rows: int, width: int, device, dtype=None, like: Optional[Tensor] = None):
         dtype = dtype or rt.act_dtype()
         self.rows, self.width = rows, width
         self._split = None
+        self._b16 = None
         if dtype == torch.bfloat16:
             pr, pw = rt.pad64(rows), rt.pad64(width)
             self.buf = (torch.empty if (pr == rows and pw == width) else torch.zeros)(pr, pw, dtype=dtype, device=device)
@@ -44,7 +45,7 @@ class Act:
         """bf16 Act over flat[offset : offset + pad64(rows) * width] (width % 64 == 0); the row tail is zeroed by whoever
         fills it (the composite entry points do)."""
         a = cls.__new__(cls)
-        a.rows, a.width, a._split = rows, width, None
+        a.rows, a.width, a._split, a._b16 = rows, width, None, None
         a.buf = flat[offset:offset + rt.pad64(rows) * width].view(rt.pad64(rows), width)
         return a
 
@@ -72,6 +73,29 @@ class Act:
         return self._split
 
 
+def _b16(act: Optional[Act]) -> Optional[Act]:
+    """Backward pass of the 'fp16x2' precision (it runs as the bf16 mode, runtime.backward_precision): the bf16 operand copy of an
+    activation the call-by-call forward saved in fp32 -- made once, on the main stream, on first use.  Anything else passes."""
+    if act is None or act.buf.dtype != torch.float32 or rt.precision() != "bf16":
+        return act
+    if act._b16 is None:
+        c = Act(act.rows, act.width, act.buf.device, dtype=torch.bfloat16)
+        ops.cast(act.live, c.live)
+        act._b16 = c
+    return act._b16
+
+
+def _in_backward_precision(fn):
+    """decorator of a Function.backward: run it in the precision the backward pass of the current mode uses"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(ctx, *grads):
+        with rt.precision_scope(rt.backward_precision()):
+            return fn(ctx, *grads)
+    return wrapper
+
+
 def to_act(x: Tensor, drop=None) -> Act:
     """fp32 [rows, width] (any row stride) -> Act in the activation dtype (a cast kernel in bf16 mode;
     in fp32 mode the tensor is used in place when dense).  drop: optional _lib.Dropout replayed/applied
@@ -82,6 +106,7 @@ def to_act(x: Tensor, drop=None) -> Act:
         a.rows, a.width = rows, width
         a.buf = x if x.stride(1) == 1 else x.contiguous()
         a._split = None
+        a._b16 = None
         return a
     a = Act(rows, width, x.device)
     ops.cast(x, a.live, drop=drop)
@@ -99,15 +124,20 @@ def _lin_fwd(x: Act, W: Tensor, conv1d: bool, out: Tensor, **ep) -> Tensor:
         if wt16 is not None:                 # W^T [out, in]: "NT"
             return ops.gemm(x.k, wt16[:W.shape[1]], out, b_t=True, **ep)
         return ops.gemm(x.k, w16[:, :W.shape[1]], out, **ep)             # W [in, out] = [K, N]: "NN"
-    if rt.split_mode() is not None:          # bf16x3: three bf16 passes; fp16x2: x = hi + lo in fp16, W rounded once to fp16
+    if rt.precision() == "fp16x2":           # x = hi + lo in fp16 planes, W rounded once to fp16 (its FP16 image)
+        h16 = rt.weight_f16(W)
+        if not conv1d:
+            return ops.gemm(x.split(), h16[:W.shape[0]], out, b_t=True, **ep)
+        return ops.gemm(x.split(), h16[:, :W.shape[1]], out, **ep)
+    if rt.split_mode() is not None:          # bf16x3: three bf16 passes
         return ops.gemm(x.split(), rt.weight_split(W), out, b_t=not conv1d, **ep)
     return ops.gemm(x.live, W, out, b_t=not conv1d, **ep)
 
 
 def _forward_only_check():
-    if rt.precision() == "fp16x2":
-        raise RuntimeError("afft_amd: precision 'fp16x2' is an evaluation (forward-only) mode -- gradients of 1e-6..1e-4 sit in "
-                           "fp16's subnormal range; train in 'bf16' (or 'bf16x3' / 'fp32' for parity-grade gradients)")
+    if rt.precision() == "fp16x2":      # every Function.backward runs under _in_backward_precision: this would be a wiring error
+        raise RuntimeError("afft_amd: a backward GEMM was reached in precision 'fp16x2' (a forward format: its backward pass runs "
+                           "in runtime.backward_precision())")
 
 
 def _lin_dgrad(dy: Act, W: Tensor, conv1d: bool, out: Tensor, **ep) -> Tensor:
@@ -348,7 +378,8 @@ def _same_drop(a, b) -> bool:
 
 
 def _note_output(y: Tensor, od, bias):
-    _TS.last_out = _Up(y.data_ptr(), tuple(y.shape), od, bias) if rt.precision() == "bf16" else None
+    ok = rt.precision() == "bf16" or rt.backward_precision() == "bf16"      # the hand-over is a bf16 operand of the BACKWARD pass
+    _TS.last_out = _Up(y.data_ptr(), tuple(y.shape), od, bias) if ok else None
 
 
 def _upstream_of(x: Tensor) -> Optional[_Up]:
@@ -494,9 +525,16 @@ def _mask_args(mask):
 # afft_{attn,mlp,cross_attn}_sublayer_{fwd,bwd} (include/afft_hip.h, csrc/sublayer.hip) enqueue exactly the kernel sequences
 # written out call by call in the three Functions below.  What stays here is bookkeeping: buffers (one allocation for the
 # saved activations, one for the backward scratch), gradient-sink state, the hand-over, readiness notifications.
-def _composite_ok(x: Tensor, pre_ln: bool, *widths: int) -> bool:
-    return (rt.composite() and pre_ln and rt.precision() == "bf16" and x.is_cuda and x.stride(0) == x.shape[1]
-            and all(w % 64 == 0 for w in widths))
+def _composite_ok(x: Tensor, pre_ln: bool, *widths: int, f16x2: bool = True) -> bool:
+    """f16x2: the sub-layer has an fp16 two-pass forward (self-attention and MLP; the cross-attention composite is bf16 only)"""
+    return (rt.composite() and pre_ln and rt.precision() in (("bf16", "fp16x2") if f16x2 else ("bf16",)) and x.is_cuda
+            and x.stride(0) == x.shape[1] and all(w % 64 == 0 for w in widths))
+
+
+def _img_h(W: Tensor):
+    """(pointer, leading dimension) of the FP16 image of a 2-D weight ('fp16x2' forward)"""
+    h = rt.weight_f16(W)
+    return h.data_ptr(), h.stride(0)
 
 
 def _img(W: Tensor):
@@ -624,8 +662,16 @@ def _attn_fwd_c(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, ep
     dev = x.device
     nseq, pr = R // L, rt.pad64(R)
     ctx.up = _upstream_of(x)
-    saved = torch.empty(pr * 5 * d, dtype=torch.bfloat16, device=dev)
-    xn, qkv, ao = Act.carve(saved, 0, R, d), Act.carve(saved, pr * d, R, 3 * d), Act.carve(saved, pr * 4 * d, R, d)
+    f16x2 = rt.precision() == "fp16x2"
+    grad = any(ctx.needs_input_grad)
+    # the bf16 activations the backward pass reads; in the fp16x2 forward they are COPIES beside the fp16 operand planes (hi + lo
+    # of xn | qkv | ao, forward-only scratch) and a forward nobody differentiates does not make them
+    saved = torch.empty(pr * 5 * d, dtype=torch.bfloat16, device=dev) if (grad or not f16x2) else None
+    planes = torch.empty(2 * pr * 5 * d, dtype=torch.float16, device=dev) if f16x2 else None
+    if saved is not None:
+        xn, qkv, ao = Act.carve(saved, 0, R, d), Act.carve(saved, pr * d, R, 3 * d), Act.carve(saved, pr * 4 * d, R, d)
+    else:
+        xn = qkv = ao = None
     stats = torch.empty(2, R, dtype=torch.float32, device=dev)
     probs = probs_out if probs_out is not None else torch.empty(nseq, H, L, L, dtype=torch.float32, device=dev)
     y = torch.empty(R, d, dtype=torch.float32, device=dev)
@@ -634,15 +680,24 @@ def _attn_fwd_c(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, ep
     s = L_.AttnSublayer()
     s.rows, s.d, s.L, s.H, s.conv1d, s.mask, s.mask_period, s.eps, s.scale = R, d, L, H, int(conv1d), mk, per, eps, scale
     s.x, s.ln_w, s.ln_b = x.data_ptr(), _ptr(ln_w), _ptr(ln_b)
-    s.w_qkv, s.ldw_qkv = _img(w_qkv)
-    s.w_proj, s.ldw_proj = _img(w_proj)
-    s.w_qkv_pk, s.w_proj_pk = _pk(w_qkv, conv1d, R), _pk(w_proj, conv1d, R)
+    if f16x2:
+        s.f16x2 = 1
+        s.w_qkv, s.ldw_qkv = _img_h(w_qkv)
+        s.w_proj, s.ldw_proj = _img_h(w_proj)
+        base = planes.data_ptr()
+        s.xn, s.qkv, s.ao = base, base + 2 * (2 * pr * d), base + 2 * (2 * pr * 4 * d)      # [hi | lo] of xn, then of qkv, then of ao
+        if saved is not None:
+            s.xn_b, s.qkv_b, s.ao_b = xn.buf.data_ptr(), qkv.buf.data_ptr(), ao.buf.data_ptr()
+    else:
+        s.w_qkv, s.ldw_qkv = _img(w_qkv)
+        s.w_proj, s.ldw_proj = _img(w_proj)
+        s.w_qkv_pk, s.w_proj_pk = _pk(w_qkv, conv1d, R), _pk(w_proj, conv1d, R)
+        s.xn, s.qkv, s.ao = xn.buf.data_ptr(), qkv.buf.data_ptr(), ao.buf.data_ptr()
     s.b_qkv, s.b_proj = _ptr(b_qkv), _ptr(b_proj)
     s.p_attn, s.k_attn = _attn_drop(drop)
     od = _out_drop(drop)
     if od is not None:
         s.out_drop = od
-    s.xn, s.qkv, s.ao = xn.buf.data_ptr(), qkv.buf.data_ptr(), ao.buf.data_ptr()
     s.mean, s.rstd, s.probs, s.y = stats[0].data_ptr(), stats[1].data_ptr(), probs.data_ptr(), y.data_ptr()
     main_raw = ops._stream()
     _fill_ws(s, dev, main_raw, None)
@@ -732,22 +787,37 @@ def _mlp_fwd_c(ctx, x, ln_w, ln_b, w1, b1, w2, b2, eps, gelu, conv1d, hidden, dr
     dev = x.device
     pr = rt.pad64(R)
     ctx.up = _upstream_of(x)
-    saved = torch.empty(pr * (d + 2 * hidden), dtype=torch.bfloat16, device=dev)
-    xn, u, h = Act.carve(saved, 0, R, d), Act.carve(saved, pr * d, R, hidden), Act.carve(saved, pr * (d + hidden), R, hidden)
+    f16x2 = rt.precision() == "fp16x2"
+    grad = any(ctx.needs_input_grad)
+    saved = torch.empty(pr * (d + 2 * hidden), dtype=torch.bfloat16, device=dev) if (grad or not f16x2) else None      # cf. _attn_fwd_c
+    planes = torch.empty(2 * pr * (d + hidden), dtype=torch.float16, device=dev) if f16x2 else None      # [hi | lo] of xn, then of h
+    if saved is not None:
+        xn, u, h = Act.carve(saved, 0, R, d), Act.carve(saved, pr * d, R, hidden), Act.carve(saved, pr * (d + hidden), R, hidden)
+    else:
+        xn = u = h = None
     stats = torch.empty(2, R, dtype=torch.float32, device=dev)
     y = torch.empty(R, d, dtype=torch.float32, device=dev)
     s = L_.MLPSublayer()
     s.rows, s.d, s.hidden, s.conv1d, s.gelu, s.eps = R, d, hidden, int(conv1d), _GELU[gelu][0], eps
     s.x, s.ln_w, s.ln_b = x.data_ptr(), _ptr(ln_w), _ptr(ln_b)
-    s.w1, s.ldw1 = _img(w1)
-    s.w2, s.ldw2 = _img(w2)
-    s.w1_pk, s.w2_pk = _pk(w1, conv1d, R), _pk(w2, conv1d, R)
+    # the pre-activation is only read by backward: a forward nobody will differentiate (no_grad) does not store it (84 MB at R = 5120)
+    if f16x2:
+        s.f16x2 = 1
+        s.w1, s.ldw1 = _img_h(w1)
+        s.w2, s.ldw2 = _img_h(w2)
+        base = planes.data_ptr()
+        s.xn, s.h = base, base + 2 * (2 * pr * d)
+        if saved is not None:
+            s.xn_b, s.u, s.h_b = xn.buf.data_ptr(), u.buf.data_ptr(), h.buf.data_ptr()
+    else:
+        s.w1, s.ldw1 = _img(w1)
+        s.w2, s.ldw2 = _img(w2)
+        s.w1_pk, s.w2_pk = _pk(w1, conv1d, R), _pk(w2, conv1d, R)
+        s.xn, s.u, s.h = xn.buf.data_ptr(), (u.buf.data_ptr() if grad else None), h.buf.data_ptr()
     s.b1, s.b2 = _ptr(b1), _ptr(b2)
     od = _out_drop(drop)
     if od is not None:
         s.out_drop = od
-    # the pre-activation is only read by backward: a forward nobody will differentiate (no_grad) does not store it (84 MB at R = 5120)
-    s.xn, s.u, s.h = xn.buf.data_ptr(), (u.buf.data_ptr() if any(ctx.needs_input_grad) else None), h.buf.data_ptr()
     s.mean, s.rstd, s.y = stats[0].data_ptr(), stats[1].data_ptr(), y.data_ptr()
     main_raw = ops._stream()
     _fill_ws(s, dev, main_raw, None)
@@ -986,6 +1056,7 @@ class AttnSublayer(torch.autograd.Function):
         return y, probs
 
     @staticmethod
+    @_in_backward_precision
     def backward(ctx, dy, _dprobs):
         if dy is None:          # (set_materialize_grads(False)) nobody used y
             _drop_shadow()      # a hand-over meant for this backward and queued notifications must not outlive it
@@ -994,7 +1065,7 @@ class AttnSublayer(torch.autograd.Function):
         if ctx.composite:
             return _attn_bwd_c(ctx, dy)
         x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, mean, rstd, probs = ctx.saved_tensors
-        xn, qkv, ao = ctx.acts
+        xn, qkv, ao = (_b16(t) for t in ctx.acts)
         L, H, scale, conv1d, pre_ln, drop = ctx.cfg
         R, d = x.shape
         nseq, hd = R // L, d // H
@@ -1059,11 +1130,12 @@ class MLPSublayer(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_in_backward_precision
     def backward(ctx, dy):
         if ctx.composite:
             return _mlp_bwd_c(ctx, dy)
         x, ln_w, ln_b, w1, b1, w2, b2, mean, rstd = ctx.saved_tensors
-        xn, u, h = ctx.acts
+        xn, u, h = (_b16(t) for t in ctx.acts)
         gelu, conv1d, hidden, pre_ln, drop = ctx.cfg
         R, d = x.shape
         dev = x.device
@@ -1105,7 +1177,7 @@ class CrossAttnSublayer(torch.autograd.Function):
         nseq, hd = R // L, d // H
         dev = x.device
         ctx.composite = False
-        if _composite_ok(x, pre_ln, d) and mem.stride(0) == d:
+        if _composite_ok(x, pre_ln, d, f16x2=False) and mem.stride(0) == d:
             return _cross_fwd_c(ctx, x, mem, nq_w, nq_b, nkv_w, nkv_b, w_q, w_k, w_v, w_proj, b_proj, L, H, mask, eps, scale,
                                 drop)
         ctx.up = _upstream_of(x) if pre_ln else None
@@ -1136,11 +1208,12 @@ class CrossAttnSublayer(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_in_backward_precision
     def backward(ctx, dy):
         if ctx.composite:
             return _cross_bwd_c(ctx, dy)
         (x, mem, nq_w, nq_b, nkv_w, nkv_b, w_q, w_k, w_v, w_proj, b_proj, mq, rq, mk, rk, probs) = ctx.saved_tensors
-        xq, mkv, q, k, v, ao = ctx.acts
+        xq, mkv, q, k, v, ao = (_b16(t) for t in ctx.acts)
         L, H, scale, pre_ln, drop = ctx.cfg
         R, d = x.shape
         nseq, hd = R // L, d // H
@@ -1199,9 +1272,10 @@ class Linear(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_in_backward_precision
     def backward(ctx, dy):
         W, b = ctx.saved_tensors
-        xa = ctx.xa
+        xa = _b16(ctx.xa)
         _drop_shadow()
         dya = to_act(dy)
         with _Side(dy.device):
@@ -1247,9 +1321,11 @@ class LinearAct(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_in_backward_precision
     def backward(ctx, dy):
         W, b, aux, y = ctx.saved_tensors
         xa, pre = ctx.acts
+        xa = _b16(xa)
         act, out_drop = ctx.cfg
         rows, n_out = xa.rows, W.shape[0]
         dev = dy.device

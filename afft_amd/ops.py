@@ -8,11 +8,11 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib as L
-from ._lib import (ACT_DGELU_ERF, ACT_DGELU_TANH, ACT_GELU_ERF, ACT_GELU_TANH, ACT_NONE, BF16, F32, MASK_CAUSAL,
+from ._lib import (ACT_DGELU_ERF, ACT_DGELU_TANH, ACT_GELU_ERF, ACT_GELU_TANH, ACT_NONE, BF16, F16, F32, MASK_CAUSAL,
                    MASK_DIAG, MASK_NONE)
 
 Tensor = torch.Tensor
-_DT = {torch.float32: F32, torch.bfloat16: BF16}
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
 
 def _dt(t: Tensor) -> int:
@@ -96,14 +96,23 @@ def gemm(a, b, out: Tensor, *, a_t: bool = False, b_t: bool = False, bias: Optio
          act: int = ACT_NONE, aux: Optional[Tensor] = None, pre: Optional[Tensor] = None,
          rowscale: Optional[Tensor] = None, residual: Optional[Tensor] = None, accumulate: bool = False,
          out2: Optional[Tensor] = None, alpha: float = 1.0, drop: Optional["L.Dropout"] = None,
-         max_workgroups: int = 0, sgd: Optional["L.SgdFused"] = None, b_packed: Optional[Tensor] = None) -> Tensor:
+         max_workgroups: int = 0, sgd: Optional["L.SgdFused"] = None, b_packed: Optional[Tensor] = None,
+         out_lo: int = 0) -> Tensor:
     """out = epilogue(alpha * A @ B).  A = a (or a.T if a_t), B = b (or b.T if b_t); a, b 2-D views -- or both `Split`
-    (two-plane bf16 splits of fp32 matrices): the bf16x3 GEMM, fp32-accurate products on the bf16 MFMA path.
-    b_packed: the fragment-packed copy of a weight `b` [N, K] used as b.T (pack_weight; afft_gemm_t.b_packed)."""
+    (two-plane bf16 splits of fp32 matrices): the bf16x3 GEMM, fp32-accurate products on the bf16 MFMA path; or a an fp16 `Split`
+    and b a plain fp16 matrix (a weight's FP16 image): the fp16 two-pass forward GEMM (afft_gemm_t.split3 = 2).
+    b_packed: the fragment-packed copy of a weight `b` [N, K] used as b.T (pack_weight; afft_gemm_t.b_packed).
+    out_lo: `out` (fp16) is the hi plane of a two-plane split of the result, the lo plane sits out_lo elements behind it."""
     d = L.GemmDesc()
-    if isinstance(a, Split):
-        if not isinstance(b, Split):
-            raise TypeError("afft_amd.gemm: both operands must be Split for a bf16x3 GEMM")
+    if isinstance(a, Split) and not isinstance(b, Split):
+        if not (a.f16 and isinstance(b, torch.Tensor) and b.dtype == torch.float16) or a_t:
+            raise TypeError("afft_amd.gemm: a Split A with a plain B is the fp16 two-pass forward GEMM (fp16 planes, fp16 B, A not transposed)")
+        sa = a
+        a = sa.planes[0]
+        M, K = sa.rows, a.shape[1]
+        Kb, N = (b.shape[1], b.shape[0]) if b_t else (b.shape[0], b.shape[1])
+        d.split3, d.a_lo, d.b_lo = 2, a.numel(), 0
+    elif isinstance(a, Split):
         sa, sb = a, b
         a, b = sa.planes[0], sb.planes[0]
         M, K = (sa.cols, a.shape[0]) if a_t else (sa.rows, a.shape[1])
@@ -151,6 +160,9 @@ def gemm(a, b, out: Tensor, *, a_t: bool = False, b_t: bool = False, bias: Optio
         d.residual, d.ldres = _p(residual), _rowmajor(residual, "residual")
     d.accumulate = 1 if accumulate else 0
     d.out, d.ldo, d.out_dtype = _p(out), _rowmajor(out, "out"), _dt(out)
+    if out_lo:
+        assert out.dtype == torch.float16 and out_lo % 8 == 0
+        d.out_lo = int(out_lo)
     if out2 is not None:
         d.out2, d.ldo2, d.out2_dtype = _p(out2), _rowmajor(out2, "out2"), _dt(out2)
     if drop is not None:
@@ -167,6 +179,17 @@ def layernorm_fwd(x: Tensor, w: Optional[Tensor], b: Optional[Tensor], eps: floa
     L.check(L.lib().afft_layernorm_fwd(_p(x), _rowmajor(x, "x"), _p(w), _p(b), eps, rows, d, _p(y),
                                        _rowmajor(y, "y"), _dt(y), _p(mean), _p(rstd), _stream()), "layernorm_fwd")
     return y
+
+
+def layernorm_fwd_split(x: Tensor, w: Optional[Tensor], b: Optional[Tensor], eps: float, y_hi: Tensor, y_lo: int,
+                        y_bf16: Optional[Tensor] = None, mean: Optional[Tensor] = None, rstd: Optional[Tensor] = None) -> Tensor:
+    """LayerNorm whose result is written as two fp16 planes (hi at y_hi, lo y_lo elements behind it) and, optionally, as a bf16 copy."""
+    assert x.dtype == torch.float32 and y_hi.dtype == torch.float16 and (y_bf16 is None or y_bf16.dtype == torch.bfloat16)
+    rows, d = x.shape
+    L.check(L.lib().afft_layernorm_fwd_split(_p(x), _rowmajor(x, "x"), _p(w), _p(b), eps, rows, d, _p(y_hi), _rowmajor(y_hi, "y_hi"),
+                                             int(y_lo), _p(y_bf16), _rowmajor(y_bf16, "y_bf16") if y_bf16 is not None else 0,
+                                             _p(mean), _p(rstd), _stream()), "layernorm_fwd_split")
+    return y_hi
 
 
 def layernorm_bwd(dy: Tensor, x: Tensor, w: Optional[Tensor], mean: Tensor, rstd: Tensor, dx_out: Tensor,
@@ -199,6 +222,19 @@ def attention_fwd(q: Tensor, k: Tensor, v: Tensor, nseq: int, L_: int, H: int, h
                                        _dt(q), nseq, L_, H, hd, scale, mask, mask_period, drop_p, drop_key, _p(out),
                                        _rowmajor(out, "out"), _p(probs), _stream()), "attention_fwd")
     return out
+
+
+def attention_fwd_split(q: Tensor, k: Tensor, v: Tensor, in_lo: int, nseq: int, L_: int, H: int, hd: int, scale: float, mask: int,
+                        out_hi: Tensor, out_lo: int, out_bf16: Optional[Tensor], probs: Optional[Tensor], drop_p: float = 0.0,
+                        drop_key: int = 0, mask_period: int = 0) -> Tensor:
+    """fp16x2 forward attention: q / k / v / out_hi are the hi planes of two-plane fp16 splits (lo planes in_lo / out_lo elements behind)"""
+    assert q.dtype == k.dtype == v.dtype == out_hi.dtype == torch.float16
+    L.check(L.lib().afft_attention_fwd_split(_p(q), _rowmajor(q, "q"), _p(k), _rowmajor(k, "k"), _p(v), _rowmajor(v, "v"), int(in_lo),
+                                             nseq, L_, H, hd, scale, mask, mask_period, drop_p, drop_key, _p(out_hi),
+                                             _rowmajor(out_hi, "out"), int(out_lo), _p(out_bf16),
+                                             _rowmajor(out_bf16, "out_bf16") if out_bf16 is not None else 0, _p(probs), _stream()),
+            "attention_fwd_split")
+    return out_hi
 
 
 def attention_bwd(dout: Tensor, q: Tensor, k: Tensor, v: Tensor, probs: Tensor, nseq: int, L_: int, H: int, hd: int,
@@ -315,22 +351,25 @@ def reduce_rows_periodic(src: Tensor, period: int, out: Tensor):
 
 
 def sgd_nesterov(p: Tensor, g: Tensor, buf: Tensor, lr: float, mom: float, wd: float, gscale: float, first,
-                 p_bf16: Optional[Tensor] = None, gscale_dev: Optional[Tensor] = None):
-    """first: bool (first step) or the AFFT_SGD_* flag word (1 = first step, 2 = plain momentum instead of Nesterov)"""
+                 p_bf16: Optional[Tensor] = None, gscale_dev: Optional[Tensor] = None, p_f16: Optional[Tensor] = None):
+    """first: bool (first step) or the AFFT_SGD_* flag word (1 = first step, 2 = plain momentum instead of Nesterov);
+    p_bf16 / p_f16: the bf16 / fp16 images of the updated weights (same element offsets as p)"""
     assert p.is_contiguous() and g.is_contiguous() and buf.is_contiguous()
     if p_bf16 is not None:
         assert p_bf16.dtype == torch.bfloat16 and p_bf16.numel() == p.numel() and p_bf16.is_contiguous()
-    L.check(L.lib().afft_sgd_nesterov(_p(p), _p(g), _dt(g), _p(buf), _p(p_bf16), p.numel(), lr, mom, wd, gscale,
-                                      _p(gscale_dev), int(first), _stream()), "sgd_nesterov")
+    if p_f16 is not None:
+        assert p_f16.dtype == torch.float16 and p_f16.numel() == p.numel() and p_f16.is_contiguous()
+    L.check(L.lib().afft_sgd_nesterov2(_p(p), _p(g), _dt(g), _p(buf), _p(p_bf16), _p(p_f16), p.numel(), lr, mom, wd, gscale,
+                                       _p(gscale_dev), int(first), _stream()), "sgd_nesterov")
 
 
 def sgd_nesterov_runs(p: Tensor, g: Tensor, buf: Tensor, runs: Tensor, lr: float, mom: float, wd: float, gscale: float, first: bool,
-                      p_bf16: Optional[Tensor] = None):
+                      p_bf16: Optional[Tensor] = None, p_f16: Optional[Tensor] = None):
     """the same update over the runs {start, length} (int64 [nruns, 2] on the device) of whole flat buffers"""
     assert runs.dtype == torch.int64 and runs.dim() == 2 and runs.shape[1] == 2 and runs.is_contiguous()
     assert p.dtype == g.dtype == buf.dtype == torch.float32
-    L.check(L.lib().afft_sgd_nesterov_runs(_p(p), _p(g), _p(buf), _p(p_bf16), _p(runs), runs.shape[0], lr, mom, wd, gscale,
-                                           int(first), _stream()), "sgd_nesterov_runs")
+    L.check(L.lib().afft_sgd_nesterov_runs2(_p(p), _p(g), _p(buf), _p(p_bf16), _p(p_f16), _p(runs), runs.shape[0], lr, mom, wd, gscale,
+                                            int(first), _stream()), "sgd_nesterov_runs")
 
 
 def pack_weight(w: Tensor, dst: Tensor) -> Tensor:

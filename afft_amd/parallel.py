@@ -69,6 +69,9 @@ class FlatParams:
         use_pk = dev.type == "cuda" and rt.packed_images()
         self.flat_pk16 = torch.zeros(off, dtype=torch.bfloat16, device=dev) if use_pk else None
         self.packed: List[tuple] = []         # (offset, param, packed flat view)
+        # FP16 images (same offsets; the B operands of the fp16 two-pass forward GEMMs, precision 'fp16x2'): allocated the first
+        # time a step runs in that precision (ensure_f16) and from then on written by every optimizer kernel beside the bf16 ones
+        self.flat_h16: Optional[Tensor] = None
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 n = p.numel()
@@ -90,6 +93,23 @@ class FlatParams:
                             self.packed.append((o, p, pk))
                         rt.adopt_weight_image(p, self.flat_p16[o:o + p.numel()].view(p.shape), vt, packed=pk)
         rt.invalidate_weight_images()
+        self.ensure_f16()
+
+    def ensure_f16(self):
+        """the FP16 images exist once the precision is 'fp16x2' (called at construction and when a step begins)"""
+        if self.flat_h16 is not None or rt.precision() != "fp16x2" or not self.flat_p.is_cuda:
+            return
+        n = self.total
+        self.flat_h16 = torch.zeros(n, dtype=torch.float16, device=self.flat_p.device)
+        with torch.no_grad():
+            ops.cast(self.flat_p.view(n // 64, 64), self.flat_h16.view(n // 64, 64))
+        for p, o in zip(self.params, self.offsets):
+            img = getattr(p, "_afft_img", None)
+            if img is not None and img.external and p.dim() == 2:
+                rt.adopt_weight_f16(p, self.flat_h16[o:o + p.numel()].view(p.shape))
+
+    def h16(self, s: int = 0, e: Optional[int] = None) -> Optional[Tensor]:
+        return None if self.flat_h16 is None else self.flat_h16[s:self.total if e is None else e]
 
     def refresh_images(self):
         """Re-derive every bf16 image from the fp32 masters (after the masters were written from outside: a parameter
@@ -98,6 +118,8 @@ class FlatParams:
             n = self.total
             with torch.no_grad():
                 ops.cast(self.flat_p.view(n // 64, 64), self.flat_p16.view(n // 64, 64))
+                if self.flat_h16 is not None:
+                    ops.cast(self.flat_p.view(n // 64, 64), self.flat_h16.view(n // 64, 64))
             self.refresh_transposed(0, n)
             self.refresh_packed(0, n)
         rt.invalidate_weight_images()
@@ -172,6 +194,7 @@ class GradReducer:
     def begin_step(self):
         from . import functional as F_
         F_.settle_joins(self.flat.flat_g.device, drop_pending=True)      # a previous backward pass that raised left its end-of-pass join undone
+        self.flat.ensure_f16()
         self._count = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._handles = []
@@ -352,12 +375,12 @@ class FusedSGD:
                 if runs is not None:
                     if runs.shape[0]:
                         ops.sgd_nesterov_runs(self.flat.flat_p, self.flat.flat_g, self.buf, runs, self.lr, self.momentum, self.wd,
-                                              gscale, self.flags(), p_bf16=self.flat.flat_p16)
+                                              gscale, self.flags(), p_bf16=self.flat.flat_p16, p_f16=self.flat.flat_h16)
                     self.flat.refresh_packed(s, e, skip=self.skip)
                     return
             p16 = self.flat.flat_p16[s:e] if self.flat.flat_p16 is not None else None
             ops.sgd_nesterov(self.flat.flat_p[s:e], grad, self.buf[s:e], self.lr, self.momentum, self.wd, gscale,
-                             self.flags(), p_bf16=p16, gscale_dev=gscale_dev)
+                             self.flags(), p_bf16=p16, gscale_dev=gscale_dev, p_f16=self.flat.h16(s, e))
             self.flat.refresh_transposed(s, e)
             self.flat.refresh_packed(s, e)
             return
@@ -375,7 +398,7 @@ class FusedSGD:
                     g_full = flat.flat_g if grad.data_ptr() == flat.flat_g[s:e].data_ptr() else None
                     if g_full is not None:
                         ops.sgd_nesterov_runs(flat.flat_p, g_full, self.buf, runs, lr, self.momentum, wd, gscale, self.flags(),
-                                              p_bf16=flat.flat_p16)
+                                              p_bf16=flat.flat_p16, p_f16=flat.flat_h16)
                         continue
                 elif fused:
                     continue
@@ -386,7 +409,7 @@ class FusedSGD:
                 n = _align(p.numel())
                 p16 = flat.flat_p16[o:o + n] if flat.flat_p16 is not None else None
                 ops.sgd_nesterov(flat.flat_p[o:o + n], grad[o - s:o - s + n], self.buf[o:o + n], lr, self.momentum, wd, gscale,
-                                 self.flags(), p_bf16=p16, gscale_dev=gscale_dev)
+                                 self.flags(), p_bf16=p16, gscale_dev=gscale_dev, p_f16=flat.h16(o, o + n))
         self.flat.refresh_transposed(s, e)
         self.flat.refresh_packed(s, e, skip=(self.skip if fused else ()))
 
@@ -422,7 +445,7 @@ class _FusedEpilogue:
 
     # ---- optimizer fused into the weight-gradient GEMM epilogues (single GPU)
     def _can_fuse(self) -> bool:
-        return (rt.fused_sgd() and rt.composite() and rt.precision() == "bf16" and rt.grad_mode() == "sink"
+        return (rt.fused_sgd() and rt.composite() and rt.precision() in ("bf16", "fp16x2") and rt.grad_mode() == "sink"
                 and self.flat.flat_p.is_cuda and self.flat.flat_p16 is not None and self.flat.flat_pT16 is None
                 and not self.reducer.comm and self.grad_clip is None and not rt.CAPTURING)
 
@@ -494,7 +517,7 @@ class _FusedEpilogue:
             n = _align(p.numel())
             lr, wd = self.opt.hyper_of(self._index[pid])
             ops.sgd_nesterov(flat.flat_p[o:o + n], flat.flat_g[o:o + n], self.opt.buf[o:o + n], lr, self.opt.momentum,
-                             wd, 1.0, self.opt.flags(), p_bf16=flat.flat_p16[o:o + n])
+                             wd, 1.0, self.opt.flags(), p_bf16=flat.flat_p16[o:o + n], p_f16=flat.h16(o, o + n))
             flat.refresh_packed(o, o + 1)
             stale.append(pid)
         if stale:
@@ -503,6 +526,9 @@ class _FusedEpilogue:
             self.opt.runs = self._runs_without(self._fused)
             return True
         return False
+
+    def _offset_of(self, p: Tensor) -> int:
+        return self.flat.offsets[self._index[id(p)]]
 
     @property
     def _index(self) -> Dict[int, int]:
@@ -516,6 +542,8 @@ class _FusedEpilogue:
         if d is not None:
             lr, wd = self.opt.hyper_of(self._index[id(p)])
             d.p_pk16 = p._afft_img.pk.data_ptr() if rt.packed_live(p) else None      # only images a forward GEMM uses are kept fresh
+            h16 = self.flat.flat_h16
+            d.p_f16 = (h16.data_ptr() + 2 * self._offset_of(p)) if h16 is not None else None
             d.lr, d.mom, d.wd, d.gscale, d.first_step = lr, self.opt.momentum, wd, 1.0, self.opt.flags() & 2
         return d
 

@@ -61,6 +61,13 @@ class precision_scope:
         return False
 
 
+def backward_precision() -> Optional[str]:
+    """The precision a backward pass runs in when it differs from the forward's: 'fp16x2' is a FORWARD format (activations hi + lo
+    in fp16, weights rounded once to fp16: logits inside the reference's 1e-3); its backward pass is the single-pass bf16 one on
+    bf16 copies of the saved activations and the bf16 weight images (gradients keep fp32's exponent range: no loss scaling)."""
+    return "bf16" if _PRECISION == "fp16x2" else None
+
+
 def act_dtype() -> torch.dtype:
     return torch.bfloat16 if _PRECISION == "bf16" else torch.float32
 
@@ -95,7 +102,7 @@ def pad64(n: int) -> int:
 
 # --------------------------------------------------------------------------- bf16 weight images
 class _WImage:
-    __slots__ = ("version", "ptr", "w", "wt", "external", "pk", "pk_live")
+    __slots__ = ("version", "ptr", "w", "wt", "external", "pk", "pk_live", "pk_version", "h", "h_version", "h_external")
 
 
 _wlist: list = []   # weak references to parameters that own an image (for invalidate_weight_images)
@@ -128,14 +135,48 @@ def weight_images(p: Tensor):
         img.external = False
         img.pk = None
         img.pk_live = False
+        img.pk_version = -1
+        img.h = None
+        img.h_version = -1
+        img.h_external = False
         img.ptr = p.data_ptr()
         p._afft_img = img
         _register(p)
     if img.version != ver:
         with torch.no_grad():
-            ops.cast(p.detach(), img.w[:p.shape[0], :p.shape[1]], img.wt[:p.shape[1], :p.shape[0]])
+            ops.cast(p.detach(), img.w[:p.shape[0], :p.shape[1]], None if img.wt is None else img.wt[:p.shape[1], :p.shape[0]])
         img.version = ver
     return img.w, img.wt
+
+
+def weight_f16(p: Tensor) -> Tensor:
+    """FP16 image [pad64(rows), pad64(cols)] of a 2-D fp32 parameter: the B operand of the fp16 two-pass forward GEMMs ('fp16x2'
+    precision; the weight is rounded ONCE to fp16, the activation side carries hi + lo).  A parameter homed in the flat buffers
+    (parallel.FlatParams) has its image there, written by the optimizer kernels beside the bf16 one (FlatParams.f16_images);
+    any other parameter gets a cast image that is redone when its version counter or storage changes."""
+    weight_images(p)                      # creates / validates the record (and the bf16 image the backward pass reads)
+    img = p._afft_img
+    if img.h_external:
+        if img.h_version != p._version:   # written from outside (load_state_dict, p.copy_): re-derive, as weight_images does
+            with torch.no_grad():
+                ops.cast(p.detach(), img.h)
+            img.h_version = p._version
+        return img.h
+    if img.h is None:
+        rows, cols = p.shape
+        img.h = torch.zeros(pad64(rows), pad64(cols), dtype=torch.float16, device=p.device)
+        img.h_version = -1
+    if img.h_version != p._version:
+        with torch.no_grad():
+            ops.cast(p.detach(), img.h[:p.shape[0], :p.shape[1]])
+        img.h_version = p._version
+    return img.h
+
+
+def adopt_weight_f16(p: Tensor, view16: Tensor):
+    """use `view16` (fp16, the shape of p, kept fresh by the optimizer kernels) as p's FP16 image"""
+    img = p._afft_img
+    img.h, img.h_version, img.h_external = view16, p._version, True
 
 
 def weight_split(p: Tensor):
@@ -185,6 +226,15 @@ def weight_packed(p: Tensor, rows: Optional[int] = None) -> Optional[Tensor]:
         with torch.no_grad():
             ops.pack_weight(p.detach(), img.pk)      # forward pass, current stream: the parameter is at rest
         img.pk_live = True
+        img.pk_version = p._version
+    elif img.pk_version != p._version:
+        # the parameter was written from outside the optimizer kernels (model.load_state_dict, p.copy_ into the flat views: they
+        # bump the version counter; the optimizer kernels write through raw pointers and keep every image fresh themselves):
+        # re-pack, exactly as weight_images() re-casts the row-major image
+        from . import ops
+        with torch.no_grad():
+            ops.pack_weight(p.detach(), img.pk)
+        img.pk_version = p._version
     return img.pk
 
 
@@ -209,6 +259,10 @@ def adopt_weight_image(p: Tensor, view16: Tensor, view16_t: Optional[Tensor] = N
     img.wt = view16_t
     img.pk = packed
     img.pk_live = False
+    img.pk_version = -1
+    img.h = None
+    img.h_version = -1
+    img.h_external = False
     img.version = p._version
     img.external = True
     img.ptr = p.data_ptr()
@@ -225,6 +279,10 @@ def invalidate_weight_images(include_external: bool = False):
         img = getattr(p, "_afft_img", None)
         if img is not None and (include_external or not img.external):
             img.version = -1
+        if img is not None and (include_external or not img.h_external):
+            img.h_version = -1
+        if img is not None and include_external:
+            img.pk_version = -1
         if getattr(p, "_afft_split", None) is not None:
             p._afft_split = None
         if img is not None or hasattr(p, "_afft_split"):

@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-enum { AFFT_F32 = 0, AFFT_BF16 = 1 };
+enum { AFFT_F32 = 0, AFFT_BF16 = 1,
+       AFFT_F16 = 2 };   /* fp16 planes of the "fp16x2" precision: outputs / copies / images only (a GEMM's operand dtype stays AFFT_BF16 =
+                          * "16-bit planes", afft_gemm_t.split3 = 2 says they are fp16) */
 enum { AFFT_ACT_NONE = 0, AFFT_ACT_GELU_ERF = 1, AFFT_ACT_GELU_TANH = 2,
        AFFT_ACT_DGELU_ERF = 3,   /* v *= d/du gelu_erf(aux[m,n])  (backward of nn.GELU)  */
        AFFT_ACT_DGELU_TANH = 4,  /* v *= d/du gelu_new(aux[m,n])  (backward of HF gelu_new) */
@@ -105,6 +107,11 @@ typedef struct {
    * B); without it, or when the cost model prefers the LDS-staged kernels, B is read row-major as before.  Same result up to
    * the summation order inside a tile (both accumulate K in order, fp32). */
   const void* b_packed;
+  /* out_dtype AFFT_F16 and out_lo != 0: `out` is the HI plane of a two-plane fp16 split of the result, hi = fp16(v), and
+   * lo = fp16(v - hi) is stored out_lo ELEMENTS behind it (same leading dimension): the producing GEMM writes the A operand of the
+   * next fp16 two-pass GEMM (split3 = 2, a_lo = out_lo) directly -- no fp32 round trip, no split kernel.  out2 (any dtype, e.g. the
+   * bf16 copy the backward pass reads) and pre are stored as before. */
+  int64_t out_lo;
 } afft_gemm_t;
 /* Nesterov-SGD update fused into the epilogue of the weight-gradient GEMM that produces the gradient (single-GPU training, no
  * gradient clipping, a weight that receives exactly one gradient contribution per step): element [m, n] of the result is the
@@ -117,7 +124,9 @@ typedef struct afft_sgd_fused {
   float* p; float* buf; void* p_bf16;
   float lr, mom, wd, gscale; int32_t first_step;   /* first_step: AFFT_SGD_* flags (below) */
   void* p_pk16;                                    /* optional: the fragment-packed bf16 image (afft_pack_weight) of the same weight, */
-} afft_sgd_fused_t;                                /* refreshed by the same epilogue (ldo % 32 == 0 and M % 16 == 0)               */
+                                                   /* refreshed by the same epilogue (ldo % 32 == 0 and M % 16 == 0)               */
+  void* p_f16;                                     /* optional: the row-major FP16 image (layout of p_bf16): the B operand of the   */
+} afft_sgd_fused_t;                                /* fp16 two-pass forward GEMMs ("fp16x2" precision)                              */
 /* `first_step` of every optimizer entry point is a flag word: AFFT_SGD_FIRST_STEP = the momentum buffer does not exist yet (it
  * starts as the gradient: torch.optim.SGD's first step); AFFT_SGD_PLAIN_MOMENTUM = torch.optim.SGD(nesterov=False):
  * p -= lr * buf instead of the Nesterov form p -= lr * (g' + mom * buf) (conf/opt/optimizer/sgd.yaml ships nesterov: false,
@@ -177,6 +186,12 @@ int afft_kernel_trace_end(afft_kernel_trace_rec_t* out, int32_t capacity);
 int afft_layernorm_fwd(const float* x, int64_t ldx, const float* w, const float* b,
                        float eps, int32_t rows, int32_t d, void* y, int64_t ldy, int32_t y_dtype,
                        float* mean, float* rstd, void* stream);
+/* The same LayerNorm with the result written as the operand planes of the "fp16x2" precision: y_hi [rows, d] fp16 = fp16(y),
+ * y_hi + y_lo (ELEMENTS) = fp16(y - hi) (the A operand of an fp16 two-pass GEMM, afft_gemm_t.split3 = 2), and -- optional --
+ * y_bf16 = bf16(y), the copy the single-pass bf16 backward reads (weight-gradient operand).  y_lo = 0: hi plane only. */
+int afft_layernorm_fwd_split(const float* x, int64_t ldx, const float* w, const float* b, float eps, int32_t rows, int32_t d,
+                             void* y_hi, int64_t ldy, int64_t y_lo, void* y_bf16, int64_t ldyb, float* mean, float* rstd,
+                             void* stream);
 /* dx_out[r] = (dx_in ? dx_in[r] : 0) + LN'(dy)[r]; dw/db are written (accumulate = 0) or added to (+=).
  * dy dtype selectable.
  * dx_bf16 (optional) receives a bf16 copy of dx_out with the dropout / DropPath mask `copy_drop` (optional) replayed
@@ -207,6 +222,14 @@ int afft_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, c
                        int32_t dtype, int32_t nseq, int32_t L, int32_t H, int32_t hd, float scale, int32_t mask,
                        int32_t mask_period, float drop_p, uint32_t drop_key, void* out, int64_t ldo, float* probs,
                        void* stream);
+/* "fp16x2" forward: q / k / v are the HI planes of two-plane fp16 splits (lo planes in_lo ELEMENTS behind, same strides); scores and
+ * P V are accumulated from three fp16 MFMA products each (hi*hi + lo*hi + hi*lo: fp32-grade, ~2^-21) so that the attention core
+ * adds no 2^-11 operand rounding to the forward pass; the result is written as planes again (out_hi, lo out_lo elements behind)
+ * and, optional, as the bf16 copy the backward pass reads.  MFMA path only: L <= 64, hd % 64 == 0. */
+int afft_attention_fwd_split(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, int64_t in_lo,
+                             int32_t nseq, int32_t L, int32_t H, int32_t hd, float scale, int32_t mask, int32_t mask_period,
+                             float drop_p, uint32_t drop_key, void* out_hi, int64_t ldo, int64_t out_lo, void* out_bf16,
+                             int64_t ldob, float* probs, void* stream);
 int afft_attention_bwd(const void* dout, int64_t lddo, const void* q, int64_t ldq, const void* k, int64_t ldk,
                        const void* v, int64_t ldv, int32_t dtype, const float* probs, int32_t nseq, int32_t L,
                        int32_t H, int32_t hd, float scale, float drop_p, uint32_t drop_key, void* dq, int64_t lddq,
@@ -341,11 +364,17 @@ int afft_group_bcast(const float* dy, int32_t G, int32_t S, int64_t W, float sca
  *   gscale_dev (optional device scalar) multiplies gscale: the gradient-clipping coefficient of afft_clip_coef. */
 int afft_sgd_nesterov(float* p, const void* g, int32_t g_dtype, float* buf, void* p_bf16, int64_t n, float lr, float mom,
                       float wd, float gscale, const float* gscale_dev, int32_t first_step, void* stream);
+/* p_f16 (optional, same element offsets as p): the FP16 image of the updated weights ("fp16x2" forward operands), written
+ * beside p_bf16 by afft_sgd_nesterov2 / afft_sgd_nesterov_runs2 -- otherwise the functions above. */
+int afft_sgd_nesterov2(float* p, const void* g, int32_t g_dtype, float* buf, void* p_bf16, void* p_f16, int64_t n, float lr,
+                       float mom, float wd, float gscale, const float* gscale_dev, int32_t first_step, void* stream);
 /* The same update over `nruns` separate runs of ONE set of flat buffers: runs = device array of nruns x {start, length}
  * (int64 elements, starts multiples of 4).  One launch for all the small parameters of a gradient bucket (LayerNorm
  * weights, biases, tokens) whose big neighbours are updated in their weight-gradient epilogues (afft_sgd_fused_t). */
 int afft_sgd_nesterov_runs(float* p, const float* g, float* buf, void* p_bf16, const int64_t* runs, int32_t nruns, float lr,
                            float mom, float wd, float gscale, int32_t first_step, void* stream);
+int afft_sgd_nesterov_runs2(float* p, const float* g, float* buf, void* p_bf16, void* p_f16, const int64_t* runs, int32_t nruns,
+                            float lr, float mom, float wd, float gscale, int32_t first_step, void* stream);
 /* Gradient clipping by global norm (train.py:254-260, torch.nn.utils.clip_grad_norm_), without a host sync:
  *   afft_sumsq: *out += scale * sum x[i]^2 over a flat fp32/bf16 buffer (scale = gscale^2 of the optimizer), ordered
  *   through the stream's workspace (see afft_mse) - the clipping coefficient is bit-reproducible;
@@ -406,6 +435,11 @@ typedef struct {       /* y = x + drop(proj(attention(split(qkv(LN(x))))))      
   const afft_sgd_fused_t* sgd_w_qkv; const afft_sgd_fused_t* sgd_w_proj;
   /* optional fragment-packed copies of the two weight images (afft_gemm_t.b_packed; nn.Linear layout only): forward GEMMs */
   const void* w_qkv_pk; const void* w_proj_pk;
+  /* f16x2 != 0 ("fp16x2" precision, FORWARD only: the backward pass is the bf16 one on the *_b copies): w_qkv / w_proj point at
+   * FP16 images; xn / qkv / ao are two-plane fp16 splits -- hi plane at the pointer, lo plane rows_pad * width elements behind it
+   * (2x the bf16 size each) -- and xn_b / qkv_b / ao_b (optional: NULL in a forward nobody differentiates) receive the bf16 copies
+   * (layout of xn / qkv / ao in the bf16 mode) that afft_attn_sublayer_bwd is then called with. */
+  int32_t f16x2; void* xn_b; void* qkv_b; void* ao_b;
 } afft_attn_sublayer_t;
 int afft_attn_sublayer_fwd(const afft_attn_sublayer_t* s, void* stream);
 int afft_attn_sublayer_bwd(const afft_attn_sublayer_t* s, void* stream, void* aux_stream);
@@ -435,6 +469,7 @@ typedef struct {       /* y = x + drop(fc2(gelu(fc1(LN(x)))))                   
   int32_t wgrad_workgroups;
   const afft_sgd_fused_t* sgd_w1; const afft_sgd_fused_t* sgd_w2;       /* as in afft_attn_sublayer_t */
   const void* w1_pk; const void* w2_pk;                                 /* as in afft_attn_sublayer_t */
+  int32_t f16x2; void* xn_b; void* h_b;  /* as in afft_attn_sublayer_t: xn / h two-plane fp16 splits, w1 / w2 FP16 images, u stays bf16 */
 } afft_mlp_sublayer_t;
 int afft_mlp_sublayer_fwd(const afft_mlp_sublayer_t* s, void* stream);
 int afft_mlp_sublayer_bwd(const afft_mlp_sublayer_t* s, void* stream, void* aux_stream);

@@ -60,10 +60,15 @@ class Split:
 
 @torch.no_grad()
 def gemm(a, b, out, *, a_t=False, b_t=False, bias=None, act=L.ACT_NONE, aux=None, pre=None, rowscale=None, residual=None,
-         accumulate=False, out2=None, alpha=1.0, drop=None, max_workgroups=0, sgd=None, b_packed=None):
-    assert sgd is None and b_packed is None, "cpu_ops test double: fused update / packed weights are GPU-only paths"
+         accumulate=False, out2=None, alpha=1.0, drop=None, max_workgroups=0, sgd=None, b_packed=None, out_lo=0):
+    assert sgd is None and b_packed is None and not out_lo, "cpu_ops test double: fused update / packed weights / plane outputs are GPU-only paths"
     _no_drop(drop)
-    if isinstance(a, Split):     # bf16x3: hi*hi + lo*hi + hi*lo over the padded planes, live part of the result
+    if isinstance(a, Split) and not isinstance(b, Split):     # fp16 two-pass forward: A = hi + lo planes, B the weight's FP16 image
+        assert a.f16 and b.dtype == torch.float16 and not a_t
+        ah, al = (p.float() for p in a.planes)
+        B = (b.t() if b_t else b).float()
+        v = alpha * (ah @ B + al @ B)[:out.shape[0], :out.shape[1]]
+    elif isinstance(a, Split):     # bf16x3: hi*hi + lo*hi + hi*lo over the padded planes, live part of the result
         ah, al = (p.float().t() if a_t else p.float() for p in a.planes)
         bh, bl = (p.float().t() if b_t else p.float() for p in b.planes)
         if a.f16:     # fp16x2: the first two segments only (A = hi + lo, B rounded once)
@@ -266,7 +271,7 @@ def reduce_rows_periodic(src, period, out):
 
 
 @torch.no_grad()
-def sgd_nesterov(p, g, buf, lr, mom, wd, gscale, first, p_bf16=None, gscale_dev=None):
+def sgd_nesterov(p, g, buf, lr, mom, wd, gscale, first, p_bf16=None, gscale_dev=None, p_f16=None):
     if gscale_dev is not None:
         gscale = gscale * float(gscale_dev)
     flags = int(first)        # AFFT_SGD_* flag word: 1 = first step, 2 = plain momentum (nesterov=False)
@@ -276,13 +281,15 @@ def sgd_nesterov(p, g, buf, lr, mom, wd, gscale, first, p_bf16=None, gscale_dev=
     p -= lr * (bb if (flags & 2) else gg + mom * bb)
     if p_bf16 is not None:
         p_bf16.copy_(p)
+    if p_f16 is not None:
+        p_f16.copy_(p)
 
 
 @torch.no_grad()
-def sgd_nesterov_runs(p, g, buf, runs, lr, mom, wd, gscale, first, p_bf16=None):
+def sgd_nesterov_runs(p, g, buf, runs, lr, mom, wd, gscale, first, p_bf16=None, p_f16=None):
     for a, n in runs.tolist():
         sgd_nesterov(p[a:a + n], g[a:a + n], buf[a:a + n], lr, mom, wd, gscale, first,
-                     p_bf16=None if p_bf16 is None else p_bf16[a:a + n])
+                     p_bf16=None if p_bf16 is None else p_bf16[a:a + n], p_f16=None if p_f16 is None else p_f16[a:a + n])
 
 
 @torch.no_grad()

@@ -72,26 +72,35 @@ def test_host_wiring_reproduces_reference_golden(name, precision):
     assert n >= 5
 
 
-def test_fp16x2_is_a_forward_only_precision():
-    """precision 'fp16x2': the forward GEMMs take fp16 hi + lo activation planes and weights rounded once to fp16 (two segments);
-    outputs within 1e-3 of the reference golden; any backward GEMM refuses to run (host wiring; the kernels: GPU tests)."""
+@pytest.mark.parametrize("name", ["t0_sa", "t1_ca", "t6_score"])
+def test_fp16x2_trains_forward_fp16_two_pass_backward_bf16(name):
+    """precision 'fp16x2': the forward GEMMs take fp16 hi + lo activation planes and the weights' FP16 images (two segments) --
+    outputs and loss within 1e-3 of the reference golden --, the backward pass runs as the bf16 mode on bf16 copies of the saved
+    activations (runtime.backward_precision): every gradient exists and sits inside the bf16 mode's bound (host wiring on the
+    call-by-call path; the kernels and the composite path: GPU tests)."""
     import afft_amd
-    z, _ = load_golden("t0_sa")
-    c, state, data, tgt, sub = case_tensors("t0_sa")
+    from afft_amd import runtime as rt
+    z, _ = load_golden(name)
+    c, state, data, tgt, sub = case_tensors(name)
     try:
         with cpu_ops.installed():
             model = _build(c, "fp16x2")
             model.load_state_dict(state, strict=True)
             model.eval()
-            out, _ = model(data, mixup_fn=None, target={"action": tgt}, target_subclips={"action": sub},
-                           target_subclips_ignore_index=None)
+            out, total = _step(model, data, tgt, sub)
+            assert rt.precision() == "fp16x2"          # the backward pass restored the mode it switched away from
             flat = flatten_outputs(out)
             for k in z.files:
                 if k.startswith("out:") and not k.endswith("modality_attns"):
                     assert rel_l2(flat[k[4:]].float(), torch.from_numpy(z[k])) < 1e-3, k
-            logits = next(v for k, v in flat.items() if k.startswith("logits/"))
-            with pytest.raises(RuntimeError, match="forward-only"):
-                logits.sum().backward()
+            assert abs(float(total) - float(z["loss:total"])) < 1e-3 * max(1.0, abs(float(z["loss:total"])))
+            params = dict(model.named_parameters())
+            n = 0
+            for k in z.files:
+                if k.startswith("grad:"):
+                    assert rel_l2(params[k[5:]].grad, torch.from_numpy(z[k])) < 0.2, k       # the bf16 row of the test above
+                    n += 1
+            assert n >= 5
     finally:
         afft_amd.set_precision("bf16")
 

@@ -282,6 +282,152 @@ def test_gemm_fp16x2(case):
         ops.gemm(ops.Split(A.t().contiguous().to(dev()), f16=True), sb, out, a_t=True, b_t=b_t)
     with pytest.raises(TypeError, match="fp16 planes"):
         ops.gemm(sa, ops.Split((Bm.t().contiguous() if b_t else Bm).to(dev())), out, b_t=b_t)
+    # B as the weight's plain FP16 image (what the training forward passes): the same result, bit for bit
+    out_b = torch.zeros(M, N, device=dev())
+    ops.gemm(sa, sb.planes[0][:N] if b_t else sb.planes[0][:, :N], out_b, b_t=b_t, bias=None if bias is None else bias.to(dev()), act=act,
+             residual=None if res is None else res.to(dev()))
+    torch.cuda.synchronize()
+    assert torch.equal(out_b, out)
+
+
+@pytest.mark.parametrize("case", [("nt_pp", 512, 768, 256, "nt", 3), ("nn_128", 130, 256, 320, "nn", 1), ("nt_tail", 300, 520, 200, "nt", 0)],
+                         ids=lambda c: c[0])
+def test_gemm_fp16x2_plane_output_feeds_the_next_gemm(case):
+    """The fp16x2 training forward: a GEMM whose B is a weight's plain FP16 image writes its result as the operand planes of the
+    next GEMM (afft_gemm_t.out_lo: hi = fp16(v), lo = fp16(v - hi)), the bf16 copy the backward pass reads (out2) and the bf16
+    pre-activation (pre).  hi / lo are bitwise what splitting the fp32 result gives; hi + lo is the result to 2^-21."""
+    from afft_amd import _lib, ops
+    name, M, N, K, layout, variant = case
+    _lib.check(_lib.lib().afft_set_gemm_variant(variant))
+    A, Bm = rnd(M, K, seed=41), rnd(K, N, seed=42)
+    b_t = layout[1] == "t"
+    sa = ops.Split(A.to(dev()), f16=True)
+    pN, pM, pK = (N + 63) // 64 * 64, (M + 63) // 64 * 64, (K + 63) // 64 * 64
+    if b_t:
+        Bh = torch.zeros(N, pK, dtype=torch.float16, device=dev())
+        Bh[:, :K] = Bm.t().half().to(dev())
+    else:
+        Bh = torch.zeros(pK, N, dtype=torch.float16, device=dev())
+        Bh[:K] = Bm.half().to(dev())
+    bias = rnd(N, seed=3).to(dev())
+    ref = torch.zeros(M, N, device=dev())
+    ops.gemm(sa, Bh, ref, b_t=b_t, bias=bias, act=1)
+    planes = torch.zeros(2, pM, pN, dtype=torch.float16, device=dev())
+    copy = torch.zeros(pM, pN, dtype=torch.bfloat16, device=dev())
+    pre = torch.zeros(pM, pN, dtype=torch.bfloat16, device=dev())
+    ops.gemm(sa, Bh, planes[0][:M, :N], b_t=b_t, bias=bias, act=1, pre=pre[:M, :N], out2=copy[:M, :N], out_lo=planes[0].numel())
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().afft_set_gemm_variant(0))
+    exact = _act(1, (A.double() @ Bm.half().double()).float() + bias.cpu(), None)
+    assert rel_l2(ref.cpu(), exact) < 1e-5
+    hi, lo = planes[0][:M, :N], planes[1][:M, :N]
+    assert torch.equal(hi, ref.half())
+    assert torch.equal(lo, (ref - ref.half().float()).half())
+    assert torch.equal(copy[:M, :N], ref.bfloat16())
+    assert float((hi.float() + lo.float() - ref).abs().max()) <= float(ref.abs().max()) * 2.0 ** -21
+    assert float(planes[:, M:].abs().max() if pM > M else 0.0) == 0.0 and float(planes[:, :, N:].abs().max() if pN > N else 0.0) == 0.0
+    # ... and the planes are the A operand of the next two-pass GEMM
+    W2 = rnd(N, 192, seed=43)
+    sp = ops.Split.__new__(ops.Split)
+    sp.planes, sp.rows, sp.cols, sp.f16 = planes, M, N, True
+    y = torch.zeros(M, 192, device=dev())
+    W2h = torch.zeros(pN, 192, dtype=torch.float16, device=dev())
+    W2h[:N] = W2.half().to(dev())
+    ops.gemm(sp, W2h, y)
+    torch.cuda.synchronize()
+    assert rel_l2(y.cpu(), (ref.cpu().double() @ W2.half().double()).float()) < 1e-5
+
+
+@pytest.mark.parametrize("rows,d", [(37, 64), (300, 1024), (130, 2048)])
+def test_layernorm_fwd_split_planes(rows, d):
+    """afft_layernorm_fwd_split: the planes and the bf16 copy are bitwise the splits / the rounding of the fp32 LayerNorm output"""
+    from afft_amd import ops
+    x, w, b = rnd(rows, d, seed=1).to(dev()), rnd(d, seed=2).to(dev()), rnd(d, seed=3).to(dev())
+    y = torch.empty(rows, d, device=dev())
+    m0, r0 = torch.empty(rows, device=dev()), torch.empty(rows, device=dev())
+    ops.layernorm_fwd(x, w, b, 1e-6, y, m0, r0)
+    pr = (rows + 63) // 64 * 64
+    planes = torch.zeros(2, pr, d, dtype=torch.float16, device=dev())
+    copy = torch.zeros(pr, d, dtype=torch.bfloat16, device=dev())
+    m1, r1 = torch.empty(rows, device=dev()), torch.empty(rows, device=dev())
+    ops.layernorm_fwd_split(x, w, b, 1e-6, planes[0][:rows], planes[0].numel(), copy[:rows], m1, r1)
+    torch.cuda.synchronize()
+    assert torch.equal(planes[0][:rows], y.half()) and torch.equal(planes[1][:rows], (y - y.half().float()).half())
+    assert torch.equal(copy[:rows], y.bfloat16()) and torch.equal(m0, m1) and torch.equal(r0, r1)
+    ops.layernorm_fwd_split(x, None, None, 1e-6, planes[0][:rows], planes[0].numel(), None)     # no affine, no copy
+    torch.cuda.synchronize()
+    assert torch.isfinite(planes.float()).all()
+
+
+ATTN_SPLIT_CASES = [(13, 5, 4, 64, 0), (64, 5, 4, 512, 0), (9, 6, 2, 256, 1), (6, 16, 4, 128, 2), (3, 32, 2, 512, 2), (3, 64, 2, 256, 3),
+                    (2, 40, 2, 64, 3)]
+
+
+@pytest.mark.parametrize("nseq,L,H,hd,mask", ATTN_SPLIT_CASES)
+def test_attention_fwd_split(nseq, L, H, hd, mask):
+    """fp16x2 forward attention on hi + lo planes (three fp16 MFMA products per matrix product): fp32-grade against float64 --
+    no 2^-11 operand rounding -- with outputs as planes + the bf16 copy; packed frames (L = 5, 6), one / two / four row tiles,
+    whole and chunked head dimensions, every mask."""
+    from afft_amd import ops
+    from oracle import afft_oracle as O
+    d = H * hd
+    R = nseq * L
+    qkv = rnd(R, 3 * d, seed=1)
+    sp = ops.Split(qkv.to(dev()), f16=True)
+    hi = sp.planes[0]
+    in_lo = hi.numel()
+    q, k, v = hi[:R, :d], hi[:R, d:2 * d], hi[:R, 2 * d:3 * d]
+    pr = (R + 63) // 64 * 64
+    oplanes = torch.zeros(2, pr, d, dtype=torch.float16, device=dev())
+    ocopy = torch.zeros(pr, d, dtype=torch.bfloat16, device=dev())
+    probs = torch.empty(nseq, H, L, L, device=dev())
+    scale = hd ** -0.5
+    period = L // 4 if mask == 3 else 0
+    ops.attention_fwd_split(q, k, v, in_lo, nseq, L, H, hd, scale, mask, oplanes[0][:R], oplanes[0].numel(), ocopy[:R], probs,
+                            mask_period=period)
+    torch.cuda.synchronize()
+    t = qkv.double().view(nseq, L, 3, H, hd).permute(2, 0, 3, 1, 4)
+    if mask == 3:
+        m = O.make_mask("causal", period, torch.float64).repeat(4, 4)
+    else:
+        m = O.make_mask(["none", "diag", "causal"][mask], L, torch.float64)
+    o_ref, p_ref = O._softmax_attend(t[0], t[1], t[2], scale, m)
+    o_ref = o_ref.reshape(R, d).float()
+    got = (oplanes[0][:R].float() + oplanes[1][:R].float()).cpu()
+    assert rel_l2(got, o_ref) < 2e-5, rel_l2(got, o_ref)
+    assert rel_l2(probs.cpu(), p_ref.float()) < 2e-5
+    assert rel_l2(ocopy[:R].float().cpu(), o_ref) < 4e-3 and rel_l2(oplanes[0][:R].float().cpu(), o_ref) < 5e-4
+    if mask:
+        assert float(probs.cpu()[..., torch.isinf(m)].abs().max()) == 0.0
+    # with dropout the kernel draws the masks of the bf16 kernel (same key, same index): compare with it on bf16-exact inputs
+    qb = bfr(qkv)
+    spb = ops.Split(qb.to(dev()), f16=True)      # bf16 values are exact in hi + lo
+    hb = spb.planes[0]
+    ops.attention_fwd_split(hb[:R, :d], hb[:R, d:2 * d], hb[:R, 2 * d:3 * d], hb.numel(), nseq, L, H, hd, scale, mask, oplanes[0][:R],
+                            oplanes[0].numel(), None, probs, drop_p=0.3, drop_key=777, mask_period=period)
+    g = qb.to(torch.bfloat16).to(dev())
+    ob = torch.empty(R, d, dtype=torch.bfloat16, device=dev())
+    pb = torch.empty(nseq, H, L, L, device=dev())
+    ops.attention_fwd(g[:, :d], g[:, d:2 * d], g[:, 2 * d:], nseq, L, H, hd, scale, mask, ob, pb, drop_p=0.3, drop_key=777, mask_period=period)
+    torch.cuda.synchronize()
+    assert rel_l2(probs.cpu(), pb.cpu()) < 1e-5
+    assert rel_l2((oplanes[0][:R].float() + oplanes[1][:R].float()).cpu(), ob.float().cpu()) < 1.5e-2
+
+
+def test_sgd_kernels_keep_the_fp16_image():
+    from afft_amd import ops
+    n = 64 * 1000
+    p, g, buf = rnd(n, seed=1).to(dev()), rnd(n, seed=2).to(dev()), rnd(n, seed=3).to(dev())
+    p16, h16 = torch.zeros(n, dtype=torch.bfloat16, device=dev()), torch.zeros(n, dtype=torch.float16, device=dev())
+    ops.sgd_nesterov(p, g, buf, 1e-2, 0.9, 1e-4, 1.0, 0, p_bf16=p16, p_f16=h16)
+    torch.cuda.synchronize()
+    assert torch.equal(h16, p.half()) and torch.equal(p16, p.bfloat16())
+    runs = torch.tensor([[0, 4096], [8192, 1000]], dtype=torch.int64, device=dev())
+    h16.zero_()
+    ops.sgd_nesterov_runs(p, g, buf, runs, 1e-2, 0.9, 1e-4, 1.0, 0, p_bf16=p16, p_f16=h16)
+    torch.cuda.synchronize()
+    assert torch.equal(h16[:4096], p[:4096].half()) and torch.equal(h16[8192:9192], p[8192:9192].half())
+    assert float(h16[4096:8192].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("cap", [8, 24, 1000])
