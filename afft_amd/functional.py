@@ -1029,7 +1029,8 @@ class AttnSublayer(torch.autograd.Function):
         # probs is returned for the caller's attention maps and takes no gradient: without this autograd hands backward a
         # freshly ZERO-FILLED tensor of its shape for it on every call (a fill kernel per attention sub-layer and step)
         ctx.set_materialize_grads(False)
-        if _composite_ok(x, pre_ln, d):
+        # fp16x2: the attention core on hi + lo planes exists on the MFMA path only (L <= 64, head dimension a multiple of 64)
+        if _composite_ok(x, pre_ln, d) and (rt.precision() != "fp16x2" or (L <= 64 and hd % 64 == 0 and hd <= 1024)):
             return _attn_fwd_c(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, eps, conv1d, scale, drop, probs_out)
         ctx.up = _upstream_of(x) if pre_ln else None
         mean, rstd = _stats(R if pre_ln else 0, dev)
