@@ -39,7 +39,9 @@ def parse():
     ap.add_argument("--config", default="cfg2", help="cfg2 (default) | ek100 | cfg1 | cfg4 | cfg5 | cfg2_cm | cfg2_tsa")
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "fp16x2"])
-    ap.add_argument("--comm-dtype", default="bf16", choices=["bf16", "fp32"], help="gradient all-reduce payload")
+    ap.add_argument("--comm-dtype", default=None, choices=["bf16", "fp32"],
+                    help="gradient all-reduce payload; default: bf16 beside --precision bf16 (whose gradients carry bf16 operand rounding anyway), fp32 "
+                         "-- what the reference's DDP exchanges, train.py:364-368 -- beside every other precision")
     ap.add_argument("--comm-algo", default="allreduce", choices=["allreduce", "rs_ag"],
                     help="gradient exchange per bucket: one all-reduce, or reduce-scatter + all-gather (fallback)")
     ap.add_argument("--no-comm-report", action="store_true", help="N > 1: skip the RCCL / exposed-communication / payload side measurements")
@@ -52,7 +54,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16, help="clips per CPU-baseline step on the bench workload (SURVEY.md 8d: 16)")
-    ap.add_argument("--no-parity-mode", action="store_true", help="skip the bf16x3 (1e-3-accurate) throughput / error side measurements")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the fp16x2 / bf16x3 (1e-3-accurate) throughput / error side measurements")
     ap.add_argument("--full-rows", action="store_true",
                     help="run the SA-Fuser's last block on every token row as the reference does (default: its MLP half on token 0 only, "
                          "the only rows that reach an output; runtime.skip_dead_rows)")
@@ -62,8 +64,13 @@ def parse():
                     help="torch.distributed timeout (s): a rank that waits longer in a collective raises instead of hanging")
     ap.add_argument("--no-reference-loop", action="store_true",
                     help="skip the side measurement of the reference's own loop (Runner + MixUp + optimizer over 151 groups + lr scheduler)")
+    ap.add_argument("--no-power", action="store_true", help="skip the package power / clock poll")
+    ap.add_argument("--no-ek100", action="store_true", help="skip the side measurement at the EK100 widths of expts/01 (d = 1024)")
     ap.add_argument("--wgrad-wgs", type=int, default=None, help="CU cap of the weight-gradient GEMMs on the auxiliary stream (default: runtime's)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.comm_dtype is None:
+        args.comm_dtype = "bf16" if args.precision == "bf16" else "fp32"
+    return args
 
 
 def make_inputs(cfg, B, T, rank, device, ncls=3806):
@@ -132,6 +139,40 @@ class GemmTimer:
             d["ms"] += r.ms
             d["fused_update_launches"] += r.fused_update
         return out
+
+
+def by_k_class(records, symbol, mfma_peak_tflops, hbm_peak_gbs=8000.0):
+    """The launches of one kernel symbol split by their reduction length K: the weight-gradient symbol holds the fuser's K = B*T*S
+    = 5120-row reductions (MFMA-bound) and the predictor's K = B*T = 1024-row ones, whose 18-20 B / parameter optimizer epilogue
+    moves more bytes than their MFMA work hides (arithmetic intensity below the ridge peak_flops / peak_bytes: HBM-bound).  Each
+    class is priced against the roof that bounds IT: frac = achieved / peak of `bound`."""
+    ridge = mfma_peak_tflops * 1e12 / (hbm_peak_gbs * 1e9)      # FLOP per byte
+    cls = {}
+    for r in records:
+        if GemmTimer.symbol(r) != symbol:
+            continue
+        d = cls.setdefault(int(r.K), {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "shapes": {}})
+        wgrad = r.a_kstrided and r.b_kstrided
+        d["launches"] += 1
+        d["ms"] += r.ms
+        d["flops"] += 2.0 * r.M * r.N * r.K
+        d["bytes"] += 2.0 * r.K * (r.M + r.N) + r.M * r.N * (18.0 if r.fused_update else 4.0 if wgrad else 2.0)
+        key = f"{r.M}x{r.N}"
+        d["shapes"][key] = d["shapes"].get(key, 0) + 1
+    out = {}
+    for K, d in sorted(cls.items()):
+        if d["ms"] <= 0:
+            continue
+        tf, gbs, ai = d["flops"] / (d["ms"] * 1e-3) / 1e12, d["bytes"] / (d["ms"] * 1e-3) / 1e9, d["flops"] / d["bytes"]
+        hbm = ai < ridge
+        out[f"K={K}"] = {"launches": d["launches"], "avg_us": round(d["ms"] / d["launches"] * 1e3, 1), "shapes_MxN": d["shapes"],
+                         "flop_per_byte": round(ai, 1), "bound": "hbm" if hbm else "mfma",
+                         "achieved": round(gbs if hbm else tf, 1), "peak": hbm_peak_gbs if hbm else mfma_peak_tflops,
+                         "unit": "GB/s" if hbm else "TFLOP/s", "frac": round((gbs / hbm_peak_gbs) if hbm else (tf / mfma_peak_tflops), 4),
+                         "tflops": round(tf, 1), "algorithmic_gbs": round(gbs, 1)}
+    return {"ridge_flop_per_byte": round(ridge, 1), "classes": out,
+            "note": "bytes = both 16-bit operands once + the result (18 B per parameter with the optimizer in the epilogue: p and momentum read and written, "
+                    "the bf16 image written; +2 B where a packed or FP16 image is kept), from the same HIP-event records as `achieved`"}
 
 
 class KernelTimer:
@@ -276,23 +317,49 @@ def cpu_baseline(name, B, steps=3):
             "cfg1_B4_clips_s": round(cfg1, 3), "thread_sweep_cfg1_clips_s": {str(k): v for k, v in sweep.items()}}
 
 
-def power_report(step_fn, seconds=2.5):
-    """Package power and graphics clock while the training step loops (rocm-smi polled from a thread, after the timed region:
-    the timing above is not perturbed).  The GEMM loops of this path run at the package power limit (profiles/r04_power.txt), so
-    the line says at which clock and power the number above was made.  None when rocm-smi is not there."""
-    import subprocess
-    import threading
+def _power_probe():
+    """A function () -> (package power in W, graphics clock in MHz) that reads IN PROCESS -- sysfs (amdgpu hwmon), else the amdsmi
+    Python binding -- or None.  No child process: `rocm-smi` is a `#!/usr/bin/env python3` script, i.e. two exec hops from a process
+    that has initialised the GPU (and, under rocprofv3, inherited the profiler's preloaded library) -- what this pool forbids --
+    and 20 forks per second pollute a profiled run."""
+    import glob
+    for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+        pw = next((os.path.join(hw, f) for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(hw, f))), None)
+        fq = os.path.join(hw, "freq1_input")
+        if pw is None or not os.path.exists(fq):
+            continue
 
-    def smi():
-        out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=10).stdout
-        card = next(iter(json.loads(out[out.index("{"):]).values()))
-        pw = next((float(v) for k, v in card.items() if "Power" in k and "(W)" in k), None)
-        clk = next((int(v.strip("()Mhz")) for k, v in card.items() if k.startswith("sclk") and "speed" in k), None)
-        return pw, clk
+        def read(pw=pw, fq=fq):
+            return float(open(pw).read()) / 1e6, int(open(fq).read()) // 1_000_000
+        try:
+            read()
+            return read, "sysfs hwmon (power1_average / freq1_input)"
+        except Exception:  # noqa: BLE001
+            continue
     try:
-        smi()
-    except Exception as ex:  # noqa: BLE001
-        return {"error": repr(ex)[:120]}
+        import amdsmi
+        amdsmi.amdsmi_init()
+        h = amdsmi.amdsmi_get_processor_handles()[0]
+
+        def read():
+            p = amdsmi.amdsmi_get_power_info(h)
+            w = p.get("current_socket_power", p.get("average_socket_power"))
+            c = amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)
+            return float(w), int(c.get("clk", c.get("cur_clk")))
+        read()
+        return read, "amdsmi Python binding"
+    except Exception:  # noqa: BLE001
+        return None, None
+
+
+def power_report(step_fn, seconds=2.5):
+    """Package power and graphics clock while the training step loops (polled in process from a thread, after the timed region:
+    the timing above is not perturbed).  The GEMM loops of this path run at the package power limit (profiles/r04_power.txt), so
+    the line says at which clock and power the number above was made.  An error entry when neither source is there."""
+    import threading
+    smi, source = _power_probe()
+    if smi is None:
+        return {"error": "no in-process power source (amdgpu hwmon in sysfs, amdsmi binding)"}
     stop, samples = threading.Event(), []
 
     def poll():
@@ -320,7 +387,8 @@ def power_report(step_fn, seconds=2.5):
         return {"error": "no samples"}
     return {"samples": len(pw), "package_power_w_avg": round(sum(pw) / len(pw), 1), "package_power_w_max": pw[-1],
             "sclk_mhz_median": ck[len(ck) // 2], "sclk_mhz_max_of_part": 2400, "ms_per_step_while_polled": round(dt * 1e3, 3),
-            "note": "rocm-smi every 50 ms over a separate loop of the same step; GEMM loops alone sit at ~1375 W (profiles/r04_power.txt)"}
+            "source": source,
+            "note": "polled every 50 ms over a separate loop of the same step; GEMM loops alone sit at ~1375 W (profiles/r04_power.txt)"}
 
 
 def parity_side_measurements(args, device, feats, tgt, sub, c):
@@ -353,7 +421,7 @@ def parity_side_measurements(args, device, feats, tgt, sub, c):
                 torch.cuda.synchronize()
                 fwd_ms[mode] = round((time.perf_counter() - t0) / 5 * 1e3, 2)
         del o
-        if mode == "bf16x3":
+        if mode in ("bf16x3", "fp16x2"):
             model.train(not args.eval_drop)
             tr = Trainer(model, wts, bucket_elems=args.bucket_melems * 1024 * 1024)
             for _ in range(3):
@@ -367,21 +435,61 @@ def parity_side_measurements(args, device, feats, tgt, sub, c):
             dt = (time.perf_counter() - t0) / n
             from afft_amd.config import gflop_per_clip
             useful = args.batch / dt * gflop_per_clip(args.config, fwd_bwd=True, executed=afft_amd.runtime.skip_dead_rows()) / 1e3   # TFLOP/s executed
-            out["parity_mode"] = {"precision": "bf16x3", "clips_per_s": round(args.batch / dt, 1), "ms_per_step": round(dt * 1e3, 2),
-                                  "steps": n,
-                                  # three bf16 MFMA passes per product: the useful-FLOP peak of this mode is a third of the dense peak
-                                  "roofline": {"bound": "mfma", "achieved": round(useful, 1), "peak": round(PEAK_BF16_TFLOPS / 3, 1),
-                                               "unit": "TFLOP/s (algorithmic, whole step)", "frac": round(useful / (PEAK_BF16_TFLOPS / 3), 4),
-                                               "executed_tflops": round(3 * useful, 1)}}
+            if mode == "bf16x3":
+                # three bf16 MFMA passes per product, forward and backward: fp32-grade gradients too (1.4e-5 / 2.8e-5)
+                passes, note = 3.0, "bf16x3: hi*hi + lo*hi + hi*lo on the bf16 MFMAs in every GEMM of the step"
+            else:
+                # forward two fp16 MFMA passes (activation hi + lo, weight rounded once), backward one bf16 pass: the step's GEMM work
+                # is (2 + 2) / 3 of the algorithmic FLOPs (backward = 2 x forward)
+                passes, note = 4.0 / 3.0, ("fp16x2: forward A_hi W + A_lo W on v_mfma_f32_16x16x32_f16 with the operand planes written by the "
+                                          "producing kernels, backward = the bf16 mode's on bf16 copies (gradients inside the bf16 bound)")
+            rec = {"precision": mode, "clips_per_s": round(args.batch / dt, 1), "ms_per_step": round(dt * 1e3, 2), "steps": n,
+                   "roofline": {"bound": "mfma", "achieved": round(useful, 1), "peak": round(PEAK_BF16_TFLOPS / passes, 1),
+                                "unit": "TFLOP/s (algorithmic, whole step)", "frac": round(useful * passes / PEAK_BF16_TFLOPS, 4),
+                                "executed_tflops": round(passes * useful, 1)},
+                   "note": note}
+            # the mode whose LOGITS meet the north-star 1e-3 at the highest training rate is the parity mode of the line
+            out["parity_mode" if mode == "fp16x2" else "parity_mode_bf16x3"] = rec
             del tr
         del model
         torch.cuda.empty_cache()
     ref = logits["fp32"]
     out["logits_rel_l2_vs_exact_fp32_mode"] = {m: float(((logits[m] - ref).norm() / ref.norm()).cpu()) for m in ("bf16", "bf16x3", "fp16x2")}
-    # fp16x2 = evaluation-only parity mode: activations hi + lo in fp16, weights rounded once to fp16, two MFMA passes
+    if "parity_mode" in out:
+        out["parity_mode"]["logits_rel_l2_vs_exact_fp32_mode"] = out["logits_rel_l2_vs_exact_fp32_mode"]["fp16x2"]
     out["eval_forward_ms"] = {"batch": args.batch, **fwd_ms}
     afft_amd.set_precision(args.precision)
     return out
+
+
+def ek100_side_measurement(args, device):
+    """The metric's namesake at its own widths (expts/01_SA-Fuser_ek100_train.txt: rgb / audio / flow 1024, objects 352, d = 1024,
+    D = 2048 -- config 'ek100'), same batch, step definition and precision as the headline: clips/s, ms/step and the whole-step
+    fraction of the dense MFMA peak.  (The headline workload is BASELINE configs[1], every width 2048.)"""
+    import afft_amd
+    from afft_amd.config import gflop_per_clip
+    from afft_amd.parallel import Trainer
+    model, c = build_model("ek100", device)
+    B, T = args.batch, c["T"]
+    feats, tgt, sub = make_inputs(c, B, T, 0, device)
+    tr = Trainer(model, {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}, bucket_elems=args.bucket_melems * 1024 * 1024)
+    model.train(not args.eval_drop)
+    for _ in range(5):
+        tr.step(feats, tgt, sub)
+    torch.cuda.synchronize()
+    n = 20
+    t0 = time.perf_counter()
+    for _ in range(n):
+        tr.step(feats, tgt, sub)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    gf = gflop_per_clip("ek100", fwd_bwd=True, executed=afft_amd.runtime.skip_dead_rows())
+    tf = B / dt * gf / 1e3
+    del tr, model
+    torch.cuda.empty_cache()
+    return {"clips_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": n, "batch": B, "precision": args.precision,
+            "gflop_per_clip_executed": round(gf, 2), "tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / PEAK_BF16_TFLOPS, 4),
+            "workload": "ek100: SA-Fuser 4-modality T=16 d=1024 (objects 352) D=2048 depth 6+6, 3806 classes, train mode, eager"}
 
 
 def reference_loop_measurements(args, device, feats, tgt, sub, c, trainer_ms):
@@ -779,7 +887,7 @@ def main():
             finally:
                 afft_amd.runtime.set_overlap_wgrad(True)
 
-    if rank == 0 and world == 1 and not captured and not args.no_roofline:
+    if rank == 0 and world == 1 and not captured and not args.no_roofline and not args.no_power:
         try:
             result["power"] = power_report(lambda: trainer.step(feats, tgt, sub, optimize=not args.no_optimizer))
         except Exception as ex:  # noqa: BLE001
@@ -801,6 +909,13 @@ def main():
         lat.sort()
         result["fwd_p50_ms"] = round(lat[len(lat) // 2], 3)
         result["fwd_p50_samples"] = len(lat)
+        gff = gflop_per_clip(args.config, fwd_bwd=False, executed=afft_amd.runtime.skip_dead_rows())
+        fwd_tf = B * gff / (result["fwd_p50_ms"] * 1e-3) / 1e3
+        passes = {"fp16x2": 2.0, "bf16x3": 3.0}.get(args.precision, 1.0)      # MFMA passes per product of the forward GEMMs
+        peak_f = 157.3 if args.precision == "fp32" else PEAK_BF16_TFLOPS
+        result["fwd_p50_roofline"] = {"bound": "mfma", "achieved": round(fwd_tf, 1), "peak": round(peak_f / passes, 1),
+                                      "unit": "TFLOP/s (algorithmic, whole evaluation forward of the batch)",
+                                      "frac": round(fwd_tf * passes / peak_f, 4), "gflop_per_clip_forward": round(gff, 2)}
         model.train(not args.eval_drop)
 
         if summ is not None:
@@ -813,7 +928,7 @@ def main():
             avg_ms = d["ms"] / d["launches"]
             avg_fl = d["flops"] / d["launches"]
             ach = avg_fl / (avg_ms * 1e-3) / 1e12
-            dtype_peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3
+            dtype_peak = 157.3 if args.precision == "fp32" else PEAK_BF16_TFLOPS      # bf16 / fp16 dense MFMA peak; exact-fp32 MFMA peak
             traffic, traffic_src = None, None
             for fn in ("r04b_gemm_hbm_traffic_pmc.json", "r03c_gemm_hbm_traffic_pmc.json", "r03b_gemm_hbm_traffic_pmc.json", "r03a_gemm_hbm_traffic_pmc.json", "r02i_gemm_hbm_traffic_pmc.json", "r02h_gemm_hbm_traffic_pmc.json", "r02g_gemm_hbm_traffic_pmc.json", "r02_gemm_hbm_traffic_pmc.json", "r01_gemm_hbm_traffic_pmc.json"):
                 try:   # HBM-side bytes per launch from separate rocprofv3 --pmc passes (tools/traffic_summary.py), committed
@@ -841,6 +956,7 @@ def main():
                          if summ_alone and dom in summ_alone and summ_alone[dom]["ms"] > 0 else None,
                 "launches_per_step": d["launches"], "avg_launch_ms": round(avg_ms, 4),
                 "avg_algorithmic_gflop_per_launch": round(avg_fl / 1e9, 2),
+                "by_k_class": by_k_class(gemm_recs, dom, dtype_peak),
                 "by_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else None}
                               for k, v in summ.items()},
@@ -855,6 +971,11 @@ def main():
                 result.update(parity_side_measurements(args, device, feats, tgt, sub, c))
             except Exception as ex:  # noqa: BLE001
                 result["parity_mode"] = {"error": repr(ex)}
+        if not args.no_ek100 and world == 1 and args.config == "cfg2" and not args.no_optimizer:
+            try:
+                result["ek100"] = ek100_side_measurement(args, device)
+            except Exception as ex:  # noqa: BLE001
+                result["ek100"] = {"error": repr(ex)}
         if not args.no_reference_loop and world == 1 and args.precision == "bf16" and not args.no_optimizer:
             try:
                 result["reference_loop"] = reference_loop_measurements(args, device, feats, tgt, sub, c, ms_per_step)
