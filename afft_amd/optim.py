@@ -26,8 +26,10 @@ What the five calls become here:
   ``state[p]['momentum_buffer']`` (views of the flat buffer: ``state_dict()`` / ``load_state_dict()`` round-trip through
   ``torch.save`` like torch's own, train.py:161-176);
 * gradient clipping (``opt.grad_clip``, train.py:254-260) needs the whole gradient before the first update: construct with
-  ``in_backward=False`` (Hydra: ``+opt.optimizer.in_backward=false``) or set ``AFFT_OPT_IN_BACKWARD=0``; ``clip_grad_norm_`` then
-  sees the complete flat gradient and ``step()`` runs the one-launch-per-bucket update.
+  ``in_backward=False`` (Hydra: ``+opt.optimizer.in_backward=false``) or set ``AFFT_OPT_IN_BACKWARD=0``; the gradient exchange is
+  then completed -- all-reduced, averaged over the ranks, untouched gradients zeroed -- by a callback at the END of
+  ``loss.backward()``, so the loop's ``clip_grad_norm_`` sees the complete, averaged flat gradient on any number of ranks, and
+  ``step()`` runs the one-launch-per-bucket update.
 
 Under ``AFFT_GRAD_MODE=autograd`` (gradients through autograd, e.g. below torch's own DistributedDataParallel, which then owns
 the all-reduce) ``zero_grad()`` zeroes the flat gradient buffer with one fill and ``step()`` is the plain fused update over it.
@@ -153,6 +155,40 @@ class SGD(torch.optim.Optimizer, _FusedEpilogue):
         self._saved_runs, self.opt.runs = self.opt.runs, (self.opt.runs if self._fuse_now else None)
         self.reducer.begin_step()
         self._armed = True
+        self._finished_in_backward = False
+        if not inb:
+            # The update waits for step(), but the GRADIENT has to be whole when backward() returns: the loop's own
+            # torch.nn.utils.clip_grad_norm_ (train.py:254-260) reads and scales p.grad between the two calls.  The first gradient
+            # that reports ready queues an end-of-backward callback that completes the exchange (joins the side streams, zeroes
+            # untouched gradients) and applies 1 / world, as parallel.DistributedDataParallel does for a foreign optimizer.
+            inner = rt.SINK.on_grad_ready
+            self._end_queued = False
+
+            def first_ready(p, inner=inner):
+                if not self._end_queued:
+                    try:
+                        torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+                        self._end_queued = True
+                    except RuntimeError:      # not inside a backward pass (a Function.backward called by hand): step() finishes
+                        pass
+                if inner is not None:
+                    inner(p)
+            rt.SINK.on_grad_ready = first_ready
+
+    def _end_of_backward(self):
+        """in_backward = False: runs when the backward pass is over (autograd-engine callback)"""
+        self._end_queued = False
+        if not self._armed or self._finished_in_backward:
+            return
+        red = self.reducer
+        red.finish_step()
+        if red.comm:
+            g, scale = red.grad_for_optimizer()
+            with torch.no_grad():
+                if g is not self.flat.flat_g:       # bf16 payload: back into the fp32 gradient buffer the loop (and step()) read
+                    self.flat.flat_g.copy_(g)
+                self.flat.flat_g.mul_(scale)
+        self._finished_in_backward = True
 
     def _disarm(self):
         rt.SINK.fused = None
@@ -167,8 +203,10 @@ class SGD(torch.optim.Optimizer, _FusedEpilogue):
         if closure is not None:
             raise NotImplementedError("afft_amd.optim.SGD.step: closures are not supported (the update runs inside backward())")
         if self._armed:
+            done = getattr(self, "_finished_in_backward", False)
             try:
-                self.reducer.finish_step()
+                if not done:
+                    self.reducer.finish_step()
                 if self._fuse_now and self._audit_fused_step():
                     self._saved_runs = self.opt.runs          # the fused set shrank: keep the rebuilt runs
             finally:
@@ -177,6 +215,8 @@ class SGD(torch.optim.Optimizer, _FusedEpilogue):
                 self.opt.end_step()
                 if self._fused is None and self._can_fuse():
                     self._enable_fused()
+            elif done:      # the exchange was completed and averaged when backward() ended (and the loop may have clipped since)
+                self.opt.step(self.flat.flat_g, 1.0, grad_clip=self.grad_clip)
             else:
                 g, scale = self.reducer.grad_for_optimizer()
                 self.opt.step(g, scale, grad_clip=self.grad_clip)

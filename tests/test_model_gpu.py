@@ -1463,3 +1463,53 @@ def test_packed_weight_images_stay_coherent_and_feed_the_forward():
     a, b = o1["logits/action"]["all-fused"].float(), o2["logits/action"]["all-fused"].float()
     assert rel_l2(a, b) < 2e-3, rel_l2(a, b)
     del lib
+
+
+def test_weight_images_follow_a_state_dict_load():
+    """after training with live fragment-packed (and, in 'fp16x2', FP16) images, model.load_state_dict() -- an in-place
+    write into the flat views that no optimizer kernel sees -- must not leave any image behind: the next forward equals the forward
+    of a FRESH model built from the same state, bitwise, in the bf16 mode (B-direct forward GEMMs on packed images) and in fp16x2."""
+    import afft_amd
+    import bench as B
+    from afft_amd import dropout as D_, runtime as rt
+    from afft_amd.parallel import Trainer
+    dev = torch.device("cuda:0")
+    wts = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
+    try:
+        for precision in ("bf16", "fp16x2"):
+            afft_amd.set_precision(precision)
+            D_.manual_seed(7)
+            model, c = B.build_model("cfg2", dev)
+            feats, tgt, sub = B.make_inputs(c, 64, c["T"], 0, dev)
+            # the state that is loaded later: every GEMM weight 5 % larger than what the model trains from (an image left behind
+            # shows as a percent-level difference of the logits, far above the comparison's tolerance)
+            state0 = {k: (v.detach() * 1.05 if v.dim() == 2 else v.detach().clone()) for k, v in model.state_dict().items()}
+            tr = Trainer(model, wts)
+            model.train()
+            for _ in range(3):
+                tr.step(feats, tgt, sub)
+            torch.cuda.synchronize()
+            if precision == "bf16":
+                assert sum(rt.packed_live(p) for _, p, _ in tr.flat.packed) >= 11
+            else:
+                assert tr.flat.flat_h16 is not None
+            model.load_state_dict(state0)          # weights move under the images
+            model.eval()
+            with torch.no_grad():
+                o1, _ = model(feats, mixup_fn=None, target=tgt, target_subclips=sub, target_subclips_ignore_index=None)
+            a = o1["logits/action"]["all-fused"].float().clone()
+            del tr, model, o1
+            torch.cuda.empty_cache()
+            fresh, _ = B.build_model("cfg2", dev)
+            fresh.load_state_dict(state0)
+            fresh.eval()
+            with torch.no_grad():
+                o2, _ = fresh(feats, mixup_fn=None, target=tgt, target_subclips=sub, target_subclips_ignore_index=None)
+            b = o2["logits/action"]["all-fused"].float()
+            # the fresh model has no packed images (ping-pong forward GEMMs): same products, another summation order inside a tile
+            tol = 2e-3 if precision == "bf16" else 1e-6
+            assert rel_l2(a, b) < tol, (precision, rel_l2(a, b))
+            del fresh, o2
+            torch.cuda.empty_cache()
+    finally:
+        afft_amd.set_precision("bf16")

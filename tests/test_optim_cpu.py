@@ -34,14 +34,18 @@ def _batch(data, tgt, sub, sl=slice(None)):
              "target_subclips": {"action": sub[sl]}}, {})
 
 
-def _loop(model, opt, sched, data, tgt, sub, steps, lrs=None, sl=slice(None), mixup_fn=None):
-    """the reference's loop body (train.py:241-265)"""
+def _loop(model, opt, sched, data, tgt, sub, steps, lrs=None, sl=slice(None), mixup_fn=None, clip=None, norms=None):
+    """the reference's loop body (train.py:241-265); clip: opt.grad_clip, applied by the LOOP as the reference does (:254-260)"""
     from afft_amd.common.runner import Runner
     runner = Runner(model, torch.device("cpu"), WTS, compute_metrics=False)
     for _ in range(steps):
         loss, _metrics = runner(_batch(data, tgt, sub, sl), mixup_fn, True)
         opt.zero_grad()
         loss.backward()
+        if clip is not None:
+            n = torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+            if norms is not None:
+                norms.append(float(n))
         opt.step()
         if sched is not None:
             sched.step()
@@ -218,30 +222,41 @@ def _ddp_worker(rank, world, port, out, kind):
                 for p in model.parameters():
                     p.add_(0.05)
         groups = _groups(model)
+        clip = None
         if kind == "afft":
             opt = SGD(groups, lr=1e-2, momentum=0.9, nesterov=True, bucket_elems=8192)
+        elif kind == "afft_loop_clip":      # the update waits for step(); the LOOP clips between backward() and step()
+            opt = SGD(groups, lr=1e-2, momentum=0.9, nesterov=True, bucket_elems=8192, in_backward=False)
+            clip = CLIP
         else:
             opt = torch.optim.SGD(groups, lr=1e-2, momentum=0.9, nesterov=True)
         ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=None, output_device=None)     # train.py:365-367
         from afft_amd.parallel import DistributedDataParallel
         assert isinstance(ddp, DistributedDataParallel) and ddp.module is model
-        assert (ddp._own is None) == (kind == "afft")
+        assert (ddp._own is None) == (kind != "torch")
         h = data[next(iter(data))].shape[0] // world
-        _loop(ddp, opt, None, data, tgt, sub, 3, sl=slice(rank * h, (rank + 1) * h))
+        norms = []
+        _loop(ddp, opt, None, data, tgt, sub, 3, sl=slice(rank * h, (rank + 1) * h), clip=clip, norms=norms)
     flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
     others = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(others, flat)
     assert all(torch.equal(o, others[0]) for o in others), "replicas diverged"
     if rank == 0:
-        torch.save({"flat": flat, "keys": list(ddp.state_dict().keys())[:3]}, out)
+        torch.save({"flat": flat, "keys": list(ddp.state_dict().keys())[:3], "norms": norms}, out)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["afft", "torch"])
+CLIP = 0.05      # well below the gradient norms of the case: the clip is active on every step
+
+
+@pytest.mark.parametrize("kind", ["afft", "torch", "afft_loop_clip"])
 def test_two_rank_reference_loop_with_ddp_wrapper(tmp_path, kind):
     """the unchanged loop on 2 gloo ranks (half batches, rank 1 starting from other weights) == one process on the full batch:
-    afft_amd.optim.SGD owns the exchange ('afft'), or the wrapper does it for torch.optim.SGD ('torch')"""
+    afft_amd.optim.SGD owns the exchange ('afft'), or the wrapper does it for torch.optim.SGD ('torch'); 'afft_loop_clip':
+    afft_amd.optim.SGD(in_backward=False) with the LOOP's torch.nn.utils.clip_grad_norm_ between backward() and step()
+    (train.py:254-260) -- the exchange is complete and averaged when backward() returns, so the norm the loop clips by is the
+    full-batch gradient's"""
     import cpu_ops
     out = str(tmp_path / f"ddp_{kind}.pt")
     mp.spawn(_ddp_worker, args=(2, _free_port(), out, kind), nprocs=2, join=True)
@@ -251,10 +266,14 @@ def test_two_rank_reference_loop_with_ddp_wrapper(tmp_path, kind):
     with cpu_ops.installed():
         model = _afft_model(c, state, "fp32")
         ref = torch.optim.SGD(_groups(model), lr=1e-2, momentum=0.9, nesterov=True)
-        _loop(model, ref, None, data, tgt, sub, 3)
+        ref_norms = []
+        _loop(model, ref, None, data, tgt, sub, 3, clip=CLIP if kind == "afft_loop_clip" else None, norms=ref_norms)
     flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
     err = float((got["flat"] - flat).norm() / flat.norm())
     assert err < 1e-6, err
+    if kind == "afft_loop_clip":
+        assert len(ref_norms) == 3 and all(n > 2 * CLIP for n in ref_norms)          # the clip really bit
+        assert all(abs(a - b) < 1e-5 * b for a, b in zip(got["norms"], ref_norms)), (got["norms"], ref_norms)
     import afft_amd
     afft_amd.set_precision("bf16")
 
