@@ -48,7 +48,6 @@ class GemmDesc(C.Structure):
         ("out2", vp), ("ldo2", i64), ("out2_dtype", i32),
         ("drop", Dropout),
         ("workspace", vp), ("workspace_bytes", i64),
-        ("max_workgroups", i32),
         ("split3", i32), ("a_lo", i64), ("b_lo", i64),
         ("sgd", SgdP),
         ("b_packed", vp),
@@ -58,7 +57,7 @@ class GemmDesc(C.Structure):
 
 u32, fp = C.c_uint32, C.POINTER(C.c_float)
 DropP = C.POINTER(Dropout)
-_WS = [("gemm_ws", vp), ("gemm_ws_bytes", i64), ("gemm_ws_aux", vp), ("gemm_ws_aux_bytes", i64), ("wgrad_workgroups", i32)]
+_WS = [("gemm_ws", vp), ("gemm_ws_bytes", i64), ("gemm_ws_aux", vp), ("gemm_ws_aux_bytes", i64)]
 _HAND = [("dx_bf16", vp), ("up_drop", DropP), ("up_dcol", vp)]
 
 
@@ -126,7 +125,7 @@ class CrossAttnSublayer(C.Structure):  # afft_cross_attn_sublayer_t
 
 class GemmTraceRec(C.Structure):   # afft_gemm_trace_rec_t
     _fields_ = [("M", i32), ("N", i32), ("K", i32), ("a_kstrided", i32), ("b_kstrided", i32), ("variant", i32), ("splitk", i32),
-                ("split3", i32), ("capped", i32), ("fused_update", i32), ("ms", f32)]
+                ("split3", i32), ("fused_update", i32), ("ms", f32)]
 
 
 class KernelTraceRec(C.Structure):   # afft_kernel_trace_rec_t

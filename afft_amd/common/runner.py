@@ -350,8 +350,14 @@ class Runner:
     def _reduce_loss(losses, loss_wts, sync: bool = True):
         keys = list(losses)
         wts = [max(float(get_loss_wts(loss_wts, k)), 0.0) for k in keys]      # a weight <= 0 drops the term from the total (runner.py:205-207)
+        if not any(w > 0 for w in wts):
+            raise RuntimeError("Runner._reduce_loss: every loss weight is <= 0 -- there is nothing to sum (the reference's "
+                               "torch.sum(torch.stack([])) fails here too, runner.py:205-207)")
         if 1 <= len(keys) <= 8:
-            loss, means = F_.ReduceLosses.apply(tuple(wts), *[losses[k] for k in keys])      # one launch each way
+            # dropped terms go in DETACHED: they keep their slot (their mean is still logged) but leave the graph, as in the
+            # reference -- no backward work through their branch, and the kernel skips them in the total (0 * NaN would poison it)
+            vals = [losses[k] if w > 0 else losses[k].detach() for k, w in zip(keys, wts)]
+            loss, means = F_.ReduceLosses.apply(tuple(wts), *vals)      # one launch each way
             losses = {k: means[i] for i, k in enumerate(keys)}
         else:
             losses = {key: torch.mean(val) for key, val in losses.items()}

@@ -485,15 +485,6 @@ int afft_attention_mfma(bool backward, const void* dout, int64_t lddo, const voi
     if (!hc) return -1;
     lds = (size_t)(backward ? 3 : 2) * np * 16 * NT * hc * 2;
   }
-  // experiment: AFFT_ATTN_BWD_HC / AFFT_ATTN_FWD_HC force the chunked path with that chunk width (a smaller LDS footprint per
-  // workgroup -> more workgroups per CU, for one more staging pass of dO)
-  static const int force_bwd = [] { const char* v = getenv("AFFT_ATTN_BWD_HC"); return v ? atoi(v) : 0; }();
-  static const int force_fwd = [] { const char* v = getenv("AFFT_ATTN_FWD_HC"); return v ? atoi(v) : 0; }();
-  const int force = backward ? force_bwd : force_fwd;
-  if (force >= 64 && force < hd && hd % force == 0 && force % 64 == 0) {
-    hc = force;
-    lds = (size_t)(backward ? 3 : 2) * np * 16 * NT * hc * 2;
-  }
   AttnArgs a;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.dout = (const bf16_t*)dout;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo;

@@ -33,7 +33,7 @@
 
 using namespace afft_gemm_detail;
 
-int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream, int x3, int max_wg);
+int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream, int x3);
 int afft_gemm_launch_bd(int rows160, int packed, afft_gemm_detail::GemmFast& g, hipStream_t stream);
 
 #ifndef AFFT_G128_EPI_UNROLL
@@ -222,16 +222,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32 g) {
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-int g_splitk_mode = 1;   // 0 off, 1 auto, 2 / 4: force that many slices wherever the shape allows (tests, tuning)
-// stream-K of the 256x256 kernel (choose_splitk): on when the plain grid's utilisation is below AFFT_SK_MAX_EFF and every
-// workgroup gets at least AFFT_SK_MIN_ITERS K-iterations.  Default 0 = never: measured on the path's shapes (profiles/
-// r03_experiments.txt section 1) the balanced launch is 8-12 % SLOWER than the plain partial round -- a K-iteration takes 1.36 us with 160
-// CUs busy and 1.82 us with 256 (the part is power-limited: +60 % CUs buy +10-20 % throughput), and the hand-over of the parked
-// tiles costs 35 us of the rest.  Forced by afft_set_gemm_splitk(2 / 4) in the tests.
-double g_sk_max_eff = [] { const char* e = getenv("AFFT_SK_MAX_EFF"); return e ? atof(e) : 0.0; }();
-int g_sk_min_iters = [] { const char* e = getenv("AFFT_SK_MIN_ITERS"); return e ? atoi(e) : 8; }();
-
-// CUs of the current device (stream-K grids, tile-shape choice): asked once per device ordinal
+int g_splitk_mode = 1;   // 128x128 kernel: 0 off, 1 auto, 2 / 4: force that many slices wherever the shape allows (tests, tuning)
+// CUs of the current device (tile-shape choice): asked once per device ordinal
 int cu_count() {
   static std::atomic<int> cached[64];
   int dev = 0;
@@ -275,47 +267,11 @@ int choose_variant(int M, int N, int K, bool A_KS, bool B_KS);
 bool bd_packed_wins(int M, int N, int K);
 extern int g_bd_mode;
 
-// stream-K of `tiles` 256x256 tiles of nk K-tiles over a grid of G workgroups (SkPlan, gemm_tiles.h): false when no XCD has a
-// partial round to cut or a piece would be empty; else the workspace geometry (leftover tiles per XCD, pieces per tile)
-bool sk_geometry(int tiles, int G, int nk, int* tlmax, int* smax) {
-  const int W = G >> 3, q = tiles >> 3, r = tiles & 7;
-  int tl_max = 0, s_max = 0;
-  for (int c = 0; c < 2; ++c) {
-    const int count = q + c;
-    if ((c == 1 && r == 0) || (c == 0 && r == 8) || count == 0) continue;
-    const SkPlan p = sk_plan(count, W, nk);
-    if (p.Tl == 0) continue;
-    if (p.Km < 1 || p.tail < 1 || (p.rem2 > 0 && p.rem2 < p.H)) return false;     // every piece at least one K-tile
-    tl_max = std::max(tl_max, p.Tl);
-    for (int il = 0; il < p.Tl; ++il) { int hf; s_max = std::max(s_max, sk_pieces(p, il, hf)); }
-  }
-  if (tl_max == 0) return false;
-  if (tlmax) *tlmax = tl_max;
-  if (smax) *smax = s_max;
-  return true;
-}
-
 // K-slices afft_gemm will use for a fast-path problem (1 = no split-K)
 int choose_splitk(int variant, int M, int N, int K) {
   if (!g_splitk_mode) return 1;
   const int nk = K / BK;
-  if (variant == 3) {
-    // 256x256 tiles, one workgroup per CU: STREAM-K (gemm_pp.hip) when the last round of the plain grid would leave the chip
-    // under-used -- 160 tiles (every N = 2048 GEMM of the fuser at B = 64) use 62 % of one round, 640 tiles 83 % of three.
-    // The return value is the stream-K grid: one workgroup per CU, a multiple of 8.  (Round 2's plain 3-slice split of these
-    // grids lost: 480 workgroups wrote and re-read 164 MB of partial tiles with 4-byte write-through stores.)
-    const int64_t t3 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
-    const int ncu = cu_count() & ~7;
-    if (t3 > kMaxSplitTiles || ncu < 8) return 1;
-    if (!sk_geometry((int)t3, ncu, nk, nullptr, nullptr)) return 1;      // nothing to cut, or a piece would be empty
-    const int64_t rounds = (t3 + ncu - 1) / ncu;
-    const double eff = (double)t3 / (double)(rounds * ncu);
-    const int64_t per_wg = t3 * nk / ncu;          // K-iterations per workgroup
-    bool on = false;
-    if (g_splitk_mode == 1) on = eff < g_sk_max_eff && per_wg >= g_sk_min_iters;
-    else if (g_splitk_mode > 1) on = true;             // forced (tests, tuning)
-    return on ? ncu : 1;
-  }
+  if (variant == 3) return 1;     // 256x256 tiles never split K (stream-K was built, measured slower on this power-limited part and removed: profiles/HISTORY.md)
   // 128x128 tiles (2 workgroups per CU = 512 slots): a grid that leaves slots empty is bound by the LDS fill rate of the CUs
   // that have a workgroup -- more workgroups pulling is the lever.  Cut K so that tiles x slices approaches 512, keeping at
   // least 16 K-steps (K = 1024) per slice: <= 128 tiles -> 2 slices (4 when K >= 6144), and -- round 2, measured on the
@@ -339,11 +295,6 @@ int64_t splitk_bytes(int variant, int M, int N, int K, int* slices) {
   const int s = variant >= 4 ? 1 : choose_splitk(variant, M, N, K);
   if (slices) *slices = s;
   if (s <= 1) return 0;
-  if (variant == 3) {      // stream-K: parked tiles [8 XCDs][leftover tiles][pieces]
-    int tlmax = 0, smax = 0;
-    sk_geometry(((M + 255) / 256) * ((N + 255) / 256), s, K / BK, &tlmax, &smax);
-    return (int64_t)8 * tlmax * smax * 256 * 256 * (int64_t)sizeof(float);
-  }
   const int64_t tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
   return tiles * s * 128 * 128 * (int64_t)sizeof(float);
 }
@@ -365,9 +316,7 @@ int launch_layout(GemmFast& g, hipStream_t stream, const afft_gemm_t* d) {
   (void)hipEventRecord(t.b, stream);
   int variant = choose_variant(g.e.M, g.e.N, g.K, A_KS, B_KS);
   if (!A_KS && !B_KS && d->b_packed && !d->split3 && g_variant == 0 && g.ldb == d->K && bd_packed_wins(g.e.M, g.e.N, g.K)) variant = 10;
-  const int tiles = ((g.e.M + 255) / 256) * ((g.e.N + 255) / 256), cap = d->max_workgroups & ~7;
-  t.r = afft_gemm_trace_rec_t{g.e.M, g.e.N, d->K, A_KS, B_KS, variant, g.splitk, d->split3,
-                              variant == 3 && A_KS && B_KS && !d->split3 && g.splitk == 1 && cap >= 8 && cap < tiles, d->sgd != nullptr, 0.f};
+  t.r = afft_gemm_trace_rec_t{g.e.M, g.e.N, d->K, A_KS, B_KS, variant, g.splitk, d->split3, d->sgd != nullptr, 0.f};
   std::lock_guard<std::mutex> lk(g_trace_mu);
   if (g_trace) g_trace->push_back(t);
   return rc;
@@ -413,7 +362,7 @@ int launch_layout_impl(GemmFast& g, hipStream_t stream, const afft_gemm_t* d) {
   g.counters = nullptr;
   if (d->split3 == 2) {     // fp16 two-pass (forward layouts only): same tile choice as bf16x3
     if constexpr (!A_KS) {
-      if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream, 2, 0);
+      if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream, 2);
       return launch_fast<2, 2, 2, A_KS, B_KS, false, 2>(g, stream);
     } else {
       afft_set_error("afft_gemm: the fp16 two-pass mode (split3 = 2) is built for the forward layouts only (A k-contiguous)");
@@ -421,7 +370,7 @@ int launch_layout_impl(GemmFast& g, hipStream_t stream, const afft_gemm_t* d) {
     }
   }
   if (d->split3) {     // bf16x3: 256x256 tiles once the grid fills the chip, else 128x128; no split-K
-    if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream, 1, 0);
+    if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream, 1);
     return launch_fast<2, 2, 2, A_KS, B_KS, false, 1>(g, stream);
   }
   int s = 1;
@@ -430,9 +379,8 @@ int launch_layout_impl(GemmFast& g, hipStream_t stream, const afft_gemm_t* d) {
     g.counters = (int*)d->workspace;
     g.ws = (float*)((char*)d->workspace + AFFT_GEMM_WS_HEADER);
     g.splitk = s;
-    if (variant == 3) sk_geometry(((g.e.M + 255) / 256) * ((g.e.N + 255) / 256), s, g.K / BK, &g.sk_tlmax, &g.sk_smax);
   }
-  if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream, 0, d->max_workgroups);
+  if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream, 0);
   if (variant >= 7 && variant <= 10) return afft_gemm_launch_bd(variant == 8 || variant == 10, variant >= 9, g, stream);
   if (variant == 4) return launch_fast<2, 2, 4, A_KS, B_KS, false>(g, stream);
   if (g.splitk > 1) return launch_fast<2, 2, 2, A_KS, B_KS, true>(g, stream);

@@ -66,33 +66,8 @@ unsigned long long* g_pp_stamp = nullptr;
 #define STAMP(var) do { } while (0)
 #endif
 
-// The kernel's argument block read again from the kernarg segment behind an opaque copy of its address.  In the looping
-// instantiations (stream-K, capped grid) the compiler otherwise hoists the ~50 scalars of the epilogue's parameters out of the
-// tile loop and keeps them alive through the main loop, which then reloads spilled SGPRs from VGPR lanes between its LDS-DMA
-// issues (16 v_readlane per two K-tiles, 17 % per K-tile).  Read after the main loop, they live only where they are used.
-__device__ __forceinline__ GemmFast reload_kernel_args() {
-  typedef const __attribute__((address_space(4))) unsigned* KArgs;
-  KArgs p = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(p));
-  // the kernarg segment starts with the kernel's FIRST parameter: gemm_bf16_pp_kernel(const GemmFast g, ...) -- keep it first
-  struct Raw { unsigned w[sizeof(GemmFast) / 4]; } raw;
-  static_assert(sizeof(GemmFast) % 4 == 0, "argument block is copied dword by dword");
-#pragma unroll
-  for (unsigned i = 0; i < sizeof(GemmFast) / 4; ++i) raw.w[i] = p[i];
-  return __builtin_bit_cast(GemmFast, raw);
-}
-
-// X3: 1 = bf16x3 operand planes, 2 = fp16 planes, two passes (gemm_tiles.h: seg_operands, mfma16).  PERSIST: the grid is capped (a multiple of 8 workgroups, one per
-// CU) and every workgroup walks the tiles bid, bid + gridDim.x, ... -- the launch then holds that many CUs and no more,
-// which is how the weight-gradient GEMMs leave the rest of the chip to the data-gradient chain of the other stream.
-//
-// SPLITK = STREAM-K (round 3).  The path's grids are rarely a whole number of rounds of 256 tiles (every N = 2048 GEMM of the
-// fuser at B = 64 is 160 tiles: 96 CUs idle for the whole launch; 5120 x 8192 is 2.5 rounds).  Here the grid is one
-// workgroup per CU (a multiple of 8), whole rounds run as before and the tiles of the partial round are cut along K so that
-// every workgroup gets the same number of K-iterations (SkPlan, gemm_tiles.h).  A piece of a tile parks its accumulators in
-// the workspace and the LAST piece of a tile to arrive adds them up in K order and runs the epilogue (handoff_combine:
-// nobody waits, bitwise reproducible).  5120x2048x8192: 80 K-iterations on each of 256 CUs instead of 128 on 160.
-template <bool A_KS, bool B_KS, bool SPLITK, int X3 = 0, bool PERSIST = false>
+// X3: 1 = bf16x3 operand planes, 2 = fp16 planes, two passes (gemm_tiles.h: seg_operands, mfma16).
+template <bool A_KS, bool B_KS, int X3 = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
 #ifdef AFFT_PP_STAMP
     , unsigned long long* stamp_out
@@ -110,56 +85,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
   const int tid = threadIdx.x, lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int gp = wave >> 2, wc = wave & 3;
-  static_assert(!(PERSIST && SPLITK), "a capped grid does not split K");
-  int vb = blockIdx.x;
-  const int nk_all = g.K / BK;
-  // stream-K: this workgroup's passes over its XCD's chunk of tiles (SkPlan).  Only (sk_step, sk_cur) are carried from pass to
-  // pass; the plan itself is recomputed from the block index wherever it is needed (sk_state, behind an opaque copy of the
-  // index so that the compiler cannot keep its dozen scalars alive across the main loop: with the plan live the loop spilled
-  // 300 SGPRs to VGPR lanes and ran 17 % slower per K-tile than the plain kernel's).
-  int sk_step = 0, sk_cur = 0;
-  struct SkState { SkPlan sp; int first, xcd, j, re; };
-  auto sk_state = [&]() {
-    SkState st;
-    int bx = (int)blockIdx.x, gx = (int)gridDim.x;
-    asm volatile("" : "+s"(bx), "+s"(gx));
-    st.xcd = bx & 7; st.j = bx >> 3;
-    int count;
-    xcd_chunk(g.tiles_m * g.tiles_n, st.xcd, st.first, count);
-    st.sp = sk_plan(count, gx >> 3, nk_all);
-    st.re = 0;
-    if (st.j >= st.sp.Tl && st.sp.rem2 > 0) st.re = (int)(((int64_t)(st.j - st.sp.Tl + 1) * st.sp.rem2) / st.sp.H);
-    return st;
-  };
-  if constexpr (SPLITK) {
-    const SkState st = sk_state();
-    const SkPlan& sp = st.sp;
-    if (st.j >= sp.Tl && sp.rem2 > 0) sk_cur = (int)(((int64_t)(st.j - sp.Tl) * sp.rem2) / sp.H);
-    if (sp.R == 0 && (sp.Tl == 0 || (st.j >= sp.Tl && sp.F == 0 && sk_cur >= st.re))) return;
-  }
-  bool sk_more = false;
-  do {    // one pass unless PERSIST / stream-K
-  int lane_ = lane0;
-  if constexpr (PERSIST || SPLITK) asm volatile("" : "+v"(lane_));   // keep the per-tile address arithmetic from being hoisted out of
-  const int lane = lane_;                                   // the tile loop: its live ranges would span the epilogue (spills)
+  const int lane = lane0;
   int tm, tn;
-  int sk_tl = 0, sk_klo = 0, sk_nk = nk_all;     // stream-K: the tile's index inside the XCD's chunk, first K-tile, K-tiles of this pass
-  if constexpr (SPLITK) {
-    const SkState st = sk_state();
-    const SkPlan& sp = st.sp;
-    const int sk_j = st.j, sk_first = st.first, sk_re = st.re;
-    if (sk_step < sp.R) sk_tl = sk_step * sp.W + sk_j;                                   // a whole tile
-    else if (sk_j < sp.Tl) { sk_tl = sp.R * sp.W + sk_j; sk_nk = sp.Km; }                // main: head of leftover tile j
-    else if (sk_step < sp.R + sp.F) {                                                    // helper: a whole tail
-      sk_tl = sp.R * sp.W + (sk_step - sp.R) * sp.H + (sk_j - sp.Tl); sk_klo = sp.Km; sk_nk = sp.tail;
-    } else {                                                                             // helper: its range of the remaining tails
-      const int il2 = sk_cur / sp.tail, off = sk_cur - il2 * sp.tail;
-      sk_tl = sp.R * sp.W + sp.F * sp.H + il2; sk_klo = sp.Km + off; sk_nk = min(sp.tail - off, sk_re - sk_cur);
-    }
-    tile_from_id(g.tiles_m, g.tiles_n, sk_first + sk_tl, tm, tn);
-  } else {
-    tile_coords(g.tiles_m, g.tiles_n, vb, tm, tn);
-  }
+  tile_coords(g.tiles_m, g.tiles_n, blockIdx.x, tm, tn);
   const int m0 = tm * 256, n0 = tn * 256;
 #ifdef AFFT_PP_SAMETILE   // diagnostic build only: every workgroup stages tile (0,0) -> all L2 hits (results are wrong)
   const int m0l = 0, n0l = 0;
@@ -167,9 +95,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
   const int m0l = m0, n0l = n0;
 #endif
   const int M = g.e.M, N = g.e.N;
-  // this pass covers K-tiles [kt_lo, kt_lo + nk) of the tile: all of them, or (stream-K) the part inside the workgroup's range
-  const int kt_lo = sk_klo;
-  const int nk = sk_nk, NH = 4 * nk; (void)NH;
+  const int nk = g.K / BK, NH = 4 * nk; (void)NH;
 
   f32x4 acc[2][2][4][2];
 #pragma unroll
@@ -216,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
     if ((AFFT_PP_DIAG & 2) && in_loop) return;
     const unsigned dst = (((m >> 2) & 1) * 4 + q) * HB;      // bytes into the ring; lds_wave carries the ring's address
     int k0; const bf16_t *Ap, *Bp;
-    seg_operands<X3>(g, kt_lo + kt, k0, Ap, Bp);
+    seg_operands<X3>(g, kt, k0, Ap, Bp);
     if (q == 0 || q == 3) {
       const int r0 = m0l + (q == 3 ? 128 : 0);
       if constexpr (A_KS) stage_ks<8, 2>(Ap, g.lda, lda2, voffA, lo, r0, k0, dst, wave, lds_wave);
@@ -347,41 +273,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
   }
 #endif
 
-  // split-K is its own instantiation: the combine code (32 more f32x4 next to the accumulators) makes the register
-  // allocator spill and costs the plain kernel 3-5 % on every shape even when it never runs
-  // from here on the argument block is `ge`: in the looping instantiations a fresh read (see reload_kernel_args)
-  const GemmFast ge_fresh = (PERSIST || SPLITK) ? reload_kernel_args() : GemmFast{};
-  const GemmFast& ge = (PERSIST || SPLITK) ? ge_fresh : g;
-  bool run_epilogue = true;
-  if constexpr (SPLITK) {   // a piece of a tile: see handoff_combine (gemm_tiles.h); only the last piece of a tile to arrive goes on
-    const SkState st = sk_state();
-    const SkPlan& sp = st.sp;
-    if (nk != nk_all) {
-      __syncthreads();    // every wave is done with the ring -> smem is free
-      const int il = sk_tl - sp.R * sp.W;       // leftover tile: pieces = the main's head, then the helpers' in K order
-      int h_first;
-      const int S = sk_pieces(sp, il, h_first);
-      const int me = st.j < sp.Tl ? 0 : 1 + (st.j - sp.Tl) - h_first;
-      constexpr int64_t SLOT = 32 * 512 * 4;     // floats per parked tile (256 KiB)
-      float* tile_ws = ge.ws + ((int64_t)(st.xcd * ge.sk_tlmax + il) * ge.sk_smax) * SLOT;
-      run_epilogue = handoff_combine<32, 512>(reinterpret_cast<f32x4(&)[32]>(acc), [&](int sl) { return tile_ws + sl * SLOT; },
-                                              ge.counters + st.first + sk_tl, S, me, tid, smem);
-    }
-    // what comes next for this workgroup
-    if (sk_step >= sp.R + sp.F && st.j >= sp.Tl) sk_cur += nk;      // helper, in the remaining tails
-    ++sk_step;
-    sk_more = sk_step < sp.R || (sp.Tl > 0 && (st.j < sp.Tl ? sk_step == sp.R : (sk_step < sp.R + sp.F || sk_cur < st.re)));
-  }
-
   // Epilogue through LDS (the ring is free now): two passes of 128 rows.  Accumulators are scattered into an fp32
   // [128][256] image (row stride 1040 B = 1 KiB + 16 B, so the 16 rows a lane group writes fall in 16 different
   // 16-byte slots), then every wave walks 16 whole rows: one conflict-free 16-byte LDS read per lane and fully
   // coalesced global accesses (bias, residual, pre-activation, outputs) in a runtime loop -- no 32-fold unrolled
   // epilogue, no 32-byte store segments.
   constexpr int ESTRIDE = 1040;
-  const DropParams dp = with_salt(ge.e.drop);
+  const DropParams dp = with_salt(g.e.drop);
   if (AFFT_PP_DIAG & 16) return;
-  if (run_epilogue)
   static_for<0, 2>([&](auto ihc) {
     constexpr int ih = decltype(ihc)::value;
     __builtin_amdgcn_s_barrier();   // pass 0: every wave is done with the ring; pass 1: pass 0 has been read back
@@ -401,27 +300,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
       const f32x4 t0 = *(const f32x4*)(smem + row * ESTRIDE + c8 * 32);
       const f32x4 t1 = *(const f32x4*)(smem + row * ESTRIDE + c8 * 32 + 16);
       float o[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-      if (!(AFFT_PP_DIAG & 8)) epilogue8(ge.e, dp, m0 + ih * 128 + row, n0 + 8 * c8, o);
+      if (!(AFFT_PP_DIAG & 8)) epilogue8(g.e, dp, m0 + ih * 128 + row, n0 + 8 * c8, o);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   });
-  if constexpr (!PERSIST && !SPLITK) break;
-  if constexpr (!SPLITK) vb += gridDim.x;
-  __builtin_amdgcn_s_barrier();   // the epilogue image has been read back everywhere before the next tile's LDS-DMA lands
-  } while (SPLITK ? sk_more : vb < g.tiles_m * g.tiles_n);
 }
 
-template <bool A_KS, bool B_KS, bool SPLITK, int X3 = 0, bool PERSIST = false>
-int launch_pp(GemmFast& g, hipStream_t stream, int grid_cap = 0) {
+template <bool A_KS, bool B_KS, int X3 = 0>
+int launch_pp(GemmFast& g, hipStream_t stream) {
   constexpr size_t lds = 128 * 1040;          // ring: 2 K-tiles x 4 half-tiles x 16 KiB = 128 KiB; epilogue image: 130 KiB
   g.tiles_m = (g.e.M + 255) / 256;
   g.tiles_n = (g.e.N + 255) / 256;
-  auto kern = gemm_bf16_pp_kernel<A_KS, B_KS, SPLITK, X3, PERSIST>;
+  auto kern = gemm_bf16_pp_kernel<A_KS, B_KS, X3>;
   static std::atomic<uint64_t> attr_done{0};
   if (int rc = afft_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, &attr_done)) return rc;
-  int grid = g.tiles_m * g.tiles_n;
-  if (PERSIST) grid = grid_cap;     // a multiple of 8, < tiles (afft_gemm_launch_pp)
-  if (SPLITK) grid = g.splitk;      // stream-K: one workgroup per CU, a multiple of 8 (gemm.hip: choose_splitk)
+  const int grid = g.tiles_m * g.tiles_n;
 #ifdef AFFT_PP_STAMP
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, g, g_pp_stamp);
 #else
@@ -438,29 +331,24 @@ int launch_pp(GemmFast& g, hipStream_t stream, int grid_cap = 0) {
 extern "C" void afft_debug_pp_stamp(void* p) { g_pp_stamp = (unsigned long long*)p; }
 #endif
 
-int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream, int x3, int max_wg) {
-  const bool sk = g.splitk > 1;
+int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream, int x3) {
 #ifndef AFFT_PP_NT_ONLY   // development switch: build only the plain NT instantiation (compile time)
-  if (x3) {    // bf16x3 operand planes; never combined with split-K or a capped grid
-    if (sk) { afft_set_error("afft_gemm: split3 with split-K"); return 1; }
-    if (x3 == 2) {   // fp16x2: forward GEMMs only (NT, and NN for [in, out] weights)
-      if (!a_ks && !b_ks) return launch_pp<false, false, false, 2>(g, stream);
-      if (!a_ks && b_ks) return launch_pp<false, true, false, 2>(g, stream);
-      afft_set_error("afft_gemm: the fp16 two-pass mode is built for the forward layouts only");
-      return 1;
-    }
-    if (!a_ks && !b_ks) return launch_pp<false, false, false, 1>(g, stream);
-    if (!a_ks && b_ks) return launch_pp<false, true, false, 1>(g, stream);
-    if (a_ks && b_ks) return launch_pp<true, true, false, 1>(g, stream);
+  if (x3 == 2) {   // fp16x2: forward GEMMs only (NT, and NN for [in, out] weights)
+    if (!a_ks && !b_ks) return launch_pp<false, false, 2>(g, stream);
+    if (!a_ks && b_ks) return launch_pp<false, true, 2>(g, stream);
+    afft_set_error("afft_gemm: the fp16 two-pass mode is built for the forward layouts only");
+    return 1;
   }
-  // capped grid: built for the weight-gradient layout only (the GEMMs that run beside another stream's chain)
-  const int cap = max_wg & ~7, tiles = ((g.e.M + 255) / 256) * ((g.e.N + 255) / 256);
-  if (!x3 && !sk && a_ks && b_ks && cap >= 8 && cap < tiles) return launch_pp<true, true, false, false, true>(g, stream, cap);
+  if (x3) {        // bf16x3 operand planes
+    if (!a_ks && !b_ks) return launch_pp<false, false, 1>(g, stream);
+    if (!a_ks && b_ks) return launch_pp<false, true, 1>(g, stream);
+    if (a_ks && b_ks) return launch_pp<true, true, 1>(g, stream);
+  }
 #endif
-  if (!a_ks && !b_ks) return sk ? launch_pp<false, false, true>(g, stream) : launch_pp<false, false, false>(g, stream);
+  if (!a_ks && !b_ks) return launch_pp<false, false>(g, stream);
 #ifndef AFFT_PP_NT_ONLY
-  if (!a_ks && b_ks) return sk ? launch_pp<false, true, true>(g, stream) : launch_pp<false, true, false>(g, stream);
-  if (a_ks && b_ks) return sk ? launch_pp<true, true, true>(g, stream) : launch_pp<true, true, false>(g, stream);
+  if (!a_ks && b_ks) return launch_pp<false, true>(g, stream);
+  if (a_ks && b_ks) return launch_pp<true, true>(g, stream);
 #endif
   afft_set_error("afft_gemm: layout (A k-strided, B k-contiguous) is not built");
   return 1;

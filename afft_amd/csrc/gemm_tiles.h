@@ -27,11 +27,9 @@ struct GemmFast {
   const bf16_t* B; int64_t ldb;  // k-contiguous: B[N][K] ; k-strided: B[K][N]
   int K;
   int tiles_m, tiles_n;
-  int splitk;   // 128x128 kernel: K is cut into `splitk` slices along gridDim.y; 256x256 kernel: > 1 = stream-K over a grid of
-                // `splitk` workgroups (gemm_pp.hip); 1 = off
-  float* ws;    // split-K: fp32 partial tiles [tile][slice][128*128]; stream-K: parked tiles [xcd][sk_tlmax][sk_smax][256*256] (below)
-  int* counters;  // split-K / stream-K: arrivals per tile (zero between launches)
-  int sk_tlmax, sk_smax;   // stream-K workspace geometry: parked tiles [xcd][sk_tlmax leftover tiles][sk_smax pieces][256*256]
+  int splitk;   // 128x128 kernel: K is cut into `splitk` slices along gridDim.y; 1 = off
+  float* ws;    // split-K: fp32 partial tiles [tile][slice][128*128]
+  int* counters;  // split-K: arrivals per tile (zero between launches)
   // bf16x3 (X3 = 1 instantiations): K counts the K-tiles of all three segments, nk_seg of them per segment; segment 0 reads
   // (A hi, B hi), 1 (A lo, B hi), 2 (A hi, B lo); the lo planes sit a_lo / b_lo elements behind A / B.
   // fp16x2 (X3 = 2): fp16 planes, the first TWO segments only (A = hi + lo, B rounded once), v_mfma_f32_16x16x32_f16
@@ -78,38 +76,10 @@ __device__ __forceinline__ void tile_from_id(int tiles_m, int tiles_n, int id, i
   tm = first_m + in_group % gsz;
   tn = in_group / gsz;
 }
-// bid: the workgroup's (virtual) index -- blockIdx.x, or blockIdx.x + i * gridDim.x for the i-th tile of a workgroup of a
-// capped grid whose size is a multiple of 8 (the XCD of bid is then the XCD the workgroup really runs on)
 __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int bid, int& tm, int& tn) {
   int first, count;
   xcd_chunk(tiles_m * tiles_n, bid & 7, first, count);
   tile_from_id(tiles_m, tiles_n, first + (bid >> 3), tm, tn);
-}
-
-// ----- stream-K plan of the 256x256 kernel (gemm_pp.hip), per XCD: W workgroups share `count` tiles of nk K-tiles each.
-// R whole rounds are plain (workgroup j runs tiles j, j + W, ... with the ordinary epilogue, all at the same K offset at the
-// same time, so the XCD's L2 serves the shared A row / B column panels as in the plain kernel).  The Tl < W LEFTOVER tiles are
-// what a plain grid would run as a partial round: workgroups 0..Tl-1 ("mains") run the first Km = Tl * nk / W K-tiles of
-// leftover tile j -- again aligned in K -- and the H = W - Tl others ("helpers") share the tails [Km, nk): helper h first
-// takes the whole tail of tiles h, h + H, ... (F of them, aligned among the helpers), then a contiguous range of what is
-// left (Tr tails, cut evenly).  Everybody gets R * nk + Km iterations (+-1).  A first attempt that cut the tile-major
-// iteration space into equal contiguous ranges lost 25 % instead: neighbouring workgroups then sit at different K offsets
-// and nothing is shared in L2 any more (5120x2048x8192: 236 us against 185 us plain).
-struct SkPlan { int W, R, Tl, Km, tail, H, F, Tr, rem2; };
-__host__ __device__ __forceinline__ SkPlan sk_plan(int count, int W, int nk) {
-  SkPlan p;
-  p.W = W; p.R = count / W; p.Tl = count - p.R * W;
-  p.Km = (int)(((long long)p.Tl * nk) / W); p.tail = nk - p.Km; p.H = W - p.Tl;
-  p.F = p.Tl / p.H; p.Tr = p.Tl - p.F * p.H; p.rem2 = p.Tr * p.tail;
-  return p;
-}
-// pieces of leftover tile il (0 = the main's head, then the helpers' pieces in K order): how many, and the first helper
-__host__ __device__ __forceinline__ int sk_pieces(const SkPlan& p, int il, int& h_first) {
-  if (il < p.F * p.H) { h_first = il % p.H; return 2; }
-  const long long x0 = (long long)(il - p.F * p.H) * p.tail, x1 = x0 + p.tail - 1;
-  h_first = (int)(((x0 + 1) * p.H - 1) / p.rem2);           // helper h owns [h * rem2 / H, (h + 1) * rem2 / H)
-  const int h_last = (int)(((x1 + 1) * p.H - 1) / p.rem2);
-  return 2 + h_last - h_first;
 }
 
 // ----- LDS-DMA staging, scalar-base form: global_load_lds_dwordx4 voff32, s[base:base+1] with M0 = LDS destination.
@@ -222,7 +192,7 @@ __device__ __forceinline__ bf16x8 frag_ks(const char* lds_tile, int kb, int unit
   return f;
 }
 
-// ----- split-K / stream-K hand-over ("last arriver"): every K-segment of a tile parks its fp32 partial (NV f32x4 per thread,
+// ----- split-K hand-over ("last arriver"): every K-segment of a tile parks its fp32 partial (NV f32x4 per thread,
 // NT threads) in the workspace and counts itself in; the segment whose count completes the tile adds the partials in
 // segment order -- bitwise the same sum whoever it is -- and returns true (it runs the epilogue); the others return false.
 // No workgroup waits for another, so nothing can deadlock, and there is no release/acquire fence (an agent-scope release
@@ -244,8 +214,7 @@ template <int NV, int NT, class SlotFn>
 __device__ __forceinline__ bool handoff_combine(f32x4 (&acc)[NV], SlotFn&& slot, int* counter, int S, int me, int tid, char* smem) {
   constexpr int SLICE_BYTES = NV * NT * 16;
   // Segment 0 looks before it parks: if every other segment has already arrived it is the last one -- it keeps its
-  // accumulators, adds the others to them in K order (a + b = b + a bitwise) and nothing of its own goes to memory.  In the
-  // stream-K plan segment 0 is the main's head, which finishes after the helpers' tails: the common case.
+  // accumulators, adds the others to them in K order (a + b = b + a bitwise) and nothing of its own goes to memory.
   bool last_without_parking = false;
   if (me == 0) {
     if (tid == 0) *(volatile int*)smem = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

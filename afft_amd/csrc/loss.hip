@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const LossTerms t, flo
     s = block_reduce(s, sh, false);
     const float m = t.n[i] > 0 ? s / (float)t.n[i] : 0.f;
     if (threadIdx.x == 0 && means) means[i] = m;
-    tot += t.w[i] * m;
+    if (t.w[i] != 0.f) tot += t.w[i] * m;     // a weight of 0 DROPS the term (runner.py:205-207): its NaN / inf must not reach the total
   }
   if (threadIdx.x == 0) *total = tot;
 }

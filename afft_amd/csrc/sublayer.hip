@@ -55,7 +55,7 @@ afft_gemm_t lin_dgrad(const void* dy, int64_t lddy, int rows, int n_out, const v
 }
 // dW (+)= dy^T x ([n_out, k_in], nn.Linear) or x^T dy ([k_in, n_out], Conv1D); the reduction runs over the padded rows
 int wgrad(const void* dy, int64_t lddy, int n_out, const void* x, int64_t ldx, int k_in, int rows, bool conv1d, float* g_out,
-          int acc, Ws ws, int max_wg, hipStream_t st, const afft_sgd_fused_t* sgd = nullptr) {
+          int acc, Ws ws, hipStream_t st, const afft_sgd_fused_t* sgd = nullptr) {
   if (!g_out) return 0;
   const void* a = conv1d ? x : dy; const void* b = conv1d ? dy : x;
   const int64_t lda = conv1d ? ldx : lddy, ldb = conv1d ? lddy : ldx;
@@ -65,7 +65,6 @@ int wgrad(const void* dy, int64_t lddy, int n_out, const void* x, int64_t ldx, i
   g.B = b; g.b_rs = ldb; g.b_cs = 1;
   g.out = g_out; g.ldo = N; g.out_dtype = AFFT_F32;
   g.accumulate = acc;
-  g.max_workgroups = max_wg;
   if (sgd) {      // the update consumes the gradient in the epilogue: first (and only) contribution of the step
     AFFT_CHECK(!acc, "sublayer: a fused update needs the weight's only gradient contribution of the step");
     g.sgd = sgd;
@@ -164,7 +163,7 @@ extern "C" int afft_attn_sublayer_bwd(const afft_attn_sublayer_t* s, void* strea
   // reads that image (one event later than the plain form, which starts beside it).
   auto side_proj = [&]() -> int {
     TRY(stream_follows(aux, st));
-    TRY(wgrad(s->dya, d, d, s->ao, d, d, R, s->conv1d, s->g_w_proj, s->acc_w_proj, wsa, s->wgrad_workgroups, aux, s->sgd_w_proj));
+    TRY(wgrad(s->dya, d, d, s->ao, d, d, R, s->conv1d, s->g_w_proj, s->acc_w_proj, wsa, aux, s->sgd_w_proj));
     if (s->g_b_proj) {
       if (od) TRY(afft_colsum(s->dya, d, AFFT_BF16, R, d, s->g_b_proj, s->acc_b_proj, wsa.p, wsa.bytes, aux));
       else TRY(afft_colsum(s->dy, d, AFFT_F32, R, d, s->g_b_proj, s->acc_b_proj, wsa.p, wsa.bytes, aux));
@@ -182,7 +181,7 @@ extern "C" int afft_attn_sublayer_bwd(const afft_attn_sublayer_t* s, void* strea
                          d / s->H, s->scale, s->p_attn, s->k_attn, dq, 3 * d, dq + 2 * d, 3 * d, dq + 4 * d, 3 * d, st));
   auto side_qkv = [&]() -> int {
     TRY(stream_follows(aux, st));
-    TRY(wgrad(s->dqkv, 3 * d, 3 * d, s->xn, d, d, R, s->conv1d, s->g_w_qkv, s->acc_w_qkv, wsa, s->wgrad_workgroups, aux, s->sgd_w_qkv));
+    TRY(wgrad(s->dqkv, 3 * d, 3 * d, s->xn, d, d, R, s->conv1d, s->g_w_qkv, s->acc_w_qkv, wsa, aux, s->sgd_w_qkv));
     if (s->g_b_qkv) TRY(afft_colsum(s->dqkv, 3 * d, AFFT_BF16, R, 3 * d, s->g_b_qkv, s->acc_b_qkv, wsa.p, wsa.bytes, aux));
     return 0;
   };
@@ -260,7 +259,7 @@ extern "C" int afft_mlp_sublayer_bwd(const afft_mlp_sublayer_t* s, void* stream_
   TRY(zero_row_tail(s->du, R, hd, st));
   auto side_fc2 = [&]() -> int {      // see afft_attn_sublayer_bwd for the ordering of a fused update
     TRY(stream_follows(aux, st));
-    TRY(wgrad(s->dya, d, d, s->h, hd, hd, R, s->conv1d, s->g_w2, s->acc_w2, wsa, s->wgrad_workgroups, aux, s->sgd_w2));
+    TRY(wgrad(s->dya, d, d, s->h, hd, hd, R, s->conv1d, s->g_w2, s->acc_w2, wsa, aux, s->sgd_w2));
     if (s->g_b2) {
       if (od) TRY(afft_colsum(s->dya, d, AFFT_BF16, R, d, s->g_b2, s->acc_b2, wsa.p, wsa.bytes, aux));
       else TRY(afft_colsum(s->dy, d, AFFT_F32, R, d, s->g_b2, s->acc_b2, wsa.p, wsa.bytes, aux));
@@ -276,7 +275,7 @@ extern "C" int afft_mlp_sublayer_bwd(const afft_mlp_sublayer_t* s, void* stream_
   if (s->sgd_w2) TRY(side_fc2());
   auto side_fc1 = [&]() -> int {
     TRY(stream_follows(aux, st));
-    TRY(wgrad(s->du, hd, hd, s->xn, d, d, R, s->conv1d, s->g_w1, s->acc_w1, wsa, s->wgrad_workgroups, aux, s->sgd_w1));
+    TRY(wgrad(s->du, hd, hd, s->xn, d, d, R, s->conv1d, s->g_w1, s->acc_w1, wsa, aux, s->sgd_w1));
     if (s->g_b1) TRY(afft_colsum(s->du, hd, AFFT_BF16, R, hd, s->g_b1, s->acc_b1, wsa.p, wsa.bytes, aux));
     return 0;
   };
@@ -335,7 +334,7 @@ extern "C" int afft_cross_attn_sublayer_bwd(const afft_cross_attn_sublayer_t* s,
   for (void* b : bufs) TRY(zero_row_tail(b, R, d, st));
   auto side_proj = [&]() -> int {      // see afft_attn_sublayer_bwd for the ordering of a fused update
     TRY(stream_follows(aux, st));
-    TRY(wgrad(s->dya, d, d, s->ao, d, d, R, false, s->g_w_proj, s->acc_w_proj, wsa, s->wgrad_workgroups, aux, s->sgd_w_proj));
+    TRY(wgrad(s->dya, d, d, s->ao, d, d, R, false, s->g_w_proj, s->acc_w_proj, wsa, aux, s->sgd_w_proj));
     if (s->g_b_proj) {
       if (od) TRY(afft_colsum(s->dya, d, AFFT_BF16, R, d, s->g_b_proj, s->acc_b_proj, wsa.p, wsa.bytes, aux));
       else TRY(afft_colsum(s->dy, d, AFFT_F32, R, d, s->g_b_proj, s->acc_b_proj, wsa.p, wsa.bytes, aux));
@@ -352,9 +351,9 @@ extern "C" int afft_cross_attn_sublayer_bwd(const afft_cross_attn_sublayer_t* s,
   const bool fused_qkv = s->sgd_w_q || s->sgd_w_k || s->sgd_w_v;
   auto side_qkv = [&]() -> int {
     TRY(stream_follows(aux, st));
-    TRY(wgrad(s->dq, d, d, s->xq, d, d, R, false, s->g_w_q, s->acc_w_q, wsa, s->wgrad_workgroups, aux, s->sgd_w_q));
-    TRY(wgrad(s->dk, d, d, s->mkv, d, d, R, false, s->g_w_k, s->acc_w_k, wsa, s->wgrad_workgroups, aux, s->sgd_w_k));
-    TRY(wgrad(s->dv, d, d, s->mkv, d, d, R, false, s->g_w_v, s->acc_w_v, wsa, s->wgrad_workgroups, aux, s->sgd_w_v));
+    TRY(wgrad(s->dq, d, d, s->xq, d, d, R, false, s->g_w_q, s->acc_w_q, wsa, aux, s->sgd_w_q));
+    TRY(wgrad(s->dk, d, d, s->mkv, d, d, R, false, s->g_w_k, s->acc_w_k, wsa, aux, s->sgd_w_k));
+    TRY(wgrad(s->dv, d, d, s->mkv, d, d, R, false, s->g_w_v, s->acc_w_v, wsa, aux, s->sgd_w_v));
     return 0;
   };
   if (!fused_qkv) TRY(side_qkv());

@@ -117,12 +117,10 @@ def to_act(x: Tensor, drop=None) -> Act:
 def _lin_fwd(x: Act, W: Tensor, conv1d: bool, out: Tensor, **ep) -> Tensor:
     """out[rows, n_out] = epilogue(x @ W^T) (nn.Linear, W [out,in]) or x @ W (HF Conv1D, W [in,out])."""
     if rt.precision() == "bf16":
-        w16, wt16 = rt.weight_images(W)      # [pad(rows), pad(cols)] and its transpose
+        w16 = rt.weight_images(W)            # [pad(rows), pad(cols)]
         if not conv1d:                       # W [out, in] is B stored [N, K]: "NT"
             pk = rt.weight_packed(W, x.k.shape[0]) if x.k.shape[1] == W.shape[1] else None
             return ops.gemm(x.k, w16[:W.shape[0]], out, b_t=True, b_packed=pk, **ep)
-        if wt16 is not None:                 # W^T [out, in]: "NT"
-            return ops.gemm(x.k, wt16[:W.shape[1]], out, b_t=True, **ep)
         return ops.gemm(x.k, w16[:, :W.shape[1]], out, **ep)             # W [in, out] = [K, N]: "NN"
     if rt.precision() == "fp16x2":           # x = hi + lo in fp16 planes, W rounded once to fp16 (its FP16 image)
         h16 = rt.weight_f16(W)
@@ -143,11 +141,9 @@ def _forward_only_check():
 def _lin_dgrad(dy: Act, W: Tensor, conv1d: bool, out: Tensor, **ep) -> Tensor:
     """out[rows, n_in] = epilogue(dy @ W) (nn.Linear) or dy @ W^T (Conv1D)."""
     if rt.precision() == "bf16":
-        w16, wt16 = rt.weight_images(W)
+        w16 = rt.weight_images(W)
         if conv1d:                           # dx = dy W^T, W [in, out] is B stored [N, K]: "NT"
             return ops.gemm(dy.k, w16[:W.shape[0]], out, b_t=True, **ep)
-        if wt16 is not None:                 # dx = dy W, W^T [in, out] is B stored [N, K]: "NT"
-            return ops.gemm(dy.k, wt16[:W.shape[1]], out, b_t=True, **ep)
         return ops.gemm(dy.k, w16[:, :W.shape[1]], out, **ep)            # W [out, in] = [K, N]: "NN"
     _forward_only_check()
     if rt.precision() == "bf16x3":
@@ -215,14 +211,13 @@ def _wgrad(dy: Act, x: Act, W: Tensor, conv1d: bool) -> Optional[Tensor]:
         at, bt = a.tn, b.tn
         _on_side(a.buf)
         _on_side(b.buf)
-    cap = rt.wgrad_workgroups() if _TS.side_stream is not None else 0
     if rt.grad_mode() == "sink":
         g, acc = rt.SINK.grad_buffer(W)
-        ops.gemm(at, bt, g, a_t=True, accumulate=acc, max_workgroups=cap)
+        ops.gemm(at, bt, g, a_t=True, accumulate=acc)
         _ready(W)
         return None
     g = torch.empty_like(W)
-    ops.gemm(at, bt, g, a_t=True, max_workgroups=cap)
+    ops.gemm(at, bt, g, a_t=True)
     return g
 
 
@@ -539,7 +534,7 @@ def _img_h(W: Tensor):
 
 def _img(W: Tensor):
     """(pointer, leading dimension) of the bf16 image of a 2-D weight"""
-    w16, _ = rt.weight_images(W)
+    w16 = rt.weight_images(W)
     return w16.data_ptr(), w16.stride(0)
 
 
@@ -622,7 +617,6 @@ def _fill_ws(s, dev, main_raw, aux_raw):
     if aux_raw is not None:
         wa = ops.gemm_workspace(dev, aux_raw)
         s.gemm_ws_aux, s.gemm_ws_aux_bytes = wa.data_ptr(), wa.numel()
-    s.wgrad_workgroups = rt.wgrad_workgroups_for(int(s.rows)) if aux_raw is not None else 0
 
 
 def _keep_for_aux(aux, *tensors):

@@ -48,14 +48,12 @@ def _rowmajor(t: Tensor, what: str):
 
 
 _WS: dict = {}      # (device index, raw stream) -> split-K scratch of that stream (afft_gemm_t.workspace), never shared
-_WS_BYTES = (132 << 20)   # header + every split-K problem of the 128x128 kernel the automatic mode picks (<= 256 tiles x 4 slices x 64 KiB = 64 MiB) and the
-                          # stream-K layouts the tests force ([8 XCDs][leftover tiles][pieces] x 256 KiB, gemm.hip: sk_geometry; stream-K itself is off by
-                          # default).  A launch whose problem needs more than this runs unsplit (afft_gemm_workspace_bytes tells how much it wants).
+_WS_BYTES = (68 << 20)    # header + every split-K problem of the 128x128 kernel the automatic mode picks (<= 256 tiles x 4 slices x 64 KiB = 64 MiB).
+                          # A launch whose problem needs more than this runs unsplit (afft_gemm_workspace_bytes tells how much it wants).
 
 
 def set_workspace_bytes(n: int):
-    """Size of the per-stream split-K scratch (tests that force split-K on the 256x256 kernel need 3 x 256 KiB per tile).
-    A launch whose problem needs more than it is given simply runs unsplit."""
+    """Size of the per-stream split-K scratch.  A launch whose problem needs more than it is given simply runs unsplit."""
     global _WS_BYTES
     if n != _WS_BYTES:
         _WS_BYTES = int(n)
@@ -96,7 +94,7 @@ def gemm(a, b, out: Tensor, *, a_t: bool = False, b_t: bool = False, bias: Optio
          act: int = ACT_NONE, aux: Optional[Tensor] = None, pre: Optional[Tensor] = None,
          rowscale: Optional[Tensor] = None, residual: Optional[Tensor] = None, accumulate: bool = False,
          out2: Optional[Tensor] = None, alpha: float = 1.0, drop: Optional["L.Dropout"] = None,
-         max_workgroups: int = 0, sgd: Optional["L.SgdFused"] = None, b_packed: Optional[Tensor] = None,
+         sgd: Optional["L.SgdFused"] = None, b_packed: Optional[Tensor] = None,
          out_lo: int = 0) -> Tensor:
     """out = epilogue(alpha * A @ B).  A = a (or a.T if a_t), B = b (or b.T if b_t); a, b 2-D views -- or both `Split`
     (two-plane bf16 splits of fp32 matrices): the bf16x3 GEMM, fp32-accurate products on the bf16 MFMA path; or a an fp16 `Split`
@@ -137,7 +135,6 @@ def gemm(a, b, out: Tensor, *, a_t: bool = False, b_t: bool = False, bias: Optio
     if a.dtype == torch.bfloat16 and not d.split3:
         ws = gemm_workspace(a.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-    d.max_workgroups = max_workgroups
     if b_packed is not None:
         assert b_packed.dtype == torch.bfloat16 and b_packed.is_contiguous() and b_t and not a_t and b_packed.numel() == N * K
         d.b_packed = _p(b_packed)

@@ -58,11 +58,6 @@ class FlatParams:
         # MFMA operand copies of the weights cost no extra pass (only GEMM weights with both dims % 64 == 0 use it;
         # odd shapes -- the 3806-row classifier, the 352-column objects mapping -- keep a padded cast image)
         self.flat_p16 = torch.zeros(off, dtype=torch.bfloat16, device=dev) if dev.type == "cuda" else None
-        # transposed bf16 images (same offsets): with both images every forward / dgrad GEMM is the k-contiguous "NT"
-        # layout; refreshed by a transpose-cast queued behind the SGD kernel of the bucket (see FusedSGD.step_range)
-        use_t = dev.type == "cuda" and rt.transposed_images()
-        self.flat_pT16 = torch.zeros(off, dtype=torch.bfloat16, device=dev) if use_t else None
-        self.transposed: List[tuple] = []     # (offset, param, transposed view) for the 2-D GEMM weights
         # fragment-packed bf16 images (same offsets and sizes; runtime.packed_images): the B operand of the "B direct" GEMM
         # kernels.  A slot per GEMM weight; an image goes live when a forward GEMM first wants it (runtime.weight_packed) and is
         # from then on written by the fused optimizer epilogue or re-packed after every other update (refresh_packed)
@@ -82,16 +77,11 @@ class FlatParams:
                 ops.cast(self.flat_p.view(off // 64, 64), self.flat_p16.view(off // 64, 64))
                 for p, o in zip(self.params, self.offsets):
                     if p.dim() == 2 and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0:
-                        vt = None
-                        if use_t:
-                            vt = self.flat_pT16[o:o + p.numel()].view(p.shape[1], p.shape[0])
-                            ops.cast(p.detach(), None, vt)
-                            self.transposed.append((o, p, vt))
                         pk = None
                         if use_pk:
                             pk = self.flat_pk16[o:o + p.numel()]
                             self.packed.append((o, p, pk))
-                        rt.adopt_weight_image(p, self.flat_p16[o:o + p.numel()].view(p.shape), vt, packed=pk)
+                        rt.adopt_weight_image(p, self.flat_p16[o:o + p.numel()].view(p.shape), packed=pk)
         rt.invalidate_weight_images()
         self.ensure_f16()
 
@@ -120,7 +110,6 @@ class FlatParams:
                 ops.cast(self.flat_p.view(n // 64, 64), self.flat_p16.view(n // 64, 64))
                 if self.flat_h16 is not None:
                     ops.cast(self.flat_p.view(n // 64, 64), self.flat_h16.view(n // 64, 64))
-            self.refresh_transposed(0, n)
             self.refresh_packed(0, n)
         rt.invalidate_weight_images()
 
@@ -133,12 +122,6 @@ class FlatParams:
             for o, p, pk in self.packed:
                 if s <= o < e and id(p) not in skip and rt.packed_live(p):
                     ops.pack_weight(p.detach(), pk)
-
-    def refresh_transposed(self, s: int, e: int):
-        """Re-cast the transposed bf16 images of the weights that live in flat range [s, e)."""
-        for o, p, vt in self.transposed:
-            if s <= o < e:
-                ops.cast(p.detach(), None, vt)
 
     def index_of(self) -> Dict[int, int]:
         return {id(p): i for i, p in enumerate(self.params)}
@@ -381,7 +364,6 @@ class FusedSGD:
             p16 = self.flat.flat_p16[s:e] if self.flat.flat_p16 is not None else None
             ops.sgd_nesterov(self.flat.flat_p[s:e], grad, self.buf[s:e], self.lr, self.momentum, self.wd, gscale,
                              self.flags(), p_bf16=p16, gscale_dev=gscale_dev, p_f16=self.flat.h16(s, e))
-            self.flat.refresh_transposed(s, e)
             self.flat.refresh_packed(s, e)
             return
         # per-parameter (lr, wd): the parameters of the bucket class by class
@@ -410,7 +392,6 @@ class FusedSGD:
                 p16 = flat.flat_p16[o:o + n] if flat.flat_p16 is not None else None
                 ops.sgd_nesterov(flat.flat_p[o:o + n], grad[o - s:o - s + n], self.buf[o:o + n], lr, self.momentum, wd, gscale,
                                  self.flags(), p_bf16=p16, gscale_dev=gscale_dev, p_f16=flat.h16(o, o + n))
-        self.flat.refresh_transposed(s, e)
         self.flat.refresh_packed(s, e, skip=(self.skip if fused else ()))
 
     def end_step(self):
@@ -446,7 +427,7 @@ class _FusedEpilogue:
     # ---- optimizer fused into the weight-gradient GEMM epilogues (single GPU)
     def _can_fuse(self) -> bool:
         return (rt.fused_sgd() and rt.composite() and rt.precision() in ("bf16", "fp16x2") and rt.grad_mode() == "sink"
-                and self.flat.flat_p.is_cuda and self.flat.flat_p16 is not None and self.flat.flat_pT16 is None
+                and self.flat.flat_p.is_cuda and self.flat.flat_p16 is not None
                 and not self.reducer.comm and self.grad_clip is None and not rt.CAPTURING)
 
     def _enable_fused(self):

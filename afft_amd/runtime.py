@@ -102,7 +102,7 @@ def pad64(n: int) -> int:
 
 # --------------------------------------------------------------------------- bf16 weight images
 class _WImage:
-    __slots__ = ("version", "ptr", "w", "wt", "external", "pk", "pk_live", "pk_version", "h", "h_version", "h_external")
+    __slots__ = ("version", "ptr", "w", "external", "pk", "pk_live", "pk_version", "h", "h_version", "h_external")
 
 
 _wlist: list = []   # weak references to parameters that own an image (for invalidate_weight_images)
@@ -116,21 +116,17 @@ def _register(p: Tensor):
         p._afft_listed = True
 
 
-def weight_images(p: Tensor):
-    """(w16, wt16): bf16 images of a 2-D fp32 parameter, zero padded to multiples of 64 --
-    w16 [pad(rows), pad(cols)] and its transpose wt16 [pad(cols), pad(rows)] (may be None).
-    With both images every forward and dgrad GEMM runs in the k-contiguous "NT" layout (the fastest operand
-    path: one ds_read_b128 per fragment); without wt16 the k-strided "NN" layout is used instead.
+def weight_images(p: Tensor) -> Tensor:
+    """w16: the bf16 image [pad64(rows), pad64(cols)] of a 2-D fp32 parameter, zero padded (the k-contiguous "NT" operand of
+    the forward GEMM of nn.Linear / the data-gradient GEMM of HF Conv1D, the k-strided "NN" operand of the other two).
     Refreshed by one cast kernel when the parameter's version counter or storage changes; parameters re-homed by
-    afft_amd.parallel.FlatParams have w16 written by the fused SGD kernel and wt16 by a transpose-cast queued right
-    behind it on the optimizer's side stream (`external`)."""
+    afft_amd.parallel.FlatParams have it written by the optimizer kernels (`external`)."""
     img = getattr(p, "_afft_img", None)
     ver = p._version
     if img is None or img.ptr != p.data_ptr() or img.w.device != p.device:
         img = _WImage()
         rows, cols = p.shape
         img.w = torch.zeros(pad64(rows), pad64(cols), dtype=torch.bfloat16, device=p.device)
-        img.wt = torch.zeros(pad64(cols), pad64(rows), dtype=torch.bfloat16, device=p.device)
         img.version = -1
         img.external = False
         img.pk = None
@@ -144,9 +140,9 @@ def weight_images(p: Tensor):
         _register(p)
     if img.version != ver:
         with torch.no_grad():
-            ops.cast(p.detach(), img.w[:p.shape[0], :p.shape[1]], None if img.wt is None else img.wt[:p.shape[1], :p.shape[0]])
+            ops.cast(p.detach(), img.w[:p.shape[0], :p.shape[1]])
         img.version = ver
-    return img.w, img.wt
+    return img.w
 
 
 def weight_f16(p: Tensor) -> Tensor:
@@ -192,9 +188,6 @@ def weight_split(p: Tensor):
         ent = (p._version, p.data_ptr(), sp)
         p._afft_split = ent
     return ent[2]
-
-
-_TRANSPOSED_IMAGES = os.environ.get("AFFT_WT_IMAGES", "0") != "0"
 
 
 _PACKED_IMAGES = os.environ.get("AFFT_PACKED_IMAGES", "1") != "0"
@@ -243,20 +236,12 @@ def packed_live(p: Tensor) -> bool:
     return bool(img is not None and img.external and img.pk is not None and img.pk_live)
 
 
-def transposed_images() -> bool:
-    """Keep a transposed bf16 image beside every GEMM weight of a Trainer (all forward / dgrad GEMMs then run NT) at
-    the price of one transpose-cast per weight per optimizer step.  Off by default: measured on cfg2 the casts cost
-    0.5 ms/step more than NT saves over the k-strided NN layout (21.6 vs 21.1 ms/step); AFFT_WT_IMAGES=1 turns it on."""
-    return _TRANSPOSED_IMAGES
-
-
-def adopt_weight_image(p: Tensor, view16: Tensor, view16_t: Optional[Tensor] = None, packed: Optional[Tensor] = None):
-    """Use `view16` (bf16, same shape as p, both dims multiples of 64, kept fresh by the optimizer kernel) and
-    optionally its transpose `view16_t` as p's MFMA images; `packed`: the fragment-packed copy of view16 (ops.pack_weight,
-    afft_gemm_t.b_packed), kept fresh by the same optimizer paths (parallel.FlatParams.refresh_packed)."""
+def adopt_weight_image(p: Tensor, view16: Tensor, packed: Optional[Tensor] = None):
+    """Use `view16` (bf16, same shape as p, both dims multiples of 64, kept fresh by the optimizer kernel) as p's MFMA image;
+    `packed`: the fragment-packed copy of view16 (ops.pack_weight, afft_gemm_t.b_packed), kept fresh by the same optimizer paths
+    (parallel.FlatParams.refresh_packed)."""
     img = _WImage()
     img.w = view16
-    img.wt = view16_t
     img.pk = packed
     img.pk_live = False
     img.pk_version = -1
@@ -350,26 +335,6 @@ SINK = GradSink()
 _AUX_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 _OVERLAP_WGRAD = os.environ.get("AFFT_OVERLAP_WGRAD", "1") != "0"
 _AUX_PRIORITY = int(os.environ.get("AFFT_AUX_PRIORITY", "0"))     # HIP stream priority of the auxiliary stream (lower = served first)
-_AUX_CUS = int(os.environ.get("AFFT_AUX_CUS", "0"))               # experiment: CU mask of the auxiliary stream (0 = all CUs)
-_MASKED_STREAMS = []                                              # raw masked streams are never destroyed (process lifetime)
-
-
-def _cu_masked_stream(idx: int, n_cus: int) -> "torch.cuda.Stream":
-    """A HIP stream whose kernels may only use the first n_cus bits of the CU mask (hipExtStreamCreateWithCUMask; the driver deals
-    mask bits round-robin over the XCDs, so a prefix of n bits leaves (256 - n) / 8 CUs of every XCD to the other streams)."""
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    words = (n_cus + 31) // 32
-    mask = (ctypes.c_uint32 * words)()
-    for b in range(n_cus):
-        mask[b // 32] |= 1 << (b % 32)
-    raw = ctypes.c_void_p()
-    with torch.cuda.device(idx):
-        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(raw), ctypes.c_uint32(words), mask)
-    if rc != 0 or not raw.value:
-        raise RuntimeError(f"hipExtStreamCreateWithCUMask({n_cus} CUs) failed: {rc}")
-    _MASKED_STREAMS.append(raw)
-    return torch.cuda.ExternalStream(raw.value, device=idx)
 
 
 def aux_stream(device) -> "torch.cuda.Stream":
@@ -377,7 +342,7 @@ def aux_stream(device) -> "torch.cuda.Stream":
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _AUX_STREAMS.get(idx)
     if st is None:
-        st = _cu_masked_stream(idx, _AUX_CUS) if _AUX_CUS > 0 else torch.cuda.Stream(device=idx, priority=_AUX_PRIORITY)
+        st = torch.cuda.Stream(device=idx, priority=_AUX_PRIORITY)
         _AUX_STREAMS[idx] = st
     return st
 
@@ -391,7 +356,6 @@ def set_overlap_wgrad(on: bool):
     _OVERLAP_WGRAD = bool(on)
 
 
-_WGRAD_WGS = int(os.environ.get("AFFT_WGRAD_WGS", "0"))
 _SKIP_DEAD_ROWS = os.environ.get("AFFT_SKIP_DEAD_ROWS", "1") != "0"
 
 
@@ -409,36 +373,6 @@ def set_skip_dead_rows(on: bool):
     global _SKIP_DEAD_ROWS
     _SKIP_DEAD_ROWS = bool(on)
 
-
-
-def wgrad_workgroups() -> int:
-    """Cap on the workgroups (= CUs) of a weight-gradient GEMM that runs on the auxiliary stream beside the data-gradient
-    chain (afft_gemm_t.max_workgroups): the chain's 160-tile GEMMs and its HBM-bound kernels then always find free CUs
-    instead of queueing behind 130-us weight-gradient tiles.  0 = no cap (one workgroup per tile)."""
-    return _WGRAD_WGS
-
-
-def set_wgrad_workgroups(n: int):
-    global _WGRAD_WGS
-    _WGRAD_WGS = max(0, int(n))
-
-
-_WGRAD_WGS_SMALL = int(os.environ.get("AFFT_WGRAD_WGS_SMALL", "0"))
-_WGRAD_SMALL_ROWS = int(os.environ.get("AFFT_WGRAD_SMALL_ROWS", "2048"))
-
-
-def wgrad_workgroups_for(rows: int) -> int:
-    """CU cap of a sub-layer's weight-gradient GEMMs by its row count: sub-layers with at most AFFT_WGRAD_SMALL_ROWS rows (the
-    predictor's M = B*T rows: its data-gradient GEMMs are 128-tile grids that fill half the chip, its weight gradients are bound
-    by the optimizer epilogue's HBM traffic, not by CUs) take AFFT_WGRAD_WGS_SMALL (0 = no cap), the others wgrad_workgroups()."""
-    if _WGRAD_WGS_SMALL > 0 and rows <= _WGRAD_SMALL_ROWS:
-        return _WGRAD_WGS_SMALL
-    return _WGRAD_WGS
-
-
-def set_wgrad_workgroups_small(n: int, rows: int = 2048):
-    global _WGRAD_WGS_SMALL, _WGRAD_SMALL_ROWS
-    _WGRAD_WGS_SMALL, _WGRAD_SMALL_ROWS = max(0, int(n)), int(rows)
 
 
 _SIDE_MIN_ROWS = int(os.environ.get("AFFT_SIDE_MIN_ROWS", "0"))

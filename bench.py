@@ -66,7 +66,6 @@ def parse():
                     help="skip the side measurement of the reference's own loop (Runner + MixUp + optimizer over 151 groups + lr scheduler)")
     ap.add_argument("--no-power", action="store_true", help="skip the package power / clock poll")
     ap.add_argument("--no-ek100", action="store_true", help="skip the side measurement at the EK100 widths of expts/01 (d = 1024)")
-    ap.add_argument("--wgrad-wgs", type=int, default=None, help="CU cap of the weight-gradient GEMMs on the auxiliary stream (default: runtime's)")
     args = ap.parse_args()
     if args.comm_dtype is None:
         args.comm_dtype = "bf16" if args.precision == "bf16" else "fp32"
@@ -121,7 +120,7 @@ class GemmTimer:
     def symbol(r) -> str:
         b = lambda x: "true" if x else "false"    # noqa: E731
         if r.variant == 3:
-            return f"gemm_bf16_pp_kernel<{b(r.a_kstrided)}, {b(r.b_kstrided)}, {b(r.splitk > 1)}, {int(r.split3)}, {b(r.capped)}>"
+            return f"gemm_bf16_pp_kernel<{b(r.a_kstrided)}, {b(r.b_kstrided)}, {int(r.split3)}>"
         if r.variant in (7, 8, 9, 10):       # B-direct kernels (csrc/gemm_bd.hip): <16-row blocks per tile, A look-ahead, B look-ahead, packed B>
             return f"gemm_bf16_bd_kernel<{10 if r.variant in (8, 10) else 16}, 3, {2 if r.variant in (8, 10) else 1}, {b(r.variant >= 9)}>"
         return f"gemm_bf16_kernel<2, 2, 2, {b(r.a_kstrided)}, {b(r.b_kstrided)}, {b(r.splitk > 1)}, {int(r.split3)}>"
@@ -766,8 +765,6 @@ def main():
     from afft_amd.parallel import Trainer
     afft_amd.set_precision(args.precision)
     afft_amd.set_grad_mode("sink")
-    if args.wgrad_wgs is not None:
-        afft_amd.runtime.set_wgrad_workgroups(args.wgrad_wgs)
     afft_amd.runtime.set_skip_dead_rows(not args.full_rows)
     D_.manual_seed(42 + rank)
 
@@ -822,8 +819,7 @@ def main():
                    "per_gpu_batch": B, "global_batch": B * world, "seq_len": T,
                    "parallelism": f"dp{world}", "grad_comm_dtype": args.comm_dtype if world > 1 else None,
                    "grad_comm_algo": args.comm_algo if world > 1 else None,
-                   "step_launch": ("hipGraph replay" + (", one stream" if args.graph == "single" else "")) if captured else "eager, 3 streams",
-                   "wgrad_cu_cap": afft_amd.runtime.wgrad_workgroups() or None},
+                   "step_launch": ("hipGraph replay" + (", one stream" if args.graph == "single" else "")) if captured else "eager, 3 streams"},
         # FLOP accounting: utilisation figures use the FLOPs this step EXECUTES.  The reference runs the last SA-Fuser block's MLP on
         # all M + 1 tokens of a frame although only token 0 reaches an output (models/fusion.py:362-365); here those dead rows are
         # not computed (same outputs, same gradients: tests/test_model_gpu.py), 7.4 % of the reference's FLOPs on this workload
@@ -940,8 +936,8 @@ def main():
                 except Exception:  # noqa: BLE001
                     pass
             result["roofline"] = {
-                "kernel": dom + " (bf16 MFMA GEMM, v_mfma_f32_16x16x32_bf16; template <A k-strided, B k-strided, split-K, operand planes (0 = plain bf16, 1 = bf16x3, 2 = fp16x2), capped "
-                          "grid>: A,B = false,false NT forward / false,true NN data gradient / true,true TN weight gradient)",
+                "kernel": dom + " (bf16 MFMA GEMM, v_mfma_f32_16x16x32_bf16; template <A k-strided, B k-strided, operand planes (0 = plain bf16, 1 = bf16x3, 2 = fp16x2)>: "
+                          "A,B = false,false NT forward / false,true NN data gradient / true,true TN weight gradient)",
                 "bound": "mfma", "achieved": round(ach, 1), "peak": dtype_peak, "unit": "TFLOP/s",
                 "frac": round(ach / dtype_peak, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(d["bytes"] / d["launches"]),

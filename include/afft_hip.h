@@ -85,10 +85,6 @@ typedef struct {
    * caller before the first use; every launch leaves them zero) followed by fp32 partial tiles.  NULL or smaller than
    * afft_gemm_workspace_bytes() for the problem: the launch simply runs without split-K. */
   void* workspace; int64_t workspace_bytes;
-  /* > 0: at most this many workgroups (rounded down to a multiple of 8, one per CU) walk the tiles of a 256x256-tile
-   * launch, i.e. the launch occupies at most that many CUs and leaves the others to kernels of other streams
-   * (the weight-gradient GEMMs beside the data-gradient chain, afft_amd/functional.py).  0 = one workgroup per tile. */
-  int32_t max_workgroups;
   /* "bf16x3": fp32-accurate products from bf16 MFMAs.  A and B each point at the HI plane of a two-plane split
    * x = hi + lo (afft_split_bf16: hi = bf16(x), lo = bf16(x - hi)); the lo plane sits a_lo / b_lo ELEMENTS behind it.
    * The kernel accumulates A_hi*B_hi + A_lo*B_hi + A_hi*B_lo in one pass over a 3x longer K (fp32 accumulate):
@@ -159,7 +155,7 @@ int afft_gemm_splitk_for(int M, int N, int K, int a_kstrided, int b_kstrided);
  * afft_gemm_trace_end synchronises those events and returns the records (at most `capacity`; return value = count, < 0 on
  * error).  One trace at a time, process-wide.  variant: 1 = 128x128 tile, 3 = 256x256 ping-pong, 10 = B-direct 160x256 (4, 7-9: tests). */
 typedef struct {
-  int32_t M, N, K, a_kstrided, b_kstrided, variant, splitk, split3, capped, fused_update;
+  int32_t M, N, K, a_kstrided, b_kstrided, variant, splitk, split3, fused_update;
   float ms;
 } afft_gemm_trace_rec_t;
 int afft_gemm_trace_begin(int32_t capacity);
@@ -397,7 +393,6 @@ int afft_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_
  * gradient pointer = that parameter does not exist (no bias) or needs no gradient.  `aux_stream` (may equal `stream` or
  * be NULL): the weight-gradient GEMMs and bias column sums are enqueued there, ordered behind the producing kernels by
  * events; NOTHING on `stream` waits for them -- the caller joins the streams when its backward pass is over.
- * `wgrad_workgroups`: afft_gemm_t.max_workgroups of those GEMMs.
  * Saved by forward for backward (caller-owned, see each struct): the bf16 activations, mean / rstd, probs.            */
 
 typedef struct {       /* y = x + drop(proj(attention(split(qkv(LN(x))))))                                          */
@@ -429,7 +424,6 @@ typedef struct {       /* y = x + drop(proj(attention(split(qkv(LN(x))))))      
   float* ln_partial;                     /* afft_layernorm_bwd workspace                                               */
   void* gemm_ws; int64_t gemm_ws_bytes;  /* afft_gemm_t.workspace of `stream`                                          */
   void* gemm_ws_aux; int64_t gemm_ws_aux_bytes;   /* ... of `aux_stream`                                                */
-  int32_t wgrad_workgroups;
   /* optional fused optimizer (afft_sgd_fused_t) per weight: that weight's gradient GEMM then runs BEHIND the data-gradient
    * GEMM that reads the weight and updates it in its epilogue; its g_w_* buffer is not written */
   const afft_sgd_fused_t* sgd_w_qkv; const afft_sgd_fused_t* sgd_w_proj;
@@ -466,7 +460,6 @@ typedef struct {       /* y = x + drop(fc2(gelu(fc1(LN(x)))))                   
   void* dx_bf16; const afft_dropout_t* up_drop; float* up_dcol;
   float* ln_partial;
   void* gemm_ws; int64_t gemm_ws_bytes; void* gemm_ws_aux; int64_t gemm_ws_aux_bytes;
-  int32_t wgrad_workgroups;
   const afft_sgd_fused_t* sgd_w1; const afft_sgd_fused_t* sgd_w2;       /* as in afft_attn_sublayer_t */
   const void* w1_pk; const void* w2_pk;                                 /* as in afft_attn_sublayer_t */
   int32_t f16x2; void* xn_b; void* h_b;  /* as in afft_attn_sublayer_t: xn / h two-plane fp16 splits, w1 / w2 FP16 images, u stays bf16 */
@@ -496,7 +489,6 @@ typedef struct {       /* y = x + drop(proj(attention(q = w_q LN_q(x), k = w_k L
   void* dx_bf16; const afft_dropout_t* up_drop; float* up_dcol;
   float* ln_partial; float* ln_partial2;
   void* gemm_ws; int64_t gemm_ws_bytes; void* gemm_ws_aux; int64_t gemm_ws_aux_bytes;
-  int32_t wgrad_workgroups;
   const afft_sgd_fused_t* sgd_w_q; const afft_sgd_fused_t* sgd_w_k; const afft_sgd_fused_t* sgd_w_v;
   const afft_sgd_fused_t* sgd_w_proj;                                    /* as in afft_attn_sublayer_t */
 } afft_cross_attn_sublayer_t;

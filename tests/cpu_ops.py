@@ -60,7 +60,7 @@ class Split:
 
 @torch.no_grad()
 def gemm(a, b, out, *, a_t=False, b_t=False, bias=None, act=L.ACT_NONE, aux=None, pre=None, rowscale=None, residual=None,
-         accumulate=False, out2=None, alpha=1.0, drop=None, max_workgroups=0, sgd=None, b_packed=None, out_lo=0):
+         accumulate=False, out2=None, alpha=1.0, drop=None, sgd=None, b_packed=None, out_lo=0):
     assert sgd is None and b_packed is None and not out_lo, "cpu_ops test double: fused update / packed weights / plane outputs are GPU-only paths"
     _no_drop(drop)
     if isinstance(a, Split) and not isinstance(b, Split):     # fp16 two-pass forward: A = hi + lo planes, B the weight's FP16 image
@@ -299,7 +299,8 @@ def loss_reduce(vals, weights, means, total):
         m = v.float().mean() if v.numel() else torch.zeros(())
         if means is not None:
             means[i] = m
-        tot = tot + w * m
+        if w != 0:
+            tot = tot + w * m
     total.copy_(tot)
 
 

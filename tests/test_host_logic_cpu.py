@@ -303,3 +303,18 @@ def test_weight_image_registry_does_not_grow_with_steps():
         assert len(rt._wlist) == before
     finally:
         ops.Split = saved
+
+
+def test_zero_weighted_loss_terms_leave_the_total_and_the_graph():
+    """a loss weight <= 0 (expts/05: past_cls_action=0) DROPS the term as in the reference (runner.py:205-207): a NaN in
+    it does not poison the total, nothing flows back through its branch, its mean is still logged; all weights <= 0 is an error."""
+    from afft_amd.common.runner import Runner
+    with cpu_ops.installed():
+        a = torch.tensor([1.0, 3.0], requires_grad=True)
+        b = torch.tensor([float("nan"), 2.0], requires_grad=True)
+        total, parts = Runner._reduce_loss({"cls_action": a, "past_cls_action": b}, {"cls_action": 2.0, "past_cls_action": 0.0}, sync=False)
+        assert float(total) == 4.0 and float(parts["cls_action"]) == 2.0 and parts["past_cls_action"] != parts["past_cls_action"]
+        total.backward()
+        assert torch.equal(a.grad, torch.tensor([1.0, 1.0])) and b.grad is None
+        with pytest.raises(RuntimeError, match="every loss weight"):
+            Runner._reduce_loss({"cls_action": a.detach()}, {"cls_action": 0.0}, sync=False)

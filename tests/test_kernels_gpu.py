@@ -58,19 +58,7 @@ GEMM_CASES = [
     ("nt_bf16_splitk2_gelu", 256, 256, 2048, "bf16", "nt", dict(bias=True, act=1, pre=True)),
     ("tn_bf16_splitk4_acc", 200, 130, 6144, "bf16", "tn", dict(out_f32=True, accumulate=True, lda_pad=256, ldb_pad=192)),
     ("nt_bf16_nosplit_gelu", 256, 256, 2048, "bf16", "nt", dict(bias=True, act=1)),
-    # 256x256 ping-pong kernel forced into STREAM-K (one workgroup per CU walks a range of the launch's K-iterations): a few
-    # tiles cut into many one-iteration segments, every layout
-    ("nt_bf16_pp_splitk3", 512, 520, 640, "bf16", "nt", dict(bias=True, act=1, pre=True)),
-    ("nn_bf16_pp_splitk3", 300, 512, 640, "bf16", "nn", dict(bias=True, residual=True, out_f32=True)),
-    ("tn_bf16_pp_splitk3", 512, 264, 704, "bf16", "tn", dict(out_f32=True)),
     ("nt_bf16_pp", 300, 520, 192, "bf16", "nt", dict(bias=True, act=2, out2=True)),
-    # stream-K ranges that hold the tail of one tile, whole tiles and the head of the next (20 / 80 / 640 tiles, row and column
-    # tails, the weight-gradient layout accumulating into fp32)
-    ("nt_bf16_pp_splitk3_sk20", 1280, 1000, 1024, "bf16", "nt", dict(bias=True, residual=True, out_f32=True, rowscale=True)),
-    ("nn_bf16_pp_splitk3_sk80", 2500, 2048, 2048, "bf16", "nn", dict(act=3)),
-    ("tn_bf16_pp_splitk3_sk48_acc", 2048, 1536, 1088, "bf16", "tn", dict(out_f32=True, accumulate=True)),
-    ("nt_bf16_pp_splitk3_sk640", 5120, 8192, 512, "bf16", "nt", dict(bias=True, act=1, pre=True)),
-    ("nt_bf16_pp_splitk3_sk160", 5120, 2048, 1024, "bf16", "nt", dict(bias=True, residual=True, out_f32=True)),   # the fuser's 160-tile grid
     ("nt_f32", 150, 130, 100, "f32", "nt", dict(bias=True, act=1, pre=True)),
     ("nn_f32", 96, 200, 77, "f32", "nn", dict(bias=True, residual=True, out_f32=True)),
     ("tn_f32", 66, 70, 130, "f32", "tn", dict(accumulate=True, out_f32=True)),
@@ -85,7 +73,7 @@ def test_gemm(case):
     from afft_amd import ops
     name, M, N, K, dt, layout, ep = case
     from afft_amd import _lib
-    _lib.check(_lib.lib().afft_set_gemm_splitk(0 if "nosplit" in name else 4 if "pp_splitk3" in name else 1))   # 1 = auto (default)
+    _lib.check(_lib.lib().afft_set_gemm_splitk(0 if "nosplit" in name else 1))   # 1 = auto (default)
     _lib.check(_lib.lib().afft_set_gemm_variant(3 if "_pp" in name else 0))
     tdt = torch.bfloat16 if dt == "bf16" else torch.float32
     a_t, b_t = layout[0] == "t", layout[1] == "t"
@@ -430,29 +418,6 @@ def test_sgd_kernels_keep_the_fp16_image():
     assert float(h16[4096:8192].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("cap", [8, 24, 1000])
-def test_gemm_weight_gradient_capped_grid(cap):
-    """max_workgroups: the 256x256 weight-gradient kernel with a capped grid (every workgroup walks several tiles) gives
-    bitwise the results of the one-workgroup-per-tile launch; a cap above the tile count is ignored."""
-    from afft_amd import _lib, ops
-    _lib.check(_lib.lib().afft_set_gemm_variant(3))
-    K, M, N = 640, 2048, 1100           # 8 x 5 = 40 tiles, column tail
-    a = bfr(rnd(K, M, seed=31)).to(torch.bfloat16).to(dev())
-    b_buf = torch.zeros(K, 1104, dtype=torch.bfloat16, device=dev())
-    b_buf[:, :N] = bfr(rnd(K, N, seed=32)).to(torch.bfloat16).to(dev())
-    b = b_buf[:, :N]
-    ref = torch.zeros(M, N, device=dev())
-    ops.gemm(a, b, ref, a_t=True)
-    for acc in (False, True):
-        out = torch.full((M, N), 0.5, device=dev())
-        want = ref + 0.5 if acc else ref
-        ops.gemm(a, b, out, a_t=True, accumulate=acc, max_workgroups=cap)
-        torch.cuda.synchronize()
-        assert torch.equal(out, want), (cap, acc)
-    _lib.check(_lib.lib().afft_set_gemm_variant(0))
-    assert rel_l2(ref.cpu(), (a.float().t() @ b.float()).cpu()) < 2e-3
-
-
 @pytest.mark.parametrize("rows,d,dt", [(37, 64, "f32"), (300, 1024, "bf16"), (130, 2048, "f32"), (5, 128, "bf16")])
 def test_layernorm_fwd_bwd(rows, d, dt):
     from afft_amd import ops
@@ -744,12 +709,12 @@ def test_fused_sgd_epilogue_keeps_the_packed_image_fresh():
 
 
 @pytest.mark.parametrize("case", [("pp", 3, 1, 2048, 1024, 640), ("pp_tail", 3, 1, 2048, 1100, 640), ("small", 1, 1, 384, 256, 320),
-                                  ("small_splitk", 1, 2, 512, 512, 1024), ("pp_capped", 3, 1, 2048, 1024, 640)],
+                                  ("small_splitk", 1, 2, 512, 512, 1024)],
                          ids=lambda c: c[0])
 def test_gemm_fused_sgd_epilogue_equals_gemm_then_update(case):
     """afft_gemm_t.sgd: the Nesterov update applied in the weight-gradient GEMM's epilogue (parameters, momentum and bf16 image
     written, gradient never stored) == the same GEMM storing the gradient followed by afft_sgd_nesterov, bit for bit: 256x256
-    and 128x128 tiles, column tails (scalar epilogue path), split-K (the last-arriving slice runs the fused epilogue), capped grid."""
+    and 128x128 tiles, column tails (scalar epilogue path), split-K (the last-arriving slice runs the fused epilogue)."""
     from afft_amd import _lib, ops
     name, variant, splitk, M, N, K = case
     _lib.check(_lib.lib().afft_set_gemm_variant(variant))
@@ -771,7 +736,7 @@ def test_gemm_fused_sgd_epilogue_equals_gemm_then_update(case):
     d = _lib.SgdFused()
     d.p, d.buf, d.p_bf16, d.lr, d.mom, d.wd, d.gscale, d.first_step = p.data_ptr(), m.data_ptr(), p16.data_ptr(), lr, mom, wd, gs, 0
     gout = torch.full((M, ld), 7.0, device=dev())
-    ops.gemm(a, b, gout[:, :N], a_t=True, sgd=d, max_workgroups=16 if name == "pp_capped" else 0)
+    ops.gemm(a, b, gout[:, :N], a_t=True, sgd=d)
     torch.cuda.synchronize()
     _lib.check(_lib.lib().afft_set_gemm_splitk(1))
     _lib.check(_lib.lib().afft_set_gemm_variant(0))
@@ -819,7 +784,7 @@ def test_epilogue_activation_accuracy(variant):
         _lib.check(_lib.lib().afft_set_gemm_variant(0))
 
 
-@pytest.mark.parametrize("variant,M,N,K,mode", [(1, 1024, 1024, 512, 4), (1, 2048, 1024, 1024, 2), (3, 1024, 2048, 768, 4)])
+@pytest.mark.parametrize("variant,M,N,K,mode", [(1, 1024, 1024, 512, 4), (1, 2048, 1024, 1024, 2)])
 def test_splitk_handoff_stress(variant, M, N, K, mode):
     """The split-K hand-off (slices park their partial tile with write-through stores, the slice that arrives last adds them up in
     slice order) under the worst timing: SHORT slices (2-4 K-tiles, the last store of a slice is a few hundred nanoseconds before

@@ -664,15 +664,11 @@ def test_trainer_fused_sgd_and_weight_images():
         tr_prev_buf = tr.opt.buf.clone()
         # images written by the SGD kernel match a fresh cast of the weights
         w = model.future_predictor.fuser.blocks[0].attn.qkv.weight
-        img, img_t = rt.weight_images(w)
+        img = rt.weight_images(w)
         assert torch.equal(img[:w.shape[0], :w.shape[1]], w.detach().to(torch.bfloat16))
-        if img_t is not None:    # AFFT_WT_IMAGES=1
-            assert torch.equal(img_t[:w.shape[1], :w.shape[0]], w.detach().to(torch.bfloat16).t())
         wc = model.future_predictor.classifiers["action"]["all-fused"][1].weight   # 50 x 128: padded cast image
-        imgc, imgc_t = rt.weight_images(wc)
+        imgc = rt.weight_images(wc)
         assert torch.equal(imgc[:50, :128], wc.detach().to(torch.bfloat16)) and float(imgc[50:].float().abs().max()) == 0
-        assert torch.equal(imgc_t[:128, :50], wc.detach().to(torch.bfloat16).t())
-        assert float(imgc_t[:, 50:].float().abs().max()) == 0
     assert losses[-1] < losses[0], losses
 
 

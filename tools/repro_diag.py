@@ -37,7 +37,7 @@ def _tap(kind, t):
     R, d = t["R"], t["d"]
     if kind == "attn_bwd_pre":
         from afft_amd import runtime as rt_
-        PRE[:] = [rt_.weight_images(t["w_proj"])[0].clone(), rt_.weight_images(t["w_qkv"])[0].clone()]
+        PRE[:] = [rt_.weight_images(t["w_proj"]).clone(), rt_.weight_images(t["w_qkv"]).clone()]
         return
     sc = t["scratch"]
     if kind == "attn_bwd":
