@@ -1217,3 +1217,80 @@ def test_errors_are_reported():
         ops.attention_fwd(a, a, a, 1, 4, 1, 4, 1.0, 3, a, None, mask_period=3)
     with pytest.raises(ValueError):
         ops.gemm(a, torch.zeros(5, 4, device=dev()), a)
+
+
+# ----------------------------------------------------------------------------- race net of the LDS-ring GEMM kernels
+def _lds_pressure_mix(stream, bufs, rounds=1):
+    """What shares a CU with a 128-KiB GEMM workgroup inside the training step: the SMALL-register kernels of the other stream
+    (<= 16 VGPRs fit beside two 248-VGPR waves per SIMD: LayerNorm-backward's column reduction, the column-sum combine, ordered sums,
+    sum of squares) and the LDS users that run on the CUs a partial round leaves free (cast with its LDS transpose, LayerNorm
+    backward).  Round 4's LEAD = 7 schedule of the ping-pong kernel lost a write-after-read race against exactly this mix
+    (profiles/r04_pp_war_race.txt); GEMMs + copies on the second stream never exposed it."""
+    from afft_amd import ops
+    with torch.cuda.stream(stream):
+        for _ in range(rounds):
+            ops.layernorm_bwd(bufs["dy"], bufs["x"], bufs["w"], bufs["mean"], bufs["rstd"], bufs["dx"], dw=bufs["dw"], db=bufs["db"],
+                              accumulate=False, dx_bf16=bufs["dxb"], dcol=bufs["dcol"], dcol_accumulate=False)
+            ops.colsum(bufs["dxb"], bufs["dcol"])
+            ops.cast(bufs["x"], bufs["xc"], bufs["xt"])
+            ops.sumsq(bufs["dx"].view(-1), bufs["ss"])
+            ops.colsum(bufs["x"], bufs["dcol"])
+
+
+RACE_CASES = [
+    # (name, variant, layout, M, N, K, packed): every kernel that refills an LDS ring while other waves may still read it
+    ("pp_nn_dgrad_proj", 3, "nn", 5120, 2048, 2048, False),      # the launch round 4's race was found in (160 tiles: 96 CUs free for the mix)
+    ("pp_nn_full_round", 3, "nn", 8192, 2048, 2048, False),      # 256 tiles: every small-register kernel of the mix lands BESIDE a GEMM workgroup
+    ("pp_nt_fwd", 3, "nt", 8192, 2048, 2048, False),
+    ("pp_tn_wgrad", 3, "tn", 2048, 8192, 1024, False),
+    ("g128_nt", 1, "nt", 1024, 2048, 2048, False),
+    ("g128_nn_splitk", 1, "nn", 1024, 2048, 2048, False),
+    ("bd_nt_packed", 0, "nt", 5120, 2048, 8192, True),
+]
+
+
+@pytest.mark.parametrize("case", RACE_CASES, ids=lambda c: c[0])
+def test_lds_ring_kernels_are_bitwise_stable_under_lds_pressure(case):
+    """2000 launches of each LDS-ring GEMM kernel beside the LDS-pressure mix on a second stream, every launch
+    compared bitwise with launch 0 (on the device: one counter, no host sync in the loop).  tools/race_net.sh builds the round-3
+    schedule (-DAFFT_PP_LEAD=7 -DAFFT_PP_ALLOW_RACY_LEAD) and runs this test against it through AFFT_LIB."""
+    from afft_amd import _lib, ops
+    name, variant, layout, M, N, K, packed = case
+    a_t, b_t = layout[0] == "t", layout[1] == "t"
+    A = bfr(rnd(K, M, seed=71) if a_t else rnd(M, K, seed=71)).to(torch.bfloat16).to(dev())
+    Bm = bfr(rnd(N, K, seed=72) if b_t else rnd(K, N, seed=72)).to(torch.bfloat16).to(dev())
+    pk = None
+    if packed:
+        pk = torch.empty(N * K, dtype=torch.bfloat16, device=dev())
+        ops.pack_weight(Bm.float(), pk)
+    odt = torch.float32 if a_t else torch.bfloat16
+    outs = [torch.empty(M, N, dtype=odt, device=dev()) for _ in range(4)]
+    rows, d = 2048, 2048
+    bufs = dict(dy=rnd(rows, d, seed=1).to(torch.bfloat16).to(dev()), x=rnd(rows, d, seed=2).to(dev()), w=rnd(d, seed=3).to(dev()),
+                mean=torch.zeros(rows, device=dev()), rstd=torch.ones(rows, device=dev()), dx=torch.empty(rows, d, device=dev()),
+                dw=torch.empty(d, device=dev()), db=torch.empty(d, device=dev()), dxb=torch.empty(rows, d, dtype=torch.bfloat16, device=dev()),
+                dcol=torch.empty(d, device=dev()), xc=torch.empty(rows, d, dtype=torch.bfloat16, device=dev()),
+                xt=torch.empty(d, rows, dtype=torch.bfloat16, device=dev()), ss=torch.zeros(1, device=dev()))
+    side = torch.cuda.Stream()
+    bad = torch.zeros((), dtype=torch.int64, device=dev())
+    _lib.check(_lib.lib().afft_set_gemm_variant(variant))
+    try:
+        def launch(o):
+            ops.gemm(A, Bm, o, a_t=a_t, b_t=b_t, b_packed=pk)
+        first = torch.empty(M, N, dtype=odt, device=dev())
+        launch(first)
+        torch.cuda.synchronize()
+        ref = ((A.float().t() if a_t else A.float()).double() @ (Bm.float().t() if b_t else Bm.float()).double()).float()
+        assert rel_l2(first.float().cpu(), ref.cpu()) < 5e-3
+        n = 2000
+        for i in range(0, n, 4):
+            _lds_pressure_mix(side, bufs)
+            for o in outs:
+                launch(o)
+            for o in outs:
+                bad += (o != first).sum()
+        torch.cuda.synchronize()
+        assert int(bad) == 0, f"{name}: {int(bad)} elements differed from launch 0 over {n} launches"
+    finally:
+        torch.cuda.synchronize()
+        _lib.check(_lib.lib().afft_set_gemm_variant(0))

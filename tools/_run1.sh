@@ -1,4 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/r05a
-timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -15 > gpurun_out/r05a/suite.log
-cat gpurun_out/r05a/suite.log
+( time timeout 900 python -m pytest tests/test_kernels_gpu.py -q -x -k "lds_ring" ) 2>&1 | tail -8 > gpurun_out/r05a/race_product.log
+cat gpurun_out/r05a/race_product.log
+bash tools/race_net.sh run 4 2>&1 | tail -30
