@@ -363,6 +363,16 @@ int launch_layout_impl(GemmFast& g, hipStream_t stream, const afft_gemm_t* d) {
   if (d->split3 == 2) {     // fp16 two-pass (forward layouts only): same tile choice as bf16x3
     if constexpr (!A_KS) {
       if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream, 2);
+      // small grids (the predictor's M = B*T rows): split-K over the 2K-long loop -- with two slices one workgroup runs the hi
+      // pass of a tile and another its lo pass, and the last to arrive adds them (slice order: bitwise repeatable)
+      int s2 = 1;
+      const int64_t need2 = splitk_bytes(variant, g.e.M, g.e.N, g.K, &s2);
+      if (s2 > 1 && d->workspace && d->workspace_bytes >= need2 + AFFT_GEMM_WS_HEADER) {
+        g.counters = (int*)d->workspace;
+        g.ws = (float*)((char*)d->workspace + AFFT_GEMM_WS_HEADER);
+        g.splitk = s2;
+        return launch_fast<2, 2, 2, A_KS, B_KS, true, 2>(g, stream);
+      }
       return launch_fast<2, 2, 2, A_KS, B_KS, false, 2>(g, stream);
     } else {
       afft_set_error("afft_gemm: the fp16 two-pass mode (split3 = 2) is built for the forward layouts only (A k-contiguous)");

@@ -86,7 +86,7 @@ int zero_row_tail(void* buf, int rows, int64_t width, hipStream_t st) {
 bool has_drop(const afft_dropout_t& d) { return d.p > 0.f || d.path_p > 0.f; }
 
 // "fp16x2" forward: A is a two-plane fp16 split (lo plane a_lo elements behind the hi plane), the weight an FP16 image
-void as_f16x2(afft_gemm_t& g, int64_t a_lo) { g.split3 = 2; g.a_lo = a_lo; g.b_lo = 0; g.workspace = nullptr; g.workspace_bytes = 0; g.b_packed = nullptr; }
+void as_f16x2(afft_gemm_t& g, int64_t a_lo) { g.split3 = 2; g.a_lo = a_lo; g.b_lo = 0; g.b_packed = nullptr; }
 
 }  // namespace
 

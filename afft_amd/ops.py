@@ -132,7 +132,7 @@ def gemm(a, b, out: Tensor, *, a_t: bool = False, b_t: bool = False, bias: Optio
     d.a_rs, d.a_cs = (a.stride(1), a.stride(0)) if a_t else (a.stride(0), a.stride(1))
     d.B = _p(b)
     d.b_rs, d.b_cs = (b.stride(1), b.stride(0)) if b_t else (b.stride(0), b.stride(1))
-    if a.dtype == torch.bfloat16 and not d.split3:
+    if a.dtype in (torch.bfloat16, torch.float16) and d.split3 != 1:      # split-K scratch: plain bf16 and the fp16 two-pass GEMMs
         ws = gemm_workspace(a.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     if b_packed is not None:

@@ -66,7 +66,8 @@ def engines_for(module: torch.nn.Module) -> List["SGD"]:
 
 class SGD(torch.optim.Optimizer, _FusedEpilogue):
     """torch.optim.SGD(params, lr, momentum, dampening=0, weight_decay, nesterov) on the flat fused path (module docstring).
-    Extra keyword arguments: comm_dtype ('fp32' | 'bf16' gradient payload), comm_algo ('allreduce' | 'rs_ag'), bucket_elems,
+    Extra keyword arguments: comm_dtype ('fp32' | 'bf16' gradient payload), comm_algo ('allreduce' | 'rs_ag' | 'sharded': the
+    update of the GEMM weights in 1 / N slices with an all-gather of their 16-bit images, parallel.GradReducer), bucket_elems,
     group, in_backward (update inside the backward pass; default on), grad_clip (clip by global norm inside step(), on the
     device, instead of the loop's clip_grad_norm_ call)."""
 
@@ -90,32 +91,47 @@ class SGD(torch.optim.Optimizer, _FusedEpilogue):
                 raise NotImplementedError("afft_amd.optim.SGD: momentum / nesterov must be the same in every group "
                                           "(train.py:189-225 varies lr and weight_decay only)")
         plist = [p for g in self.param_groups for p in g["params"]]
-        self.flat = FlatParams(plist)
+        algo = comm_algo or os.environ.get("AFFT_COMM_ALGO", "allreduce")
+        self.flat = FlatParams(plist, sharded_layout=(algo == "sharded"))
         if len(self.flat.params) != len(plist):
             raise ValueError("afft_amd.optim.SGD: every parameter must require grad and appear once (train.py:219-224 drops the "
                              "lr = 0 groups and clears requires_grad on their parameters)")
         own_comm = rt.grad_mode() == "sink"       # autograd mode: whoever wraps the model (torch DDP) reduces
         self.reducer = GradReducer(self.flat, group=group, bucket_elems=bucket_elems,
                                    comm_dtype=comm_dtype or os.environ.get("AFFT_COMM_DTYPE", "fp32"),
-                                   comm_algo=comm_algo or os.environ.get("AFFT_COMM_ALGO", "allreduce"))
+                                   comm_algo=algo)
         if not own_comm:
             self.reducer.comm = False
         self.opt = FusedSGD(self.flat, lr, g0["momentum"], weight_decay, nesterov=bool(g0["nesterov"]))
         self.grad_clip = grad_clip
         if in_backward is None:
             in_backward = os.environ.get("AFFT_OPT_IN_BACKWARD", "1") != "0"
-        self.in_backward = bool(in_backward) and grad_clip is None and self.flat.flat_p.is_cuda
+        self.in_backward = bool(in_backward) and grad_clip is None and (self.flat.flat_p.is_cuda or algo == "sharded")
         self._fused = None
         self._armed = False
         self._fuse_now = False
         self._saved_runs = None
         self._names: Dict[int, str] = {id(p): g.get("name", "?") for g in self.param_groups for p in g["params"]}
-        self._group_of: List[dict] = [g for g in self.param_groups for _ in g["params"]]
+        self._group_of: List[dict] = self._groups_in_flat_order()
+        self.reducer.opt_buf = self.opt.buf
         if self.reducer.world > 1 and self.reducer.comm:
             self.sync_parameters(group)
         _ENGINES.append(weakref.ref(self))
 
     # ------------------------------------------------------------------ helpers
+    def _groups_in_flat_order(self) -> List[dict]:
+        """the parameter group of every parameter of the flat buffers, in THEIR order (the sharded layout moves the GEMM weights first)"""
+        gmap = {id(p): g for g in self.param_groups for p in g["params"]}
+        return [gmap[id(p)] for p in self.flat.params]
+
+    def sync_masters(self):
+        """sharded update (comm_algo = 'sharded'): whole fp32 masters and momentum on every rank (a collective); state_dict() calls it"""
+        self.reducer.sync_masters()
+
+    def state_dict(self):
+        self.sync_masters()
+        return super().state_dict()
+
     def _name_of(self, p: Tensor) -> str:
         return self._names.get(id(p), "?")
 
@@ -240,7 +256,7 @@ class SGD(torch.optim.Optimizer, _FusedEpilogue):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        self._group_of = [g for g in self.param_groups for _ in g["params"]]
+        self._group_of = self._groups_in_flat_order()
         any_buf = False
         with torch.no_grad():
             for p, o in zip(self.flat.params, self.flat.offsets):

@@ -33,9 +33,13 @@ def _align(n: int, a: int = 64) -> int:
 class FlatParams:
     """Re-homes every trainable parameter of `model` (and its .grad) in contiguous fp32 buffers."""
 
-    def __init__(self, model):
+    def __init__(self, model, sharded_layout: bool = False):
         """model: an nn.Module (its trainable parameters, in module order) or an iterable of parameters (the optimizer's
-        param_groups, flattened: afft_amd.optim.SGD)"""
+        param_groups, flattened: afft_amd.optim.SGD).
+        sharded_layout (the N > 1 sharded update, GradReducer comm_algo = 'sharded'): the GEMM weights that own a bf16 image in
+        the flat buffers come FIRST (module order), everything else -- biases, LayerNorm weights, tokens, odd-shaped matrices:
+        what the kernels read as fp32 every step -- behind them, from element `split` on.  The first region is updated in 1 / N
+        slices (only its 16-bit images have to be whole on every rank), the second stays replicated."""
         src = model.parameters() if isinstance(model, torch.nn.Module) else model
         self.params: List[Tensor] = []
         seen = set()
@@ -44,6 +48,13 @@ class FlatParams:
                 seen.add(id(p))
                 self.params.append(p)
         assert self.params, "no trainable parameters"
+        self.sharded_layout = bool(sharded_layout)
+        if self.sharded_layout:
+            big = [p for p in self.params if self.owns_image(p)]
+            self.params = big + [p for p in self.params if not self.owns_image(p)]
+            self.n_big = len(big)
+        else:
+            self.n_big = 0
         dev = self.params[0].device
         self.offsets: List[int] = []
         off = 0
@@ -52,6 +63,9 @@ class FlatParams:
             self.offsets.append(off)
             off += _align(p.numel())
         self.total = off
+        self.split = self.offsets[self.n_big] if self.n_big < len(self.params) else off      # first element of the replicated region
+        if not self.sharded_layout:
+            self.split = 0
         self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
         # bf16 image of every parameter at the same element offsets: written by the fused SGD kernel, so the
@@ -61,7 +75,8 @@ class FlatParams:
         # fragment-packed bf16 images (same offsets and sizes; runtime.packed_images): the B operand of the "B direct" GEMM
         # kernels.  A slot per GEMM weight; an image goes live when a forward GEMM first wants it (runtime.weight_packed) and is
         # from then on written by the fused optimizer epilogue or re-packed after every other update (refresh_packed)
-        use_pk = dev.type == "cuda" and rt.packed_images()
+        # (the sharded update cannot keep them: a rank's slice of the flat buffer is not a slice of a packed image)
+        use_pk = dev.type == "cuda" and rt.packed_images() and not self.sharded_layout
         self.flat_pk16 = torch.zeros(off, dtype=torch.bfloat16, device=dev) if use_pk else None
         self.packed: List[tuple] = []         # (offset, param, packed flat view)
         # FP16 images (same offsets; the B operands of the fp16 two-pass forward GEMMs, precision 'fp16x2'): allocated the first
@@ -76,7 +91,7 @@ class FlatParams:
             if self.flat_p16 is not None:
                 ops.cast(self.flat_p.view(off // 64, 64), self.flat_p16.view(off // 64, 64))
                 for p, o in zip(self.params, self.offsets):
-                    if p.dim() == 2 and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0:
+                    if self.owns_image(p):
                         pk = None
                         if use_pk:
                             pk = self.flat_pk16[o:o + p.numel()]
@@ -84,6 +99,12 @@ class FlatParams:
                         rt.adopt_weight_image(p, self.flat_p16[o:o + p.numel()].view(p.shape), packed=pk)
         rt.invalidate_weight_images()
         self.ensure_f16()
+
+    @staticmethod
+    def owns_image(p: Tensor) -> bool:
+        """a GEMM weight whose 16-bit images live in the flat buffers (both dimensions multiples of 64; odd shapes -- the 3806-row
+        classifier, the 352-column objects mapping -- keep a padded cast image that is redone from the fp32 master every step)"""
+        return p.dim() == 2 and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0
 
     def ensure_f16(self):
         """the FP16 images exist once the precision is 'fp16x2' (called at construction and when a step begins)"""
@@ -133,11 +154,20 @@ class GradReducer:
 
     def __init__(self, flat: FlatParams, group=None, bucket_elems: int = 32 * 1024 * 1024, comm_dtype: str = "fp32",
                  force_comm: bool = False, comm_algo: str = "allreduce"):
-        """comm_algo: 'allreduce' (one all-reduce per bucket) or 'rs_ag' (reduce-scatter + all-gather of the same bucket: the
+        """comm_algo: 'allreduce' (one all-reduce per bucket), 'rs_ag' (reduce-scatter + all-gather of the same bucket: the
         same bytes per link as a ring all-reduce, in two collectives the library schedules independently -- the fallback
-        for a fabric on which the all-reduce picks a slow algorithm; xGMI is point-to-point)."""
-        if comm_algo not in ("allreduce", "rs_ag"):
-            raise ValueError("comm_algo must be 'allreduce' or 'rs_ag'")
+        for a fabric on which the all-reduce picks a slow algorithm; xGMI is point-to-point) or 'sharded'
+        (the flat buffers must have the sharded layout): per bucket of GEMM weights the gradient is reduce-SCATTERED, every rank
+        runs the update on its 1 / N slice of parameters, momentum and 16-bit images only, and the slices of the IMAGES -- what
+        the next forward pass reads -- are all-gathered: 2 B instead of 4 B per parameter in the second half of the exchange and
+        1 / N of the optimizer's HBM traffic.  The fp32 masters and momentum of the other ranks' slices go stale until
+        sync_masters() (checkpoints, state_dict()).  The small replicated region behind FlatParams.split is all-reduced and
+        updated everywhere as before.  Needs the update inside the backward pass (on_bucket); without it a step falls back to
+        reduce-scatter + all-gather of the gradient."""
+        if comm_algo not in ("allreduce", "rs_ag", "sharded"):
+            raise ValueError("comm_algo must be 'allreduce', 'rs_ag' or 'sharded'")
+        if comm_algo == "sharded" and not flat.sharded_layout:
+            raise ValueError("comm_algo 'sharded' needs FlatParams(..., sharded_layout=True)")
         self.comm_algo = comm_algo
         self.flat = flat
         self.group = group
@@ -148,7 +178,11 @@ class GradReducer:
         self.buckets: List[tuple] = []        # (start, end) element ranges, in parameter order
         self.bucket_of: List[int] = []        # param index -> bucket index
         start, cur = 0, 0
+        split = flat.split if comm_algo == "sharded" else 0      # a bucket never straddles the sharded / replicated boundary
         for i, (p, o) in enumerate(zip(flat.params, flat.offsets)):
+            if split and o == split and cur > start:
+                self.buckets.append((start, cur))
+                start = cur
             self.bucket_of.append(len(self.buckets))
             cur = o + _align(p.numel())
             if cur - start >= bucket_elems:
@@ -156,6 +190,8 @@ class GradReducer:
                 start = cur
         if cur > start:
             self.buckets.append((start, cur))
+        self.masters_stale = False            # sharded: fp32 masters / momentum of the other ranks' slices are behind (sync_masters)
+        self.opt_buf: Optional[Tensor] = None  # sharded: the optimizer's momentum buffer (set by whoever owns the optimizer), for sync_masters
         self.bucket_of = [min(b, len(self.buckets) - 1) for b in self.bucket_of]
         self._pidx = flat.index_of()
         self.expected: Optional[List[int]] = None     # ready-callbacks per bucket per step (learned on step 1)
@@ -199,17 +235,68 @@ class GradReducer:
             return self.flat_g16[s:e]
         return self.flat.flat_g[s:e]
 
+    # ---- sharded update
+    def sharded_bucket(self, b: int) -> bool:
+        s, e = self.buckets[b]
+        return (self.comm_algo == "sharded" and self.comm and self.on_bucket is not None and e <= self.flat.split
+                and (e - s) % self.world == 0)
+
+    def shard_of(self, s: int, e: int):
+        """this rank's slice of bucket [s, e)"""
+        n = (e - s) // self.world
+        r = dist.get_rank(self.group)
+        return s + r * n, s + (r + 1) * n
+
+    def _launch_sharded(self, s: int, e: int):
+        """reduce-scatter the bucket's gradient, update this rank's slice, all-gather the slices of the 16-bit images"""
+        ss, se = self.shard_of(s, e)
+        g = self._grad_slice(s, e)
+        dist.reduce_scatter_tensor(g[ss - s:se - s], g, group=self.group)
+        self.on_bucket(ss, se, g[ss - s:se - s], 1.0 / self.world)
+        for img in (self.flat.flat_p16, self.flat.flat_h16):
+            if img is not None:
+                dist.all_gather_into_tensor(img[s:e], img[ss:se], group=self.group)
+        if self.flat.flat_p16 is None:      # CPU tensors (gloo tests): no images -- the fp32 slices themselves are what the next forward reads
+            dist.all_gather_into_tensor(self.flat.flat_p[s:e], self.flat.flat_p[ss:se], group=self.group)
+        self.masters_stale = True           # (the momentum of the other ranks' slices at least)
+
+    def sync_masters(self):
+        """Sharded update: bring the fp32 masters and the momentum of the other ranks' slices up to date (all-gather of every
+        sharded bucket) -- before a checkpoint / state_dict(), or before anything else reads the fp32 values of a GEMM weight.
+        A collective: every rank calls it."""
+        if not self.masters_stale:
+            return
+        if self._use_cuda:
+            torch.cuda.current_stream().wait_stream(self.side_stream)
+            if self.opt_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.opt_stream)
+        with torch.no_grad():
+            for (s, e) in self.buckets:
+                if e <= self.flat.split and (e - s) % self.world == 0:
+                    ss, se = self.shard_of(s, e)
+                    dist.all_gather_into_tensor(self.flat.flat_p[s:e], self.flat.flat_p[ss:se], group=self.group)
+                    if self.opt_buf is not None:
+                        dist.all_gather_into_tensor(self.opt_buf[s:e], self.opt_buf[ss:se], group=self.group)
+        self.masters_stale = False
+
     def _launch(self, b: int):
         self._launched[b] = True
         s, e = self.buckets[b]
         if not self._use_cuda:     # CPU tensors (gloo; the build container's tests): same protocol, no streams
+            if self.sharded_bucket(b):
+                if self.flat_g16 is not None:
+                    self.flat_g16[s:e].copy_(self.flat.flat_g[s:e])
+                self._launch_sharded(s, e)
+                return
             if self.comm:
                 if self.flat_g16 is not None:      # bf16 payload
                     self.flat_g16[s:e].copy_(self.flat.flat_g[s:e])
-                if self.comm_algo == "rs_ag" or self.flat_g16 is not None:
+                if self.comm_algo != "allreduce" or self.flat_g16 is not None or self.on_bucket is not None:
                     self._reduce(self._grad_slice(s, e))
                 else:
                     self._handles.append(dist.all_reduce(self.flat.flat_g[s:e], group=self.group, async_op=True))
+            if self.on_bucket is not None:
+                self.on_bucket(s, e, self._grad_slice(s, e), 1.0 / self.world)
             return
         ev = torch.cuda.Event()
         ev.record()
@@ -217,10 +304,15 @@ class GradReducer:
         if rt.overlap_wgrad():    # weight gradients of this bucket were enqueued on the auxiliary stream
             self.side_stream.wait_stream(rt.aux_stream(self.flat.flat_g.device))
         with torch.cuda.stream(self.side_stream):
+            if self.comm and self.flat_g16 is not None:
+                n = e - s
+                ops.cast(self.flat.flat_g[s:e].view(n // 64, 64), self.flat_g16[s:e].view(n // 64, 64))
+            if self.sharded_bucket(b):
+                # one stream for the three steps of a bucket (reduce-scatter -> update of the slice -> all-gather of the images):
+                # they depend on each other; bucket b + 1's collectives queue behind on the same stream, as RCCL would order them anyway
+                self._launch_sharded(s, e)
+                return
             if self.comm:
-                if self.flat_g16 is not None:
-                    n = e - s
-                    ops.cast(self.flat.flat_g[s:e].view(n // 64, 64), self.flat_g16[s:e].view(n // 64, 64))
                 # RCCL enqueues behind the work already on this stream; later work on this stream follows it
                 self._reduce(self._grad_slice(s, e))
             if self.on_bucket is not None:
@@ -235,7 +327,7 @@ class GradReducer:
 
     def _reduce(self, g: Tensor):
         """sum `g` (a contiguous bucket of the flat gradient buffer) over the ranks, in place"""
-        if self.comm_algo == "allreduce" or g.numel() % self.world != 0:
+        if self.comm_algo == "allreduce" or g.numel() % self.world != 0 or (self.comm_algo == "sharded" and self.on_bucket is not None):
             dist.all_reduce(g, group=self.group)
             return
         n = g.numel() // self.world
@@ -366,14 +458,16 @@ class FusedSGD:
                              self.flags(), p_bf16=p16, gscale_dev=gscale_dev, p_f16=self.flat.h16(s, e))
             self.flat.refresh_packed(s, e)
             return
-        # per-parameter (lr, wd): the parameters of the bucket class by class
+        # per-parameter (lr, wd): the parameters of the range class by class.  [s, e) may cut a parameter at either end (the
+        # sharded update hands over 1 / N of a bucket): every parameter is clipped to the range
         flat = self.flat
         classes: Dict[tuple, list] = {}
         for i, o in enumerate(flat.offsets):
-            if s <= o < e:
+            if o < e and o + _align(flat.params[i].numel()) > s:
                 classes.setdefault(self.hyper[i], []).append(i)
+        whole = all(s <= flat.offsets[i] and flat.offsets[i] + _align(flat.params[i].numel()) <= e for idx in classes.values() for i in idx)
         for (lr, wd), idx in classes.items():
-            if grad.dtype == torch.float32 and gscale_dev is None and grad.numel() == e - s:
+            if grad.dtype == torch.float32 and gscale_dev is None and grad.numel() == e - s and whole:
                 runs = self._runs_of(s, e, tuple(idx), fused)
                 if runs.shape[0]:
                     # the runs kernel addresses the whole flat buffers: hand it the gradient at its flat position
@@ -384,14 +478,14 @@ class FusedSGD:
                         continue
                 elif fused:
                     continue
-            for i in idx:       # bf16 / clipped gradients: one launch per parameter
+            for i in idx:       # bf16 / clipped gradients, cut parameters: one launch per parameter (piece)
                 p, o = flat.params[i], flat.offsets[i]
                 if fused and id(p) in self.skip:
                     continue
-                n = _align(p.numel())
-                p16 = flat.flat_p16[o:o + n] if flat.flat_p16 is not None else None
-                ops.sgd_nesterov(flat.flat_p[o:o + n], grad[o - s:o - s + n], self.buf[o:o + n], lr, self.momentum, wd, gscale,
-                                 self.flags(), p_bf16=p16, gscale_dev=gscale_dev, p_f16=flat.h16(o, o + n))
+                lo, hi = max(o, s), min(o + _align(p.numel()), e)
+                p16 = flat.flat_p16[lo:hi] if flat.flat_p16 is not None else None
+                ops.sgd_nesterov(flat.flat_p[lo:hi], grad[lo - s:hi - s], self.buf[lo:hi], lr, self.momentum, wd, gscale,
+                                 self.flags(), p_bf16=p16, gscale_dev=gscale_dev, p_f16=flat.h16(lo, hi))
         self.flat.refresh_packed(s, e, skip=(self.skip if fused else ()))
 
     def end_step(self):
@@ -542,17 +636,20 @@ class Trainer(_FusedEpilogue):
                  comm_algo: str = "allreduce"):
         from .common.runner import BasicLossAccuracy, Runner
         self.model = model
-        self.flat = FlatParams(model)
+        self.flat = FlatParams(model, sharded_layout=(comm_algo == "sharded"))
         self.reducer = GradReducer(self.flat, group=group, bucket_elems=bucket_elems, comm_dtype=comm_dtype,
                                    force_comm=force_comm, comm_algo=comm_algo)
         self.opt = FusedSGD(self.flat, lr, momentum, weight_decay)
+        self.reducer.opt_buf = self.opt.buf
+        if comm_algo == "sharded":      # checkpoints see whole fp32 masters on every rank (a collective: every rank saves or none)
+            model.register_state_dict_pre_hook(lambda *a, **k: self.reducer.sync_masters())
         if self.reducer.world > 1:
             self.sync_parameters(group)
         self.loss_fn = BasicLossAccuracy(compute_metrics=False)
         self._reduce = Runner._reduce_loss
         self.loss_wts = loss_wts
         self.grad_clip = grad_clip     # opt.grad_clip of the reference's config; needs the whole gradient first
-        self.overlap_optimizer = overlap_optimizer and self.flat.flat_p.is_cuda and grad_clip is None
+        self.overlap_optimizer = overlap_optimizer and grad_clip is None and (self.flat.flat_p.is_cuda or comm_algo == "sharded")
         self._fused: Optional[Dict[int, object]] = None    # id(weight) -> _lib.SgdFused, once learned (see _enable_fused)
 
     def sync_parameters(self, group=None, src: int = 0):
@@ -756,6 +853,11 @@ class DistributedDataParallel(torch.nn.Module):
             red = GradReducer(flat, group=process_group, bucket_elems=elems, comm_dtype=comm_dtype, comm_algo=comm_algo)
             red.defer_all = True      # a foreign zero_grad(set_to_none=True) between forward and backward detaches p.grad from the
             self._own = (flat, red)   # flat buffer: gradients are gathered into it when backward is over, then reduced
+
+    def state_dict(self, *args, **kwargs):
+        for e in self._engines:      # sharded update: whole fp32 masters on every rank before they are read (a collective)
+            e.sync_masters()
+        return super().state_dict(*args, **kwargs)
 
     # ---- foreign optimizer: the wrapper brackets the backward pass itself
     def _begin(self):

@@ -42,8 +42,9 @@ def parse():
     ap.add_argument("--comm-dtype", default=None, choices=["bf16", "fp32"],
                     help="gradient all-reduce payload; default: bf16 beside --precision bf16 (whose gradients carry bf16 operand rounding anyway), fp32 "
                          "-- what the reference's DDP exchanges, train.py:364-368 -- beside every other precision")
-    ap.add_argument("--comm-algo", default="allreduce", choices=["allreduce", "rs_ag"],
-                    help="gradient exchange per bucket: one all-reduce, or reduce-scatter + all-gather (fallback)")
+    ap.add_argument("--comm-algo", default=None, choices=["allreduce", "rs_ag", "sharded"],
+                    help="gradient exchange per bucket: 'sharded' (default for N > 1: reduce-scatter, update of the rank's 1 / N slice, all-gather of the "
+                         "16-bit weight images), one all-reduce + replicated update, or reduce-scatter + all-gather of the gradient + replicated update")
     ap.add_argument("--no-comm-report", action="store_true", help="N > 1: skip the RCCL / exposed-communication / payload side measurements")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+loss+bwd(+all-reduce) only")
     ap.add_argument("--eval-drop", action="store_true", help="disable dropout (eval-mode layers) in the timed steps")
@@ -69,6 +70,8 @@ def parse():
     args = ap.parse_args()
     if args.comm_dtype is None:
         args.comm_dtype = "bf16" if args.precision == "bf16" else "fp32"
+    if args.comm_algo is None:      # N > 1: the sharded update (1 / N of the optimizer's HBM traffic per GPU, 16-bit all-gather); N = 1: no exchange
+        args.comm_algo = "sharded" if args.gpus > 1 else "allreduce"
     return args
 
 
@@ -832,7 +835,8 @@ def main():
         # N = 1 updates the sub-layer weights inside their weight-gradient GEMM epilogues; with a gradient exchange the summed
         # gradient has to exist first, so N > 1 runs the per-bucket update kernel (about +0.5 ms/step on cfg2): the N = 1 point
         # of a scaling curve and the ranks of its N > 1 points differ by that, by construction
-        "optimizer_path": "none" if args.no_optimizer else "fused-epilogue" if trainer._fused else "separate",
+        "optimizer_path": ("none" if args.no_optimizer else "fused-epilogue" if trainer._fused else
+                           "sharded" if (world > 1 and args.comm_algo == "sharded" and trainer.overlap_optimizer) else "separate"),
     }
 
     # the same workload with the reference's full row set (the last SA-Fuser block's MLP on all M + 1 tokens of a frame), in the same
