@@ -310,6 +310,29 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const AttnArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, c15 = lane & 15;
 
+  // The saved probabilities in both register layouts (A: query on the lane, keys on registers; B: the transpose), loaded FIRST:
+  // fp32 from global, ~2 us of latency that used to sit between the two MFMA phases of a workgroup and now runs under the staging
+  // of the operand tiles (masked / out-of-range pairs read as 0 and carry dropout scale 0).
+  float pA[NT][NT][4], pB[NT][NT][4];
+#pragma unroll
+  for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        {
+          const int qi = qt * 16 + c15, kj = kt * 16 + 4 * g + r;
+          const int sq = qi / L, i = qi - sq * L;
+          pA[qt][kt][r] = pair_valid(a.mask, a.period, L, rows_valid, qi, kj)
+                              ? a.probs[((((int64_t)(seq0 + sq)) * H + h) * L + i) * L + (kj - sq * L)] : 0.f;
+        }
+        {
+          const int qi = qt * 16 + 4 * g + r, kj = kt * 16 + c15;
+          const int sq = qi / L, i = qi - sq * L;
+          pB[qt][kt][r] = pair_valid(a.mask, a.period, L, rows_valid, qi, kj)
+                              ? a.probs[((((int64_t)(seq0 + sq)) * H + h) * L + i) * L + (kj - sq * L)] : 0.f;
+        }
+      }
   // dP in both layouts from the same fragments:  A: dP^T[key][query] (keys on regs) ; B: dP[query][key] (queries on regs)
   f32x4 dpa[NT][NT], dpb[NT][NT];
 #pragma unroll
@@ -358,7 +381,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const AttnArgs a) {
         float pv = 0.f, m = 0.f;
         if (pair_valid(a.mask, a.period, L, rows_valid, qi, kj)) {
           const int64_t pidx = ((((int64_t)(seq0 + sq)) * H + h) * L + i) * L + (kj - sq * L);
-          pv = a.probs[pidx];
+          pv = pA[qt][kt][r];
           m = (a.dthresh && !drop_keep(dkey, (unsigned)pidx, a.dthresh)) ? 0.f : a.dinv;
         }
         p[kt][r] = pv;
@@ -392,7 +415,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const AttnArgs a) {
         float pv = 0.f, m = 0.f;
         if (pair_valid(a.mask, a.period, L, rows_valid, qi, kj)) {
           const int64_t pidx = ((((int64_t)(seq0 + sq)) * H + h) * L + i) * L + (kj - sq * L);
-          pv = a.probs[pidx];
+          pv = pB[qt][kt][r];
           m = (a.dthresh && !drop_keep(dkey, (unsigned)pidx, a.dthresh)) ? 0.f : a.dinv;
         }
         p[kt][r] = pv;

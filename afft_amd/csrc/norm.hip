@@ -1,6 +1,8 @@
 // LayerNorm forward / backward (HBM-bound; one wave per row, 16-byte accesses, wave-level reductions).
 // nn.LayerNorm semantics (biased variance, eps inside the sqrt): models/fusion.py:281,362,
 // models/transformerblock.py:122,127,150-152 (eps 1e-6) and HF GPT-2 ln_1/ln_2/ln_f (eps 1e-5).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -68,8 +70,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // until the end, when the 4 row groups add them into one [2][d] LDS slab in a fixed order (deterministic).
 constexpr int LNB_RG = 4, LNB_CS = 4;
 
-template <int NV>  // float4 chunks per lane inside a slice: d/4 <= LNB_CS * 64 * NV
-__global__ __launch_bounds__(1024) void ln_bwd_kernel(const void* __restrict__ dy, int64_t lddy, int dy_dtype,
+template <int NV, bool DY32>  // float4 chunks per lane inside a slice: d/4 <= LNB_CS * 64 * NV; DY32: dy is fp32 (else bf16)
+__global__ __launch_bounds__(1024) void ln_bwd_kernel(const void* __restrict__ dy, int64_t lddy,
                                                       const float* __restrict__ x, int64_t ldx,
                                                       const float* __restrict__ w, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, int rows, int d,
@@ -93,22 +95,63 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const void* __restrict__ d
   }
   const float inv_d = 1.0f / (float)d;
   int buf = 0;
+  // Software pipeline: the loads of row step i + 1 (dy, x, the incoming dx, the row's statistics) are issued BEFORE step i is
+  // computed, so they are in flight across its reductions, its barrier and its stores -- a workgroup runs only ~5 row steps at
+  // 5120 rows, each of which used to expose one full HBM round trip (2.3 TB/s alone).
+  struct Pre { float4 x; typename std::conditional<DY32, uint4, uint2>::type dy; };
+  Pre nxt[NV];
+  float nmu = 0.f, nrs = 0.f;
+  auto prefetch = [&](int row) {
+    if (row >= rows) return;
+    nmu = mean[row];
+    nrs = rstd[row];
+    const float* xr = x + (int64_t)row * ldx;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+      const int q = q0 + lane + 64 * t;
+      if (q < q1) {
+        nxt[t].x = *(const float4*)(xr + 4 * q);
+        if constexpr (DY32) nxt[t].dy = *(const uint4*)((const float*)dy + (int64_t)row * lddy + 4 * q);
+        else nxt[t].dy = *(const uint2*)((const bf16_t*)dy + (int64_t)row * lddy + 4 * q);
+      }
+    }
+  };
+  constexpr bool PIPE = NV <= 2;      // d <= 2048: the second register set fits (no spills at 16 waves per CU); wider rows load in place
+  if (PIPE) prefetch(blockIdx.x * LNB_RG + rg);
   for (int base = blockIdx.x * LNB_RG; base < rows; base += gridDim.x * LNB_RG, buf ^= 1) {
     const int row = base + rg;
     const bool live = row < rows;
     float g[NV][4], xh[NV][4];
+    float4 din[NV];
     float c1 = 0.f, c2 = 0.f, rs = 0.f;
+    if (!PIPE) prefetch(row);
+    Pre cur[NV];
+#pragma unroll
+    for (int t = 0; t < NV; ++t) cur[t] = nxt[t];
+    const float mu = nmu;
+    rs = nrs;
+    if (PIPE) prefetch(row + gridDim.x * LNB_RG);       // the next row step of this wave: in flight from here on
+    if (live && dx_in) {                      // this step's incoming dx is only needed behind the barrier: its latency hides under the reductions
+#pragma unroll
+      for (int t = 0; t < NV; ++t) {
+        const int q = q0 + lane + 64 * t;
+        if (q < q1) din[t] = *(const float4*)(dx_in + (int64_t)row * lddx + 4 * q);
+      }
+    }
     if (live) {
-      const float mu = mean[row];
-      rs = rstd[row];
-      const float* xr = x + (int64_t)row * ldx;
 #pragma unroll
       for (int t = 0; t < NV; ++t) {
         const int q = q0 + lane + 64 * t;
         if (q < q1) {
           float dyv[4];
-          load4(dy, (int64_t)row * lddy + 4 * q, dy_dtype, dyv);
-          const float4 xv = *(const float4*)(xr + 4 * q);
+          if constexpr (DY32) {
+            dyv[0] = __uint_as_float(cur[t].dy.x); dyv[1] = __uint_as_float(cur[t].dy.y);
+            dyv[2] = __uint_as_float(cur[t].dy.z); dyv[3] = __uint_as_float(cur[t].dy.w);
+          } else {
+            dyv[0] = __uint_as_float(cur[t].dy.x << 16); dyv[1] = __uint_as_float(cur[t].dy.x & 0xffff0000u);
+            dyv[2] = __uint_as_float(cur[t].dy.y << 16); dyv[3] = __uint_as_float(cur[t].dy.y & 0xffff0000u);
+          }
+          const float4 xv = cur[t].x;
           xh[t][0] = (xv.x - mu) * rs; xh[t][1] = (xv.y - mu) * rs; xh[t][2] = (xv.z - mu) * rs; xh[t][3] = (xv.w - mu) * rs;
           g[t][0] = dyv[0] * ww[t].x; g[t][1] = dyv[1] * ww[t].y; g[t][2] = dyv[2] * ww[t].z; g[t][3] = dyv[3] * ww[t].w;
           pw[t].x += dyv[0] * xh[t][0]; pw[t].y += dyv[1] * xh[t][1]; pw[t].z += dyv[2] * xh[t][2]; pw[t].w += dyv[3] * xh[t][3];
@@ -134,10 +177,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const void* __restrict__ d
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = rs * (g[t][r] - c1 - xh[t][r] * c2);
           const int64_t idx = (int64_t)row * lddx + 4 * q;
-          if (dx_in) {
-            const float4 a = *(const float4*)(dx_in + idx);
-            o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w;
-          }
+          if (dx_in) { o[0] += din[t].x; o[1] += din[t].y; o[2] += din[t].z; o[3] += din[t].w; }
           *(float4*)(dx_out + idx) = make_float4(o[0], o[1], o[2], o[3]);
           if (dx_bf16 || nslab == 3) {   // the copy the upstream GEMMs consume: their output-dropout mask replayed
             if (drop.thresh || drop.path_thresh) {
@@ -268,8 +308,10 @@ extern "C" int afft_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype
   const int nslab = dcol ? 3 : 2;
   const DropParams drop = make_drop(copy_drop);
   const size_t lds = (size_t)nslab * d * sizeof(float) + 2 * LNB_RG * LNB_CS * 2 * sizeof(float);
-#define LN_BWD(NV) hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(grid), dim3(1024), lds, stream, dy, lddy, dy_dtype, x, ldx, w, mean, rstd, rows, d, dx_in, dx_out, lddx, (bf16_t*)dx_bf16, drop, nslab, partial)
-  switch (nv) { case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; default: LN_BWD(4); }
+  AFFT_CHECK(dy_dtype == AFFT_F32 || dy_dtype == AFFT_BF16, "layernorm_bwd: dy is fp32 or bf16");
+#define LN_BWD(NV, F) hipLaunchKernelGGL((ln_bwd_kernel<NV, F>), dim3(grid), dim3(1024), lds, stream, dy, lddy, x, ldx, w, mean, rstd, rows, d, dx_in, dx_out, lddx, (bf16_t*)dx_bf16, drop, nslab, partial)
+  if (dy_dtype == AFFT_F32) { switch (nv) { case 1: LN_BWD(1, true); break; case 2: LN_BWD(2, true); break; default: LN_BWD(4, true); } }
+  else { switch (nv) { case 1: LN_BWD(1, false); break; case 2: LN_BWD(2, false); break; default: LN_BWD(4, false); } }
 #undef LN_BWD
   AFFT_LAUNCH_CHECK();
   if (dw || db || dcol) {

@@ -320,28 +320,38 @@ def cpu_baseline(name, B, steps=3):
 
 
 def _power_probe():
-    """A function () -> (package power in W, graphics clock in MHz) that reads IN PROCESS -- sysfs (amdgpu hwmon), else the amdsmi
-    Python binding -- or None.  No child process: `rocm-smi` is a `#!/usr/bin/env python3` script, i.e. two exec hops from a process
-    that has initialised the GPU (and, under rocprofv3, inherited the profiler's preloaded library) -- what this pool forbids --
-    and 20 forks per second pollute a profiled run."""
+    """A function () -> (package power in W, graphics clock in MHz) of THE GPU THIS PROCESS USES, read IN PROCESS -- sysfs (amdgpu
+    hwmon), else the amdsmi Python binding -- or None.  No child process: `rocm-smi` is a `#!/usr/bin/env python3` script, i.e. two
+    exec hops from a process that has initialised the GPU (and, under rocprofv3, inherited the profiler's preloaded library) -- what
+    this pool forbids -- and 20 forks per second pollute a profiled run.  The device is matched by its PCI address: a box shows
+    every card of the node in sysfs, the process sees one."""
     import glob
-    for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
-        pw = next((os.path.join(hw, f) for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(hw, f))), None)
-        fq = os.path.join(hw, "freq1_input")
-        if pw is None or not os.path.exists(fq):
+    try:
+        pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+    except Exception:  # noqa: BLE001
+        return None, None
+    for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+        devdir = os.path.join(card, "device")
+        if os.path.basename(os.path.realpath(devdir)).lower() != bdf:
             continue
+        for hw in sorted(glob.glob(os.path.join(devdir, "hwmon", "hwmon*"))):
+            pw = next((os.path.join(hw, f) for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(hw, f))), None)
+            fq = os.path.join(hw, "freq1_input")
+            if pw is None or not os.path.exists(fq):
+                continue
 
-        def read(pw=pw, fq=fq):
-            return float(open(pw).read()) / 1e6, int(open(fq).read()) // 1_000_000
-        try:
-            read()
-            return read, "sysfs hwmon (power1_average / freq1_input)"
-        except Exception:  # noqa: BLE001
-            continue
+            def read(pw=pw, fq=fq):
+                return float(open(pw).read()) / 1e6, int(open(fq).read()) // 1_000_000
+            try:
+                read()
+                return read, f"sysfs hwmon of {bdf} (power1_average / freq1_input)"
+            except Exception:  # noqa: BLE001
+                continue
     try:
         import amdsmi
         amdsmi.amdsmi_init()
-        h = amdsmi.amdsmi_get_processor_handles()[0]
+        h = next(x for x in amdsmi.amdsmi_get_processor_handles() if str(amdsmi.amdsmi_get_gpu_device_bdf(x)).lower() == bdf)
 
         def read():
             p = amdsmi.amdsmi_get_power_info(h)
@@ -349,7 +359,7 @@ def _power_probe():
             c = amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)
             return float(w), int(c.get("clk", c.get("cur_clk")))
         read()
-        return read, "amdsmi Python binding"
+        return read, f"amdsmi Python binding, {bdf}"
     except Exception:  # noqa: BLE001
         return None, None
 
