@@ -481,6 +481,258 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const AttnArgs a) {
 
 bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5 backward: every wave owns a COLUMN SLICE of the head (SL = hd / 4 channels) from start to end.
+//   * its slices of V, dO, Q, K are fetched with fully coalesced 16-byte loads issued back to back at kernel start (64 registers
+//     of reads in flight per lane) and pass through two WAVE-PRIVATE LDS buffers -- no workgroup barrier for staging;
+//   * dP = dO V^T is summed over the head dimension: each wave multiplies its own slice (a quarter of the MFMAs the redundant
+//     form spent) and the four partial 16 x 16 tiles meet through 2 KiB of LDS -- the kernel's only workgroup barrier;
+//   * the three output products run on the wave's slice (A operands by ds_read_tr from its buffers), and each result goes back
+//     through the buffer that has just been consumed so that it is STORED as whole 256-byte row segments (the old kernel stored
+//     8 bytes per lane in 32-byte runs);
+//   * 8 KiB of LDS per wave: 40 KiB per workgroup, four workgroups per CU instead of two.
+// hd % 128 == 0, hd <= 512, L <= 32 (NT <= 2); everything else takes attn_bwd_mfma_kernel.
+__device__ __forceinline__ void wave_lds_sync() {      // LDS operations of ONE wave execute in order: drain, and keep the compiler from reordering across
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void attn_bwd_sliced_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned dkey = a.dkey ^ (a.salt ? *a.salt : 0u);
+  constexpr int R = 16 * NT;
+  const int hd = a.hd, L = a.L, H = a.H;
+  const int SL = hd >> 2;                // channels per wave
+  const int rb = SL * 2;                 // bytes per LDS row
+  const int cpr = SL >> 3;               // 16-byte chunks per row
+  const int grp = blockIdx.x / H, h = blockIdx.x % H;
+  const int seq0 = grp * a.G;
+  const int nsq = min(a.G, a.nseq - seq0);
+  const int rows_valid = nsq * L;
+  const int64_t row0 = (int64_t)seq0 * L;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, c15 = lane & 15;
+  const int64_t c0 = (int64_t)h * hd + wave * SL;        // first channel of this wave's slice
+  char* bufA = smem + wave * (2 * R * rb);               // wave-private: V, later K, later output staging
+  char* bufB = bufA + R * rb;                            //               dO, later Q, later output staging
+  float* red = (float*)(smem + 4 * (2 * R * rb));        // [4 waves][2 NT^2][64 lanes] f32x4: the partial dP tiles
+  constexpr int NP = (R * 16 + 63) / 64;                 // 16-byte pieces per lane of a slice at SL = 128 (fewer lanes / pieces are live below)
+  const int npieces = R * cpr;
+
+  // ---- all reads of the kernel, back to back: probabilities (fp32, both register layouts) and the four operand slices
+  float pA[NT][NT][4], pB[NT][NT][4];
+#pragma unroll
+  for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        {
+          const int qi = qt * 16 + c15, kj = kt * 16 + 4 * g + r;
+          const int sq = qi / L, i = qi - sq * L;
+          pA[qt][kt][r] = pair_valid(a.mask, a.period, L, rows_valid, qi, kj)
+                              ? a.probs[((((int64_t)(seq0 + sq)) * H + h) * L + i) * L + (kj - sq * L)] : 0.f;
+        }
+        {
+          const int qi = qt * 16 + 4 * g + r, kj = kt * 16 + c15;
+          const int sq = qi / L, i = qi - sq * L;
+          pB[qt][kt][r] = pair_valid(a.mask, a.period, L, rows_valid, qi, kj)
+                              ? a.probs[((((int64_t)(seq0 + sq)) * H + h) * L + i) * L + (kj - sq * L)] : 0.f;
+        }
+      }
+  uint4 rv[NP], rd[NP], rk[NP], rq[NP];
+  auto fetch = [&](const bf16_t* __restrict__ src, int64_t ld, uint4 (&dst)[NP]) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int p = lane + 64 * j;
+      const int row = p / cpr, ch = p - row * cpr;
+      dst[j] = make_uint4(0u, 0u, 0u, 0u);
+      if (p < npieces && row < rows_valid) dst[j] = *(const uint4*)(src + (row0 + row) * ld + c0 + ch * 8);
+    }
+  };
+  auto put = [&](char* buf, const uint4 (&srcr)[NP]) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int p = lane + 64 * j;
+      const int row = p / cpr, ch = p - row * cpr;
+      if (p < npieces) *(uint4*)(buf + tile_off(row, ch, rb)) = srcr[j];
+    }
+  };
+  fetch(a.v, a.ldv, rv);
+  fetch(a.dout, a.lddo, rd);
+  fetch(a.k, a.ldk, rk);
+  fetch(a.q, a.ldq, rq);
+
+  // ---- phase 1: this wave's share of dP (both layouts) from its slices of V and dO
+  put(bufA, rv);
+  put(bufB, rd);
+  wave_lds_sync();
+  f32x4 dpa[NT][NT], dpb[NT][NT];
+#pragma unroll
+  for (int x = 0; x < NT; ++x)
+#pragma unroll
+    for (int y = 0; y < NT; ++y) { dpa[x][y] = f32x4{0.f, 0.f, 0.f, 0.f}; dpb[x][y] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int ks = 0; ks < SL / 32; ++ks) {
+    const int ch = ks * 4 + g;
+    bf16x8 vf[NT], df[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      vf[t] = row_frag(bufA, t * 16 + c15, ch, rb);
+      df[t] = row_frag(bufB, t * 16 + c15, ch, rb);
+    }
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < NT; ++qt) {
+        dpa[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kt], df[qt], dpa[kt][qt], 0, 0, 0);
+        dpb[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[qt], vf[kt], dpb[qt][kt], 0, 0, 0);
+      }
+  }
+  // the four partial tiles meet (fixed order: wave 0 + 1 + 2 + 3, the same bits on every run)
+  {
+    f32x4* mine = (f32x4*)red + (wave * 2 * NT * NT) * 64 + lane;
+#pragma unroll
+    for (int x = 0; x < NT; ++x)
+#pragma unroll
+      for (int y = 0; y < NT; ++y) {
+        mine[((x * NT + y) * 2 + 0) * 64] = dpa[x][y];
+        mine[((x * NT + y) * 2 + 1) * 64] = dpb[x][y];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int x = 0; x < NT; ++x)
+#pragma unroll
+      for (int y = 0; y < NT; ++y) {
+        f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, sb = sa;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const f32x4* o = (const f32x4*)red + (w * 2 * NT * NT) * 64 + lane;
+          sa += o[((x * NT + y) * 2 + 0) * 64];
+          sb += o[((x * NT + y) * 2 + 1) * 64];
+        }
+        dpa[x][y] = sa;
+        dpb[x][y] = sb;
+      }
+  }
+
+  // ---- softmax backward in both layouts (as attn_bwd_mfma_kernel)
+  bf16x4 dsa[NT][NT];   // dS^T * scale  (B operand for dQ)
+#pragma unroll
+  for (int qt = 0; qt < NT; ++qt) {
+    const int qi = qt * 16 + c15;
+    const int sq = qi / L, i = qi - sq * L;
+    float p[NT][4], dp[NT][4];
+    float dot = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kj = kt * 16 + 4 * g + r;
+        float pv = 0.f, m = 0.f;
+        if (pair_valid(a.mask, a.period, L, rows_valid, qi, kj)) {
+          const int64_t pidx = ((((int64_t)(seq0 + sq)) * H + h) * L + i) * L + (kj - sq * L);
+          pv = pA[qt][kt][r];
+          m = (a.dthresh && !drop_keep(dkey, (unsigned)pidx, a.dthresh)) ? 0.f : a.dinv;
+        }
+        p[kt][r] = pv;
+        dp[kt][r] = dpa[kt][qt][r] * m;
+        dot += pv * dp[kt][r];
+      }
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      float v4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v4[r] = p[kt][r] * (dp[kt][r] - dot) * a.scale;
+      dsa[kt][qt] = pack4(v4);
+    }
+  }
+  bf16x4 dsb[NT][NT];   // dS * scale  (B operand for dK)
+  bf16x4 ppb[NT][NT];   // dropped-out P (B operand for dV)
+#pragma unroll
+  for (int qt = 0; qt < NT; ++qt) {
+    float p[NT][4], dp[NT][4], pm[NT][4], dot[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qi = qt * 16 + 4 * g + r;
+      const int sq = qi / L, i = qi - sq * L;
+      float d = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+        const int kj = kt * 16 + c15;
+        float pv = 0.f, m = 0.f;
+        if (pair_valid(a.mask, a.period, L, rows_valid, qi, kj)) {
+          const int64_t pidx = ((((int64_t)(seq0 + sq)) * H + h) * L + i) * L + (kj - sq * L);
+          pv = pB[qt][kt][r];
+          m = (a.dthresh && !drop_keep(dkey, (unsigned)pidx, a.dthresh)) ? 0.f : a.dinv;
+        }
+        p[kt][r] = pv;
+        pm[kt][r] = pv * m;
+        dp[kt][r] = dpb[qt][kt][r] * m;
+        d += pv * dp[kt][r];
+      }
+      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+      dot[r] = d;
+    }
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      float v4[4], pd[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v4[r] = p[kt][r] * (dp[kt][r] - dot[r]) * a.scale;
+        pd[r] = pm[kt][r];
+      }
+      dsb[qt][kt] = pack4(v4);
+      ppb[qt][kt] = pack4(pd);
+    }
+  }
+
+  // ---- the three products on this wave's slice; results leave through the buffer that was just consumed
+  // out^T[c][u-th row tile] = sum_t X^T[c][rows of tile t] * Bop[t][u]
+  auto product = [&](const char* xbuf, const bf16x4 (&bop)[NT][NT], char* stage, bf16_t* __restrict__ dst, int64_t ld) {
+    const int ncb = SL >> 4;
+    for (int cb = 0; cb < ncb; ++cb) {
+      f32x4 o[NT];
+#pragma unroll
+      for (int u = 0; u < NT; ++u) o[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const bf16x4 xT = tr_frag(xbuf, t * 16, cb, lane, rb);
+#pragma unroll
+        for (int u = 0; u < NT; ++u) o[u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xT, bop[t][u], o[u], 0, 0, 0);
+      }
+      // D[row = channel cb*16 + 4g + r][col = row index u*16 + c15] -> stage[row u*16 + c15][channels cb*16 + 4g .. +3] (8 bytes)
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        uint2 w2;
+        w2.x = (unsigned)f2bf(o[u][0]) | ((unsigned)f2bf(o[u][1]) << 16);
+        w2.y = (unsigned)f2bf(o[u][2]) | ((unsigned)f2bf(o[u][3]) << 16);
+        *(uint2*)(stage + tile_off(u * 16 + c15, cb * 2 + (g >> 1), rb) + (g & 1) * 8) = w2;
+      }
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int p = lane + 64 * j;
+      const int row = p / cpr, ch = p - row * cpr;
+      if (p < npieces && row < rows_valid) *(uint4*)(dst + (row0 + row) * ld + c0 + ch * 8) = *(const uint4*)(stage + tile_off(row, ch, rb));
+    }
+    wave_lds_sync();       // the staging buffer is free again
+  };
+  // dV^T = dO^T P'      : reads bufB (dO), leaves through bufA (V is dead since phase 1)
+  product(bufB, ppb, bufA, a.dv, a.lddv);
+  // dQ^T = K^T dS^T     : K -> bufA, leaves through bufB (dO is dead now)
+  put(bufA, rk);
+  wave_lds_sync();
+  product(bufA, dsa, bufB, a.dq, a.lddq);
+  // dK^T = Q^T dS       : Q -> bufB, leaves through bufA
+  put(bufB, rq);
+  wave_lds_sync();
+  product(bufB, dsb, bufA, a.dk, a.lddk);
+}
+
 }  // namespace
 
 // Returns 0 when launched, -1 when the shape is not handled by the MFMA path (caller falls back), >0 on error.
@@ -537,7 +789,14 @@ int afft_attention_mfma(bool backward, const void* dout, int64_t lddo, const voi
     else if (NT == 2) AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<2, false>));
     else AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<4, false>));
   } else {
-    if (NT == 1) AFFT_ATTN_LAUNCH(attn_bwd_mfma_kernel<1>);
+    static const bool staged = [] { const char* e = getenv("AFFT_ATTN_BWD_STAGED"); return e && e[0] == '1'; }();
+    if (!staged && NT <= 2 && hd % 128 == 0 && hd <= 512 && lddq % 8 == 0 && lddk % 8 == 0 && lddv % 8 == 0 && al16(dq) && al16(dk) && al16(dv)) {
+      // column-sliced backward (attn_bwd_sliced_kernel): 2 wave-private buffers of [16 NT][hd / 4] bf16 per wave + the partial dP tiles
+      lds = (size_t)4 * 2 * 16 * NT * (hd / 4) * 2 + (size_t)4 * 2 * NT * NT * 64 * 16;
+      if (NT == 1) AFFT_ATTN_LAUNCH(attn_bwd_sliced_kernel<1>);
+      else AFFT_ATTN_LAUNCH(attn_bwd_sliced_kernel<2>);
+    }
+    else if (NT == 1) AFFT_ATTN_LAUNCH(attn_bwd_mfma_kernel<1>);
     else if (NT == 2) AFFT_ATTN_LAUNCH(attn_bwd_mfma_kernel<2>);
     else AFFT_ATTN_LAUNCH(attn_bwd_mfma_kernel<4>);
   }
