@@ -789,8 +789,7 @@ int afft_attention_mfma(bool backward, const void* dout, int64_t lddo, const voi
     else if (NT == 2) AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<2, false>));
     else AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<4, false>));
   } else {
-    static const bool staged = [] { const char* e = getenv("AFFT_ATTN_BWD_STAGED"); return e && e[0] == '1'; }();
-    if (!staged && NT <= 2 && hd % 128 == 0 && hd <= 512 && lddq % 8 == 0 && lddk % 8 == 0 && lddv % 8 == 0 && al16(dq) && al16(dk) && al16(dv)) {
+    if (NT <= 2 && hd % 128 == 0 && hd <= 512 && lddq % 8 == 0 && lddk % 8 == 0 && lddv % 8 == 0 && al16(dq) && al16(dk) && al16(dv)) {
       // column-sliced backward (attn_bwd_sliced_kernel): 2 wave-private buffers of [16 NT][hd / 4] bf16 per wave + the partial dP tiles
       lds = (size_t)4 * 2 * 16 * NT * (hd / 4) * 2 + (size_t)4 * 2 * NT * NT * 64 * 16;
       if (NT == 1) AFFT_ATTN_LAUNCH(attn_bwd_sliced_kernel<1>);

@@ -512,9 +512,8 @@ extern "C" int afft_colsum(const void* src, int64_t lds_, int32_t dtype, int32_t
   const int strips = (cols + 255) / 256;
   // row blocks the workspace has room for: 1 KiB of partials per (strip, block), behind the header the split-K GEMMs of the
   // same stream keep their counters in (so that one scratch buffer per stream serves both)
-  static const bool use_ws = [] { const char* e = getenv("AFFT_COLSUM_BLOCKS"); return !(e && e[0] == '0'); }();   // experiments: 0 = form 2 always
   int64_t room = 0;
-  if (use_ws && workspace && workspace_bytes > AFFT_GEMM_WS_HEADER) room = (workspace_bytes - AFFT_GEMM_WS_HEADER) / ((int64_t)strips * 1024);
+  if (workspace && workspace_bytes > AFFT_GEMM_WS_HEADER) room = (workspace_bytes - AFFT_GEMM_WS_HEADER) / ((int64_t)strips * 1024);
   int rpb = v4 ? 128 : 64;
   int nby = (rows + rpb - 1) / rpb;
   if (nby > 1 && room < nby) {

@@ -605,7 +605,7 @@ def _publish_handover(ho: _HandOut, up: Optional[_Up], dx: Tensor):
 def _streams(dev, rows: int = 1 << 30):
     """(raw main stream, raw auxiliary stream or None, torch auxiliary stream or None)"""
     main = ops._stream()
-    if rt.overlap_wgrad() and rows >= rt.side_min_rows():
+    if rt.overlap_wgrad():
         aux = rt.aux_stream(dev)
         return main, aux.cuda_stream, aux
     return main, None, None

@@ -299,7 +299,7 @@ class CrossModalFusionPrediction(nn.Module, metaclass=abc.ABCMeta):
         tail -- and two views of its output."""
         past, fut = out['past_futures'], out['future']
         whole = out.pop('_seen_then_predicted', None)
-        if rt.merge_heads() and past.keys() == fut.keys():
+        if past.keys() == fut.keys():
             T = next(iter(past.values())).shape[1]
             if whole is None:
                 whole = {m: torch.cat([past[m], fut[m]], dim=1) for m in past}

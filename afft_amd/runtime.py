@@ -334,7 +334,6 @@ SINK = GradSink()
 
 _AUX_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 _OVERLAP_WGRAD = os.environ.get("AFFT_OVERLAP_WGRAD", "1") != "0"
-_AUX_PRIORITY = int(os.environ.get("AFFT_AUX_PRIORITY", "0"))     # HIP stream priority of the auxiliary stream (lower = served first)
 
 
 def aux_stream(device) -> "torch.cuda.Stream":
@@ -342,7 +341,7 @@ def aux_stream(device) -> "torch.cuda.Stream":
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _AUX_STREAMS.get(idx)
     if st is None:
-        st = torch.cuda.Stream(device=idx, priority=_AUX_PRIORITY)
+        st = torch.cuda.Stream(device=idx)
         _AUX_STREAMS[idx] = st
     return st
 
@@ -373,33 +372,6 @@ def set_skip_dead_rows(on: bool):
     global _SKIP_DEAD_ROWS
     _SKIP_DEAD_ROWS = bool(on)
 
-
-
-_SIDE_MIN_ROWS = int(os.environ.get("AFFT_SIDE_MIN_ROWS", "0"))
-
-
-def side_min_rows() -> int:
-    """Sub-layers with fewer rows than this keep their weight gradients on the main stream (composite path): two streams of
-    SMALL GEMMs (the predictor's M = 1024 launches) slow each other by more than the overlap gains.  0 = every sub-layer overlaps."""
-    return _SIDE_MIN_ROWS
-
-
-def set_side_min_rows(n: int):
-    global _SIDE_MIN_ROWS
-    _SIDE_MIN_ROWS = max(0, int(n))
-
-
-_MERGE_HEADS = os.environ.get("AFFT_MERGE_HEADS", "1") != "0"
-
-
-def merge_heads() -> bool:
-    """One classifier GEMM over the rows of past_futures and future together (models/future_prediction.py) instead of one each."""
-    return _MERGE_HEADS
-
-
-def set_merge_heads(on: bool):
-    global _MERGE_HEADS
-    _MERGE_HEADS = bool(on)
 
 
 _COMPOSITE = os.environ.get("AFFT_COMPOSITE", "1") != "0"
