@@ -940,7 +940,7 @@ def main():
             ach = avg_fl / (avg_ms * 1e-3) / 1e12
             dtype_peak = 157.3 if args.precision == "fp32" else PEAK_BF16_TFLOPS      # bf16 / fp16 dense MFMA peak; exact-fp32 MFMA peak
             traffic, traffic_src = None, None
-            for fn in ("r04b_gemm_hbm_traffic_pmc.json", "r03c_gemm_hbm_traffic_pmc.json", "r03b_gemm_hbm_traffic_pmc.json", "r03a_gemm_hbm_traffic_pmc.json", "r02i_gemm_hbm_traffic_pmc.json", "r02h_gemm_hbm_traffic_pmc.json", "r02g_gemm_hbm_traffic_pmc.json", "r02_gemm_hbm_traffic_pmc.json", "r01_gemm_hbm_traffic_pmc.json"):
+            for fn in ("r05_gemm_hbm_traffic_pmc.json", "r04b_gemm_hbm_traffic_pmc.json", "r03c_gemm_hbm_traffic_pmc.json", "r03b_gemm_hbm_traffic_pmc.json", "r03a_gemm_hbm_traffic_pmc.json", "r02i_gemm_hbm_traffic_pmc.json", "r02h_gemm_hbm_traffic_pmc.json", "r02g_gemm_hbm_traffic_pmc.json", "r02_gemm_hbm_traffic_pmc.json", "r01_gemm_hbm_traffic_pmc.json"):
                 try:   # HBM-side bytes per launch from separate rocprofv3 --pmc passes (tools/traffic_summary.py), committed
                     tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
                     hit = [v for k, v in tj.items() if isinstance(v, dict) and (k == dom or dom.startswith(k.rstrip(">")))]

@@ -1249,7 +1249,7 @@ def test_bench_launches_itself_for_two_ranks():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 16
-    assert d["optimizer_path"] == "separate" and "REHEARSAL" in d["data"]
+    assert d["optimizer_path"] == "sharded" and d["config"]["grad_comm_algo"] == "sharded" and "REHEARSAL" in d["data"]      # the N > 1 default: sharded update
     r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, cwd=root, env=env,
                         capture_output=True, text=True, timeout=900)
     assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
