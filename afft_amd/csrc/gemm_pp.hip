@@ -22,9 +22,6 @@ using namespace afft_gemm_detail;
 #ifndef AFFT_PP_DMA_AT
 #define AFFT_PP_DMA_AT 4
 #endif
-#ifndef AFFT_PP_ONE_BARRIER
-#define AFFT_PP_ONE_BARRIER 1   // 1 = one workgroup barrier per phase (group 0 behind its MFMA segment, group 1 behind its L segment: see the
-#endif                          // schedule below); 0 = rounds 1-4: two barriers per phase, the groups in lock step one slot apart
 #ifndef AFFT_PP_DIAG
 #define AFFT_PP_DIAG 0    // diagnostic builds only (wrong results): 1 = no fragment reads, 2 = no LDS-DMA in the loop, 4 = no MFMA,
                           // 8 = no global accesses in the epilogue, 16 = no epilogue at all
@@ -199,7 +196,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
     else if (out == 1) wait_vmcnt_only<2>();
     else wait_vmcnt_only<0>();
     STAMP(t2);
-    if (!AFFT_PP_ONE_BARRIER || gp == 1 || n < 0) __builtin_amdgcn_s_barrier();      // n < 0: the prologue's rendezvous, both groups
+    __builtin_amdgcn_s_barrier();
     STAMP(t3);
     sL += t1 - t0; sW += t2 - t1; sB1 += t3 - t2;
   };
@@ -225,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
     if (AFFT_PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     STAMP(t4);
-    if (!AFFT_PP_ONE_BARRIER || gp == 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
     STAMP(t5);
     sC += t4 - t3; sB2 += t5 - t4; t0 = t5;
   };
@@ -236,7 +233,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
   static_for<0, LEAD>([&](auto mc) { issue(decltype(mc)::value, decltype(mc)::value & 3); });
   wait_then_barrier(-1);
   load_b(0, 0, I0{});                          // K-tile 0's first B fragments (later ones are read a phase early)
-  if (!AFFT_PP_ONE_BARRIER && gp == 1) __builtin_amdgcn_s_barrier();   // two-barrier schedule: group 1 runs one slot behind group 0
+  if (gp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one slot behind group 0
   STAMP(t0);
   sL = sW = sB1 = sC = sB2 = 0;
   unsigned long long tstart = t0; (void)tstart;
@@ -265,7 +262,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
     ktile(I0{}, kt);
     if (kt + 1 < nk) ktile(I1{}, kt + 1);
   }
-  if (!AFFT_PP_ONE_BARRIER && gp == 0) __builtin_amdgcn_s_barrier();
+  if (gp == 0) __builtin_amdgcn_s_barrier();
 #if AFFT_PP_CLAMP
   wait_vmcnt_only<0>();            // the overshoot LDS-DMA has landed before the ring is reused (split-K combine / epilogue image)
 #endif
