@@ -35,6 +35,9 @@ using namespace afft_gemm_detail;
 
 int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream, int x3);
 int afft_gemm_launch_bd(int rows160, int packed, afft_gemm_detail::GemmFast& g, hipStream_t stream);
+#ifdef AFFT_EXPERIMENT_Q4      // tools/experiments/gemm_q4.hip (tools/experiments/build_q4.sh): the four-quadrant kernel, variant 11
+int afft_gemm_launch_q4(afft_gemm_detail::GemmFast& g, hipStream_t stream);
+#endif
 
 #ifndef AFFT_G128_EPI_UNROLL
 #define AFFT_G128_EPI_UNROLL 1   // 2 (what pays in gemm_pp.hip) measured 1-3 % slower on the EK100-width and cfg4 steps
@@ -391,6 +394,9 @@ int launch_layout_impl(GemmFast& g, hipStream_t stream, const afft_gemm_t* d) {
     g.splitk = s;
   }
   if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream, 0);
+#ifdef AFFT_EXPERIMENT_Q4
+  if (variant == 11) { g.splitk = 1; g.ws = nullptr; g.counters = nullptr; return afft_gemm_launch_q4(g, stream); }
+#endif
   if (variant >= 7 && variant <= 10) return afft_gemm_launch_bd(variant == 8 || variant == 10, variant >= 9, g, stream);
   if (variant == 4) return launch_fast<2, 2, 4, A_KS, B_KS, false>(g, stream);
   if (g.splitk > 1) return launch_fast<2, 2, 2, A_KS, B_KS, true>(g, stream);
@@ -402,6 +408,9 @@ bool bd_ok(int N, bool A_KS, bool B_KS) { return !A_KS && !B_KS && N >= 16 && N 
 
 int choose_variant(int M, int N, int K, bool A_KS, bool B_KS) {
   if (g_variant >= 7 && g_variant <= 10) { if (bd_ok(N, A_KS, B_KS)) return g_variant; }
+#ifdef AFFT_EXPERIMENT_Q4
+  else if (g_variant == 11) { if (!A_KS && !B_KS) return 11; }      // four-quadrant kernel: k-contiguous operands only
+#endif
   else if (g_variant != 0) return g_variant;
   // measured (profiles/r01_gemm_variants_bench2.txt): the 256x256 ping-pong kernel (1 workgroup/CU) wins once its
   // grid covers >= ~60 % of the CUs; below that (GPT-2's M = 1024 GEMMs, small weight gradients) two independent
@@ -479,6 +488,9 @@ extern "C" int afft_set_gemm_splitk(int mode) {
 }
 
 extern "C" int afft_set_gemm_variant(int v) {
+#ifdef AFFT_EXPERIMENT_Q4
+  if (v == 11) { g_variant = v; return 0; }
+#endif
   if (v != 0 && v != 1 && v != 3 && v != 4 && !(v >= 7 && v <= 10)) { afft_set_error("afft_set_gemm_variant: %d is not 0 (auto), 1 (128x128), 3 (256x256 ping-pong), 4 (128x128, 4 stages), 7 / 8 (B-direct 256x256 / 160x256 tiles on NT layouts, B row-major; other layouts as auto), 9 / 10 (the same, B points at a fragment-packed image)", v); return 1; }
   g_variant = v;
   return 0;
