@@ -25,7 +25,7 @@ class Dropout(C.Structure):
 
 class SgdFused(C.Structure):      # afft_sgd_fused_t
     _fields_ = [("p", vp), ("buf", vp), ("p_bf16", vp), ("lr", f32), ("mom", f32), ("wd", f32), ("gscale", f32), ("first_step", i32),
-                ("p_pk16", vp), ("p_f16", vp)]
+                ("p_pk16", vp), ("p_f16", vp), ("p_f8", vp)]
 
 
 SgdP = C.POINTER(SgdFused)
@@ -52,6 +52,8 @@ class GemmDesc(C.Structure):
         ("sgd", SgdP),
         ("b_packed", vp),
         ("out_lo", i64),
+        ("a8", vp), ("a8_ld", i64), ("b8", vp), ("b8_ld", i64),
+        ("out_lo8", vp),
     ]
 
 
@@ -79,7 +81,7 @@ class AttnSublayer(C.Structure):      # afft_attn_sublayer_t
         ("g_w_proj", vp), ("acc_w_proj", i32), ("g_b_proj", vp), ("acc_b_proj", i32),
         ("g_ln_w", vp), ("g_ln_b", vp), ("acc_ln", i32),
         ("dx", vp)] + _HAND + [("ln_partial", vp)] + _WS + [("sgd_w_qkv", SgdP), ("sgd_w_proj", SgdP), ("w_qkv_pk", vp), ("w_proj_pk", vp),
-                                                       ("f16x2", i32), ("xn_b", vp), ("qkv_b", vp), ("ao_b", vp)]
+                                                       ("f16x2", i32), ("xn_b", vp), ("qkv_b", vp), ("ao_b", vp), ("w_qkv8", vp), ("w_proj8", vp)]
 
 
 class MLPSublayer(C.Structure):       # afft_mlp_sublayer_t
@@ -98,7 +100,7 @@ class MLPSublayer(C.Structure):       # afft_mlp_sublayer_t
         ("g_w2", vp), ("acc_w2", i32), ("g_b2", vp), ("acc_b2", i32),
         ("g_ln_w", vp), ("g_ln_b", vp), ("acc_ln", i32),
         ("dx", vp)] + _HAND + [("ln_partial", vp)] + _WS + [("sgd_w1", SgdP), ("sgd_w2", SgdP), ("w1_pk", vp), ("w2_pk", vp),
-                                                       ("f16x2", i32), ("xn_b", vp), ("h_b", vp)]
+                                                       ("f16x2", i32), ("xn_b", vp), ("h_b", vp), ("w1_8", vp), ("w2_8", vp)]
 
 
 class CrossAttnSublayer(C.Structure):  # afft_cross_attn_sublayer_t
@@ -151,14 +153,16 @@ _SIGS = {
     "afft_split_bf16": ([vp, i64, i32, i32, vp, i64, i32, i64, vp], C.c_int),
     "afft_split_f16": ([vp, i64, i32, i32, vp, i64, i32, i64, vp], C.c_int),
     "afft_layernorm_fwd": ([vp, i64, vp, vp, f32, i32, i32, vp, i64, i32, vp, vp, vp], C.c_int),
-    "afft_layernorm_fwd_split": ([vp, i64, vp, vp, f32, i32, i32, vp, i64, i64, vp, i64, vp, vp, vp], C.c_int),
+    "afft_layernorm_fwd_split": ([vp, i64, vp, vp, f32, i32, i32, vp, i64, i64, vp, i64, vp, vp, vp, vp], C.c_int),
+    "afft_quant_e4m3": ([vp, i64, i32, i32, f32, vp, i64, i32, vp, vp], C.c_int),
+    "afft_gemm_lo8_ok": ([C.c_int, C.c_int, C.c_int], C.c_int),
     "afft_layernorm_bwd_nparts": ([i32], C.c_int),
     "afft_layernorm_bwd": ([vp, i64, i32, vp, i64, vp, vp, vp, i32, i32, vp, vp, i64, vp, C.POINTER(Dropout), vp, vp, i32,
                             vp, i32, vp, vp], C.c_int),
     "afft_attention_fwd": ([vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, i32, i32, f32, C.c_uint32,
                             vp, i64, vp, vp], C.c_int),
     "afft_attention_fwd_split": ([vp, i64, vp, i64, vp, i64, i64, i32, i32, i32, i32, f32, i32, i32, f32, C.c_uint32,
-                                  vp, i64, i64, vp, i64, vp, vp], C.c_int),
+                                  vp, i64, i64, vp, i64, vp, vp, vp], C.c_int),
     "afft_attention_bwd": ([vp, i64, vp, i64, vp, i64, vp, i64, i32, vp, i32, i32, i32, i32, f32, f32, C.c_uint32,
                             vp, i64, vp, i64, vp, i64, vp], C.c_int),
     "afft_softmax_ce": ([vp, i64, i32, i32, vp, vp, i64, vp, f32, vp, vp, vp, i64, i32, vp, vp], C.c_int),
@@ -172,8 +176,8 @@ _SIGS = {
     "afft_reduce_rows_periodic": ([vp, i64, i32, i32, i32, vp, i64, vp], C.c_int),
     "afft_sgd_nesterov": ([vp, vp, i32, vp, vp, i64, f32, f32, f32, f32, vp, i32, vp], C.c_int),
     "afft_sgd_nesterov_runs": ([vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, i32, vp], C.c_int),
-    "afft_sgd_nesterov2": ([vp, vp, i32, vp, vp, vp, i64, f32, f32, f32, f32, vp, i32, vp], C.c_int),
-    "afft_sgd_nesterov_runs2": ([vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, i32, vp], C.c_int),
+    "afft_sgd_nesterov2": ([vp, vp, i32, vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, i32, vp], C.c_int),
+    "afft_sgd_nesterov_runs2": ([vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, i32, vp], C.c_int),
     "afft_sumsq": ([vp, i32, i64, f32, vp, vp, i64, vp], C.c_int),
     "afft_group_sum": ([vp, i32, i32, i64, f32, vp, vp], C.c_int),
     "afft_set_dropout_salt": ([vp], C.c_int),

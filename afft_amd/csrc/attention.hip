@@ -230,7 +230,7 @@ int afft_attention_mfma(bool backward, const void* dout, int64_t lddo, const voi
                         int64_t ldk, const void* v, int64_t ldv, float* probs, int nseq, int L, int H, int hd,
                         float scale, int mask, float drop_p, unsigned drop_key, void* out, int64_t ldo, void* dq,
                         int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, hipStream_t stream,
-                        int planes = 0, int64_t in_lo = 0, int64_t out_lo = 0, void* out_b = nullptr, int64_t ldob = 0);
+                        int planes = 0, int64_t in_lo = 0, int64_t out_lo = 0, void* out_b = nullptr, int64_t ldob = 0, void* out_lo8 = nullptr);
 static bool use_mfma_attention() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("AFFT_ATTN_GENERIC"); v = (e && e[0] == '1') ? 0 : 1; }
@@ -276,7 +276,7 @@ extern "C" int afft_attention_fwd(const void* q, int64_t ldq, const void* k, int
 extern "C" int afft_attention_fwd_split(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, int64_t in_lo,
                                         int32_t nseq, int32_t L, int32_t H, int32_t hd, float scale, int32_t mask, int32_t mask_period,
                                         float drop_p, uint32_t drop_key, void* out_hi, int64_t ldo, int64_t out_lo, void* out_bf16,
-                                        int64_t ldob, float* probs, void* stream_) {
+                                        int64_t ldob, float* probs, void* out_lo8, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(q && k && v && out_hi, "attention_fwd_split: null pointer");
   AFFT_CHECK(L >= 1 && L <= 64, "attention_fwd_split: sequence length %d outside 1..64 (MFMA path only)", L);
@@ -286,13 +286,14 @@ extern "C" int afft_attention_fwd_split(const void* q, int64_t ldq, const void* 
   AFFT_CHECK(!(mask == AFFT_MASK_DIAG && L == 1), "attention_fwd_split: diagonal mask with L=1 masks every key");
   AFFT_CHECK(drop_p >= 0.f && drop_p < 1.f, "attention_fwd_split: dropout p outside [0,1)");
   AFFT_CHECK(in_lo > 0, "attention_fwd_split: the inputs are two-plane splits (in_lo > 0)");
+  AFFT_CHECK(!out_lo8 || (out_lo == 0 && (((uintptr_t)out_lo8) & 3) == 0), "attention_fwd_split: out_lo8 excludes out_lo and must be 4-byte aligned");
   if (nseq == 0) return 0;
   const int64_t rw_ = (int64_t)nseq * L * H * hd, pb_ = probs ? (int64_t)nseq * H * L * L * 4 : 0;
   AfftKernelScope ktrace(AFFT_K_ATTN_FWD, nseq * L, H * hd, (3 * 4 + (out_lo ? 4 : 2) + (out_bf16 ? 2 : 0)) * rw_ + pb_,
                          3 * 4 * (int64_t)nseq * H * L * L * hd, stream);
   const int rc = afft_attention_mfma(false, nullptr, 0, q, ldq, k, ldk, v, ldv, probs, nseq, L, H, hd, scale,
                                      mask | (mask == AFFT_MASK_BLOCKCAUSAL ? mask_period << 8 : 0), drop_p, drop_key, out_hi, ldo,
-                                     nullptr, 0, nullptr, 0, nullptr, 0, stream, 1, in_lo, out_lo, out_bf16, ldob);
+                                     nullptr, 0, nullptr, 0, nullptr, 0, stream, 1, in_lo, out_lo, out_bf16, ldob, out_lo8);
   AFFT_CHECK(rc >= 0, "attention_fwd_split: shape not handled by the MFMA path (hd %d must be a multiple of 64 and <= 1024, 16-byte aligned rows)", hd);
   return rc;
 }

@@ -40,6 +40,7 @@ struct AttnArgs {
   int64_t in_lo, out_lo;  // elements from a hi plane to its lo plane (inputs; output)
   bf16_t* out_b;          // optional bf16 copy of the output (what the bf16 backward reads)
   int64_t ldob;
+  unsigned char* out_lo8; // optional: the output's lo part as an e4m3 byte plane (row pitch ldo bytes) instead of the fp16 plane
 };
 
 __device__ __forceinline__ bool pair_valid(int mask, int period, int L, int rows_valid, int qi, int kj) {
@@ -273,7 +274,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
           const int64_t col = (int64_t)h * hd + c * hc + cb * 16 + 4 * (lane >> 4);
           if constexpr (PL) {
             const float ov[4] = {o[qt][0], o[qt][1], o[qt][2], o[qt][3]};
-            if (a.out_lo) store_split<4>(a.out, (row0 + qi) * a.ldo + col, a.out_lo, ov);
+            if (a.out_lo8) store_split8<4>(a.out, a.out_lo8, (row0 + qi) * a.ldo + col, ov);
+            else if (a.out_lo) store_split<4>(a.out, (row0 + qi) * a.ldo + col, a.out_lo, ov);
             else store4(a.out, (row0 + qi) * a.ldo + col, AFFT_F16, ov);
             if (a.out_b) store_o4(a.out_b + (row0 + qi) * a.ldob + col, o[qt]);
           } else {
@@ -740,7 +742,7 @@ int afft_attention_mfma(bool backward, const void* dout, int64_t lddo, const voi
                         int64_t ldk, const void* v, int64_t ldv, float* probs, int nseq, int L, int H, int hd,
                         float scale, int mask, float drop_p, unsigned drop_key, void* out, int64_t ldo, void* dq,
                         int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, hipStream_t stream,
-                        int planes, int64_t in_lo, int64_t out_lo, void* out_b, int64_t ldob) {
+                        int planes, int64_t in_lo, int64_t out_lo, void* out_b, int64_t ldob, void* out_lo8) {
   if (L > 64 || hd % 64 != 0 || hd > 1024) return -1;
   if (planes && (backward || in_lo % 8 || out_lo % 4 || ldob % 4 || (((uintptr_t)out_b) & 7))) return -1;
   if (ldq % 8 || ldk % 8 || ldv % 8 || !al16(q) || !al16(k) || !al16(v)) return -1;
@@ -766,7 +768,7 @@ int afft_attention_mfma(bool backward, const void* dout, int64_t lddo, const voi
   a.out = (bf16_t*)out; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
   a.ldo = ldo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.probs = probs;
-  a.in_lo = in_lo; a.out_lo = out_lo; a.out_b = (bf16_t*)out_b; a.ldob = ldob;
+  a.in_lo = in_lo; a.out_lo = out_lo; a.out_b = (bf16_t*)out_b; a.ldob = ldob; a.out_lo8 = (unsigned char*)out_lo8;
   a.nseq = nseq; a.L = L; a.H = H; a.hd = hd; a.G = (16 * NT) / L; a.hc = hc;
   a.scale = scale; a.mask = mask & 0xff; a.period = mask >> 8;   // block-causal period rides in the upper bits
   afft_dropout_t dd = {drop_p, drop_key, 0.f, 0u, 1};

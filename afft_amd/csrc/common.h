@@ -245,7 +245,7 @@ __device__ __forceinline__ void sgd_update(float& p, float& buf, float g, float 
   buf = bb;
   p = __fmaf_rn(-lr, (flags & AFFT_SGD_PLAIN_MOMENTUM) ? bb : __fmaf_rn(mom, bb, gg), p);
 }
-struct SgdEpi { float* p; float* buf; bf16_t* p16; float lr, mom, wd, gscale; int first; bf16_t* p16k; bf16_t* p16h; };   // p16h: fp16 image (row-major, like p16)
+struct SgdEpi { float* p; float* buf; bf16_t* p16; float lr, mom, wd, gscale; int first; bf16_t* p16k; bf16_t* p16h; unsigned char* p8; };   // p16h: fp16 image (row-major, like p16); p8: e4m3(2^8 p) bytes
 // element offset of the 8-element fragment that holds W[m][n .. n + 7] (n % 8 == 0) in the fragment-packed image of a [rows, ld] weight
 // (afft_pack_weight, include/afft_hip.h)
 __device__ __forceinline__ int64_t packed_frag(int m, int n, int64_t ld) {
@@ -265,6 +265,7 @@ struct EpiParams {
   int accumulate;
   void* out; int64_t ldo; int out_dtype;
   int64_t out_lo;   // != 0 (out_dtype AFFT_F16): out is the HI plane of a two-plane fp16 split, the lo plane sits out_lo elements behind it
+  unsigned char* out_lo8;   // != NULL (out_dtype AFFT_F16): the lo part goes out as e4m3(2^11 (v - hi)) bytes, row pitch ldo bytes
   void* out2; int64_t ldo2; int out2_dtype;
   int vec4;  // host-verified: every ld % 4 == 0 and bases 16-byte aligned -> 4-wide accesses legal
   int vec8;  // host-verified: every ld % 8 == 0 and bases 16-byte aligned -> 8-wide accesses legal (16-B bf16 stores)
@@ -313,6 +314,52 @@ __device__ __forceinline__ void store_split(void* base, int64_t idx, int64_t lo_
   *(hN*)((bf16_t*)base + idx) = h;
   *(hN*)((bf16_t*)base + idx + lo_off) = l;
 }
+
+// v_cvt_pk_fp8_f32 does NOT saturate: a value beyond e4m3's 448 becomes the NaN code (found the hard way: a weight of 2.0 times the
+// image scale 2^8 turned every logit into NaN).  Everything headed for an e4m3 byte is clamped to +-448 first (NaN stays NaN).
+__device__ __forceinline__ float e4m3_clamp(float x) { return __builtin_amdgcn_fmed3f(x, -448.0f, 448.0f); }
+template <bool HI>
+__device__ __forceinline__ int pk_e4m3_(float a, float b, int old) { return __builtin_amdgcn_cvt_pk_fp8_f32(e4m3_clamp(a), e4m3_clamp(b), old, HI); }
+#define pk_e4m3(a, b, old, hi) pk_e4m3_<hi>(a, b, old)
+template <int N>      // dst[idx .. idx + N) = e4m3(scale * v): the weight byte image (scale 2^8)
+__device__ __forceinline__ void store_e4m3(unsigned char* dst, int64_t idx, const float (&v)[N], float scale) {
+  static_assert(N == 4 || N == 8, "4 or 8 values");
+  int w0 = 0;
+  w0 = pk_e4m3(v[0] * scale, v[1] * scale, w0, false);
+  w0 = pk_e4m3(v[2] * scale, v[3] * scale, w0, true);
+  if constexpr (N == 4) {
+    *(int*)(dst + idx) = w0;
+  } else {
+    int w1 = 0;
+    w1 = pk_e4m3(v[4] * scale, v[5] * scale, w1, false);
+    w1 = pk_e4m3(v[6] * scale, v[7] * scale, w1, true);
+    *(int2*)(dst + idx) = make_int2(w0, w1);
+  }
+}
+// hi = fp16(v) at idx of `base`; lo = e4m3(2^11 (v - hi)) at byte idx of `lo8` (the A operand of the fp16 + fp8 GEMM, afft_gemm_t.split3 = 3).
+// v_cvt_pk_fp8_f32 is the OCP e4m3fn conversion on gfx950 (saturating); |v - hi| <= 2^-11 |v| ... 2^11 (v - hi) <= |v| / 2.
+template <int N>
+__device__ __forceinline__ void store_split8(void* base, unsigned char* lo8, int64_t idx, const float (&v)[N]) {
+  static_assert(N == 4 || N == 8, "4 or 8 values");
+  typedef __attribute__((ext_vector_type(N))) _Float16 hN;
+  hN h;
+  float l[N];
+#pragma unroll
+  for (int r = 0; r < N; ++r) { h[r] = (_Float16)v[r]; l[r] = (v[r] - (float)h[r]) * 2048.0f; }
+  *(hN*)((bf16_t*)base + idx) = h;
+  int w0 = 0;
+  w0 = pk_e4m3(l[0], l[1], w0, false);
+  w0 = pk_e4m3(l[2], l[3], w0, true);
+  if constexpr (N == 4) {
+    *(int*)(lo8 + idx) = w0;
+  } else {
+    int w1 = 0;
+    w1 = pk_e4m3(l[4], l[5], w1, false);
+    w1 = pk_e4m3(l[6], l[7], w1, true);
+    *(int2*)(lo8 + idx) = make_int2(w0, w1);
+  }
+}
+__device__ __forceinline__ unsigned char f2e4m3(float f) { return (unsigned char)(pk_e4m3(f, 0.f, 0, false) & 0xff); }
 
 __host__ __device__ __forceinline__ bool act_needs_aux(int act) {
   act &= 0xff;
@@ -380,6 +427,7 @@ __device__ __forceinline__ void epilogue4(const EpiParams& e, const DropParams& 
       store4(e.sgd.buf, idx, AFFT_F32, bv);
       if (e.sgd.p16) store4(e.sgd.p16, idx, AFFT_BF16, pv);
       if (e.sgd.p16h) store4(e.sgd.p16h, idx, AFFT_F16, pv);
+      if (e.sgd.p8) store_e4m3<4>(e.sgd.p8, idx, pv, 256.0f);
       if (e.sgd.p16k) store4(e.sgd.p16k, packed_frag(m, n & ~7, e.ldo) + (n & 7), AFFT_BF16, pv);
     } else {
       for (int r = 0; r < 4 && n + r < e.N; ++r) {
@@ -388,6 +436,7 @@ __device__ __forceinline__ void epilogue4(const EpiParams& e, const DropParams& 
         e.sgd.p[idx + r] = pv; e.sgd.buf[idx + r] = bv;
         if (e.sgd.p16) e.sgd.p16[idx + r] = f2bf(pv);
         if (e.sgd.p16h) e.sgd.p16h[idx + r] = f2h(pv);
+        if (e.sgd.p8) e.sgd.p8[idx + r] = f2e4m3(pv * 256.0f);
         if (e.sgd.p16k) e.sgd.p16k[packed_frag(m, (n + r) & ~7, e.ldo) + ((n + r) & 7)] = f2bf(pv);
       }
     }
@@ -424,7 +473,8 @@ __device__ __forceinline__ void epilogue4(const EpiParams& e, const DropParams& 
       float4 t = *(const float4*)((const float*)e.out + (int64_t)m * e.ldo + n);
       v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
     }
-    if (e.out_lo) store_split<4>(e.out, (int64_t)m * e.ldo + n, e.out_lo, v);
+    if (e.out_lo8) store_split8<4>(e.out, e.out_lo8, (int64_t)m * e.ldo + n, v);
+    else if (e.out_lo) store_split<4>(e.out, (int64_t)m * e.ldo + n, e.out_lo, v);
     else store4(e.out, (int64_t)m * e.ldo + n, e.out_dtype, v);
     if (e.out2) store4(e.out2, (int64_t)m * e.ldo2 + n, e.out2_dtype, v);
   } else {
@@ -444,6 +494,7 @@ __device__ __forceinline__ void epilogue4(const EpiParams& e, const DropParams& 
       if (e.accumulate) x += ((const float*)e.out)[(int64_t)m * e.ldo + nn];
       st_any(e.out, (int64_t)m * e.ldo + nn, e.out_dtype, x);
       if (e.out_lo) ((bf16_t*)e.out)[(int64_t)m * e.ldo + nn + e.out_lo] = f2h(x - h2f(f2h(x)));
+      if (e.out_lo8) e.out_lo8[(int64_t)m * e.ldo + nn] = f2e4m3((x - h2f(f2h(x))) * 2048.0f);
       if (e.out2) st_any(e.out2, (int64_t)m * e.ldo2 + nn, e.out2_dtype, x);
     }
   }
@@ -506,6 +557,7 @@ __device__ __forceinline__ void epilogue8(const EpiParams& e, const DropParams& 
     store8(e.sgd.buf, idx, AFFT_F32, bv);
     if (e.sgd.p16) store8(e.sgd.p16, idx, AFFT_BF16, pv);
     if (e.sgd.p16h) store8(e.sgd.p16h, idx, AFFT_F16, pv);
+    if (e.sgd.p8) store_e4m3<8>(e.sgd.p8, idx, pv, 256.0f);
     if (e.sgd.p16k) store8(e.sgd.p16k, packed_frag(m, n, e.ldo), AFFT_BF16, pv);
     return;
   }
@@ -545,7 +597,8 @@ __device__ __forceinline__ void epilogue8(const EpiParams& e, const DropParams& 
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] += t[r];
   }
-  if (e.out_lo) store_split<8>(e.out, (int64_t)m * e.ldo + n, e.out_lo, v);
+  if (e.out_lo8) store_split8<8>(e.out, e.out_lo8, (int64_t)m * e.ldo + n, v);
+  else if (e.out_lo) store_split<8>(e.out, (int64_t)m * e.ldo + n, e.out_lo, v);
   else store8(e.out, (int64_t)m * e.ldo + n, e.out_dtype, v);
   if (e.out2) store8(e.out2, (int64_t)m * e.ldo2 + n, e.out2_dtype, v);
 }

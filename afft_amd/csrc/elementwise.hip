@@ -331,7 +331,8 @@ __global__ __launch_bounds__(256) void reduce_rows_periodic_kernel(const float* 
 }
 
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const void* __restrict__ g_, int g_dtype,
-                                                  float* __restrict__ buf, bf16_t* __restrict__ p16, bf16_t* __restrict__ p16h, int64_t n, float lr,
+                                                  float* __restrict__ buf, bf16_t* __restrict__ p16, bf16_t* __restrict__ p16h,
+                                                  unsigned char* __restrict__ p8, int64_t n, float lr,
                                                   float mom, float wd, float gscale, const float* __restrict__ gscale_dev,
                                                   int first) {
   if (gscale_dev) gscale *= *gscale_dev;   // clip coefficient computed on the device (afft_clip_coef)
@@ -351,6 +352,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const v
       *(float4*)(p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
       if (p16) store4(p16, i, AFFT_BF16, pp);
       if (p16h) store4(p16h, i, AFFT_F16, pp);
+      if (p8) store_e4m3<4>(p8, i, pp, 256.0f);
     } else {
       for (int64_t j = i; j < n; ++j) {
         float pj = p[j], bj = (first & AFFT_SGD_FIRST_STEP) ? 0.f : buf[j];
@@ -359,6 +361,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const v
         p[j] = pj;
         if (p16) p16[j] = f2bf(pj);
         if (p16h) p16h[j] = f2h(pj);
+        if (p8) p8[j] = f2e4m3(pj * 256.0f);
       }
     }
   }
@@ -366,7 +369,8 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const v
 
 // the same update over a table of runs {start, length}: block b owns run b (runs are short: biases, LayerNorm weights)
 __global__ __launch_bounds__(256) void sgd_runs_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
-                                                       bf16_t* __restrict__ p16, bf16_t* __restrict__ p16h, const int64_t* __restrict__ runs, float lr, float mom,
+                                                       bf16_t* __restrict__ p16, bf16_t* __restrict__ p16h, unsigned char* __restrict__ p8,
+                                                       const int64_t* __restrict__ runs, float lr, float mom,
                                                        float wd, float gscale, int first) {
   const int64_t s0 = runs[2 * blockIdx.x], len = runs[2 * blockIdx.x + 1];
   for (int64_t j = s0 + threadIdx.x; j < s0 + len; j += 256) {
@@ -376,24 +380,25 @@ __global__ __launch_bounds__(256) void sgd_runs_kernel(float* __restrict__ p, co
     p[j] = pj;
     if (p16) p16[j] = f2bf(pj);
     if (p16h) p16h[j] = f2h(pj);
+    if (p8) p8[j] = f2e4m3(pj * 256.0f);
   }
 }
 
 }  // namespace
 
-extern "C" int afft_sgd_nesterov_runs2(float* p, const float* g, float* buf, void* p_bf16, void* p_f16, const int64_t* runs, int32_t nruns,
+extern "C" int afft_sgd_nesterov_runs2(float* p, const float* g, float* buf, void* p_bf16, void* p_f16, void* p_f8, const int64_t* runs, int32_t nruns,
                                        float lr, float mom, float wd, float gscale, int32_t first_step, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(p && g && buf && (runs || nruns == 0), "sgd_runs: null pointer");
   if (nruns <= 0) return 0;
-  hipLaunchKernelGGL(sgd_runs_kernel, dim3(nruns), dim3(256), 0, stream, p, g, buf, (bf16_t*)p_bf16, (bf16_t*)p_f16, runs, lr, mom, wd, gscale,
+  hipLaunchKernelGGL(sgd_runs_kernel, dim3(nruns), dim3(256), 0, stream, p, g, buf, (bf16_t*)p_bf16, (bf16_t*)p_f16, (unsigned char*)p_f8, runs, lr, mom, wd, gscale,
                      first_step);
   AFFT_LAUNCH_CHECK();
   return 0;
 }
 extern "C" int afft_sgd_nesterov_runs(float* p, const float* g, float* buf, void* p_bf16, const int64_t* runs, int32_t nruns,
                                       float lr, float mom, float wd, float gscale, int32_t first_step, void* stream_) {
-  return afft_sgd_nesterov_runs2(p, g, buf, p_bf16, nullptr, runs, nruns, lr, mom, wd, gscale, first_step, stream_);
+  return afft_sgd_nesterov_runs2(p, g, buf, p_bf16, nullptr, nullptr, runs, nruns, lr, mom, wd, gscale, first_step, stream_);
 }
 
 namespace {
@@ -466,6 +471,50 @@ static int split_planes(bool f16, const float* src, int64_t lds_, int32_t rows, 
                               rows_pad, plane_stride, src_vec);
   else hipLaunchKernelGGL(split_bf16_kernel<false>, dim3((int)blocks), dim3(256), 0, stream, src, lds_, rows, cols, (bf16_t*)hi, ldd,
                           rows_pad, plane_stride, src_vec);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
+namespace {
+// e4m3 byte image (optionally of the fp16 split's lo part): 8 columns per thread, zero-filled out to [rows_pad, ldd]
+__global__ __launch_bounds__(256) void quant_e4m3_kernel(const float* __restrict__ src, int64_t lds_, int rows, int cols, float scale,
+                                                         unsigned char* __restrict__ dst, int64_t ldd, int rows_pad, bf16_t* __restrict__ hi,
+                                                         int src_vec) {
+  const int nq = (int)(ldd >> 3);
+  const int64_t total = (int64_t)rows_pad * nq;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / nq), c = (int)(i - (int64_t)r * nq) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r < rows) {
+      const float* p = src + (int64_t)r * lds_ + c;
+      if (src_vec && c + 7 < cols) load8(p, 0, AFFT_F32, v);
+      else
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (c + k < cols) v[k] = p[k];
+    }
+    if (hi) {
+      f16x8_v hv;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { hv[k] = (_Float16)v[k]; v[k] -= (float)hv[k]; }
+      *(f16x8_v*)(hi + (int64_t)r * ldd + c) = hv;
+    }
+    store_e4m3<8>(dst, (int64_t)r * ldd + c, v, scale);
+  }
+}
+}  // namespace
+
+extern "C" int afft_quant_e4m3(const float* src, int64_t lds_, int32_t rows, int32_t cols, float scale, void* dst, int64_t ldd,
+                               int32_t rows_pad, void* hi, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(src && dst, "quant_e4m3: null pointer");
+  AFFT_CHECK(rows >= 0 && cols >= 0 && rows_pad >= rows && ldd >= cols && ldd % 8 == 0, "quant_e4m3: bad sizes (ldd %% 8 == 0)");
+  AFFT_CHECK((((uintptr_t)dst) & 7) == 0 && (((uintptr_t)hi) & 15) == 0, "quant_e4m3: misaligned planes");
+  if (rows_pad == 0 || ldd == 0) return 0;
+  const int src_vec = lds_ % 4 == 0 && (((uintptr_t)src) & 15) == 0;
+  int64_t blocks = ((int64_t)rows_pad * (ldd / 8) + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(quant_e4m3_kernel, dim3((int)blocks), dim3(256), 0, stream, src, lds_, rows, cols, scale, (unsigned char*)dst, ldd,
+                     rows_pad, (bf16_t*)hi, src_vec);
   AFFT_LAUNCH_CHECK();
   return 0;
 }
@@ -979,7 +1028,7 @@ extern "C" int afft_clip_coef(const float* sumsq, float max_norm, float* coef, f
   return 0;
 }
 
-extern "C" int afft_sgd_nesterov2(float* p, const void* g, int32_t g_dtype, float* buf, void* p_bf16, void* p_f16, int64_t n, float lr,
+extern "C" int afft_sgd_nesterov2(float* p, const void* g, int32_t g_dtype, float* buf, void* p_bf16, void* p_f16, void* p_f8, int64_t n, float lr,
                                   float mom, float wd, float gscale, const float* gscale_dev, int32_t first_step, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(p && g && buf, "sgd: null pointer");
@@ -996,12 +1045,12 @@ extern "C" int afft_sgd_nesterov2(float* p, const void* g, int32_t g_dtype, floa
     return (int64_t)(v > 0 ? v : 256);
   }();
   if (blocks > max_blocks) blocks = max_blocks;
-  hipLaunchKernelGGL(sgd_kernel, dim3((int)blocks), dim3(256), 0, stream, p, g, g_dtype, buf, (bf16_t*)p_bf16, (bf16_t*)p_f16, n, lr, mom, wd,
+  hipLaunchKernelGGL(sgd_kernel, dim3((int)blocks), dim3(256), 0, stream, p, g, g_dtype, buf, (bf16_t*)p_bf16, (bf16_t*)p_f16, (unsigned char*)p_f8, n, lr, mom, wd,
                      gscale, gscale_dev, first_step);
   AFFT_LAUNCH_CHECK();
   return 0;
 }
 extern "C" int afft_sgd_nesterov(float* p, const void* g, int32_t g_dtype, float* buf, void* p_bf16, int64_t n, float lr, float mom,
                                  float wd, float gscale, const float* gscale_dev, int32_t first_step, void* stream_) {
-  return afft_sgd_nesterov2(p, g, g_dtype, buf, p_bf16, nullptr, n, lr, mom, wd, gscale, gscale_dev, first_step, stream_);
+  return afft_sgd_nesterov2(p, g, g_dtype, buf, p_bf16, nullptr, nullptr, n, lr, mom, wd, gscale, gscale_dev, first_step, stream_);
 }

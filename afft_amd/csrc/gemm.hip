@@ -363,6 +363,13 @@ int launch_layout_impl(GemmFast& g, hipStream_t stream, const afft_gemm_t* d) {
   g.splitk = 1;
   g.ws = nullptr;
   g.counters = nullptr;
+  if (d->split3 == 3) {     // fp16 hi pass + fp8 lo pass: NT on the 256x256 kernel (callers ask afft_gemm_lo8_ok first)
+    if constexpr (!A_KS && !B_KS) {
+      if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream, 3);
+    }
+    afft_set_error("afft_gemm: split3 = 3 needs the NT layout and a problem the 256x256 kernel takes (afft_gemm_lo8_ok)");
+    return 1;
+  }
   if (d->split3 == 2) {     // fp16 two-pass (forward layouts only): same tile choice as bf16x3
     if constexpr (!A_KS) {
       if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream, 2);
@@ -431,6 +438,10 @@ int choose_variant(int M, int N, int K, bool A_KS, bool B_KS) {
 
 extern "C" int afft_gemm_variant_for(int M, int N, int K, int a_kstrided, int b_kstrided) {
   return choose_variant(M, N, K, a_kstrided != 0, b_kstrided != 0);
+}
+
+extern "C" int afft_gemm_lo8_ok(int M, int N, int K) {
+  return (g_variant == 0 || g_variant == 3) && K % 128 == 0 && K >= 128 && choose_variant(M, N, 2 * K, false, false) == 3 ? 1 : 0;
 }
 
 extern "C" int afft_gemm_packed_wanted(int M, int N, int K) {
@@ -518,10 +529,13 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
   AFFT_CHECK(!d->out_lo || (d->out_dtype == AFFT_F16 && !d->accumulate && d->out_lo % 8 == 0),
              "afft_gemm: out_lo (two-plane fp16 output) needs out_dtype AFFT_F16, no accumulate, and a 16-byte aligned plane offset");
   e.out_lo = d->out_lo;
+  AFFT_CHECK(!d->out_lo8 || (d->out_dtype == AFFT_F16 && !d->out_lo && !d->accumulate && (((uintptr_t)d->out_lo8) & 7) == 0 && d->ldo % 8 == 0),
+             "afft_gemm: out_lo8 (fp16 hi + e4m3 lo output) needs out_dtype AFFT_F16, no out_lo, no accumulate, 8-byte aligned rows");
+  e.out_lo8 = (unsigned char*)d->out_lo8;
   e.out2 = d->out2; e.ldo2 = d->ldo2; e.out2_dtype = d->out2_dtype;
   AFFT_CHECK(d->drop.p >= 0.f && d->drop.p < 1.f && d->drop.path_p >= 0.f && d->drop.path_p < 1.f, "afft_gemm: dropout p outside [0,1)");
   e.drop = make_drop(&d->drop);
-  e.sgd = SgdEpi{nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 1.f, 0, nullptr, nullptr};
+  e.sgd = SgdEpi{nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 1.f, 0, nullptr, nullptr, nullptr};
   if (d->sgd) {
     AFFT_CHECK(d->sgd->p && d->sgd->buf, "afft_gemm: fused update without parameter / momentum buffers");
     AFFT_CHECK(!d->accumulate && !d->bias && d->act == AFFT_ACT_NONE && !d->residual && !d->rowscale && !d->pre && !d->out2 &&
@@ -529,7 +543,7 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
     AFFT_CHECK(!d->sgd->p_pk16 || (d->ldo % 32 == 0 && d->M % 16 == 0 && ((uintptr_t)d->sgd->p_pk16 & 15) == 0),
                "afft_gemm: a fragment-packed image needs a [16 a, 32 b] weight");
     e.sgd = SgdEpi{d->sgd->p, d->sgd->buf, (bf16_t*)d->sgd->p_bf16, d->sgd->lr, d->sgd->mom, d->sgd->wd, d->sgd->gscale,
-                   d->sgd->first_step, (bf16_t*)d->sgd->p_pk16, (bf16_t*)d->sgd->p_f16};
+                   d->sgd->first_step, (bf16_t*)d->sgd->p_pk16, (bf16_t*)d->sgd->p_f16, (unsigned char*)d->sgd->p_f8};
   }
   auto ok4 = [](const void* p, int64_t ld, int dtype) {
     if (!p) return true;
@@ -553,15 +567,19 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
   fast = fast && (a_kc || a_ks) && (b_kc || b_ks) && lda % 8 == 0 && ldb % 8 == 0 && lda >= 8 && ldb >= 8;
   fast = fast && !(a_ks && !a_kc && b_kc && !b_ks);   // (A k-strided, B k-contiguous) does not occur on the path
 
-  AFFT_CHECK(d->split3 >= 0 && d->split3 <= 2, "afft_gemm: split3 is 0, 1 (bf16x3) or 2 (fp16 two-pass)");
+  AFFT_CHECK(d->split3 >= 0 && d->split3 <= 3, "afft_gemm: split3 is 0, 1 (bf16x3), 2 (fp16 two-pass) or 3 (fp16 + fp8 lo pass)");
+  AFFT_CHECK(d->split3 != 3 || (d->a8 && d->b8 && d->K % 128 == 0 && d->a8_ld % 16 == 0 && d->b8_ld % 16 == 0 && d->a8_ld >= d->K && d->b8_ld >= d->K &&
+                                aligned16(d->a8) && aligned16(d->b8)),
+             "afft_gemm: split3 = 3 needs the two e4m3 byte planes (16-byte aligned rows) and K %% 128 == 0");
   AFFT_CHECK(!d->split3 || fast, "afft_gemm: split3 needs 16-bit planes in a fast-path layout (K %% 64 == 0, 16-byte aligned rows)");
   if (fast) {
     GemmFast g;
     g.A = (const bf16_t*)d->A; g.B = (const bf16_t*)d->B;
     g.lda = lda; g.ldb = ldb;
-    g.K = d->split3 == 2 ? 2 * d->K : d->split3 ? 3 * d->K : d->K;
+    g.K = d->split3 == 3 ? d->K + d->K / 2 : d->split3 == 2 ? 2 * d->K : d->split3 ? 3 * d->K : d->K;      // in 64-wide K-tiles of 128 B per row
     g.nk_seg = d->K / BK;
     g.a_lo = d->a_lo; g.b_lo = d->b_lo;
+    g.A8 = (const bf16_t*)d->a8; g.B8 = (const bf16_t*)d->b8; g.lda8 = d->a8_ld / 2; g.ldb8 = d->b8_ld / 2;
     g.e = e;
     // bf16-operand kernels: activation math on v_exp_f32 / v_rcp_f32 (common.h: AFFT_ACT_FAST, |error| ~2e-7) instead of the
     // library's erff / tanhf, whose 45-80 instructions per element showed as +64..140 us per launch; AFFT_EXACT_ACT=1 keeps them

@@ -107,6 +107,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 aF[4][2], bF[2][2][2];   // A fragments of the live half; B fragments of both halves
+  bf16x16 aP[4], bP[2][2];        // X3 = 3: the same as pairs (k-substeps 0 | 1 in one 8-register tuple, see gemm_tiles.h)
+  (void)aP; (void)bP;
   if (AFFT_PP_DIAG & 1) {
     for (int i = 0; i < 4; ++i) for (int s = 0; s < 2; ++s) for (int e = 0; e < 8; ++e) aF[i][s][e] = (short)(lane * 37 + i);
     for (int a = 0; a < 2; ++a) for (int j = 0; j < 2; ++j) for (int s = 0; s < 2; ++s) for (int e = 0; e < 8; ++e) bF[a][j][s][e] = (short)(lane * 11 + j);
@@ -118,6 +120,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
   const LaneOffsets lo = lane_offsets(wave, lane);
   const unsigned voffA = A_KS ? lo.ks_row * lda2 + lo.ks_c16 : lo.kc_row * lda2 + lo.kc_chunk16;
   const unsigned voffB = B_KS ? lo.ks_row * ldb2 + lo.ks_c16 : lo.kc_row * ldb2 + lo.kc_chunk16;
+  const unsigned lda8_2 = X3 == 3 ? (unsigned)(g.lda8 * 2) : 0u, ldb8_2 = X3 == 3 ? (unsigned)(g.ldb8 * 2) : 0u;
+  const unsigned voffA8 = lo.kc_row * lda8_2 + lo.kc_chunk16, voffB8 = lo.kc_row * ldb8_2 + lo.kc_chunk16;
+  (void)voffA8; (void)voffB8;
   bool in_loop = false; (void)in_loop;
   auto issue = [&](int m, int q) {   // q = m & 3 (compile-time at every call site)
 #if AFFT_PP_CLAMP == 2
@@ -143,19 +148,26 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
     const unsigned dst = (((m >> 2) & 1) * 4 + q) * HB;      // bytes into the ring; lds_wave carries the ring's address
     int k0; const bf16_t *Ap, *Bp;
     seg_operands<X3>(g, kt, k0, Ap, Bp);
+    const bool lo8 = X3 == 3 && kt >= g.nk_seg;      // the fp8 segment: byte planes, their own row pitches (one staging call either way)
     if (q == 0 || q == 3) {
       const int r0 = m0l + (q == 3 ? 128 : 0);
       if constexpr (A_KS) stage_ks<8, 2>(Ap, g.lda, lda2, voffA, lo, r0, k0, dst, wave, lds_wave);
-      else stage_kc<8, 2>(Ap, g.lda, lda2, voffA, lo, r0, M, k0, dst, wave, lds_wave);
+      else stage_kc<8, 2>(Ap, lo8 ? g.lda8 : g.lda, lo8 ? lda8_2 : lda2, lo8 ? voffA8 : voffA, lo, r0, M, k0, dst, wave, lds_wave);
     } else {
       const int c0 = n0l + (q == 2 ? 128 : 0);
       if constexpr (B_KS) stage_ks<8, 2>(Bp, g.ldb, ldb2, voffB, lo, c0, k0, dst, wave, lds_wave);
-      else stage_kc<8, 2>(Bp, g.ldb, ldb2, voffB, lo, c0, N, k0, dst, wave, lds_wave);
+      else stage_kc<8, 2>(Bp, lo8 ? g.ldb8 : g.ldb, lo8 ? ldb8_2 : ldb2, lo8 ? voffB8 : voffB, lo, c0, N, k0, dst, wave, lds_wave);
     }
   };
   auto load_a = [&](int kt, int ih) {
     if (AFFT_PP_DIAG & 1) return;
     const char* base = smem + ((kt & 1) * 4 + (ih ? 3 : 0)) * HB;
+    if constexpr (X3 == 3) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        aP[i] = frag_pair(frag_kc(base, gp * 64 + i * 16 + (lane & 15), lane >> 4), frag_kc(base, gp * 64 + i * 16 + (lane & 15), 4 + (lane >> 4)));
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -168,6 +180,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
     constexpr int slot = decltype(slotc)::value;
     if (AFFT_PP_DIAG & 1) return;
     const char* base = smem + ((kt & 1) * 4 + 1 + jh) * HB;
+    if constexpr (X3 == 3) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bP[slot][j] = frag_pair(frag_kc(base, wc * 32 + j * 16 + (lane & 15), lane >> 4), frag_kc(base, wc * 32 + j * 16 + (lane & 15), 4 + (lane >> 4)));
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -200,11 +218,29 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
     STAMP(t3);
     sL += t1 - t0; sW += t2 - t1; sB1 += t3 - t2;
   };
-  auto compute = [&](auto ihc, auto jhc, auto slotc, int dma_m, int dma_q) {
+  auto compute = [&](auto ihc, auto jhc, auto slotc, int dma_m, int dma_q, auto lo8c) {
     constexpr int ih = decltype(ihc)::value, jh = decltype(jhc)::value, slot = decltype(slotc)::value;
+    constexpr bool lo8 = decltype(lo8c)::value;      // compile-time: with both MFMA forms behind a run-time branch in one loop body the
+                                                     // register allocator spilled 241 registers; two loops, one form each, spill none
     (void)dma_m; (void)dma_q;
     __builtin_amdgcn_sched_barrier(0);
     if (AFFT_PP_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+    if constexpr (X3 == 3) {
+      if constexpr (lo8) {      // fp8 segment: 8 block-scaled MFMAs of 128 k instead of 16 of 32 k (the same fragment pairs, taken whole)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[ih][jh][i][j] = mfma_lo8(bP[slot][j], aP[i], acc[ih][jh][i][j]);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[ih][jh][i][j] = mfma16<3>(frag_half(bP[slot][j], s), frag_half(aP[i], s), acc[ih][jh][i][j]);
+      }
+    } else
     if (!(AFFT_PP_DIAG & 4))
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -243,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
   // that the next K-tile's first B fragments can be read during phase 3, whose own operands are all resident:
   // LDS reads per phase 8 / 4 / 8 / 4 instead of 12 / 4 / 8 / 0 (the L segment has to fit under 16 MFMAs).
   in_loop = true;
-  auto ktile = [&](auto Pc, int kt) {
+  auto ktile = [&](auto Pc, int kt, auto lo8) {
     using SP = std::integral_constant<int, decltype(Pc)::value>;
     using SQ = std::integral_constant<int, 1 - decltype(Pc)::value>;
     const int n = 4 * kt;
@@ -253,14 +289,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
       else if (AFFT_PP_DMA_FIRST) { issue(m, q); reads(); } else { reads(); issue(m, q); }
       if (AFFT_PP_PRIO == 2) __builtin_amdgcn_s_setprio(0);
     };
-    L([&] { load_a(kt, 0); }, n + 0 + LEAD, (0 + LEAD) & 3);            wait_then_barrier(n + 0); compute(I0{}, I0{}, SP{}, n + 0 + LEAD, (0 + LEAD) & 3);
-    L([&] { load_b(kt, 1, SQ{}); }, n + 1 + LEAD, (1 + LEAD) & 3);      wait_then_barrier(n + 1); compute(I0{}, I1{}, SQ{}, n + 1 + LEAD, (1 + LEAD) & 3);
-    L([&] { load_a(kt, 1); }, n + 2 + LEAD, (2 + LEAD) & 3);            wait_then_barrier(n + 2); compute(I1{}, I1{}, SQ{}, n + 2 + LEAD, (2 + LEAD) & 3);
-    L([&] { load_b(kt + 1, 0, SQ{}); }, n + 3 + LEAD, (3 + LEAD) & 3);  wait_then_barrier(n + 3); compute(I1{}, I0{}, SP{}, n + 3 + LEAD, (3 + LEAD) & 3);
+    L([&] { load_a(kt, 0); }, n + 0 + LEAD, (0 + LEAD) & 3);            wait_then_barrier(n + 0); compute(I0{}, I0{}, SP{}, n + 0 + LEAD, (0 + LEAD) & 3, lo8);
+    L([&] { load_b(kt, 1, SQ{}); }, n + 1 + LEAD, (1 + LEAD) & 3);      wait_then_barrier(n + 1); compute(I0{}, I1{}, SQ{}, n + 1 + LEAD, (1 + LEAD) & 3, lo8);
+    L([&] { load_a(kt, 1); }, n + 2 + LEAD, (2 + LEAD) & 3);            wait_then_barrier(n + 2); compute(I1{}, I1{}, SQ{}, n + 2 + LEAD, (2 + LEAD) & 3, lo8);
+    L([&] { load_b(kt + 1, 0, SQ{}); }, n + 3 + LEAD, (3 + LEAD) & 3);  wait_then_barrier(n + 3); compute(I1{}, I0{}, SP{}, n + 3 + LEAD, (3 + LEAD) & 3, lo8);
   };
-  for (int kt = 0; kt < nk; kt += 2) {
-    ktile(I0{}, kt);
-    if (kt + 1 < nk) ktile(I1{}, kt + 1);
+  const int nk_first = X3 == 3 ? g.nk_seg : nk;      // X3 = 3: fp16 segment (an even number of K-tiles: K % 128 == 0), then the fp8 segment
+  for (int kt = 0; kt < nk_first; kt += 2) {
+    ktile(I0{}, kt, std::false_type{});
+    if (kt + 1 < nk_first) ktile(I1{}, kt + 1, std::false_type{});
+  }
+  if constexpr (X3 == 3) {
+    for (int kt = nk_first; kt < nk; kt += 2) {
+      ktile(I0{}, kt, std::true_type{});
+      if (kt + 1 < nk) ktile(I1{}, kt + 1, std::true_type{});
+    }
   }
   if (gp == 0) __builtin_amdgcn_s_barrier();
 #if AFFT_PP_CLAMP
@@ -333,6 +376,11 @@ extern "C" void afft_debug_pp_stamp(void* p) { g_pp_stamp = (unsigned long long*
 
 int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream, int x3) {
 #ifndef AFFT_PP_NT_ONLY   // development switch: build only the plain NT instantiation (compile time)
+  if (x3 == 3) {   // fp16 + fp8 lo pass: nn.Linear forward GEMMs (NT) only
+    if (!a_ks && !b_ks) return launch_pp<false, false, 3>(g, stream);
+    afft_set_error("afft_gemm: the fp16 + fp8 mode (split3 = 3) is built for the NT layout only");
+    return 1;
+  }
   if (x3 == 2) {   // fp16x2: forward GEMMs only (NT, and NN for [in, out] weights)
     if (!a_ks && !b_ks) return launch_pp<false, false, 2>(g, stream);
     if (!a_ks && b_ks) return launch_pp<false, true, 2>(g, stream);

@@ -35,22 +35,45 @@ struct GemmFast {
   // fp16x2 (X3 = 2): fp16 planes, the first TWO segments only (A = hi + lo, B rounded once), v_mfma_f32_16x16x32_f16
   int nk_seg;
   int64_t a_lo, b_lo;
+  // fp16 + fp8 (X3 = 3, "fp16x2" with the lo pass on the block-scaled fp8 MFMA): segment 0 = nk_seg K-tiles of (A hi fp16, B fp16
+  // image); segment 1 = nk_seg / 2 K-tiles of 128 k each of (A8 = e4m3(2^11 (a - hi)), B8 = e4m3(2^8 b)), byte planes addressed as
+  // bf16_t arrays of half the length (a K-tile is 128 B per row either way): lda8 / ldb8 are their row pitches in bf16_t units
+  const bf16_t* A8; const bf16_t* B8; int64_t lda8, ldb8;
   EpiParams e;
 };
 
 // global K-tile index -> K offset inside the segment and the operand planes of that segment (wave-uniform SALU work)
 // the MFMA of every bf16-path kernel: 16-bit operands by the instantiation's plane format (X3 = 2: fp16, else bf16)
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+// the lo pass of X3 = 3: one v_mfma_scale_f32_16x16x128_f8f6f4 per pair of 16-byte fragments (k-substeps 0 and 1 of a 128-byte row:
+// lane group g holds bytes 16g.. and 64 + 16g.. of its row in BOTH operands, so the k sets pair up whatever order the instruction
+// walks them in); e4m3 operands with constant block scales 2^-8 (srcA = the weight fragment) and 2^-11 (srcB = the activation's)
+// The fragments of such a kernel are kept as PAIRS (k-substeps 0 and 1 side by side in one 8-register tuple): the block-scaled MFMA
+// takes the tuple whole, the fp16 MFMA of the first segment takes its halves (sub-registers: no copies).  Assembling the tuple from
+// two separately allocated 4-register fragments at the point of use cost 208 spilled registers in the first build.
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+typedef __attribute__((ext_vector_type(16))) short bf16x16;
+__device__ __forceinline__ bf16x16 frag_pair(bf16x8 s0, bf16x8 s1) { return __builtin_shufflevector(s0, s1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15); }
+__device__ __forceinline__ bf16x8 frag_half(bf16x16 p, int s) {
+  return s ? __builtin_shufflevector(p, p, 8, 9, 10, 11, 12, 13, 14, 15) : __builtin_shufflevector(p, p, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ f32x4 mfma_lo8(bf16x16 b, bf16x16 a, f32x4 c) {
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_bit_cast(i32x8_t, b), __builtin_bit_cast(i32x8_t, a), c, 0, 0, 0, 127 - 8, 0,
+                                                          127 - 11);
+}
+
 template <int X3>
 __device__ __forceinline__ f32x4 mfma16(bf16x8 b, bf16x8 a, f32x4 c) {
-  if constexpr (X3 == 2) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, b), __builtin_bit_cast(f16x8_t, a), c, 0, 0, 0);
+  if constexpr (X3 == 2 || X3 == 3) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, b), __builtin_bit_cast(f16x8_t, a), c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c, 0, 0, 0);
 }
 
 template <int X3>
 __device__ __forceinline__ void seg_operands(const GemmFast& g, int kt, int& k0, const bf16_t*& A, const bf16_t*& B) {
   A = g.A; B = g.B;
-  if constexpr (X3) {
+  if constexpr (X3 == 3) {
+    if (kt >= g.nk_seg) { kt -= g.nk_seg; A = g.A8; B = g.B8; }
+  } else if constexpr (X3) {
     const int s1 = kt >= g.nk_seg, s2 = kt >= 2 * g.nk_seg;
     kt -= (s1 + s2) * g.nk_seg;
     if (s1 && !s2) A += g.a_lo;

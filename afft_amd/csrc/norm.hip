@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ w, const float* __restrict__ b,
                                                      float eps, int rows, int d, void* __restrict__ y, int64_t ldy,
                                                      int y_dtype, float* __restrict__ mean, float* __restrict__ rstd,
-                                                     int64_t y_lo, bf16_t* __restrict__ y2, int64_t ldy2) {
+                                                     int64_t y_lo, bf16_t* __restrict__ y2, int64_t ldy2, unsigned char* __restrict__ y_lo8) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * LN_WAVES + wave;
   if (row >= rows) return;
@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         const float4 bb = *(const float4*)(b + 4 * q);
         o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w;
       }
-      if (y_lo) store_split<4>(y, (int64_t)row * ldy + 4 * q, y_lo, o);     // fp16x2 operand planes (afft_layernorm_fwd_split)
+      if (y_lo8) store_split8<4>(y, y_lo8, (int64_t)row * ldy + 4 * q, o);  // fp16 hi + e4m3 lo (the fp8 lo pass)
+      else if (y_lo) store_split<4>(y, (int64_t)row * ldy + 4 * q, y_lo, o);     // fp16x2 operand planes (afft_layernorm_fwd_split)
       else store4(y, (int64_t)row * ldy + 4 * q, y_dtype, o);
       if (y2) store4(y2, (int64_t)row * ldy2 + 4 * q, AFFT_BF16, o);
     }
@@ -260,7 +261,8 @@ extern "C" int afft_layernorm_bwd_nparts(int32_t rows) {
 }
 
 static int ln_fwd_launch(const float* x, int64_t ldx, const float* w, const float* b, float eps, int32_t rows, int32_t d, void* y,
-                         int64_t ldy, int32_t y_dtype, int64_t y_lo, void* y2, int64_t ldy2, float* mean, float* rstd, hipStream_t stream) {
+                         int64_t ldy, int32_t y_dtype, int64_t y_lo, void* y2, int64_t ldy2, float* mean, float* rstd, hipStream_t stream,
+                         void* y_lo8 = nullptr) {
   AFFT_CHECK(x && y, "layernorm_fwd: null pointer");
   AFFT_CHECK(d > 0 && d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldy2 % 4 == 0 && y_lo % 4 == 0,
              "layernorm_fwd: d/ld must be multiples of 4 (d=%d)", d);
@@ -269,9 +271,9 @@ static int ln_fwd_launch(const float* x, int64_t ldx, const float* w, const floa
   AFFT_CHECK(nv != 0, "layernorm_fwd: d=%d exceeds 4096", d);
   if (rows == 0) return 0;
   AfftKernelScope ktrace(AFFT_K_LN_FWD, rows, d,
-                         (int64_t)rows * d * (4 + (y_dtype == AFFT_F32 ? 4 : 2) + (y_lo ? 2 : 0) + (y2 ? 2 : 0)) + (int64_t)rows * 8, 0, stream);
+                         (int64_t)rows * d * (4 + (y_dtype == AFFT_F32 ? 4 : 2) + (y_lo ? 2 : 0) + (y_lo8 ? 1 : 0) + (y2 ? 2 : 0)) + (int64_t)rows * 8, 0, stream);
   const int grid = (rows + LN_WAVES - 1) / LN_WAVES;
-#define LN_FWD(NV) hipLaunchKernelGGL(ln_fwd_kernel<NV>, dim3(grid), dim3(256), 0, stream, x, ldx, w, b, eps, rows, d, y, ldy, y_dtype, mean, rstd, y_lo, (bf16_t*)y2, ldy2)
+#define LN_FWD(NV) hipLaunchKernelGGL(ln_fwd_kernel<NV>, dim3(grid), dim3(256), 0, stream, x, ldx, w, b, eps, rows, d, y, ldy, y_dtype, mean, rstd, y_lo, (bf16_t*)y2, ldy2, (unsigned char*)y_lo8)
   switch (nv) { case 1: LN_FWD(1); break; case 2: LN_FWD(2); break; case 4: LN_FWD(4); break; case 8: LN_FWD(8); break; default: LN_FWD(16); }
 #undef LN_FWD
   AFFT_LAUNCH_CHECK();
@@ -286,8 +288,9 @@ extern "C" int afft_layernorm_fwd(const float* x, int64_t ldx, const float* w, c
 
 extern "C" int afft_layernorm_fwd_split(const float* x, int64_t ldx, const float* w, const float* b, float eps, int32_t rows, int32_t d,
                                         void* y_hi, int64_t ldy, int64_t y_lo, void* y_bf16, int64_t ldyb, float* mean, float* rstd,
-                                        void* stream_) {
-  return ln_fwd_launch(x, ldx, w, b, eps, rows, d, y_hi, ldy, AFFT_F16, y_lo, y_bf16, ldyb, mean, rstd, (hipStream_t)stream_);
+                                        void* y_lo8, void* stream_) {
+  AFFT_CHECK(!y_lo8 || y_lo == 0, "layernorm_fwd_split: give the lo part as an fp16 plane (y_lo) or as an e4m3 byte plane (y_lo8), not both");
+  return ln_fwd_launch(x, ldx, w, b, eps, rows, d, y_hi, ldy, AFFT_F16, y_lo, y_bf16, ldyb, mean, rstd, (hipStream_t)stream_, y_lo8);
 }
 
 extern "C" int afft_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx,

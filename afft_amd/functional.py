@@ -526,6 +526,14 @@ def _composite_ok(x: Tensor, pre_ln: bool, *widths: int, f16x2: bool = True) -> 
             and x.stride(0) == x.shape[1] and all(w % 64 == 0 for w in widths))
 
 
+def _lo8_ok(conv1d: bool, R: int, *shapes) -> bool:
+    """the fp8 lo pass for a sub-layer: nn.Linear weights and every (N, K) of its GEMMs on the 256x256 kernel (afft_gemm_lo8_ok)"""
+    if conv1d or not rt.lo8():
+        return False
+    lib = L_.lib()
+    return all(lib.afft_gemm_lo8_ok(int(R), int(n), int(k)) for n, k in shapes)
+
+
 def _img_h(W: Tensor):
     """(pointer, leading dimension) of the FP16 image of a 2-D weight ('fp16x2' forward)"""
     h = rt.weight_f16(W)
@@ -678,6 +686,9 @@ def _attn_fwd_c(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, ep
         s.f16x2 = 1
         s.w_qkv, s.ldw_qkv = _img_h(w_qkv)
         s.w_proj, s.ldw_proj = _img_h(w_proj)
+        if _lo8_ok(conv1d, R, (3 * d, d), (d, d)):      # second pass on the block-scaled fp8 MFMA: e4m3 lo planes of xn / ao, e4m3 weight images
+            s.f16x2 = 2
+            s.w_qkv8, s.w_proj8 = rt.weight_f8(w_qkv).data_ptr(), rt.weight_f8(w_proj).data_ptr()
         base = planes.data_ptr()
         s.xn, s.qkv, s.ao = base, base + 2 * (2 * pr * d), base + 2 * (2 * pr * 4 * d)      # [hi | lo] of xn, then of qkv, then of ao
         if saved is not None:
@@ -799,6 +810,9 @@ def _mlp_fwd_c(ctx, x, ln_w, ln_b, w1, b1, w2, b2, eps, gelu, conv1d, hidden, dr
         s.f16x2 = 1
         s.w1, s.ldw1 = _img_h(w1)
         s.w2, s.ldw2 = _img_h(w2)
+        if _lo8_ok(conv1d, R, (hidden, d), (d, hidden)):
+            s.f16x2 = 2
+            s.w1_8, s.w2_8 = rt.weight_f8(w1).data_ptr(), rt.weight_f8(w2).data_ptr()
         base = planes.data_ptr()
         s.xn, s.h = base, base + 2 * (2 * pr * d)
         if saved is not None:

@@ -95,14 +95,25 @@ def gemm(a, b, out: Tensor, *, a_t: bool = False, b_t: bool = False, bias: Optio
          rowscale: Optional[Tensor] = None, residual: Optional[Tensor] = None, accumulate: bool = False,
          out2: Optional[Tensor] = None, alpha: float = 1.0, drop: Optional["L.Dropout"] = None,
          sgd: Optional["L.SgdFused"] = None, b_packed: Optional[Tensor] = None,
-         out_lo: int = 0) -> Tensor:
+         out_lo: int = 0, a8: Optional[Tensor] = None, b8: Optional[Tensor] = None, out_lo8: Optional[Tensor] = None) -> Tensor:
     """out = epilogue(alpha * A @ B).  A = a (or a.T if a_t), B = b (or b.T if b_t); a, b 2-D views -- or both `Split`
     (two-plane bf16 splits of fp32 matrices): the bf16x3 GEMM, fp32-accurate products on the bf16 MFMA path; or a an fp16 `Split`
     and b a plain fp16 matrix (a weight's FP16 image): the fp16 two-pass forward GEMM (afft_gemm_t.split3 = 2).
     b_packed: the fragment-packed copy of a weight `b` [N, K] used as b.T (pack_weight; afft_gemm_t.b_packed).
-    out_lo: `out` (fp16) is the hi plane of a two-plane split of the result, the lo plane sits out_lo elements behind it."""
+    out_lo: `out` (fp16) is the hi plane of a two-plane split of the result, the lo plane sits out_lo elements behind it.
+    a8 / b8 (uint8, the shapes of a / b): the lo pass on the block-scaled fp8 MFMA (afft_gemm_t.split3 = 3): a = the fp16 HI plane of the
+    activation (a plain fp16 matrix), a8 = e4m3(2^11 (x - hi)), b = the weight's FP16 image, b8 = e4m3(2^8 w); out_lo8: the result's lo
+    part as an e4m3 byte plane (pitch = out's element pitch)."""
     d = L.GemmDesc()
-    if isinstance(a, Split) and not isinstance(b, Split):
+    if a8 is not None:
+        if not (a.dtype == b.dtype == torch.float16 and a8.dtype == b8.dtype == torch.uint8 and b_t and not a_t):
+            raise TypeError("afft_amd.gemm: the fp8 lo pass takes fp16 a / b (NT) with uint8 e4m3 planes a8 / b8")
+        assert a8.shape == a.shape and b8.shape == b.shape and a8.stride(1) == 1 and b8.stride(1) == 1
+        M, K = a.shape
+        Kb, N = b.shape[1], b.shape[0]
+        d.split3 = 3
+        d.a8, d.a8_ld, d.b8, d.b8_ld = _p(a8), a8.stride(0), _p(b8), b8.stride(0)
+    elif isinstance(a, Split) and not isinstance(b, Split):
         if not (a.f16 and isinstance(b, torch.Tensor) and b.dtype == torch.float16) or a_t:
             raise TypeError("afft_amd.gemm: a Split A with a plain B is the fp16 two-pass forward GEMM (fp16 planes, fp16 B, A not transposed)")
         sa = a
@@ -160,6 +171,9 @@ def gemm(a, b, out: Tensor, *, a_t: bool = False, b_t: bool = False, bias: Optio
     if out_lo:
         assert out.dtype == torch.float16 and out_lo % 8 == 0
         d.out_lo = int(out_lo)
+    if out_lo8 is not None:
+        assert out.dtype == torch.float16 and out_lo8.dtype == torch.uint8 and out_lo8.stride(0) == out.stride(0) and out_lo8.shape == out.shape
+        d.out_lo8 = _p(out_lo8)
     if out2 is not None:
         d.out2, d.ldo2, d.out2_dtype = _p(out2), _rowmajor(out2, "out2"), _dt(out2)
     if drop is not None:
@@ -178,14 +192,28 @@ def layernorm_fwd(x: Tensor, w: Optional[Tensor], b: Optional[Tensor], eps: floa
     return y
 
 
+def quant_e4m3(src: Tensor, scale: float, dst: Tensor, hi: Optional[Tensor] = None) -> Tensor:
+    """dst (uint8 [rows_pad, ldd]) = e4m3(scale * src), zero-filled outside src's shape; with hi (fp16 [rows_pad, ldd]): hi = fp16(src) and
+    dst = e4m3(scale * (src - hi)) -- include/afft_hip.h afft_quant_e4m3"""
+    assert src.dtype == torch.float32 and dst.dtype == torch.uint8 and dst.dim() == 2 and dst.stride(1) == 1 and dst.is_contiguous()
+    if hi is not None:
+        assert hi.dtype == torch.float16 and hi.shape == dst.shape and hi.is_contiguous()
+    rows, cols = src.shape
+    L.check(L.lib().afft_quant_e4m3(_p(src), _rowmajor(src, "src"), rows, cols, float(scale), _p(dst), dst.shape[1], dst.shape[0], _p(hi),
+                                    _stream()), "quant_e4m3")
+    return dst
+
+
 def layernorm_fwd_split(x: Tensor, w: Optional[Tensor], b: Optional[Tensor], eps: float, y_hi: Tensor, y_lo: int,
-                        y_bf16: Optional[Tensor] = None, mean: Optional[Tensor] = None, rstd: Optional[Tensor] = None) -> Tensor:
-    """LayerNorm whose result is written as two fp16 planes (hi at y_hi, lo y_lo elements behind it) and, optionally, as a bf16 copy."""
+                        y_bf16: Optional[Tensor] = None, mean: Optional[Tensor] = None, rstd: Optional[Tensor] = None,
+                        y_lo8: Optional[Tensor] = None) -> Tensor:
+    """LayerNorm whose result is written as two fp16 planes (hi at y_hi, lo y_lo elements behind it) -- or hi + an e4m3 byte plane y_lo8 --
+    and, optionally, as a bf16 copy."""
     assert x.dtype == torch.float32 and y_hi.dtype == torch.float16 and (y_bf16 is None or y_bf16.dtype == torch.bfloat16)
     rows, d = x.shape
     L.check(L.lib().afft_layernorm_fwd_split(_p(x), _rowmajor(x, "x"), _p(w), _p(b), eps, rows, d, _p(y_hi), _rowmajor(y_hi, "y_hi"),
                                              int(y_lo), _p(y_bf16), _rowmajor(y_bf16, "y_bf16") if y_bf16 is not None else 0,
-                                             _p(mean), _p(rstd), _stream()), "layernorm_fwd_split")
+                                             _p(mean), _p(rstd), _p(y_lo8), _stream()), "layernorm_fwd_split")
     return y_hi
 
 
@@ -223,13 +251,13 @@ def attention_fwd(q: Tensor, k: Tensor, v: Tensor, nseq: int, L_: int, H: int, h
 
 def attention_fwd_split(q: Tensor, k: Tensor, v: Tensor, in_lo: int, nseq: int, L_: int, H: int, hd: int, scale: float, mask: int,
                         out_hi: Tensor, out_lo: int, out_bf16: Optional[Tensor], probs: Optional[Tensor], drop_p: float = 0.0,
-                        drop_key: int = 0, mask_period: int = 0) -> Tensor:
+                        drop_key: int = 0, mask_period: int = 0, out_lo8: Optional[Tensor] = None) -> Tensor:
     """fp16x2 forward attention: q / k / v / out_hi are the hi planes of two-plane fp16 splits (lo planes in_lo / out_lo elements behind)"""
     assert q.dtype == k.dtype == v.dtype == out_hi.dtype == torch.float16
     L.check(L.lib().afft_attention_fwd_split(_p(q), _rowmajor(q, "q"), _p(k), _rowmajor(k, "k"), _p(v), _rowmajor(v, "v"), int(in_lo),
                                              nseq, L_, H, hd, scale, mask, mask_period, drop_p, drop_key, _p(out_hi),
                                              _rowmajor(out_hi, "out"), int(out_lo), _p(out_bf16),
-                                             _rowmajor(out_bf16, "out_bf16") if out_bf16 is not None else 0, _p(probs), _stream()),
+                                             _rowmajor(out_bf16, "out_bf16") if out_bf16 is not None else 0, _p(probs), _p(out_lo8), _stream()),
             "attention_fwd_split")
     return out_hi
 
@@ -348,7 +376,8 @@ def reduce_rows_periodic(src: Tensor, period: int, out: Tensor):
 
 
 def sgd_nesterov(p: Tensor, g: Tensor, buf: Tensor, lr: float, mom: float, wd: float, gscale: float, first,
-                 p_bf16: Optional[Tensor] = None, gscale_dev: Optional[Tensor] = None, p_f16: Optional[Tensor] = None):
+                 p_bf16: Optional[Tensor] = None, gscale_dev: Optional[Tensor] = None, p_f16: Optional[Tensor] = None,
+                 p_f8: Optional[Tensor] = None):
     """first: bool (first step) or the AFFT_SGD_* flag word (1 = first step, 2 = plain momentum instead of Nesterov);
     p_bf16 / p_f16: the bf16 / fp16 images of the updated weights (same element offsets as p)"""
     assert p.is_contiguous() and g.is_contiguous() and buf.is_contiguous()
@@ -356,16 +385,18 @@ def sgd_nesterov(p: Tensor, g: Tensor, buf: Tensor, lr: float, mom: float, wd: f
         assert p_bf16.dtype == torch.bfloat16 and p_bf16.numel() == p.numel() and p_bf16.is_contiguous()
     if p_f16 is not None:
         assert p_f16.dtype == torch.float16 and p_f16.numel() == p.numel() and p_f16.is_contiguous()
-    L.check(L.lib().afft_sgd_nesterov2(_p(p), _p(g), _dt(g), _p(buf), _p(p_bf16), _p(p_f16), p.numel(), lr, mom, wd, gscale,
+    if p_f8 is not None:
+        assert p_f8.dtype == torch.uint8 and p_f8.numel() == p.numel() and p_f8.is_contiguous()
+    L.check(L.lib().afft_sgd_nesterov2(_p(p), _p(g), _dt(g), _p(buf), _p(p_bf16), _p(p_f16), _p(p_f8), p.numel(), lr, mom, wd, gscale,
                                        _p(gscale_dev), int(first), _stream()), "sgd_nesterov")
 
 
 def sgd_nesterov_runs(p: Tensor, g: Tensor, buf: Tensor, runs: Tensor, lr: float, mom: float, wd: float, gscale: float, first: bool,
-                      p_bf16: Optional[Tensor] = None, p_f16: Optional[Tensor] = None):
+                      p_bf16: Optional[Tensor] = None, p_f16: Optional[Tensor] = None, p_f8: Optional[Tensor] = None):
     """the same update over the runs {start, length} (int64 [nruns, 2] on the device) of whole flat buffers"""
     assert runs.dtype == torch.int64 and runs.dim() == 2 and runs.shape[1] == 2 and runs.is_contiguous()
     assert p.dtype == g.dtype == buf.dtype == torch.float32
-    L.check(L.lib().afft_sgd_nesterov_runs2(_p(p), _p(g), _p(buf), _p(p_bf16), _p(p_f16), _p(runs), runs.shape[0], lr, mom, wd, gscale,
+    L.check(L.lib().afft_sgd_nesterov_runs2(_p(p), _p(g), _p(buf), _p(p_bf16), _p(p_f16), _p(p_f8), _p(runs), runs.shape[0], lr, mom, wd, gscale,
                                             int(first), _stream()), "sgd_nesterov_runs")
 
 

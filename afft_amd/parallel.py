@@ -82,6 +82,7 @@ class FlatParams:
         # FP16 images (same offsets; the B operands of the fp16 two-pass forward GEMMs, precision 'fp16x2'): allocated the first
         # time a step runs in that precision (ensure_f16) and from then on written by every optimizer kernel beside the bf16 ones
         self.flat_h16: Optional[Tensor] = None
+        self.flat_p8: Optional[Tensor] = None      # e4m3(2^8 p) byte images (the fp8 lo pass of 'fp16x2': runtime.lo8), allocated with flat_h16
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 n = p.numel()
@@ -114,13 +115,22 @@ class FlatParams:
         self.flat_h16 = torch.zeros(n, dtype=torch.float16, device=self.flat_p.device)
         with torch.no_grad():
             ops.cast(self.flat_p.view(n // 64, 64), self.flat_h16.view(n // 64, 64))
+        if rt.lo8():
+            self.flat_p8 = torch.zeros(n, dtype=torch.uint8, device=self.flat_p.device)
+            with torch.no_grad():
+                ops.quant_e4m3(self.flat_p.view(n // 64, 64), 256.0, self.flat_p8.view(n // 64, 64))
         for p, o in zip(self.params, self.offsets):
             img = getattr(p, "_afft_img", None)
             if img is not None and img.external and p.dim() == 2:
                 rt.adopt_weight_f16(p, self.flat_h16[o:o + p.numel()].view(p.shape))
+                if self.flat_p8 is not None:
+                    rt.adopt_weight_f8(p, self.flat_p8[o:o + p.numel()].view(p.shape))
 
     def h16(self, s: int = 0, e: Optional[int] = None) -> Optional[Tensor]:
         return None if self.flat_h16 is None else self.flat_h16[s:self.total if e is None else e]
+
+    def p8(self, s: int = 0, e: Optional[int] = None) -> Optional[Tensor]:
+        return None if self.flat_p8 is None else self.flat_p8[s:self.total if e is None else e]
 
     def refresh_images(self):
         """Re-derive every bf16 image from the fp32 masters (after the masters were written from outside: a parameter
@@ -131,6 +141,8 @@ class FlatParams:
                 ops.cast(self.flat_p.view(n // 64, 64), self.flat_p16.view(n // 64, 64))
                 if self.flat_h16 is not None:
                     ops.cast(self.flat_p.view(n // 64, 64), self.flat_h16.view(n // 64, 64))
+                if self.flat_p8 is not None:
+                    ops.quant_e4m3(self.flat_p.view(n // 64, 64), 256.0, self.flat_p8.view(n // 64, 64))
             self.refresh_packed(0, n)
         rt.invalidate_weight_images()
 
@@ -253,7 +265,7 @@ class GradReducer:
         g = self._grad_slice(s, e)
         dist.reduce_scatter_tensor(g[ss - s:se - s], g, group=self.group)
         self.on_bucket(ss, se, g[ss - s:se - s], 1.0 / self.world)
-        for img in (self.flat.flat_p16, self.flat.flat_h16):
+        for img in (self.flat.flat_p16, self.flat.flat_h16, self.flat.flat_p8):
             if img is not None:
                 dist.all_gather_into_tensor(img[s:e], img[ss:se], group=self.group)
         if self.flat.flat_p16 is None:      # CPU tensors (gloo tests): no images -- the fp32 slices themselves are what the next forward reads
@@ -450,12 +462,12 @@ class FusedSGD:
                 if runs is not None:
                     if runs.shape[0]:
                         ops.sgd_nesterov_runs(self.flat.flat_p, self.flat.flat_g, self.buf, runs, self.lr, self.momentum, self.wd,
-                                              gscale, self.flags(), p_bf16=self.flat.flat_p16, p_f16=self.flat.flat_h16)
+                                              gscale, self.flags(), p_bf16=self.flat.flat_p16, p_f16=self.flat.flat_h16, p_f8=self.flat.flat_p8)
                     self.flat.refresh_packed(s, e, skip=self.skip)
                     return
             p16 = self.flat.flat_p16[s:e] if self.flat.flat_p16 is not None else None
             ops.sgd_nesterov(self.flat.flat_p[s:e], grad, self.buf[s:e], self.lr, self.momentum, self.wd, gscale,
-                             self.flags(), p_bf16=p16, gscale_dev=gscale_dev, p_f16=self.flat.h16(s, e))
+                             self.flags(), p_bf16=p16, gscale_dev=gscale_dev, p_f16=self.flat.h16(s, e), p_f8=self.flat.p8(s, e))
             self.flat.refresh_packed(s, e)
             return
         # per-parameter (lr, wd): the parameters of the range class by class.  [s, e) may cut a parameter at either end (the
@@ -474,7 +486,7 @@ class FusedSGD:
                     g_full = flat.flat_g if grad.data_ptr() == flat.flat_g[s:e].data_ptr() else None
                     if g_full is not None:
                         ops.sgd_nesterov_runs(flat.flat_p, g_full, self.buf, runs, lr, self.momentum, wd, gscale, self.flags(),
-                                              p_bf16=flat.flat_p16, p_f16=flat.flat_h16)
+                                              p_bf16=flat.flat_p16, p_f16=flat.flat_h16, p_f8=flat.flat_p8)
                         continue
                 elif fused:
                     continue
@@ -485,7 +497,7 @@ class FusedSGD:
                 lo, hi = max(o, s), min(o + _align(p.numel()), e)
                 p16 = flat.flat_p16[lo:hi] if flat.flat_p16 is not None else None
                 ops.sgd_nesterov(flat.flat_p[lo:hi], grad[lo - s:hi - s], self.buf[lo:hi], lr, self.momentum, wd, gscale,
-                                 self.flags(), p_bf16=p16, gscale_dev=gscale_dev, p_f16=flat.h16(lo, hi))
+                                 self.flags(), p_bf16=p16, gscale_dev=gscale_dev, p_f16=flat.h16(lo, hi), p_f8=flat.p8(lo, hi))
         self.flat.refresh_packed(s, e, skip=(self.skip if fused else ()))
 
     def end_step(self):
@@ -592,7 +604,7 @@ class _FusedEpilogue:
             n = _align(p.numel())
             lr, wd = self.opt.hyper_of(self._index[pid])
             ops.sgd_nesterov(flat.flat_p[o:o + n], flat.flat_g[o:o + n], self.opt.buf[o:o + n], lr, self.opt.momentum,
-                             wd, 1.0, self.opt.flags(), p_bf16=flat.flat_p16[o:o + n], p_f16=flat.h16(o, o + n))
+                             wd, 1.0, self.opt.flags(), p_bf16=flat.flat_p16[o:o + n], p_f16=flat.h16(o, o + n), p_f8=flat.p8(o, o + n))
             flat.refresh_packed(o, o + 1)
             stale.append(pid)
         if stale:
@@ -619,6 +631,7 @@ class _FusedEpilogue:
             d.p_pk16 = p._afft_img.pk.data_ptr() if rt.packed_live(p) else None      # only images a forward GEMM uses are kept fresh
             h16 = self.flat.flat_h16
             d.p_f16 = (h16.data_ptr() + 2 * self._offset_of(p)) if h16 is not None else None
+            d.p_f8 = (self.flat.flat_p8.data_ptr() + self._offset_of(p)) if self.flat.flat_p8 is not None else None
             d.lr, d.mom, d.wd, d.gscale, d.first_step = lr, self.opt.momentum, wd, 1.0, self.opt.flags() & 2
         return d
 

@@ -102,7 +102,8 @@ def pad64(n: int) -> int:
 
 # --------------------------------------------------------------------------- bf16 weight images
 class _WImage:
-    __slots__ = ("version", "ptr", "w", "external", "pk", "pk_live", "pk_version", "h", "h_version", "h_external")
+    __slots__ = ("version", "ptr", "w", "external", "pk", "pk_live", "pk_version", "h", "h_version", "h_external", "e", "e_version",
+                 "e_external")
 
 
 _wlist: list = []   # weak references to parameters that own an image (for invalidate_weight_images)
@@ -135,6 +136,9 @@ def weight_images(p: Tensor) -> Tensor:
         img.h = None
         img.h_version = -1
         img.h_external = False
+        img.e = None
+        img.e_version = -1
+        img.e_external = False
         img.ptr = p.data_ptr()
         p._afft_img = img
         _register(p)
@@ -167,6 +171,49 @@ def weight_f16(p: Tensor) -> Tensor:
             ops.cast(p.detach(), img.h[:p.shape[0], :p.shape[1]])
         img.h_version = p._version
     return img.h
+
+
+_LO8 = os.environ.get("AFFT_LO8", "1") != "0"
+
+
+def lo8() -> bool:
+    """'fp16x2' forward: run the second pass A_lo W of the big nn.Linear GEMMs on the block-scaled fp8 MFMA (afft_gemm_t.split3 = 3:
+    A_lo and W as e4m3 bytes with constant block scales, twice the bf16 rate) instead of a second fp16 pass.  The term it computes is
+    ~2^-12 of the product, so its 2^-4 operand rounding is ~2^-16 of the result -- below the fp16 rounding of the weight the mode
+    already carries.  AFFT_LO8=0 / set_lo8(False): both passes in fp16."""
+    return _LO8
+
+
+def set_lo8(on: bool):
+    global _LO8
+    _LO8 = bool(on)
+
+
+def weight_f8(p: Tensor) -> Tensor:
+    """e4m3 byte image e4m3(2^8 p) [pad64(rows), pad64(cols)] of a 2-D parameter (afft_gemm_t.b8): in the flat buffers when the parameter
+    is homed there (written by the optimizer kernels), else a quantised copy redone when the parameter changes"""
+    weight_images(p)
+    img = p._afft_img
+    if img.e_external:
+        if img.e_version != p._version:
+            with torch.no_grad():
+                ops.quant_e4m3(p.detach(), 256.0, img.e)
+            img.e_version = p._version
+        return img.e
+    if img.e is None:
+        rows, cols = p.shape
+        img.e = torch.zeros(pad64(rows), pad64(cols), dtype=torch.uint8, device=p.device)
+        img.e_version = -1
+    if img.e_version != p._version:
+        with torch.no_grad():
+            ops.quant_e4m3(p.detach(), 256.0, img.e)
+        img.e_version = p._version
+    return img.e
+
+
+def adopt_weight_f8(p: Tensor, view8: Tensor):
+    img = p._afft_img
+    img.e, img.e_version, img.e_external = view8, p._version, True
 
 
 def adopt_weight_f16(p: Tensor, view16: Tensor):
@@ -248,6 +295,9 @@ def adopt_weight_image(p: Tensor, view16: Tensor, packed: Optional[Tensor] = Non
     img.h = None
     img.h_version = -1
     img.h_external = False
+    img.e = None
+    img.e_version = -1
+    img.e_external = False
     img.version = p._version
     img.external = True
     img.ptr = p.data_ptr()
@@ -266,6 +316,8 @@ def invalidate_weight_images(include_external: bool = False):
             img.version = -1
         if img is not None and (include_external or not img.h_external):
             img.h_version = -1
+        if img is not None and (include_external or not img.e_external):
+            img.e_version = -1
         if img is not None and include_external:
             img.pk_version = -1
         if getattr(p, "_afft_split", None) is not None:

@@ -108,7 +108,18 @@ typedef struct {
    * next fp16 two-pass GEMM (split3 = 2, a_lo = out_lo) directly -- no fp32 round trip, no split kernel.  out2 (any dtype, e.g. the
    * bf16 copy the backward pass reads) and pre are stored as before. */
   int64_t out_lo;
+  /* split3 = 3, "fp16x2 with an fp8 lo pass" (NT layout on the 256x256 kernel only: afft_gemm_lo8_ok): A points at the fp16 HI plane, B at
+   * the weight's FP16 image (first pass, as split3 = 2); the second pass A_lo W runs on the block-scaled fp8 MFMA
+   * (v_mfma_scale_f32_16x16x128_f8f6f4, twice the bf16 rate) over two BYTE planes: a8[m, k] = e4m3(2^11 (a - hi)) (row pitch a8_ld bytes)
+   * and b8[n, k] = e4m3(2^8 w) (row pitch b8_ld bytes), with the constant block scales 2^-11 and 2^-8.  The correction term it adds
+   * is ~2^-12 of the product, so its own 2^-4 operand rounding stays ~2^-16 of the result -- far below the weight's fp16 rounding.
+   * out_lo8 (with out_dtype AFFT_F16): the result is stored as the same pair for the NEXT such GEMM: hi at out, the e4m3 lo byte plane
+   * at out_lo8 (row pitch ldo bytes, i.e. the element pitch of out). */
+  const void* a8; int64_t a8_ld; const void* b8; int64_t b8_ld;
+  void* out_lo8;
 } afft_gemm_t;
+/* 1 when a split3 = 3 problem of this size runs (NT, the 256x256 kernel's territory, K a multiple of 128) */
+int afft_gemm_lo8_ok(int M, int N, int K);
 /* Nesterov-SGD update fused into the epilogue of the weight-gradient GEMM that produces the gradient (single-GPU training, no
  * gradient clipping, a weight that receives exactly one gradient contribution per step): element [m, n] of the result is the
  * gradient g of p[m * ldo + n] and is never stored;  g' = gscale*g + wd*p ; buf = mom*buf + g' (g' on the first step) ;
@@ -122,7 +133,9 @@ typedef struct afft_sgd_fused {
   void* p_pk16;                                    /* optional: the fragment-packed bf16 image (afft_pack_weight) of the same weight, */
                                                    /* refreshed by the same epilogue (ldo % 32 == 0 and M % 16 == 0)               */
   void* p_f16;                                     /* optional: the row-major FP16 image (layout of p_bf16): the B operand of the   */
-} afft_sgd_fused_t;                                /* fp16 two-pass forward GEMMs ("fp16x2" precision)                              */
+                                                   /* fp16 two-pass forward GEMMs ("fp16x2" precision)                              */
+  void* p_f8;                                      /* optional: the e4m3 byte image e4m3(2^8 p) (afft_gemm_t.b8), same element offsets */
+} afft_sgd_fused_t;
 /* `first_step` of every optimizer entry point is a flag word: AFFT_SGD_FIRST_STEP = the momentum buffer does not exist yet (it
  * starts as the gradient: torch.optim.SGD's first step); AFFT_SGD_PLAIN_MOMENTUM = torch.optim.SGD(nesterov=False):
  * p -= lr * buf instead of the Nesterov form p -= lr * (g' + mom * buf) (conf/opt/optimizer/sgd.yaml ships nesterov: false,
@@ -187,7 +200,7 @@ int afft_layernorm_fwd(const float* x, int64_t ldx, const float* w, const float*
  * y_bf16 = bf16(y), the copy the single-pass bf16 backward reads (weight-gradient operand).  y_lo = 0: hi plane only. */
 int afft_layernorm_fwd_split(const float* x, int64_t ldx, const float* w, const float* b, float eps, int32_t rows, int32_t d,
                              void* y_hi, int64_t ldy, int64_t y_lo, void* y_bf16, int64_t ldyb, float* mean, float* rstd,
-                             void* stream);
+                             void* y_lo8, void* stream);      /* y_lo8 (optional, then y_lo = 0): the lo part as the e4m3 byte plane of afft_gemm_t.a8, row pitch ldy bytes */
 /* dx_out[r] = (dx_in ? dx_in[r] : 0) + LN'(dy)[r]; dw/db are written (accumulate = 0) or added to (+=).
  * dy dtype selectable.
  * dx_bf16 (optional) receives a bf16 copy of dx_out with the dropout / DropPath mask `copy_drop` (optional) replayed
@@ -225,7 +238,7 @@ int afft_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, c
 int afft_attention_fwd_split(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, int64_t in_lo,
                              int32_t nseq, int32_t L, int32_t H, int32_t hd, float scale, int32_t mask, int32_t mask_period,
                              float drop_p, uint32_t drop_key, void* out_hi, int64_t ldo, int64_t out_lo, void* out_bf16,
-                             int64_t ldob, float* probs, void* stream);
+                             int64_t ldob, float* probs, void* out_lo8, void* stream);      /* out_lo8: as y_lo8 above (row pitch ldo bytes) */
 int afft_attention_bwd(const void* dout, int64_t lddo, const void* q, int64_t ldq, const void* k, int64_t ldk,
                        const void* v, int64_t ldv, int32_t dtype, const float* probs, int32_t nseq, int32_t L,
                        int32_t H, int32_t hd, float scale, float drop_p, uint32_t drop_key, void* dq, int64_t lddq,
@@ -281,6 +294,12 @@ int afft_pack_weight(const float* src, int64_t lds, int32_t rows, int32_t cols, 
  * lo = hi + plane_stride elements. */
 int afft_split_bf16(const float* src, int64_t lds, int32_t rows, int32_t cols, void* hi, int64_t ldd, int32_t rows_pad,
                     int64_t plane_stride, void* stream);
+/* e4m3 byte image dst[r, c] = e4m3(scale * src[r, c]) (OCP e4m3fn, saturating), dst row pitch ldd BYTES, columns cols..ldd-1 and rows
+ * rows..rows_pad-1 zero-filled: the weight image afft_gemm_t.b8 (scale 2^8) of a parameter that is not homed in the flat buffers.
+ * With hi != NULL (fp16 [rows_pad, ldd], row pitch ldd elements) the source is split instead: hi = fp16(x) and dst = e4m3(scale * (x - hi))
+ * -- the operand pair (A, a8) of afft_gemm_t.split3 = 3 with scale 2^11. */
+int afft_quant_e4m3(const float* src, int64_t lds, int32_t rows, int32_t cols, float scale, void* dst, int64_t ldd, int32_t rows_pad,
+                    void* hi, void* stream);
 /* The same with fp16 planes (hi = fp16(x), lo = fp16(x - hi)): operands of afft_gemm_t.split3 = 2. */
 int afft_split_f16(const float* src, int64_t lds, int32_t rows, int32_t cols, void* hi, int64_t ldd, int32_t rows_pad,
                    int64_t plane_stride, void* stream);
@@ -362,14 +381,14 @@ int afft_sgd_nesterov(float* p, const void* g, int32_t g_dtype, float* buf, void
                       float wd, float gscale, const float* gscale_dev, int32_t first_step, void* stream);
 /* p_f16 (optional, same element offsets as p): the FP16 image of the updated weights ("fp16x2" forward operands), written
  * beside p_bf16 by afft_sgd_nesterov2 / afft_sgd_nesterov_runs2 -- otherwise the functions above. */
-int afft_sgd_nesterov2(float* p, const void* g, int32_t g_dtype, float* buf, void* p_bf16, void* p_f16, int64_t n, float lr,
-                       float mom, float wd, float gscale, const float* gscale_dev, int32_t first_step, void* stream);
+int afft_sgd_nesterov2(float* p, const void* g, int32_t g_dtype, float* buf, void* p_bf16, void* p_f16, void* p_f8, int64_t n, float lr,
+                       float mom, float wd, float gscale, const float* gscale_dev, int32_t first_step, void* stream);      /* p_f8: e4m3(2^8 p) bytes */
 /* The same update over `nruns` separate runs of ONE set of flat buffers: runs = device array of nruns x {start, length}
  * (int64 elements, starts multiples of 4).  One launch for all the small parameters of a gradient bucket (LayerNorm
  * weights, biases, tokens) whose big neighbours are updated in their weight-gradient epilogues (afft_sgd_fused_t). */
 int afft_sgd_nesterov_runs(float* p, const float* g, float* buf, void* p_bf16, const int64_t* runs, int32_t nruns, float lr,
                            float mom, float wd, float gscale, int32_t first_step, void* stream);
-int afft_sgd_nesterov_runs2(float* p, const float* g, float* buf, void* p_bf16, void* p_f16, const int64_t* runs, int32_t nruns,
+int afft_sgd_nesterov_runs2(float* p, const float* g, float* buf, void* p_bf16, void* p_f16, void* p_f8, const int64_t* runs, int32_t nruns,
                             float lr, float mom, float wd, float gscale, int32_t first_step, void* stream);
 /* Gradient clipping by global norm (train.py:254-260, torch.nn.utils.clip_grad_norm_), without a host sync:
  *   afft_sumsq: *out += scale * sum x[i]^2 over a flat fp32/bf16 buffer (scale = gscale^2 of the optimizer), ordered
@@ -434,6 +453,10 @@ typedef struct {       /* y = x + drop(proj(attention(split(qkv(LN(x))))))      
    * (2x the bf16 size each) -- and xn_b / qkv_b / ao_b (optional: NULL in a forward nobody differentiates) receive the bf16 copies
    * (layout of xn / qkv / ao in the bf16 mode) that afft_attn_sublayer_bwd is then called with. */
   int32_t f16x2; void* xn_b; void* qkv_b; void* ao_b;
+  /* f16x2 = 2: the lo pass of the two GEMMs on the block-scaled fp8 MFMA (afft_gemm_t.split3 = 3; nn.Linear layout, shapes for which
+   * afft_gemm_lo8_ok says yes): w_qkv8 / w_proj8 = the weights' e4m3 byte images (row pitch ldw_* bytes); the lo planes of xn and ao are
+   * e4m3 BYTE planes (rows_pad * d bytes, directly behind their hi planes); qkv keeps its fp16 lo plane (the attention kernel reads it). */
+  const void* w_qkv8; const void* w_proj8;
 } afft_attn_sublayer_t;
 int afft_attn_sublayer_fwd(const afft_attn_sublayer_t* s, void* stream);
 int afft_attn_sublayer_bwd(const afft_attn_sublayer_t* s, void* stream, void* aux_stream);
@@ -463,6 +486,7 @@ typedef struct {       /* y = x + drop(fc2(gelu(fc1(LN(x)))))                   
   const afft_sgd_fused_t* sgd_w1; const afft_sgd_fused_t* sgd_w2;       /* as in afft_attn_sublayer_t */
   const void* w1_pk; const void* w2_pk;                                 /* as in afft_attn_sublayer_t */
   int32_t f16x2; void* xn_b; void* h_b;  /* as in afft_attn_sublayer_t: xn / h two-plane fp16 splits, w1 / w2 FP16 images, u stays bf16 */
+  const void* w1_8; const void* w2_8;    /* f16x2 = 2: as in afft_attn_sublayer_t; the lo planes of xn and h are e4m3 byte planes            */
 } afft_mlp_sublayer_t;
 int afft_mlp_sublayer_fwd(const afft_mlp_sublayer_t* s, void* stream);
 int afft_mlp_sublayer_bwd(const afft_mlp_sublayer_t* s, void* stream, void* aux_stream);

@@ -271,7 +271,7 @@ def reduce_rows_periodic(src, period, out):
 
 
 @torch.no_grad()
-def sgd_nesterov(p, g, buf, lr, mom, wd, gscale, first, p_bf16=None, gscale_dev=None, p_f16=None):
+def sgd_nesterov(p, g, buf, lr, mom, wd, gscale, first, p_bf16=None, gscale_dev=None, p_f16=None, p_f8=None):
     if gscale_dev is not None:
         gscale = gscale * float(gscale_dev)
     flags = int(first)        # AFFT_SGD_* flag word: 1 = first step, 2 = plain momentum (nesterov=False)
@@ -286,7 +286,7 @@ def sgd_nesterov(p, g, buf, lr, mom, wd, gscale, first, p_bf16=None, gscale_dev=
 
 
 @torch.no_grad()
-def sgd_nesterov_runs(p, g, buf, runs, lr, mom, wd, gscale, first, p_bf16=None, p_f16=None):
+def sgd_nesterov_runs(p, g, buf, runs, lr, mom, wd, gscale, first, p_bf16=None, p_f16=None, p_f8=None):
     for a, n in runs.tolist():
         sgd_nesterov(p[a:a + n], g[a:a + n], buf[a:a + n], lr, mom, wd, gscale, first,
                      p_bf16=None if p_bf16 is None else p_bf16[a:a + n], p_f16=None if p_f16 is None else p_f16[a:a + n])

@@ -326,6 +326,59 @@ def test_gemm_fp16x2_plane_output_feeds_the_next_gemm(case):
     assert rel_l2(y.cpu(), (ref.cpu().double() @ W2.half().double()).float()) < 1e-5
 
 
+def _e4m3_decode(b):
+    """uint8 tensor of OCP e4m3fn codes -> float32 values"""
+    b = b.to(torch.int32)
+    s, e, m = b >> 7, (b >> 3) & 15, b & 7
+    v = torch.where(e == 0, m.float() / 8.0 * 2.0 ** -6, (1.0 + m.float() / 8.0) * torch.pow(2.0, (e - 7).float()))
+    return torch.where(s == 1, -v, v)
+
+
+@pytest.mark.parametrize("M,N,K", [(5120, 2048, 2048), (3000, 4096, 1024), (4096, 4096, 128)])
+def test_gemm_fp16_hi_pass_plus_fp8_lo_pass(M, N, K):
+    """afft_gemm_t.split3 = 3: first pass A_hi W on the fp16 MFMA, second pass A_lo W on the block-scaled fp8 MFMA over e4m3 byte planes
+    (a8 = e4m3(2^11 (a - hi)), b8 = e4m3(2^8 w), constant scales).  Against float64 on the SAME quantised operands the result is
+    fp32-grade (the kernel computes what it says); against the exact product the error is the weight's fp16 rounding, like the
+    two-pass fp16 GEMM's (the lo term carries ~2^-12 of the product: its 2^-4 operand rounding vanishes); the plane output feeds the
+    next such GEMM."""
+    from afft_amd import _lib, ops
+    assert _lib.lib().afft_gemm_lo8_ok(M, N, K) == 1
+    A, W = rnd(M, K, seed=51), rnd(N, K, seed=52, scale=0.05)
+    hi = torch.zeros(M, K, dtype=torch.float16, device=dev())
+    a8 = torch.zeros(M, K, dtype=torch.uint8, device=dev())
+    ops.quant_e4m3(A.to(dev()), 2048.0, a8, hi=hi)
+    w16 = W.half().to(dev())
+    w8 = torch.zeros(N, K, dtype=torch.uint8, device=dev())
+    ops.quant_e4m3(W.to(dev()), 256.0, w8)
+    torch.cuda.synchronize()
+    assert torch.equal(hi.cpu(), A.half())
+    lo_ref = (A - A.half().float()) * 2048.0
+    assert rel_l2(_e4m3_decode(a8.cpu()), lo_ref) < 0.05 and rel_l2(_e4m3_decode(w8.cpu()), W * 256.0) < 0.05      # 3 mantissa bits
+    bias = rnd(N, seed=3).to(dev())
+    out = torch.zeros(M, N, device=dev())
+    ops.gemm(hi, w16, out, b_t=True, bias=bias, a8=a8, b8=w8)
+    torch.cuda.synchronize()
+    quant = (hi.cpu().double() @ w16.cpu().double().t()
+             + (_e4m3_decode(a8.cpu()).double() @ _e4m3_decode(w8.cpu()).double().t()) * 2.0 ** -19).float() + bias.cpu()
+    exact = (A.double() @ W.double().t()).float() + bias.cpu()
+    assert rel_l2(out.cpu(), quant) < 2e-5, rel_l2(out.cpu(), quant)
+    e = rel_l2(out.cpu(), exact)
+    two_pass = torch.zeros(M, N, device=dev())
+    ops.gemm(ops.Split(A.to(dev()), f16=True), w16, two_pass, b_t=True, bias=bias)
+    torch.cuda.synchronize()
+    e2 = rel_l2(two_pass.cpu(), exact)
+    print(f"[{M}x{N}x{K}] vs exact: fp16 + fp8 lo pass {e:.2e}, two fp16 passes {e2:.2e}")
+    assert e < 1.15 * e2 + 1e-6 and e < 4e-4
+    # plane output: hi fp16 + e4m3 lo bytes of the result
+    oh = torch.zeros(M, N, dtype=torch.float16, device=dev())
+    o8 = torch.zeros(M, N, dtype=torch.uint8, device=dev())
+    ops.gemm(hi, w16, oh, b_t=True, bias=bias, a8=a8, b8=w8, out_lo8=o8)
+    torch.cuda.synchronize()
+    assert torch.equal(oh, out.half())
+    lo = (out - out.half().float()).cpu() * 2048.0
+    assert rel_l2(_e4m3_decode(o8.cpu()), lo) < 0.05
+
+
 @pytest.mark.parametrize("rows,d", [(37, 64), (300, 1024), (130, 2048)])
 def test_layernorm_fwd_split_planes(rows, d):
     """afft_layernorm_fwd_split: the planes and the bf16 copy are bitwise the splits / the rounding of the fp32 LayerNorm output"""
@@ -345,6 +398,12 @@ def test_layernorm_fwd_split_planes(rows, d):
     ops.layernorm_fwd_split(x, None, None, 1e-6, planes[0][:rows], planes[0].numel(), None)     # no affine, no copy
     torch.cuda.synchronize()
     assert torch.isfinite(planes.float()).all()
+    # the lo part as an e4m3 byte plane (the fp8 lo pass)
+    lo8 = torch.zeros(pr, d, dtype=torch.uint8, device=dev())
+    ops.layernorm_fwd_split(x, w, b, 1e-6, planes[0][:rows], 0, copy[:rows], y_lo8=lo8[:rows])
+    torch.cuda.synchronize()
+    assert torch.equal(planes[0][:rows], y.half()) and torch.equal(copy[:rows], y.bfloat16())
+    assert rel_l2(_e4m3_decode(lo8[:rows].cpu()), ((y - y.half().float()) * 2048.0).cpu()) < 0.05
 
 
 ATTN_SPLIT_CASES = [(13, 5, 4, 64, 0), (64, 5, 4, 512, 0), (9, 6, 2, 256, 1), (6, 16, 4, 128, 2), (3, 32, 2, 512, 2), (3, 64, 2, 256, 3),

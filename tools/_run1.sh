@@ -1,14 +1,9 @@
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out/r05f
-for d in 0 1 2 3 7; do
-  if [ $d = 0 ]; then unset AFFT_LIB; else export AFFT_LIB=$PWD/afft_amd/lib/libafft_hip_q4d$d.so; fi
-  python - <<PY 2>&1 | tee -a gpurun_out/r05f/q4_diag.txt
-import sys, os
-sys.path.insert(0, 'tools'); sys.path.insert(0, '.')
-import gemm_bench as GB
-r = GB.bench("nt", 8192, 8192, 8192, 11)
-print("diag $d: q4 8192^3 %.4f ms %.1f TFLOP/s" % r)
-PY
+#!/bin/bash
+# scratch: lo8 A/B
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "fp8_lo_pass or fp16" 2>&1 | tail -5 > gpurun_out/lo8_tests.txt
+for v in 0 1; do
+  AFFT_LO8=$v timeout 300 python bench.py --precision fp16x2 --no-ek100 --no-power --steps 20 --warmup 5 > gpurun_out/lo8_bench_$v.json 2> gpurun_out/lo8_bench_$v.err
 done
-unset AFFT_LIB
-python tools/q4_power.py 2>&1 | tail -5 | tee -a gpurun_out/r05f/q4_diag.txt
+AFFT_LO8=1 timeout 900 python -m pytest tests/test_model_gpu.py -q -x -k "fp16x2" 2>&1 | tail -8 > gpurun_out/lo8_model_tests.txt
