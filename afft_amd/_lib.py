@@ -168,10 +168,14 @@ _SIGS = {
     "afft_softmax_ce": ([vp, i64, i32, i32, vp, vp, i64, vp, f32, vp, vp, vp, i64, i32, vp, vp], C.c_int),
     "afft_loss_reduce": ([C.POINTER(vp), C.POINTER(i64), C.POINTER(f32), i32, vp, vp, vp], C.c_int),
     "afft_loss_reduce_bwd": ([C.POINTER(vp), C.POINTER(i64), C.POINTER(f32), i32, vp, vp], C.c_int),
+    "afft_softmax_ce_frames": ([vp, i64, i64, i32, i32, i32, vp, vp, i64, vp, f32, vp, vp, i64, i64, i32, vp, vp], C.c_int),
+    "afft_mse_loss": ([vp, i64, vp, i64, i32, i32, f32, vp, vp, i64, vp], C.c_int),
+    "afft_mse_frames_bwd": ([vp, i64, i32, i32, vp, i64, i32, i32, i32, i32, f32, vp, vp, vp, vp], C.c_int),
     "afft_mse": ([vp, i64, vp, i64, i32, i32, f32, vp, f32, vp, vp, i64, vp, i64, vp, i64, vp], C.c_int),
     "afft_cast": ([vp, i64, i32, i32, vp, i64, i32, vp, i64, i32, C.POINTER(Dropout), vp], C.c_int),
     "afft_assemble_tokens": ([C.POINTER(vp), C.POINTER(i64), i32, vp, i64, vp, i32, i32, i32, vp, vp], C.c_int),
     "afft_colsum": ([vp, i64, i32, i32, i32, vp, i32, vp, i64, vp], C.c_int),
+    "afft_gather_frames": ([vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp], C.c_int),
     "afft_add_rows_periodic": ([vp, i64, vp, i64, i32, i32, i32, vp, i64, vp], C.c_int),
     "afft_reduce_rows_periodic": ([vp, i64, i32, i32, i32, vp, i64, vp], C.c_int),
     "afft_sgd_nesterov": ([vp, vp, i32, vp, vp, i64, f32, f32, f32, f32, vp, i32, vp], C.c_int),

@@ -47,16 +47,19 @@ class MultiDimCrossEntropy(nn.Module):
 
     def forward(self, inp, tgt, one_hot: bool = False, ignore_index: Union[torch.Tensor, None] = None):
         C = inp.size(-1)
-        inp2 = inp.reshape(-1, C)
-        rows = inp2.shape[0]
+        landing = getattr(inp, "_afft_landing", None)
+        # a (clips, frames, C) view with contiguous classes (one half of the merged classifier output) is walked where it lies;
+        # anything else is flattened to rows (a copy when the leading dimensions do not collapse)
+        inp2 = inp if (inp.dim() == 3 and inp.stride(2) == 1 and inp.dtype == torch.float32) else inp.reshape(-1, C)
+        rows = inp.numel() // C
         if not one_hot:
             labels = tgt.reshape(-1).to(torch.int64).contiguous()
-            return F_.SoftmaxCE.apply(inp2, labels, None, None)
+            return F_.SoftmaxCE.apply(inp2, labels, None, None, landing)
         soft = tgt.reshape(-1, C).to(torch.float32).contiguous()
         keep = None
         if ignore_index is not None:
             keep = (~ignore_index.reshape(-1)).to(torch.uint8).contiguous()
-        row_loss = F_.SoftmaxCE.apply(inp2, None, soft, keep)
+        row_loss = F_.SoftmaxCE.apply(inp2, None, soft, keep, landing)
         if keep is not None:
             row_loss = row_loss * (float(rows) / keep.sum().clamp(min=1).to(torch.float32))
         return row_loss

@@ -305,6 +305,28 @@ __global__ __launch_bounds__(256) void colsum4_kernel(const void* __restrict__ s
   }
 }
 
+// out[clip, t, :] = sum over the sources that cover frame t of src[clip, t + off, :], zeros where none does: concatenation along the
+// frame axis, its backward (slices that overlap are added), "token 0 of every frame" and its zero-filled backward -- one launch each,
+// every output element written exactly once (no fill in front, no add behind).
+struct FrameSrcs { const float* p[4]; int64_t clip_stride[4]; int64_t frame_stride[4]; int lo[4], hi[4], off[4]; int n; };
+__global__ __launch_bounds__(256) void gather_frames_kernel(const FrameSrcs s, float* __restrict__ out, int64_t out_clip_stride,
+                                                           int64_t out_frame_stride, int frames, int C4) {
+  const int clip = blockIdx.y;
+  const int total = frames * C4;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int t = i / C4, c = (i - t * C4) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < s.n && t >= s.lo[k] && t < s.hi[k]) {
+        const f32x4 x = *(const f32x4*)(s.p[k] + (int64_t)clip * s.clip_stride[k] + (int64_t)(t + s.off[k]) * s.frame_stride[k] + c);
+        v[0] += x[0]; v[1] += x[1]; v[2] += x[2]; v[3] += x[3];
+      }
+    *(f32x4*)(out + (int64_t)clip * out_clip_stride + (int64_t)t * out_frame_stride + c) = v;
+  }
+}
+
+
 __global__ __launch_bounds__(256) void add_rows_periodic_kernel(const float* __restrict__ x, int64_t ldx,
                                                                 const float* __restrict__ table, int64_t ldt,
                                                                 int period, int d, float* __restrict__ y, int64_t ldy) {
@@ -584,6 +606,29 @@ extern "C" int afft_colsum(const void* src, int64_t lds_, int32_t dtype, int32_t
   if (v4 && dtype == AFFT_BF16) hipLaunchKernelGGL(colsum4_kernel<16>, dim3((cols + 63) / 64), dim3(256), 0, stream, src, lds_, dtype, rows, cols, accumulate, out);
   else if (v4) hipLaunchKernelGGL(colsum4_kernel<8>, dim3((cols + 31) / 32), dim3(256), 0, stream, src, lds_, dtype, rows, cols, accumulate, out);
   else hipLaunchKernelGGL(colsum_kernel, dim3((cols + 255) / 256), dim3(256), 0, stream, src, lds_, dtype, rows, cols, accumulate, out);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int afft_gather_frames(float* out, int64_t out_clip_stride, int64_t out_frame_stride, int32_t clips, int32_t frames,
+                                  int32_t C, int32_t nsrc, const float* const* src, const int64_t* clip_stride,
+                                  const int64_t* frame_stride, const int32_t* lo, const int32_t* hi, const int32_t* off, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(out && nsrc >= 0 && nsrc <= 4 && C > 0 && C % 4 == 0, "gather_frames: bad argument (at most 4 sources, C a multiple of 4)");
+  AFFT_CHECK(out_clip_stride % 4 == 0 && out_frame_stride % 4 == 0 && ((uintptr_t)out & 15) == 0, "gather_frames: unaligned output");
+  FrameSrcs s{};
+  s.n = nsrc;
+  for (int k = 0; k < nsrc; ++k) {
+    AFFT_CHECK(src[k] && clip_stride[k] % 4 == 0 && frame_stride[k] % 4 == 0 && ((uintptr_t)src[k] & 15) == 0, "gather_frames: unaligned source");
+    AFFT_CHECK(lo[k] >= 0 && hi[k] <= frames && lo[k] + off[k] >= 0, "gather_frames: a source's frame range leaves the output or starts before the source");
+    s.p[k] = src[k]; s.clip_stride[k] = clip_stride[k]; s.frame_stride[k] = frame_stride[k]; s.lo[k] = lo[k]; s.hi[k] = hi[k]; s.off[k] = off[k];
+  }
+  if (clips == 0 || frames == 0) return 0;
+  const int total = frames * (C / 4);
+  int gx = (total + 255) / 256;
+  const int want = (2048 + clips - 1) / clips;      // ~2048 workgroups in all
+  if (gx > want) gx = want < 1 ? 1 : want;
+  hipLaunchKernelGGL(gather_frames_kernel, dim3(gx, clips), dim3(256), 0, stream, s, out, out_clip_stride, out_frame_stride, frames, C / 4);
   AFFT_LAUNCH_CHECK();
   return 0;
 }

@@ -22,10 +22,15 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
                                                          const uint8_t* __restrict__ keep, float gscale,
                                                          const float* __restrict__ row_g,
                                                          void* __restrict__ dlogits,
-                                                         int64_t ldd, int d_dtype, float* __restrict__ row_loss) {
+                                                         int64_t ldd, int d_dtype, float* __restrict__ row_loss,
+                                                         int period, int64_t lgs, int64_t dgs) {
+  // row r = frame r % period of clip r / period: logits at clip * lgs + frame * ldl, its gradient at clip * dgs + frame * ldd
+  // (a (B, n, C) slice of a wider (B, L, C) tensor is walked where it lies; period = rows: plain [rows, C])
   __shared__ float sh[4];
   const int row = blockIdx.x, tid = threadIdx.x;
-  const float* x = logits + (int64_t)row * ldl;
+  const int clip = row / period, frame = row - clip * period;
+  const float* x = logits + (int64_t)clip * lgs + (int64_t)frame * ldl;
+  const int64_t drow = (int64_t)clip * dgs + (int64_t)frame * ldd;
   bool kept = true;
   int64_t lab = -1;
   if (labels) { lab = labels[row]; kept = lab != -1; }
@@ -34,7 +39,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
   const bool bad = labels && (lab >= C || lab < -1);
   if (keep) kept = kept && keep[row] != 0;
   if (!kept) {  // uniform per block
-    if (dlogits) for (int c = tid; c < ldd; c += 256) st_any(dlogits, (int64_t)row * ldd + c, d_dtype, 0.f);
+    if (dlogits) for (int c = tid; c < ldd; c += 256) st_any(dlogits, drow + c, d_dtype, 0.f);
     if (row_loss && tid == 0) row_loss[row] = 0.f;
     return;
   }
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
         const float tc = t ? t[c] : (c == lab ? 1.f : 0.f);
         g = bad ? NAN : gscale * (p * tsum - tc);
       }
-      st_any(dlogits, (int64_t)row * ldd + c, d_dtype, g);
+      st_any(dlogits, drow + c, d_dtype, g);
     }
   }
 }
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, i
                                                   const float* __restrict__ g_dev, float lscale,
                                                   float* __restrict__ loss_sum, float* __restrict__ partials,
                                                   float* __restrict__ da, int64_t ldda, float* __restrict__ db,
-                                                  int64_t lddb) {
+                                                  int64_t lddb, int accumulate) {
   __shared__ float sh[4];
   float acc = 0.f;
   const int64_t total = (int64_t)rows * d;
@@ -97,7 +102,42 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, i
   // one workgroup: it IS the sum.  More: the partial goes to the caller's scratch and ordered_sum_kernel adds them up in
   // workgroup order behind this kernel (no float atomics: the loss scalar has the same bits on every run)
   if (threadIdx.x == 0) {
-    if (gridDim.x == 1) *loss_sum += acc * lscale; else partials[blockIdx.x] = acc;
+    if (gridDim.x == 1) *loss_sum = (accumulate ? *loss_sum : 0.f) + acc * lscale; else partials[blockIdx.x] = acc;
+  }
+}
+
+// Backward of the MSE between frame ranges of two (clips, frames, C) tensors: the FULL gradients of both are written in one pass
+// -- 2 g (a - b) inside the ranges, zeros outside -- so that no fill kernel runs in front and no slice-backward behind.
+__global__ __launch_bounds__(256) void mse_frames_bwd_kernel(const float* __restrict__ a, int64_t a_cs, int a_off, int a_len,
+                                                             const float* __restrict__ b, int64_t b_cs, int b_off, int b_len,
+                                                             int clips, int n, float gscale, const float* __restrict__ g_dev,
+                                                             float* __restrict__ da, float* __restrict__ db) {
+  if (g_dev) gscale *= g_dev[0];
+  const int clip = blockIdx.y;
+  const float* ar = a + (int64_t)clip * a_cs;
+  const float* br = b + (int64_t)clip * b_cs;
+  float* dar = da ? da + (int64_t)clip * a_len : nullptr;
+  float* dbr = db ? db + (int64_t)clip * b_len : nullptr;
+  const int span = max(a_len, b_len);
+  for (int i = (blockIdx.x * 256 + threadIdx.x) * 4; i < span; i += gridDim.x * 1024) {      // lengths and offsets are multiples of 4
+    if (dar && i < a_len) {
+      const int j = i - a_off;
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+      if (j >= 0 && j < n) {
+        const f32x4 x = *(const f32x4*)(ar + i), y = *(const f32x4*)(br + b_off + j);
+        for (int e = 0; e < 4; ++e) g[e] = 2.f * gscale * (x[e] - y[e]);
+      }
+      *(f32x4*)(dar + i) = g;
+    }
+    if (dbr && i < b_len) {
+      const int j = i - b_off;
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+      if (j >= 0 && j < n) {
+        const f32x4 x = *(const f32x4*)(ar + a_off + j), y = *(const f32x4*)(br + i);
+        for (int e = 0; e < 4; ++e) g[e] = -2.f * gscale * (x[e] - y[e]);
+      }
+      *(f32x4*)(dbr + i) = g;
+    }
   }
 }
 
@@ -167,7 +207,7 @@ extern "C" int afft_softmax_ce(const float* logits, int64_t ldl, int32_t rows, i
   AFFT_CHECK(!loss_sum || row_loss, "softmax_ce: loss_sum is the ordered sum of row_loss: give row_loss as well");
   if (rows == 0) return 0;
   hipLaunchKernelGGL(softmax_ce_kernel, dim3(rows), dim3(256), 0, stream, logits, ldl, C, labels, soft, lds, keep,
-                     gscale, row_g, dlogits, ldd, d_dtype, row_loss);
+                     gscale, row_g, dlogits, ldd, d_dtype, row_loss, rows, (int64_t)0, (int64_t)0);
   AFFT_LAUNCH_CHECK();
   if (loss_sum) {
     hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(256), 0, stream, row_loss, (int64_t)rows, 1.0f, loss_sum, 1);
@@ -176,10 +216,44 @@ extern "C" int afft_softmax_ce(const float* logits, int64_t ldl, int32_t rows, i
   return 0;
 }
 
-extern "C" int afft_mse(const float* a, int64_t lda, const float* b, int64_t ldb, int32_t rows, int32_t d,
-                        float gscale, const float* g_dev, float lscale, float* loss_sum, float* da, int64_t ldda,
-                        float* db, int64_t lddb, void* workspace, int64_t workspace_bytes, void* stream_) {
+extern "C" int afft_softmax_ce_frames(const float* logits, int64_t clip_stride, int64_t ldl, int32_t clips, int32_t frames, int32_t C,
+                                      const int64_t* labels, const float* soft, int64_t lds, const uint8_t* keep, float gscale,
+                                      const float* row_g, void* dlogits, int64_t d_clip_stride, int64_t ldd, int32_t d_dtype,
+                                      float* row_loss, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(logits, "softmax_ce_frames: null logits");
+  AFFT_CHECK((labels != nullptr) != (soft != nullptr), "softmax_ce_frames: give exactly one of labels / soft targets");
+  AFFT_CHECK(C > 0 && ldl >= C && (!dlogits || ldd >= C) && frames > 0, "softmax_ce_frames: bad sizes");
+  if (clips == 0) return 0;
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(clips * frames), dim3(256), 0, stream, logits, ldl, C, labels, soft, lds, keep,
+                     gscale, row_g, dlogits, ldd, d_dtype, row_loss, frames, clip_stride, d_clip_stride);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int afft_mse_frames_bwd(const float* a, int64_t a_clip_stride, int32_t a_off, int32_t a_len, const float* b,
+                                   int64_t b_clip_stride, int32_t b_off, int32_t b_len, int32_t clips, int32_t n, float gscale,
+                                   const float* g_dev, float* da, float* db, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(a && b, "mse_frames_bwd: null pointer");
+  AFFT_CHECK(((a_off | a_len | b_off | b_len | n) & 3) == 0 && (a_clip_stride & 3) == 0 && (b_clip_stride & 3) == 0,
+             "mse_frames_bwd: offsets, lengths and clip strides must be multiples of 4 floats");
+  AFFT_CHECK(a_off >= 0 && b_off >= 0 && a_off + n <= a_len && b_off + n <= b_len, "mse_frames_bwd: the frame range leaves the tensor");
+  AFFT_CHECK((((uintptr_t)a | (uintptr_t)b | (uintptr_t)da | (uintptr_t)db) & 15) == 0, "mse_frames_bwd: 16-byte aligned pointers");
+  if (clips == 0 || (!da && !db)) return 0;
+  const int span = a_len > b_len ? a_len : b_len;
+  int gx = (span / 4 + 255) / 256;
+  if (gx > 64) gx = 64;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(mse_frames_bwd_kernel, dim3(gx, clips), dim3(256), 0, stream, a, a_clip_stride, a_off, a_len, b, b_clip_stride,
+                     b_off, b_len, clips, n, gscale, g_dev, da, db);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
+static int mse_launch(const float* a, int64_t lda, const float* b, int64_t ldb, int32_t rows, int32_t d,
+                      float gscale, const float* g_dev, float lscale, float* loss_sum, float* da, int64_t ldda,
+                      float* db, int64_t lddb, void* workspace, int64_t workspace_bytes, int accumulate, hipStream_t stream) {
   AFFT_CHECK(a && b, "mse: null pointer");
   if (rows == 0 || d == 0) return 0;
   const int64_t total = (int64_t)rows * d;
@@ -189,11 +263,25 @@ extern "C" int afft_mse(const float* a, int64_t lda, const float* b, int64_t ldb
              "mse: the loss sum needs the stream's workspace (header + AFFT_REDUCE_PARTIALS floats)");
   float* scratch = workspace ? (float*)((char*)workspace + AFFT_GEMM_WS_HEADER) : nullptr;
   hipLaunchKernelGGL(mse_kernel, dim3(grid), dim3(256), 0, stream, a, lda, b, ldb, rows, d, gscale, g_dev, lscale, loss_sum,
-                     scratch, da, ldda, db, lddb);
+                     scratch, da, ldda, db, lddb, accumulate);
   AFFT_LAUNCH_CHECK();
   if (loss_sum && grid > 1) {
-    hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(256), 0, stream, scratch, (int64_t)grid, lscale, loss_sum, 1);
+    hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(256), 0, stream, scratch, (int64_t)grid, lscale, loss_sum, accumulate);
     AFFT_LAUNCH_CHECK();
   }
   return 0;
+}
+
+extern "C" int afft_mse(const float* a, int64_t lda, const float* b, int64_t ldb, int32_t rows, int32_t d,
+                        float gscale, const float* g_dev, float lscale, float* loss_sum, float* da, int64_t ldda,
+                        float* db, int64_t lddb, void* workspace, int64_t workspace_bytes, void* stream_) {
+  return mse_launch(a, lda, b, ldb, rows, d, gscale, g_dev, lscale, loss_sum, da, ldda, db, lddb, workspace, workspace_bytes, 1,
+                    (hipStream_t)stream_);
+}
+
+extern "C" int afft_mse_loss(const float* a, int64_t lda, const float* b, int64_t ldb, int32_t rows, int32_t d, float lscale,
+                             float* loss, void* workspace, int64_t workspace_bytes, void* stream_) {
+  AFFT_CHECK(loss, "mse_loss: null output");
+  return mse_launch(a, lda, b, ldb, rows, d, 0.f, nullptr, lscale, loss, nullptr, 0, nullptr, 0, workspace, workspace_bytes, 0,
+                    (hipStream_t)stream_);
 }

@@ -1455,15 +1455,86 @@ class TakeRows(torch.autograd.Function):
         rows = Rall // stride_rows
         _forget_output()
         ctx.shape = (Rall, d, stride_rows)
-        return X.view(rows, stride_rows * d)[:, :d].contiguous()
+        X3 = X.view(rows, stride_rows, d)
+        if _frames_ok(X3):
+            y = torch.empty(rows, d, dtype=X.dtype, device=X.device)
+            ops.gather_frames(y.view(rows, 1, d), [(X3, 0, 1, 0)])
+            return y
+        return X3[:, 0].contiguous()
 
     @staticmethod
     def backward(ctx, dy):
         Rall, d, s = ctx.shape
         _drop_shadow()
-        dX = torch.zeros(Rall, d, dtype=dy.dtype, device=dy.device)
-        dX.view(Rall // s, s * d)[:, :d].copy_(dy)
+        dX = torch.empty(Rall, d, dtype=dy.dtype, device=dy.device)
+        dy3 = dy.view(Rall // s, 1, d) if dy.is_contiguous() else dy.reshape(Rall // s, 1, d)
+        if _frames_ok(dy3):
+            ops.gather_frames(dX.view(Rall // s, s, d), [(dy3, 0, 1, 0)])      # token-0 rows <- dy, zeros elsewhere: one launch
+        else:
+            dX.zero_()
+            dX.view(Rall // s, s * d)[:, :d].copy_(dy)
         return dX, None
+
+
+def _frames_ok(t: Tensor) -> bool:
+    """a (clips, frames, C) fp32 tensor ops.gather_frames can walk in place"""
+    return (t.dtype == torch.float32 and t.dim() == 3 and t.stride(2) == 1 and t.shape[2] % 4 == 0 and t.stride(0) % 4 == 0
+            and t.stride(1) % 4 == 0 and t.data_ptr() % 16 == 0)
+
+
+class SeenThenPredicted(torch.autograd.Function):
+    """whole = [z_1, z_hat_2 .. z_hat_{T+k}] (models/future_prediction.py:161-170: the observed first frame, then the predictions), and
+    its two ends as views: past_futures = whole[:, :T], future = whole[:, T:].  One launch forward; backward, the gradients of the
+    three (whole: the merged classifier heads; past_futures: the feature-regression loss; future) are added and split into dz (frame 0,
+    zeros elsewhere) and dz_hat by one launch each -- autograd's own graph for cat + two slices is a cat, two zero fills, two copies
+    and an add."""
+
+    @staticmethod
+    def forward(ctx, z, zh, T):
+        ctx.set_materialize_grads(False)
+        B, Tz, C = zh.shape
+        ctx.cfg = (tuple(z.shape), tuple(zh.shape), T)
+        if _frames_ok(z) and _frames_ok(zh):
+            whole = torch.empty(B, 1 + Tz, C, dtype=torch.float32, device=zh.device)
+            ops.gather_frames(whole, [(z, 0, 1, 0), (zh, 1, 1 + Tz, -1)])
+        else:
+            whole = torch.cat([z[:, :1], zh], dim=1)
+        return whole, whole[:, :T], whole[:, T:]
+
+    @staticmethod
+    def backward(ctx, g_whole, g_past, g_fut):
+        zs, zhs, T = ctx.cfg
+        B, Tz, C = zhs
+        gs = [g for g in (g_whole, g_past, g_fut) if g is not None]
+        if not gs:
+            return None, None, None
+        dev, dt = gs[0].device, gs[0].dtype
+        if all(_frames_ok(g) for g in gs):
+            dz = dzh = None
+            if ctx.needs_input_grad[0]:
+                dz = torch.empty(zs, dtype=dt, device=dev)
+                ops.gather_frames(dz, [(g, 0, 1, 0) for g in (g_whole, g_past) if g is not None])
+            if ctx.needs_input_grad[1]:
+                dzh = torch.empty(zhs, dtype=dt, device=dev)
+                srcs = []
+                if g_whole is not None:
+                    srcs.append((g_whole, 0, Tz, 1))
+                if g_past is not None and T > 1:
+                    srcs.append((g_past, 0, T - 1, 1))
+                if g_fut is not None and Tz > T - 1:
+                    srcs.append((g_fut, T - 1, Tz, 1 - T))
+                ops.gather_frames(dzh, srcs)
+            return dz, dzh, None
+        tot = torch.zeros(B, 1 + Tz, C, dtype=dt, device=dev)
+        if g_whole is not None:
+            tot += g_whole
+        if g_past is not None:
+            tot[:, :T] += g_past
+        if g_fut is not None:
+            tot[:, T:] += g_fut
+        dz = torch.zeros(zs, dtype=dt, device=dev)
+        dz[:, :1] = tot[:, :1]
+        return dz, tot[:, 1:].contiguous(), None
 
 
 # --------------------------------------------------------------------------- SA-Fuser token assembly
@@ -1645,11 +1716,40 @@ class ElementDropout(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- losses
+class GradLanding:
+    """Where the gradients of the two halves SplitRows hands out are to be written: ONE buffer of the whole tensor's shape, so that
+    a loss kernel that knows the record (SoftmaxCE) stores its gradient in place and SplitRows.backward has nothing left to copy."""
+
+    def __init__(self, shape, n):
+        self.shape, self.n, self.dx = tuple(shape), n, None
+
+    def half(self, which: int, device, dtype=torch.float32) -> Tensor:
+        if self.dx is None:
+            self.dx = torch.empty(self.shape, dtype=dtype, device=device)
+        return self.dx[:, :self.n] if which == 0 else self.dx[:, self.n:]
+
+    def holds(self, which: int, g: Tensor) -> bool:
+        if self.dx is None or g is None:
+            return False
+        v = self.dx[:, :self.n] if which == 0 else self.dx[:, self.n:]
+        return g.data_ptr() == v.data_ptr() and g.shape == v.shape and g.stride() == v.stride() and g.dtype == v.dtype
+
+
 class SoftmaxCE(torch.autograd.Function):
-    """Per-row softmax cross-entropy (reduction='none'); ignored rows give 0.  common/runner.py:13-37."""
+    """Per-row softmax cross-entropy (reduction='none'); ignored rows give 0.  common/runner.py:13-37.
+    logits: [rows, C], or a (clips, frames, C) view with contiguous classes (a half of the merged classifier output): walked in
+    place.  landing = (GradLanding, half) makes backward write the gradient straight into the record's buffer."""
 
     @staticmethod
-    def forward(ctx, logits, labels, soft, keep):
+    def forward(ctx, logits, labels, soft, keep, landing=None):
+        ctx.landing = landing
+        if logits.dim() == 3:
+            clips, frames, C = logits.shape
+            assert logits.stride(2) == 1
+            row_loss = torch.empty(clips * frames, dtype=torch.float32, device=logits.device)
+            ops.softmax_ce_frames(logits, C, labels=labels, soft=soft, keep=keep, row_loss=row_loss)
+            ctx.save_for_backward(logits, labels, soft, keep)
+            return row_loss
         rows, C = logits.shape
         row_loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
         lg = logits if logits.stride(1) == 1 else logits.contiguous()
@@ -1660,11 +1760,21 @@ class SoftmaxCE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rows):
         lg, labels, soft, keep = ctx.saved_tensors
+        if lg.dim() == 3:
+            C = lg.shape[2]
+            if ctx.landing is not None and ctx.landing[0].shape[2] == C:
+                d = ctx.landing[0].half(ctx.landing[1], lg.device)
+                assert d.shape == lg.shape
+            else:
+                d = torch.empty(lg.shape, dtype=torch.float32, device=lg.device)
+            ops.softmax_ce_frames(lg, C, labels=labels, soft=soft, keep=keep, dlogits3=d, row_g=g_rows.contiguous())
+            flush_ready()
+            return d, None, None, None, None
         rows, C = lg.shape
         d = torch.empty(rows, C, dtype=torch.float32, device=lg.device)
         ops.softmax_ce(lg, C, labels=labels, soft=soft, keep=keep, dlogits=d, row_g=g_rows.contiguous())
         flush_ready()
-        return d, None, None, None
+        return d, None, None, None, None
 
 
 class MSE(torch.autograd.Function):
@@ -1687,8 +1797,8 @@ class MSE(torch.autograd.Function):
         else:
             av, bv = a, b
         rows, d = av.shape
-        out = torch.zeros((), dtype=torch.float32, device=a.device)
-        ops.mse(av, bv, 1.0, out, None, None, lscale=1.0 / (rows * d))
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        ops.mse_loss(av, bv, 1.0 / (rows * d), out)
         ctx.save_for_backward(a, b)
         return out
 
@@ -1704,13 +1814,20 @@ class MSE(torch.autograd.Function):
             return da, db
         a_lo, b_lo, nt = ctx.rng
         B, _, C = a.shape
-        da = torch.zeros(a.shape, dtype=torch.float32, device=a.device)
-        db = torch.zeros(b.shape, dtype=torch.float32, device=a.device)
-        av = torch.as_strided(a, (B, nt * C), (a.stride(0), 1), a.storage_offset() + a_lo * C)
-        bv = torch.as_strided(b, (B, nt * C), (b.stride(0), 1), b.storage_offset() + b_lo * C)
-        dav = torch.as_strided(da, (B, nt * C), (da.stride(0), 1), a_lo * C)
-        dbv = torch.as_strided(db, (B, nt * C), (db.stride(0), 1), b_lo * C)
-        ops.mse(av, bv, 1.0 / (B * nt * C), None, dav, dbv, g_dev=g.contiguous())
+        need_a, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        da = torch.empty(a.shape, dtype=torch.float32, device=a.device) if need_a else None
+        db = torch.empty(b.shape, dtype=torch.float32, device=a.device) if need_b else None
+        if C % 4 == 0 and a.stride(0) % 4 == 0 and b.stride(0) % 4 == 0:
+            ops.mse_frames_bwd(a, b, a_lo, b_lo, nt, 1.0 / (B * nt * C), g.contiguous(), da, db)      # writes zeros outside the ranges
+        else:
+            av = torch.as_strided(a, (B, nt * C), (a.stride(0), 1), a.storage_offset() + a_lo * C)
+            bv = torch.as_strided(b, (B, nt * C), (b.stride(0), 1), b.storage_offset() + b_lo * C)
+            dav = dbv = None
+            if da is not None:
+                dav = torch.as_strided(da.zero_(), (B, nt * C), (da.stride(0), 1), a_lo * C)
+            if db is not None:
+                dbv = torch.as_strided(db.zero_(), (B, nt * C), (db.stride(0), 1), b_lo * C)
+            ops.mse(av, bv, 1.0 / (B * nt * C), None, dav, dbv, g_dev=g.contiguous())
         flush_ready()
         return da, db, None, None, None
 
@@ -1731,10 +1848,13 @@ class ReduceLosses(torch.autograd.Function):
         ctx.weights, ctx.shapes = tuple(weights), [v.shape for v in vals]
         ctx.needs = list(ctx.needs_input_grad[1:])
         ctx.mark_non_differentiable(means)
+        ctx.set_materialize_grads(False)      # `means` takes no gradient: without this autograd zero-fills one for it every step
         return total, means
 
     @staticmethod
     def backward(ctx, g_total, _g_means):
+        if g_total is None:
+            return (None,) * (1 + len(ctx.shapes))
         grads = [torch.empty(shp, dtype=torch.float32, device=g_total.device) if need else None
                  for shp, need in zip(ctx.shapes, ctx.needs)]
         ops.loss_reduce_bwd(grads, ctx.weights, g_total.contiguous())
@@ -1744,22 +1864,33 @@ class ReduceLosses(torch.autograd.Function):
 class SplitRows(torch.autograd.Function):
     """(x[:, :n], x[:, n:]) of x (B, L, C) as two views whose gradients are written side by side into ONE buffer: autograd's own
     slicing would zero-fill a full-size gradient per slice, copy into it and add the two (5 kernels on the (B, T + 1, 3806) logits
-    of the merged classifier heads; here 2 copies)."""
+    of the merged classifier heads).  With a GradLanding record (split_rows below) the loss kernels write their gradients into that
+    buffer themselves and backward launches nothing; a gradient that arrives from anywhere else is copied in."""
 
     @staticmethod
-    def forward(ctx, x, n):
-        ctx.n, ctx.shape = n, x.shape
+    def forward(ctx, x, n, landing=None):
+        ctx.n, ctx.shape, ctx.landing = n, x.shape, landing
         return x[:, :n], x[:, n:]
 
     @staticmethod
     def backward(ctx, ga, gb):
-        dx = torch.empty(ctx.shape, dtype=ga.dtype if ga is not None else gb.dtype, device=(ga if ga is not None else gb).device)
-        if ga is not None:
-            dx[:, :ctx.n].copy_(ga)
+        ref = ga if ga is not None else gb
+        rec = ctx.landing
+        if rec is not None and rec.dx is not None and rec.dx.dtype == ref.dtype:
+            dx = rec.dx
         else:
-            dx[:, :ctx.n].zero_()
-        if gb is not None:
-            dx[:, ctx.n:].copy_(gb)
-        else:
-            dx[:, ctx.n:].zero_()
-        return dx, None
+            dx, rec = torch.empty(ctx.shape, dtype=ref.dtype, device=ref.device), None
+        for which, g, view in ((0, ga, dx[:, :ctx.n]), (1, gb, dx[:, ctx.n:])):
+            if g is None:
+                view.zero_()
+            elif rec is None or not rec.holds(which, g):
+                view.copy_(g)
+        return dx, None, None
+
+
+def split_rows(x: Tensor, n: int):
+    """SplitRows with the landing record attached to both halves (`_afft_landing`: read by MultiDimCrossEntropy)"""
+    rec = GradLanding(x.shape, n)
+    a, b = SplitRows.apply(x, n, rec)
+    a._afft_landing, b._afft_landing = (rec, 0), (rec, 1)
+    return a, b

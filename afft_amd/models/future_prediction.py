@@ -158,7 +158,7 @@ class BaseFuturePredictor(nn.Module):
             outs.append(self._map(self.decoder, new))
             if output_id + 1 < output_len:
                 seq = torch.cat([seq, h[:, -1:, :]], dim=1)
-        return torch.cat(outs, dim=1), addl_endpoints
+        return (outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)), addl_endpoints
 
 
 # --------------------------------------------------------------------------- cross-modal fusion + prediction
@@ -285,12 +285,12 @@ class CrossModalFusionPrediction(nn.Module, metaclass=abc.ABCMeta):
         cut = T - 1
         # [z_1, z_hat_2 .. z_hat_{T+k}] ONCE per modality: past_futures and future are its two ends (views) -- and the merged
         # classifier heads (_with_logits) take it whole, instead of a second concatenation of the same rows
-        seen_then_predicted = {m: torch.cat([z[m][:, :1], zh], dim=1) for m, zh in z_hat.items()}
+        joined = {m: F_.SeenThenPredicted.apply(z[m], zh, T) for m, zh in z_hat.items()}
         out = {'orig_past': z,
-               'future': {m: sp[:, T:] for m, sp in seen_then_predicted.items()},
+               'future': {m: j[2] for m, j in joined.items()},
                'all-fused': {m: f[:, cut:] for m, f in fusions.items()},
-               'past_futures': {m: sp[:, :T] for m, sp in seen_then_predicted.items()}}
-        out['_seen_then_predicted'] = seen_then_predicted
+               'past_futures': {m: j[1] for m, j in joined.items()}}
+        out['_seen_then_predicted'] = {m: j[0] for m, j in joined.items()}
         return out
 
     def _with_logits(self, out: dict) -> dict:
@@ -305,7 +305,7 @@ class CrossModalFusionPrediction(nn.Module, metaclass=abc.ABCMeta):
                 whole = {m: torch.cat([past[m], fut[m]], dim=1) for m in past}
             both = self.apply_classifier(whole)
             for key, per_mod in both.items():
-                halves = {m: F_.SplitRows.apply(v, T) for m, v in per_mod.items()}
+                halves = {m: F_.split_rows(v, T) for m, v in per_mod.items()}
                 out[PAST_LOGITS_PREFIX + key] = {m: h[0] for m, h in halves.items()}
                 out[key] = {m: h[1] for m, h in halves.items()}
             return out

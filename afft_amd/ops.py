@@ -292,6 +292,29 @@ def softmax_ce(logits: Tensor, C_: int, *, labels: Optional[Tensor] = None, soft
                                     _dt(dlogits) if dlogits is not None else 0, _p(row_loss), _stream()), "softmax_ce")
 
 
+def softmax_ce_frames(logits3: Tensor, C_: int, *, labels: Optional[Tensor] = None, soft: Optional[Tensor] = None,
+                      keep: Optional[Tensor] = None, row_g: Optional[Tensor] = None, dlogits3: Optional[Tensor] = None,
+                      row_loss: Optional[Tensor] = None):
+    """softmax_ce on a (clips, frames, >= C) VIEW (e.g. x[:, :n] of a wider tensor): no flattening copy; dlogits3 is a view of the
+    same kind (its own strides).  Row r of labels / soft / keep / row_g / row_loss = frame r % frames of clip r // frames."""
+    clips, frames = logits3.shape[0], logits3.shape[1]
+    assert logits3.dtype == torch.float32 and logits3.dim() == 3 and logits3.stride(2) == 1
+    rows = clips * frames
+    if labels is not None:
+        assert labels.dtype == torch.int64 and labels.numel() == rows and labels.is_contiguous()
+    if soft is not None:
+        assert soft.dtype == torch.float32 and soft.shape[0] == rows
+    if keep is not None:
+        assert keep.dtype == torch.uint8 and keep.numel() == rows
+    if dlogits3 is not None:
+        assert dlogits3.dim() == 3 and dlogits3.shape[:2] == logits3.shape[:2] and dlogits3.stride(2) == 1
+    L.check(L.lib().afft_softmax_ce_frames(_p(logits3), logits3.stride(0), logits3.stride(1), clips, frames, C_, _p(labels), _p(soft),
+                                           _rowmajor(soft, "soft") if soft is not None else 0, _p(keep), 1.0, _p(row_g),
+                                           _p(dlogits3), dlogits3.stride(0) if dlogits3 is not None else 0,
+                                           dlogits3.stride(1) if dlogits3 is not None else 0,
+                                           _dt(dlogits3) if dlogits3 is not None else 0, _p(row_loss), _stream()), "softmax_ce_frames")
+
+
 def loss_reduce(vals, weights, means: Optional[Tensor], total: Tensor):
     """means[i] = mean(vals[i]), total[0] = sum_i weights[i] * means[i]: Runner._reduce_loss in one launch (afft_loss_reduce)"""
     n = len(vals)
@@ -323,6 +346,27 @@ def mse(a: Tensor, b: Tensor, gscale: float, loss_sum: Optional[Tensor], da: Opt
                              _p(da), _rowmajor(da, "da") if da is not None else 0, _p(db),
                              _rowmajor(db, "db") if db is not None else 0, _p(ws), ws.numel() if ws is not None else 0,
                              _stream()), "mse")
+
+
+def mse_loss(a: Tensor, b: Tensor, lscale: float, loss: Tensor):
+    """loss[0] = lscale * sum (a - b)^2, written (ordered sum through the current stream's scratch)"""
+    rows, d = a.shape
+    assert a.dtype == b.dtype == torch.float32 and b.shape == a.shape
+    ws = gemm_workspace(a.device)
+    L.check(L.lib().afft_mse_loss(_p(a), _rowmajor(a, "a"), _p(b), _rowmajor(b, "b"), rows, d, lscale, _p(loss), _p(ws), ws.numel(),
+                                  _stream()), "mse_loss")
+
+
+def mse_frames_bwd(a: Tensor, b: Tensor, a_lo: int, b_lo: int, nt: int, gscale: float, g_dev: Optional[Tensor],
+                   da: Optional[Tensor], db: Optional[Tensor]):
+    """a (B, Ta, C), b (B, Tb, C) fp32 with contiguous frames; da / db contiguous tensors of the same shapes, written whole:
+    the gradient of mean-free sum((a[:, a_lo:a_lo+nt] - b[:, b_lo:b_lo+nt])^2) * gscale * g_dev inside the ranges, zeros outside."""
+    B, Ta, C_ = a.shape
+    Tb = b.shape[1]
+    assert a.dtype == b.dtype == torch.float32 and a.stride(2) == 1 and b.stride(2) == 1 and a.stride(1) == C_ and b.stride(1) == C_
+    assert (da is None or (da.is_contiguous() and da.shape == a.shape)) and (db is None or (db.is_contiguous() and db.shape == b.shape))
+    L.check(L.lib().afft_mse_frames_bwd(_p(a), a.stride(0), a_lo * C_, Ta * C_, _p(b), b.stride(0), b_lo * C_, Tb * C_, B, nt * C_,
+                                        gscale, _p(g_dev), _p(da), _p(db), _stream()), "mse_frames_bwd")
 
 
 def cast(src: Tensor, dst: Optional[Tensor], dst_t: Optional[Tensor] = None, zero_pad: bool = False,
@@ -358,6 +402,26 @@ def colsum(src: Tensor, out: Tensor, accumulate: bool = False):
     ws = gemm_workspace(src.device)
     L.check(L.lib().afft_colsum(_p(src), _rowmajor(src, "src"), _dt(src), rows, cols, _p(out),
                                 1 if accumulate else 0, _p(ws), ws.numel(), _stream()), "colsum")
+    return out
+
+
+def gather_frames(out: Tensor, srcs):
+    """out (clips, frames, C) fp32 (any clip / frame strides, contiguous C) = sum over srcs of their frames, zeros where none covers:
+    srcs = [(tensor (clips, f_k, C), lo, hi, off), ...]: source k contributes src_k[:, t + off] to out[:, t] for lo <= t < hi."""
+    clips, frames, C_ = out.shape
+    n = len(srcs)
+    assert n <= 4 and out.dtype == torch.float32 and out.stride(2) == 1
+    for t, lo, hi, off in srcs:
+        assert t.dtype == torch.float32 and t.dim() == 3 and t.shape[0] == clips and t.shape[2] == C_ and t.stride(2) == 1
+        assert 0 <= lo <= hi <= frames and lo + off >= 0 and (hi == lo or hi - 1 + off < t.shape[1])
+    ptrs = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t, *_ in srcs])
+    cs = (C.c_int64 * max(n, 1))(*[t.stride(0) for t, *_ in srcs])
+    fs = (C.c_int64 * max(n, 1))(*[t.stride(1) for t, *_ in srcs])
+    lo = (C.c_int32 * max(n, 1))(*[s[1] for s in srcs])
+    hi = (C.c_int32 * max(n, 1))(*[s[2] for s in srcs])
+    off = (C.c_int32 * max(n, 1))(*[s[3] for s in srcs])
+    L.check(L.lib().afft_gather_frames(_p(out), out.stride(0), out.stride(1), clips, frames, C_, n, ptrs, cs, fs, lo, hi, off, _stream()),
+            "gather_frames")
     return out
 
 

@@ -707,7 +707,10 @@ class Trainer(_FusedEpilogue):
             losses, _ = self.loss_fn(outputs, out_t['target'], out_t['target_subclips'], mixup_enable=mixup_fn is not None,
                                      target_subclips_ignore_index=out_t['target_subclips_ignore_index'])
             loss, parts = self._reduce(losses, self.loss_wts, sync=False)
-            loss.backward()
+            one = getattr(self, "_one", None)      # the seed gradient, kept: autograd would allocate and fill a new one every step
+            if one is None or one.device != loss.device or one.dtype != loss.dtype:
+                one = self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
+            loss.backward(gradient=one)
             self.reducer.finish_step()
             if fuse and self._audit_fused_step():
                 saved_runs = self.opt.runs      # the set shrank: keep the rebuilt runs

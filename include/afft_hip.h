@@ -256,6 +256,13 @@ int afft_attention_bwd(const void* dout, int64_t lddo, const void* q, int64_t ld
 int afft_softmax_ce(const float* logits, int64_t ldl, int32_t rows, int32_t C, const int64_t* labels,
                     const float* soft, int64_t lds, const uint8_t* keep, float gscale, const float* row_g,
                     float* loss_sum, void* dlogits, int64_t ldd, int32_t d_dtype, float* row_loss, void* stream);
+/* The same on frames [0, frames) of `clips` clips laid out (clips, L >= frames, >= C): row r of labels / soft / keep / row_g /
+ * row_loss is frame r % frames of clip r / frames, its logits sit at logits + clip * clip_stride + frame * ldl and its gradient at
+ * dlogits + clip * d_clip_stride + frame * ldd.  The past / future halves of the merged classifier output (models/future_prediction.py:283-285
+ * applies the same heads to both) are walked where they lie, and their gradients land side by side in ONE buffer. */
+int afft_softmax_ce_frames(const float* logits, int64_t clip_stride, int64_t ldl, int32_t clips, int32_t frames, int32_t C,
+                           const int64_t* labels, const float* soft, int64_t lds, const uint8_t* keep, float gscale, const float* row_g,
+                           void* dlogits, int64_t d_clip_stride, int64_t ldd, int32_t d_dtype, float* row_loss, void* stream);
 /* Runner._reduce_loss (common/runner.py:198-213) in one launch: term i = n[i] fp32 per-row losses at x[i] (HOST arrays of nterms <= 8
  * device pointers / counts / weights); means[i] = mean(x[i]) (may be NULL), total[0] = sum_i w[i] * means[i], in a fixed order (bit-stable).
  * afft_loss_reduce_bwd: g[i][0 .. n[i]) = g_total[0] * w[i] / n[i] (g_total NULL = 1; g[i] NULL skips a term): the upstream
@@ -274,6 +281,16 @@ int afft_loss_reduce_bwd(float* const* g, const int64_t* n, const float* w, int3
 int afft_mse(const float* a, int64_t lda, const float* b, int64_t ldb, int32_t rows, int32_t d, float gscale,
              const float* g_dev, float lscale, float* loss_sum, float* da, int64_t ldda, float* db, int64_t lddb,
              void* workspace, int64_t workspace_bytes, void* stream);
+/* loss[0] = lscale * sum (a-b)^2: overwritten, not added to (no zero-fill in front). */
+int afft_mse_loss(const float* a, int64_t lda, const float* b, int64_t ldb, int32_t rows, int32_t d, float lscale, float* loss,
+                  void* workspace, int64_t workspace_bytes, void* stream);
+/* Backward of the MSE between n-float ranges of two (clips, len) fp32 tensors (common/runner.py:164-166 compares [:, 1:] of the
+ * predicted and the observed features): da[clips, a_len] and db[clips, b_len] are WRITTEN whole -- +/- gscale*g_dev[0]*2*(a-b) on
+ * [a_off, a_off+n) / [b_off, b_off+n), zeros elsewhere.  a / b rows start at clip * clip_stride; offsets, lengths and strides
+ * are multiples of 4 floats; da or db may be NULL. */
+int afft_mse_frames_bwd(const float* a, int64_t a_clip_stride, int32_t a_off, int32_t a_len, const float* b, int64_t b_clip_stride,
+                        int32_t b_off, int32_t b_len, int32_t clips, int32_t n, float gscale, const float* g_dev, float* da, float* db,
+                        void* stream);
 
 /* ------------------------------------------------------------------ data movement / elementwise
  * fp32 [rows, cols] -> dst dtype copy; if dst_t != NULL also writes the transpose [cols, rows] (ld = ldt).
@@ -317,6 +334,13 @@ int afft_assemble_tokens(const float* const* feats, const int64_t* ldf, int32_t 
  * them up in block order.  NULL: one workgroup per column strip walks all the rows (~1.5x the time on a [5120, 8192] input). */
 int afft_colsum(const void* src, int64_t lds, int32_t dtype, int32_t rows, int32_t cols, float* out,
                 int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+/* out[clip, t, 0..C) = sum over the (at most 4) sources k with lo[k] <= t < hi[k] of src[k][clip, t + off[k], 0..C), zeros where no
+ * source covers t; every output element is written exactly once.  Strides in floats (multiples of 4; C % 4 == 0).  One launch for:
+ * torch.cat along the frame axis (models/future_prediction.py:161-170 builds past_futures = [z_1, z_hat_2..] this way) and its backward
+ * (overlapping slice gradients are added), "token 0 of every frame" (models/fusion.py:362-365) and its zero-filled backward. */
+int afft_gather_frames(float* out, int64_t out_clip_stride, int64_t out_frame_stride, int32_t clips, int32_t frames, int32_t C,
+                       int32_t nsrc, const float* const* src, const int64_t* clip_stride, const int64_t* frame_stride,
+                       const int32_t* lo, const int32_t* hi, const int32_t* off, void* stream);
 /* y[r, :] = x[r, :] + table[(r % period), :]   (GPT-2 wpe / CA-Fuser position embedding; fp32) */
 int afft_add_rows_periodic(const float* x, int64_t ldx, const float* table, int64_t ldt, int32_t rows,
                            int32_t period, int32_t d, float* y, int64_t ldy, void* stream);

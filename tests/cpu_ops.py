@@ -216,6 +216,28 @@ def softmax_ce(logits, C_, *, labels=None, soft=None, keep=None, gscale=1.0, row
 
 
 @torch.no_grad()
+def softmax_ce_frames(logits3, C_, *, labels=None, soft=None, keep=None, row_g=None, dlogits3=None, row_loss=None):
+    clips, frames = logits3.shape[:2]
+    d2 = None if dlogits3 is None else torch.zeros(clips * frames, dlogits3.shape[2])
+    softmax_ce(logits3.reshape(clips * frames, -1), C_, labels=labels, soft=soft, keep=keep, row_g=row_g, dlogits=d2, row_loss=row_loss)
+    if dlogits3 is not None:
+        dlogits3.copy_(d2.view(clips, frames, -1))
+
+
+def mse_loss(a, b, lscale, loss):
+    loss.copy_(lscale * ((a - b) ** 2).sum())
+
+
+def mse_frames_bwd(a, b, a_lo, b_lo, nt, gscale, g_dev, da, db):
+    g = gscale * (float(g_dev) if g_dev is not None else 1.0) * 2.0 * (a[:, a_lo:a_lo + nt] - b[:, b_lo:b_lo + nt])
+    if da is not None:
+        da.zero_()
+        da[:, a_lo:a_lo + nt] = g
+    if db is not None:
+        db.zero_()
+        db[:, b_lo:b_lo + nt] = -g
+
+
 def mse(a, b, gscale, loss_sum, da, db, g_dev=None, lscale=1.0):
     diff = a - b
     if loss_sum is not None:
@@ -255,6 +277,15 @@ def colsum(src, out, accumulate=False):
     t = src.float().sum(0)
     n = t.numel()
     out[:n].copy_(out[:n] + t if accumulate else t)
+    return out
+
+
+@torch.no_grad()
+def gather_frames(out, srcs):
+    out.zero_()
+    for t, lo, hi, off in srcs:
+        if hi > lo:
+            out[:, lo:hi] += t[:, lo + off:hi + off]
     return out
 
 
@@ -390,8 +421,8 @@ def softmax_rows(x, y):
     return y
 
 
-_NAMES = ["Split", "gemm", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "softmax_ce", "mse", "cast",
-          "assemble_tokens", "colsum", "add_rows_periodic", "reduce_rows_periodic", "sgd_nesterov", "sgd_nesterov_runs", "loss_reduce", "loss_reduce_bwd", "sumsq", "clip_coef",
+_NAMES = ["Split", "gemm", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "softmax_ce", "softmax_ce_frames", "mse", "mse_loss", "mse_frames_bwd", "cast",
+          "assemble_tokens", "colsum", "gather_frames", "add_rows_periodic", "reduce_rows_periodic", "sgd_nesterov", "sgd_nesterov_runs", "loss_reduce", "loss_reduce_bwd", "sumsq", "clip_coef",
           "group_sum", "group_bcast", "act_bwd", "softmax_small_fwd", "softmax_small_bwd", "weighted_sum_fwd",
           "weighted_sum_bwd", "softmax_rows"]
 

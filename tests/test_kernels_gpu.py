@@ -1353,3 +1353,94 @@ def test_lds_ring_kernels_are_bitwise_stable_under_lds_pressure(case):
     finally:
         torch.cuda.synchronize()
         _lib.check(_lib.lib().afft_set_gemm_variant(0))
+
+
+# ----------------------------------------------------------------------------- round 5: glue kernels that replaced torch-native launches
+@pytest.mark.parametrize("clips,L,n0,C", [(64, 17, 16, 3806), (3, 5, 1, 11), (5, 7, 7, 40)])
+def test_softmax_ce_on_frame_slices_lands_both_gradients_in_one_buffer(clips, L, n0, C):
+    """afft_softmax_ce_frames: the two halves x[:, :n0], x[:, n0:] of a (clips, L, C) classifier output (leading dimension padded to 64)
+    are walked where they lie, and their gradients are written into the halves of one (clips, L, C) buffer -- against torch on the
+    flattened copies (what the reference's MultiDimCrossEntropy does, common/runner.py:13-37)."""
+    from afft_amd import ops
+    ld = ((C + 63) // 64) * 64
+    buf = torch.zeros(clips, L, ld)
+    buf[:, :, :C] = rnd(clips, L, C, seed=71, scale=3.0)
+    x = buf.to(dev())[:, :, :C]
+    dx = torch.full((clips, L, C), 9.0, device=dev())
+    g = torch.Generator().manual_seed(5)
+    for lo, hi in ((0, n0), (n0, L)):
+        n = hi - lo
+        if n == 0:
+            continue
+        labels = torch.randint(0, C, (clips * n,), generator=g)
+        labels[::3] = -1
+        row_g = rnd(clips * n, seed=72).abs() + 0.1
+        rl = torch.empty(clips * n, device=dev())
+        ops.softmax_ce_frames(x[:, lo:hi], C, labels=labels.to(dev()), row_loss=rl)
+        ops.softmax_ce_frames(x[:, lo:hi], C, labels=labels.to(dev()), row_g=row_g.to(dev()), dlogits3=dx[:, lo:hi])
+        ref_in = buf[:, lo:hi, :C].reshape(-1, C).double().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(ref_in, labels, ignore_index=-1, reduction="none")
+        (ref * row_g.double()).sum().backward()
+        torch.cuda.synchronize()
+        assert rel_l2(rl.cpu(), ref.float()) < 1e-5
+        assert rel_l2(dx[:, lo:hi].cpu().reshape(-1, C), ref_in.grad.float()) < 1e-5
+    assert not bool((dx == 9.0).any())          # every element of the shared buffer was written
+
+
+@pytest.mark.parametrize("B,Ta,Tb,C,a_lo,b_lo,nt", [(64, 16, 16, 2048, 1, 1, 15), (3, 4, 6, 64, 1, 2, 3), (2, 5, 5, 8, 0, 0, 5)])
+def test_mse_between_frame_ranges_writes_whole_gradients(B, Ta, Tb, C, a_lo, b_lo, nt):
+    """afft_mse_loss overwrites its scalar (no zero fill in front) and afft_mse_frames_bwd writes the FULL gradients of both tensors,
+    zeros outside the compared frames (common/runner.py:164-166 compares [:, 1:])"""
+    from afft_amd import ops
+    a, b = rnd(B, Ta, C, seed=81), rnd(B, Tb, C, seed=82)
+    ad, bd = a.to(dev()), b.to(dev())
+    av = torch.as_strided(ad, (B, nt * C), (ad.stride(0), 1), a_lo * C)
+    bv = torch.as_strided(bd, (B, nt * C), (bd.stride(0), 1), b_lo * C)
+    loss = torch.full((), 123.0, device=dev())
+    ops.mse_loss(av, bv, 1.0 / (B * nt * C), loss)
+    ar, br = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = ((ar[:, a_lo:a_lo + nt] - br[:, b_lo:b_lo + nt]) ** 2).mean()
+    (ref * 0.7).backward()
+    da, db = torch.full_like(ad, 5.0), torch.full_like(bd, 5.0)
+    ops.mse_frames_bwd(ad, bd, a_lo, b_lo, nt, 1.0 / (B * nt * C), torch.tensor(0.7, device=dev()), da, db)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ref)) < 2e-6 * abs(float(ref))
+    assert rel_l2(da.cpu(), ar.grad.float()) < 1e-6 and rel_l2(db.cpu(), br.grad.float()) < 1e-6
+    assert float(da.cpu()[:, :a_lo].abs().sum()) == 0.0 and float(db.cpu()[:, :b_lo].abs().sum()) == 0.0
+    only_a = torch.full_like(ad, 5.0)
+    ops.mse_frames_bwd(ad, bd, a_lo, b_lo, nt, 1.0 / (B * nt * C), torch.tensor(0.7, device=dev()), only_a, None)
+    torch.cuda.synchronize()
+    assert torch.equal(only_a, da)
+
+
+def test_gather_frames_is_cat_slice_backward_and_token0():
+    """afft_gather_frames against torch: concatenation along frames, the summed backward of overlapping slices, token 0 of every frame and
+    its zero-filled backward; sources with strides of their own (views)"""
+    from afft_amd import ops
+    B, T, C, k = 5, 6, 72, 2
+    z, zh = rnd(B, T, C, seed=91).to(dev()), rnd(B, T - 1 + k, C, seed=92).to(dev())
+    whole = torch.full((B, T + k, C), 3.0, device=dev())
+    ops.gather_frames(whole, [(z, 0, 1, 0), (zh, 1, T + k, -1)])
+    assert torch.equal(whole, torch.cat([z[:, :1], zh], 1))
+    gw, gp, gf = rnd(B, T + k, C, seed=93).to(dev()), rnd(B, T, C, seed=94).to(dev()), rnd(B, k, C, seed=95).to(dev())
+    tot = gw.clone(); tot[:, :T] += gp; tot[:, T:] += gf
+    dzh = torch.full_like(zh, 3.0)
+    ops.gather_frames(dzh, [(gw, 0, T - 1 + k, 1), (gp, 0, T - 1, 1), (gf, T - 1, T - 1 + k, 1 - T)])
+    assert rel_l2(dzh.cpu(), tot[:, 1:].cpu()) < 1e-6
+    dz = torch.full_like(z, 3.0)
+    ops.gather_frames(dz, [(gw, 0, 1, 0), (gp, 0, 1, 0)])
+    ref = torch.zeros_like(z); ref[:, :1] = tot[:, :1]
+    assert rel_l2(dz.cpu(), ref.cpu()) < 1e-6 and float(dz[:, 1:].abs().sum()) == 0.0
+    # token 0 of every frame of a [rows * S, d] stream, from a strided view, and back
+    S, d = 5, 128
+    wide = rnd(B * T * S, d + 64, seed=96).to(dev())
+    X = wide[:, :d]                                         # row stride d + 64
+    y = torch.empty(B * T, d, device=dev())
+    ops.gather_frames(y.view(B * T, 1, d), [(torch.as_strided(X, (B * T, S, d), (S * X.stride(0), X.stride(0), 1)), 0, 1, 0)])
+    assert torch.equal(y, X[::S])
+    dX = torch.full((B * T * S, d), 3.0, device=dev())
+    ops.gather_frames(dX.view(B * T, S, d), [(y.view(B * T, 1, d), 0, 1, 0)])
+    ref = torch.zeros_like(dX); ref[::S] = y
+    assert torch.equal(dX, ref)
+    ops.gather_frames(dX.view(B * T, S, d), [])              # no source: zeros
+    assert float(dX.abs().sum()) == 0.0
