@@ -81,7 +81,7 @@ class AttnSublayer(C.Structure):      # afft_attn_sublayer_t
         ("g_w_proj", vp), ("acc_w_proj", i32), ("g_b_proj", vp), ("acc_b_proj", i32),
         ("g_ln_w", vp), ("g_ln_b", vp), ("acc_ln", i32),
         ("dx", vp)] + _HAND + [("ln_partial", vp)] + _WS + [("sgd_w_qkv", SgdP), ("sgd_w_proj", SgdP), ("w_qkv_pk", vp), ("w_proj_pk", vp),
-                                                       ("f16x2", i32), ("xn_b", vp), ("qkv_b", vp), ("ao_b", vp), ("w_qkv8", vp), ("w_proj8", vp)]
+                                                       ("f16x2", i32), ("xn_b", vp), ("qkv_b", vp), ("ao_b", vp), ("w_qkv8", vp), ("w_proj8", vp), ("take", i32)]
 
 
 class MLPSublayer(C.Structure):       # afft_mlp_sublayer_t
@@ -168,6 +168,7 @@ _SIGS = {
     "afft_softmax_ce": ([vp, i64, i32, i32, vp, vp, i64, vp, f32, vp, vp, vp, i64, i32, vp, vp], C.c_int),
     "afft_loss_reduce": ([C.POINTER(vp), C.POINTER(i64), C.POINTER(f32), i32, vp, vp, vp], C.c_int),
     "afft_loss_reduce_bwd": ([C.POINTER(vp), C.POINTER(i64), C.POINTER(f32), i32, vp, vp], C.c_int),
+    "afft_layernorm_bwd_take": ([vp, i64, i32, vp, i64, vp, vp, vp, i32, i32, vp, i64, i32, vp, i64, vp, vp, vp, vp, i32, vp, i32, vp, vp], C.c_int),
     "afft_softmax_ce_frames": ([vp, i64, i64, i32, i32, i32, vp, vp, i64, vp, f32, vp, vp, i64, i64, i32, vp, vp], C.c_int),
     "afft_mse_loss": ([vp, i64, vp, i64, i32, i32, f32, vp, vp, i64, vp], C.c_int),
     "afft_mse_frames_bwd": ([vp, i64, i32, i32, vp, i64, i32, i32, i32, i32, f32, vp, vp, vp, vp], C.c_int),

@@ -78,7 +78,8 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const void* __restrict__ d
                                                       const float* __restrict__ rstd, int rows, int d,
                                                       const float* __restrict__ dx_in, float* __restrict__ dx_out,
                                                       int64_t lddx, bf16_t* __restrict__ dx_bf16,
-                                                      const DropParams drop_, int nslab, float* __restrict__ partial) {
+                                                      const DropParams drop_, int nslab, float* __restrict__ partial,
+                                                      int64_t lddx_in, int in_take) {
   const DropParams drop = with_salt(drop_);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* slab = (float*)smem;                      // [nslab][d]: dw, db (, column sums of the masked copy)
@@ -132,11 +133,15 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const void* __restrict__ d
     const float mu = nmu;
     rs = nrs;
     if (PIPE) prefetch(row + gridDim.x * LNB_RG);       // the next row step of this wave: in flight from here on
+    // in_take > 1: the incoming dx is [rows / in_take, d] and belongs to rows 0, in_take, ..: the others take none
+    const bool has_in = dx_in && (in_take <= 1 || row % in_take == 0);
     if (live && dx_in) {                      // this step's incoming dx is only needed behind the barrier: its latency hides under the reductions
+      const int64_t in_row = in_take > 1 ? row / in_take : row;
 #pragma unroll
       for (int t = 0; t < NV; ++t) {
         const int q = q0 + lane + 64 * t;
-        if (q < q1) din[t] = *(const float4*)(dx_in + (int64_t)row * lddx + 4 * q);
+        din[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < q1 && has_in) din[t] = *(const float4*)(dx_in + in_row * lddx_in + 4 * q);
       }
     }
     if (live) {
@@ -298,7 +303,17 @@ extern "C" int afft_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype
                                   const float* dx_in, float* dx_out, int64_t lddx, void* dx_bf16,
                                   const afft_dropout_t* copy_drop, float* dw, float* db, int32_t accumulate,
                                   float* dcol, int32_t dcol_accumulate, float* partial, void* stream_) {
+  return afft_layernorm_bwd_take(dy, lddy, dy_dtype, x, ldx, w, mean, rstd, rows, d, dx_in, lddx, 1, dx_out, lddx, dx_bf16, copy_drop, dw, db,
+                                 accumulate, dcol, dcol_accumulate, partial, stream_);
+}
+
+extern "C" int afft_layernorm_bwd_take(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* w,
+                                       const float* mean, const float* rstd, int32_t rows, int32_t d, const float* dx_in, int64_t lddx_in,
+                                       int32_t in_take, float* dx_out, int64_t lddx, void* dx_bf16, const afft_dropout_t* copy_drop,
+                                       float* dw, float* db, int32_t accumulate, float* dcol, int32_t dcol_accumulate, float* partial,
+                                       void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(in_take >= 1 && lddx_in % 4 == 0, "layernorm_bwd: bad in_take / lddx_in");
   AFFT_CHECK(dy && x && mean && rstd && dx_out && partial, "layernorm_bwd: null pointer");
   AFFT_CHECK(d > 0 && d % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "layernorm_bwd: d/ld must be multiples of 4");
   AFFT_CHECK(d <= 4096, "layernorm_bwd: d=%d exceeds 4096", d);
@@ -312,7 +327,7 @@ extern "C" int afft_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype
   const DropParams drop = make_drop(copy_drop);
   const size_t lds = (size_t)nslab * d * sizeof(float) + 2 * LNB_RG * LNB_CS * 2 * sizeof(float);
   AFFT_CHECK(dy_dtype == AFFT_F32 || dy_dtype == AFFT_BF16, "layernorm_bwd: dy is fp32 or bf16");
-#define LN_BWD(NV, F) hipLaunchKernelGGL((ln_bwd_kernel<NV, F>), dim3(grid), dim3(1024), lds, stream, dy, lddy, x, ldx, w, mean, rstd, rows, d, dx_in, dx_out, lddx, (bf16_t*)dx_bf16, drop, nslab, partial)
+#define LN_BWD(NV, F) hipLaunchKernelGGL((ln_bwd_kernel<NV, F>), dim3(grid), dim3(1024), lds, stream, dy, lddy, x, ldx, w, mean, rstd, rows, d, dx_in, dx_out, lddx, (bf16_t*)dx_bf16, drop, nslab, partial, lddx_in, in_take)
   if (dy_dtype == AFFT_F32) { switch (nv) { case 1: LN_BWD(1, true); break; case 2: LN_BWD(2, true); break; default: LN_BWD(4, true); } }
   else { switch (nv) { case 1: LN_BWD(1, false); break; case 2: LN_BWD(2, false); break; default: LN_BWD(4, false); } }
 #undef LN_BWD

@@ -103,6 +103,8 @@ extern "C" int afft_attn_sublayer_fwd(const afft_attn_sublayer_t* s, void* strea
   AFFT_CHECK(s->rows > 0 && s->L > 0 && s->rows % s->L == 0 && s->H > 0 && s->d % 64 == 0 && s->d % s->H == 0,
              "attn_sublayer_fwd: bad geometry (rows %d, L %d, d %d, H %d)", s->rows, s->L, s->d, s->H);
   const int R = s->rows, d = s->d;
+  const int take = s->take > 1 ? s->take : 1, Ry = R / take;      // rows that leave the sub-layer (token 0 of every `take` rows)
+  AFFT_CHECK(take == 1 || (take == s->L && Ry % 64 == 0), "attn_sublayer_fwd: take must be L, with rows / take a multiple of 64");
   const Ws ws = {s->gemm_ws, s->gemm_ws_bytes};
   if (s->f16x2) {
     // fp16 two-pass forward: every activation a GEMM reads is carried as hi + lo fp16 planes written by its producer (LayerNorm,
@@ -127,10 +129,10 @@ extern "C" int afft_attn_sublayer_fwd(const afft_attn_sublayer_t* s, void* strea
     const char* q = (const char*)s->qkv;
     TRY(afft_attention_fwd_split(q, 3 * d, q + 2 * d, 3 * d, q + 4 * d, 3 * d, lo3, R / s->L, s->L, s->H, d / s->H, s->scale, s->mask,
                                  s->mask_period, s->p_attn, s->k_attn, s->ao, d, lo8 ? 0 : lo1, s->ao_b, d, s->probs, lo8 ? ao8 : nullptr, st));
-    g = lin_fwd(s->ao, d, R, d, s->w_proj, s->ldw_proj, d, s->conv1d, ws);
-    if (lo8) as_f16_lo8(g, ao8, d, s->w_proj8, s->ldw_proj); else as_f16x2(g, lo1);
+    g = lin_fwd(s->ao, (int64_t)d * take, Ry, d, s->w_proj, s->ldw_proj, d, s->conv1d, ws);
+    if (lo8) as_f16_lo8(g, ao8, (int64_t)d * take, s->w_proj8, s->ldw_proj); else as_f16x2(g, lo1);
     g.bias = s->b_proj;
-    g.residual = s->x; g.ldres = d;
+    g.residual = s->x; g.ldres = (int64_t)d * take;
     g.drop = s->out_drop;
     g.out = s->y; g.ldo = d; g.out_dtype = AFFT_F32;
     return afft_gemm(&g, st);
@@ -147,9 +149,9 @@ extern "C" int afft_attn_sublayer_fwd(const afft_attn_sublayer_t* s, void* strea
   const char* q = (const char*)s->qkv;
   TRY(afft_attention_fwd(q, 3 * d, q + 2 * d, 3 * d, q + 4 * d, 3 * d, AFFT_BF16, R / s->L, s->L, s->H, d / s->H, s->scale,
                          s->mask, s->mask_period, s->p_attn, s->k_attn, s->ao, d, s->probs, st));
-  g = lin_fwd(s->ao, d, R, d, s->w_proj, s->ldw_proj, d, s->conv1d, ws);
+  g = lin_fwd(s->ao, (int64_t)d * take, Ry, d, s->w_proj, s->ldw_proj, d, s->conv1d, ws);
   g.bias = s->b_proj;
-  g.residual = s->x; g.ldres = d;
+  g.residual = s->x; g.ldres = (int64_t)d * take;
   g.drop = s->out_drop;
   g.out = s->y; g.ldo = d; g.out_dtype = AFFT_F32;
   if (!s->conv1d) g.b_packed = s->w_proj_pk;
@@ -161,28 +163,32 @@ extern "C" int afft_attn_sublayer_bwd(const afft_attn_sublayer_t* s, void* strea
   AFFT_CHECK(s && s->x && s->dy && s->dya && s->dao && s->dqkv && s->dxn && s->dx && s->ln_partial && s->xn && s->qkv && s->ao &&
              s->probs && s->mean && s->rstd, "attn_sublayer_bwd: null pointer");
   const int R = s->rows, d = s->d;
+  const int take = s->take > 1 ? s->take : 1, Ry = R / take;      // see afft_attn_sublayer_fwd: dy / dya are [Ry, d]
+  AFFT_CHECK(take == 1 || (take == s->L && Ry % 64 == 0), "attn_sublayer_bwd: take must be L, with rows / take a multiple of 64");
   const Ws ws = {s->gemm_ws, s->gemm_ws_bytes}, wsa = {aux == st ? s->gemm_ws : s->gemm_ws_aux, aux == st ? s->gemm_ws_bytes : s->gemm_ws_aux_bytes};
   const bool od = has_drop(s->out_drop);
   if (!s->dya_ready) {
-    TRY(zero_row_tail(s->dya, R, d, st));
-    TRY(afft_cast(s->dy, d, R, d, s->dya, d, AFFT_BF16, nullptr, 0, 0, od ? &s->out_drop : nullptr, st));
+    TRY(zero_row_tail(s->dya, Ry, d, st));
+    TRY(afft_cast(s->dy, d, Ry, d, s->dya, d, AFFT_BF16, nullptr, 0, 0, od ? &s->out_drop : nullptr, st));
   }
-  TRY(zero_row_tail(s->dao, R, d, st));
+  if (take > 1) {      // the projection's data gradient lands on every take-th row of dao: the rows between are zero
+    if (hipMemsetAsync(s->dao, 0, (size_t)pad64(R) * d * 2, st) != hipSuccess) { afft_set_error("sublayer: memset failed"); (void)hipGetLastError(); return 2; }
+  } else TRY(zero_row_tail(s->dao, R, d, st));
   TRY(zero_row_tail(s->dqkv, R, 3 * d, st));
   // A weight gradient with a fused update rewrites the weight's bf16 image: it is enqueued BEHIND the data-gradient GEMM that
   // reads that image (one event later than the plain form, which starts beside it).
   auto side_proj = [&]() -> int {
     TRY(stream_follows(aux, st));
-    TRY(wgrad(s->dya, d, d, s->ao, d, d, R, s->conv1d, s->g_w_proj, s->acc_w_proj, wsa, aux, s->sgd_w_proj));
+    TRY(wgrad(s->dya, d, d, s->ao, (int64_t)d * take, d, Ry, s->conv1d, s->g_w_proj, s->acc_w_proj, wsa, aux, s->sgd_w_proj));
     if (s->g_b_proj) {
-      if (od) TRY(afft_colsum(s->dya, d, AFFT_BF16, R, d, s->g_b_proj, s->acc_b_proj, wsa.p, wsa.bytes, aux));
-      else TRY(afft_colsum(s->dy, d, AFFT_F32, R, d, s->g_b_proj, s->acc_b_proj, wsa.p, wsa.bytes, aux));
+      if (od) TRY(afft_colsum(s->dya, d, AFFT_BF16, Ry, d, s->g_b_proj, s->acc_b_proj, wsa.p, wsa.bytes, aux));
+      else TRY(afft_colsum(s->dy, d, AFFT_F32, Ry, d, s->g_b_proj, s->acc_b_proj, wsa.p, wsa.bytes, aux));
     }
     return 0;
   };
   if (!s->sgd_w_proj) TRY(side_proj());
-  afft_gemm_t g = lin_dgrad(s->dya, d, R, d, s->w_proj, s->ldw_proj, d, s->conv1d, ws);
-  g.out = s->dao; g.ldo = d; g.out_dtype = AFFT_BF16;
+  afft_gemm_t g = lin_dgrad(s->dya, d, Ry, d, s->w_proj, s->ldw_proj, d, s->conv1d, ws);
+  g.out = s->dao; g.ldo = (int64_t)d * take; g.out_dtype = AFFT_BF16;
   TRY(afft_gemm(&g, st));
   if (s->sgd_w_proj) TRY(side_proj());
   const char* q = (const char*)s->qkv;
@@ -200,8 +206,8 @@ extern "C" int afft_attn_sublayer_bwd(const afft_attn_sublayer_t* s, void* strea
   g.out = s->dxn; g.ldo = d; g.out_dtype = AFFT_BF16;
   TRY(afft_gemm(&g, st));
   if (s->sgd_w_qkv) TRY(side_qkv());
-  return afft_layernorm_bwd(s->dxn, d, AFFT_BF16, s->x, d, s->ln_w, s->mean, s->rstd, R, d, s->dy, s->dx, d, s->dx_bf16, s->up_drop,
-                            s->g_ln_w, s->g_ln_b, s->acc_ln, s->up_dcol, 0, s->ln_partial, st);
+  return afft_layernorm_bwd_take(s->dxn, d, AFFT_BF16, s->x, d, s->ln_w, s->mean, s->rstd, R, d, s->dy, d, take, s->dx, d, s->dx_bf16,
+                                 s->up_drop, s->g_ln_w, s->g_ln_b, s->acc_ln, s->up_dcol, 0, s->ln_partial, st);
 }
 
 // ======================================================================================= MLP sub-layer

@@ -13,6 +13,7 @@ import ctypes as C
 import threading
 from typing import NamedTuple, List, Optional, Tuple
 
+import os
 import torch
 
 from . import _lib as L_, ops, runtime as rt
@@ -526,6 +527,15 @@ def _composite_ok(x: Tensor, pre_ln: bool, *widths: int, f16x2: bool = True) -> 
             and x.stride(0) == x.shape[1] and all(w % 64 == 0 for w in widths))
 
 
+def attn_take_ok(x: Tensor, L: int, H: int, pre_ln: bool = True) -> bool:
+    """AttnSublayer(take=L) -- the output projection on token 0 of every sequence only -- exists on the composite path, for row
+    counts whose quotient by L is a multiple of 64 (the weight-gradient GEMM reduces over whole 64-row K-tiles of the strided rows)"""
+    R, d = x.shape
+    hd = d // H
+    return (L > 1 and R % L == 0 and (R // L) % 64 == 0 and _composite_ok(x, pre_ln, d) and os.environ.get("AFFT_ATTN_TAKE", "1") != "0"
+            and (rt.precision() != "fp16x2" or (L <= 64 and hd % 64 == 0 and hd <= 1024)))
+
+
 def _lo8_ok(conv1d: bool, R: int, *shapes) -> bool:
     """the fp8 lo pass for a sub-layer: nn.Linear weights and every (N, K) of its GEMMs on the 256x256 kernel (afft_gemm_lo8_ok)"""
     if conv1d or not rt.lo8():
@@ -659,10 +669,11 @@ def _ln_partial(rows: int, d: int, dev) -> Tensor:
     return torch.empty(L_.lib().afft_layernorm_bwd_nparts(rows) * 3 * d, dtype=torch.float32, device=dev)
 
 
-def _attn_fwd_c(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, eps, conv1d, scale, drop, probs_out=None):
+def _attn_fwd_c(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, eps, conv1d, scale, drop, probs_out=None, take=0):
     R, d = x.shape
     dev = x.device
     nseq, pr = R // L, rt.pad64(R)
+    Ry = R // take if take else R        # rows that leave the sub-layer
     ctx.up = _upstream_of(x)
     f16x2 = rt.precision() == "fp16x2"
     grad = any(ctx.needs_input_grad)
@@ -676,17 +687,18 @@ def _attn_fwd_c(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, ep
         xn = qkv = ao = None
     stats = torch.empty(2, R, dtype=torch.float32, device=dev)
     probs = probs_out if probs_out is not None else torch.empty(nseq, H, L, L, dtype=torch.float32, device=dev)
-    y = torch.empty(R, d, dtype=torch.float32, device=dev)
+    y = torch.empty(Ry, d, dtype=torch.float32, device=dev)
     scale = float(scale) if scale else float(d // H) ** -0.5
     mk, per = _mask_args(mask)
     s = L_.AttnSublayer()
     s.rows, s.d, s.L, s.H, s.conv1d, s.mask, s.mask_period, s.eps, s.scale = R, d, L, H, int(conv1d), mk, per, eps, scale
+    s.take = int(take)
     s.x, s.ln_w, s.ln_b = x.data_ptr(), _ptr(ln_w), _ptr(ln_b)
     if f16x2:
         s.f16x2 = 1
         s.w_qkv, s.ldw_qkv = _img_h(w_qkv)
         s.w_proj, s.ldw_proj = _img_h(w_proj)
-        if _lo8_ok(conv1d, R, (3 * d, d), (d, d)):      # second pass on the block-scaled fp8 MFMA: e4m3 lo planes of xn / ao, e4m3 weight images
+        if _lo8_ok(conv1d, R, (3 * d, d)) and _lo8_ok(conv1d, Ry, (d, d)):      # second pass on the block-scaled fp8 MFMA: e4m3 lo planes of xn / ao, e4m3 weight images
             s.f16x2 = 2
             s.w_qkv8, s.w_proj8 = rt.weight_f8(w_qkv).data_ptr(), rt.weight_f8(w_proj).data_ptr()
         base = planes.data_ptr()
@@ -696,7 +708,7 @@ def _attn_fwd_c(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, ep
     else:
         s.w_qkv, s.ldw_qkv = _img(w_qkv)
         s.w_proj, s.ldw_proj = _img(w_proj)
-        s.w_qkv_pk, s.w_proj_pk = _pk(w_qkv, conv1d, R), _pk(w_proj, conv1d, R)
+        s.w_qkv_pk, s.w_proj_pk = _pk(w_qkv, conv1d, R), _pk(w_proj, conv1d, Ry)
         s.xn, s.qkv, s.ao = xn.buf.data_ptr(), qkv.buf.data_ptr(), ao.buf.data_ptr()
     s.b_qkv, s.b_proj = _ptr(b_qkv), _ptr(b_proj)
     s.p_attn, s.k_attn = _attn_drop(drop)
@@ -711,6 +723,7 @@ def _attn_fwd_c(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, ep
     ctx.acts = (xn, qkv, ao, saved)
     ctx.cfg = (L, H, scale, conv1d, True, drop)
     ctx.mask = (mk, per)
+    ctx.take = int(take)
     ctx.composite = True
     ctx.mark_non_differentiable(probs)
     _note_output(y, od, b_proj)
@@ -732,6 +745,7 @@ def _attn_bwd_c(ctx, dy):
     scratch = torch.empty(pr * 6 * d, dtype=torch.bfloat16, device=dev)      # dya | dao | dqkv | dxn
     s = L_.AttnSublayer()
     s.rows, s.d, s.L, s.H, s.conv1d, s.eps, s.scale = R, d, L, H, int(conv1d), 0.0, scale
+    s.take = ctx.take
     s.mask, s.mask_period = ctx.mask
     s.x, s.ln_w = x.data_ptr(), _ptr(ln_w)
     s.w_qkv, s.ldw_qkv = _img(w_qkv)
@@ -1025,10 +1039,12 @@ class AttnSublayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, eps, conv1d, pre_ln=True, scale=None,
-                drop=None, probs_out=None):
+                drop=None, probs_out=None, take=0):
         """probs_out: fp32 [nseq, H, L, L] to write the attention maps into (the caller's slice of ONE buffer for all its blocks:
-        the SA-Fuser returns the stacked maps, models/fusion.py:144 -- no torch.stack copy of every block's maps per forward)"""
+        the SA-Fuser returns the stacked maps, models/fusion.py:144 -- no torch.stack copy of every block's maps per forward)
+        take = L: y is [nseq, d], token 0 of every sequence (attn_take_ok says whether this call can do that)"""
         R, d = x.shape
+        assert take in (0, L) and (not take or attn_take_ok(x, L, H, pre_ln)), "AttnSublayer: take needs the composite path (attn_take_ok)"
         nseq, hd = R // L, d // H
         dev = x.device
         ctx.composite = False
@@ -1039,7 +1055,7 @@ class AttnSublayer(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         # fp16x2: the attention core on hi + lo planes exists on the MFMA path only (L <= 64, head dimension a multiple of 64)
         if _composite_ok(x, pre_ln, d) and (rt.precision() != "fp16x2" or (L <= 64 and hd % 64 == 0 and hd <= 1024)):
-            return _attn_fwd_c(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, eps, conv1d, scale, drop, probs_out)
+            return _attn_fwd_c(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, eps, conv1d, scale, drop, probs_out, take)
         ctx.up = _upstream_of(x) if pre_ln else None
         mean, rstd = _stats(R if pre_ln else 0, dev)
         if pre_ln:
@@ -1070,9 +1086,9 @@ class AttnSublayer(torch.autograd.Function):
         if dy is None:          # (set_materialize_grads(False)) nobody used y
             _drop_shadow()      # a hand-over meant for this backward and queued notifications must not outlive it
             flush_ready()
-            return (None,) * 16
+            return (None,) * 17
         if ctx.composite:
-            return _attn_bwd_c(ctx, dy)
+            return _attn_bwd_c(ctx, dy) + (None,)
         x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, mean, rstd, probs = ctx.saved_tensors
         xn, qkv, ao = (_b16(t) for t in ctx.acts)
         L, H, scale, conv1d, pre_ln, drop = ctx.cfg

@@ -199,10 +199,17 @@ class Block(nn.Module):
         DropPath group index is the same in both."""
         a = self.attn
         dp = _dp_rate(self.drop_path)
-        x2, probs = F_.AttnSublayer.apply(x2, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias,
-                                          a.proj.weight, a.proj.bias, L, a.num_heads, mask, self.norm1.eps, False,
-                                          True, a.scale, D_.with_path(a.drop_cfg(), dp, L), probs_out)
-        x0 = F_.TakeRows.apply(x2, L)
+        if F_.attn_take_ok(x2, L, a.num_heads):
+            # the output projection, its residual / bias / dropout and everything behind them in backward on the token-0 rows only
+            # (4/5 of the projection's forward, data-gradient and weight-gradient work at S = 5 never reaches an output)
+            x0, probs = F_.AttnSublayer.apply(x2, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias,
+                                              a.proj.weight, a.proj.bias, L, a.num_heads, mask, self.norm1.eps, False,
+                                              True, a.scale, D_.with_path(a.drop_cfg(), dp, 1), probs_out, L)
+        else:
+            x2, probs = F_.AttnSublayer.apply(x2, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias,
+                                              a.proj.weight, a.proj.bias, L, a.num_heads, mask, self.norm1.eps, False,
+                                              True, a.scale, D_.with_path(a.drop_cfg(), dp, L), probs_out)
+            x0 = F_.TakeRows.apply(x2, L)
         m = self.mlp.mlp
         x0 = F_.MLPSublayer.apply(x0, self.norm2.weight, self.norm2.bias, m[0].weight, m[0].bias, m[2].weight,
                                   m[2].bias, self.norm2.eps, "erf", False, True,

@@ -244,6 +244,13 @@ int afft_attention_bwd(const void* dout, int64_t lddo, const void* q, int64_t ld
                        int32_t H, int32_t hd, float scale, float drop_p, uint32_t drop_key, void* dq, int64_t lddq,
                        void* dk, int64_t lddk, void* dv, int64_t lddv, void* stream);
 
+/* afft_layernorm_bwd whose incoming residual gradient dx_in is [rows / in_take, d] (row pitch lddx_in) and belongs to rows 0, in_take,
+ * 2 in_take, ..: the other rows take no residual gradient (afft_attn_sublayer_t.take). */
+int afft_layernorm_bwd_take(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* w, const float* mean,
+                            const float* rstd, int32_t rows, int32_t d, const float* dx_in, int64_t lddx_in, int32_t in_take,
+                            float* dx_out, int64_t lddx, void* dx_bf16, const afft_dropout_t* copy_drop, float* dw, float* db,
+                            int32_t accumulate, float* dcol, int32_t dcol_accumulate, float* partial, void* stream);
+
 /* ------------------------------------------------------------------ losses (common/runner.py:13-37,112-168)
  * Softmax cross-entropy over C classes, fwd + bwd in one pass.
  *   hard: labels int64[rows], label -1 = ignored row (loss 0, grad 0); any other label outside [0, C) makes the row's
@@ -481,6 +488,12 @@ typedef struct {       /* y = x + drop(proj(attention(split(qkv(LN(x))))))      
    * afft_gemm_lo8_ok says yes): w_qkv8 / w_proj8 = the weights' e4m3 byte images (row pitch ldw_* bytes); the lo planes of xn and ao are
    * e4m3 BYTE planes (rows_pad * d bytes, directly behind their hi planes); qkv keeps its fp16 lo plane (the attention kernel reads it). */
   const void* w_qkv8; const void* w_proj8;
+  /* take > 1: only the first token of every `take` = L rows leaves the sub-layer (the SA-Fuser's last block, models/fusion.py:362-365
+   * returns token 0 of every frame): attention runs over all rows, the output projection (+ residual, bias, dropout) on rows
+   * 0, take, 2 take, .. only; y, dy and dya are [rows / take, d].  Backward: the projection's data gradient lands on those rows of
+   * dao (the rest zero), its weight gradient reduces over rows / take rows, the residual gradient enters the LayerNorm backward on
+   * those rows only.  Needs rows / take % 64 == 0; f16x2 = 2 only if the projection at rows / take rows passes afft_gemm_lo8_ok. */
+  int32_t take;
 } afft_attn_sublayer_t;
 int afft_attn_sublayer_fwd(const afft_attn_sublayer_t* s, void* stream);
 int afft_attn_sublayer_bwd(const afft_attn_sublayer_t* s, void* stream, void* aux_stream);

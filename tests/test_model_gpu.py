@@ -1509,3 +1509,48 @@ def test_weight_images_follow_a_state_dict_load():
             torch.cuda.empty_cache()
     finally:
         afft_amd.set_precision("bf16")
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16x2"])
+@pytest.mark.parametrize("dim,heads,S,nseq", [(256, 4, 5, 128), (2048, 4, 5, 1024)])
+def test_last_block_projection_on_token_rows_equals_all_rows(precision, dim, heads, S, nseq):
+    """AttnSublayer(take = S) -- the SA-Fuser's last block (models/fusion.py:362-365 keeps token 0 of every frame): attention over all
+    rows, the output projection / residual / everything behind them in backward on the token-0 rows only -- against the full-row
+    sub-layer followed by the row selection: the rows that leave agree to GEMM-tile rounding, and so does every gradient (input,
+    LayerNorm, qkv and projection weights and biases; the dropped rows contribute exact zeros in the full-row run).  cfg2's own
+    geometry (1024 frames x 5 tokens x 2048) and a small one; a row count whose quotient is not a multiple of 64 takes the old path."""
+    import afft_amd
+    from afft_amd import functional as F_, runtime as rt
+    from afft_amd.models.transformerblock import Block
+    afft_amd.set_precision(precision)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    blk = Block(dim, heads, mlp_ratio=2.0, qkv_bias=True).to(dev).eval()
+    x = (torch.randn(nseq * S, dim, generator=torch.Generator().manual_seed(4)) * 0.5).to(dev)
+    assert F_.attn_take_ok(x, S, heads) and not F_.attn_take_ok(x[:S * 65], S, heads)
+    gy = torch.randn(nseq, dim, generator=torch.Generator().manual_seed(5)).to(dev)
+    a = blk.attn
+    res = {}
+    for take in (S, 0):
+        for p in blk.parameters():
+            p.grad = None
+        rt.SINK.begin_step()
+        xi = x.clone().requires_grad_(True)
+        y, probs = F_.AttnSublayer.apply(xi, blk.norm1.weight, blk.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
+                                         S, heads, "none", blk.norm1.eps, False, True, a.scale, None, None, take)
+        if not take:
+            y = F_.TakeRows.apply(y, S)
+        assert y.shape == (nseq, dim)
+        (y * gy).sum().backward()
+        rt.SINK.finish_step(list(blk.parameters()))
+        torch.cuda.synchronize()
+        res[take] = (y.detach().clone(), probs.clone(), xi.grad.clone(),
+                     {k: p.grad.clone() for k, p in blk.named_parameters() if p.grad is not None})
+    afft_amd.set_precision("bf16")
+    (y1, p1, dx1, g1), (y0, p0, dx0, g0) = res[S], res[0]
+    assert rel_l2(p1, p0) < 1e-5      # bit-equal unless the two runs differ in where the fp8 lo pass is eligible (fp16x2)
+    assert rel_l2(y1, y0) < 1e-5, rel_l2(y1, y0)
+    assert rel_l2(dx1, dx0) < 5e-3, rel_l2(dx1, dx0)
+    assert set(g1) == set(g0) and {"attn.proj.weight", "attn.proj.bias", "attn.qkv.weight", "norm1.weight"} <= set(g1)
+    for k in g0:
+        assert rel_l2(g1[k], g0[k]) < 5e-3, (k, rel_l2(g1[k], g0[k]))
