@@ -50,6 +50,23 @@ struct AfftKernelScope {
   }
 };
 
+// cross-stream ordering: "everything enqueued on `from` so far happens before what is enqueued on `to` next"
+static inline int afft_stream_follows(hipStream_t to, hipStream_t from) {
+  if (to == from) return 0;
+  static thread_local hipEvent_t ev = nullptr;     // re-recording is safe: a wait captures the record that precedes it
+  if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+    afft_set_error("hipEventCreate failed");
+    (void)hipGetLastError();
+    return 2;
+  }
+  if (hipEventRecord(ev, from) != hipSuccess || hipStreamWaitEvent(to, ev, 0) != hipSuccess) {
+    afft_set_error("event record / wait failed");
+    (void)hipGetLastError();
+    return 2;
+  }
+  return 0;
+}
+
 #define AFFT_LAUNCH_CHECK()                                                     \
   do {                                                                          \
     hipError_t e_ = hipGetLastError();                                          \

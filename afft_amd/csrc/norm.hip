@@ -333,6 +333,7 @@ extern "C" int afft_layernorm_bwd_take(const void* dy, int64_t lddy, int32_t dy_
 #undef LN_BWD
   AFFT_LAUNCH_CHECK();
   if (dw || db || dcol) {
+    // (round 5: this launch on the auxiliary stream -- it feeds the optimizer, not the chain -- measured 0.2 ms per step SLOWER)
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((nslab * d + 63) / 64), dim3(64 * LNR_PL), 0, stream, partial, grid, d, nslab, dw, db,
                        accumulate, dcol, dcol_accumulate);
     AFFT_LAUNCH_CHECK();

@@ -6,21 +6,7 @@
 namespace {
 
 // ---- cross-stream ordering: "everything enqueued on `from` so far happens before what is enqueued on `to` next"
-int stream_follows(hipStream_t to, hipStream_t from) {
-  if (to == from) return 0;
-  static thread_local hipEvent_t ev = nullptr;     // re-recording is safe: a wait captures the record that precedes it
-  if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
-    afft_set_error("sublayer: hipEventCreate failed");
-    (void)hipGetLastError();
-    return 2;
-  }
-  if (hipEventRecord(ev, from) != hipSuccess || hipStreamWaitEvent(to, ev, 0) != hipSuccess) {
-    afft_set_error("sublayer: event record / wait failed");
-    (void)hipGetLastError();
-    return 2;
-  }
-  return 0;
-}
+int stream_follows(hipStream_t to, hipStream_t from) { return afft_stream_follows(to, from); }
 
 #define TRY(expr) do { if (int rc_ = (expr)) return rc_; } while (0)
 
@@ -306,8 +292,8 @@ extern "C" int afft_mlp_sublayer_bwd(const afft_mlp_sublayer_t* s, void* stream_
   g.out = s->dxn; g.ldo = d; g.out_dtype = AFFT_BF16;
   TRY(afft_gemm(&g, st));
   if (s->sgd_w1) TRY(side_fc1());
-  return afft_layernorm_bwd(s->dxn, d, AFFT_BF16, s->x, d, s->ln_w, s->mean, s->rstd, R, d, s->dy, s->dx, d, s->dx_bf16, s->up_drop,
-                            s->g_ln_w, s->g_ln_b, s->acc_ln, s->up_dcol, 0, s->ln_partial, st);
+  return afft_layernorm_bwd_take(s->dxn, d, AFFT_BF16, s->x, d, s->ln_w, s->mean, s->rstd, R, d, s->dy, d, 1, s->dx, d, s->dx_bf16, s->up_drop,
+                                 s->g_ln_w, s->g_ln_b, s->acc_ln, s->up_dcol, 0, s->ln_partial, st);
 }
 
 // ======================================================================================= cross-attention sub-layer

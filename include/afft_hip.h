@@ -245,7 +245,7 @@ int afft_attention_bwd(const void* dout, int64_t lddo, const void* q, int64_t ld
                        void* dk, int64_t lddk, void* dv, int64_t lddv, void* stream);
 
 /* afft_layernorm_bwd whose incoming residual gradient dx_in is [rows / in_take, d] (row pitch lddx_in) and belongs to rows 0, in_take,
- * 2 in_take, ..: the other rows take no residual gradient (afft_attn_sublayer_t.take). */
+ * 2 in_take, ..: the other rows take no residual gradient (afft_attn_sublayer_t.take; in_take = 1: every row). */
 int afft_layernorm_bwd_take(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* w, const float* mean,
                             const float* rstd, int32_t rows, int32_t d, const float* dx_in, int64_t lddx_in, int32_t in_take,
                             float* dx_out, int64_t lddx, void* dx_bf16, const afft_dropout_t* copy_drop, float* dw, float* db,
