@@ -1,10 +1,14 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for i in 1 2 3 4; do
-timeout 300 python bench.py --no-ek100 --no-power --no-cpu-baseline --no-parity-mode --no-reference-loop --steps 40 --warmup 5 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bf16 new', d['value'], d['ms_per_step'])"
-AFFT_LIB=$GRAFT_REPO_ROOT/tools/experiments/libafft_prev.so timeout 300 python bench.py --no-ek100 --no-power --no-cpu-baseline --no-parity-mode --no-reference-loop --steps 40 --warmup 5 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bf16 prev lib', d['value'], d['ms_per_step'])"
-done
+cat > /tmp/st.py <<'PY'
+import os, sys
+sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+from tools.gemm_bench import bench
+name = os.environ.get("AFFT_LIB", "default").split("libafft_hip")[-1]
+for lay, M, N, K in (("nt", 5120, 8192, 2048), ("nt", 5120, 2048, 8192), ("nt", 8192, 8192, 8192), ("nt", 1024, 6144, 2048), ("nn", 5120, 8192, 2048), ("tn", 2048, 8192, 5120), ("tn", 8192, 8192, 8192)):
+    t = min(bench(lay, M, N, K, 30)[0] for _ in range(3))
+    tiles = ((M + 255) // 256) * ((N + 255) // 256); rounds = (tiles + 255) // 256
+    print(name, lay, M, N, K, "%.1f us %.0f TF  | %.2f us per K-tile and round" % (t * 1e3, 2.0 * M * N * K / t / 1e9, t * 1e3 / (rounds * K / 64)))
+PY
+python /tmp/st.py 2>&1 | grep -v amdgpu.ids
+AFFT_LIB=$GRAFT_REPO_ROOT/afft_amd/lib/libafft_hip_sametile.so python /tmp/st.py 2>&1 | grep -v amdgpu.ids

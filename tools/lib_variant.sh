@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/../afft_amd/csrc"
 name=$1; shift
 mkdir -p build_var/$name
-for f in gemm gemm_pp gemm_w4 norm attention attention_mfma loss elementwise sublayer; do
+for f in gemm gemm_pp gemm_bd norm attention attention_mfma loss elementwise sublayer; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 "$@" -c $f.hip -o build_var/$name/$f.o &
 done
 wait
