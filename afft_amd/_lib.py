@@ -176,6 +176,7 @@ _SIGS = {
     "afft_cast": ([vp, i64, i32, i32, vp, i64, i32, vp, i64, i32, C.POINTER(Dropout), vp], C.c_int),
     "afft_assemble_tokens": ([C.POINTER(vp), C.POINTER(i64), i32, vp, i64, vp, i32, i32, i32, vp, vp], C.c_int),
     "afft_colsum": ([vp, i64, i32, i32, i32, vp, i32, vp, i64, vp], C.c_int),
+    "afft_zero": ([vp, i64, vp], C.c_int),
     "afft_gather_frames": ([vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp], C.c_int),
     "afft_add_rows_periodic": ([vp, i64, vp, i64, i32, i32, i32, vp, i64, vp], C.c_int),
     "afft_reduce_rows_periodic": ([vp, i64, i32, i32, i32, vp, i64, vp], C.c_int),

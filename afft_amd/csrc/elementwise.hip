@@ -610,6 +610,21 @@ extern "C" int afft_colsum(const void* src, int64_t lds_, int32_t dtype, int32_t
   return 0;
 }
 
+// zero fill by a kernel (16-byte stores): a hipMemsetAsync of this size inside a stream capture became a memset node that crashed
+// hipGraph instantiation on ROCm 7.0 depending on the buffer's address (found in round 5)
+__global__ __launch_bounds__(256) void zero16_kernel(uint4* __restrict__ p, int64_t n16) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) p[i] = make_uint4(0, 0, 0, 0);
+}
+extern "C" int afft_zero(void* p, int64_t bytes, void* stream_) {
+  AFFT_CHECK(p && bytes >= 0 && bytes % 16 == 0 && ((uintptr_t)p & 15) == 0, "afft_zero: a 16-byte aligned pointer and a multiple of 16 bytes");
+  if (bytes == 0) return 0;
+  const int64_t n16 = bytes / 16;
+  const int grid = (int)std::min<int64_t>((n16 + 255) / 256, 2048);
+  hipLaunchKernelGGL(zero16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, (uint4*)p, n16);
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int afft_gather_frames(float* out, int64_t out_clip_stride, int64_t out_frame_stride, int32_t clips, int32_t frames,
                                   int32_t C, int32_t nsrc, const float* const* src, const int64_t* clip_stride,
                                   const int64_t* frame_stride, const int32_t* lo, const int32_t* hi, const int32_t* off, void* stream_) {

@@ -61,12 +61,7 @@ int wgrad(const void* dy, int64_t lddy, int n_out, const void* x, int64_t ldx, i
 int zero_row_tail(void* buf, int rows, int64_t width, hipStream_t st) {
   const int pr = pad64(rows);
   if (pr == rows) return 0;
-  if (hipMemsetAsync((char*)buf + (size_t)rows * width * 2, 0, (size_t)(pr - rows) * width * 2, st) != hipSuccess) {
-    afft_set_error("sublayer: memset failed");
-    (void)hipGetLastError();
-    return 2;
-  }
-  return 0;
+  return afft_zero((char*)buf + (size_t)rows * width * 2, (int64_t)(pr - rows) * width * 2, st);      // widths are multiples of 64: 16-byte sizes
 }
 
 bool has_drop(const afft_dropout_t& d) { return d.p > 0.f || d.path_p > 0.f; }
@@ -158,7 +153,7 @@ extern "C" int afft_attn_sublayer_bwd(const afft_attn_sublayer_t* s, void* strea
     TRY(afft_cast(s->dy, d, Ry, d, s->dya, d, AFFT_BF16, nullptr, 0, 0, od ? &s->out_drop : nullptr, st));
   }
   if (take > 1) {      // the projection's data gradient lands on every take-th row of dao: the rows between are zero
-    if (hipMemsetAsync(s->dao, 0, (size_t)pad64(R) * d * 2, st) != hipSuccess) { afft_set_error("sublayer: memset failed"); (void)hipGetLastError(); return 2; }
+    TRY(afft_zero(s->dao, (int64_t)pad64(R) * d * 2, st));      // a kernel, not hipMemsetAsync: see afft_zero
   } else TRY(zero_row_tail(s->dao, R, d, st));
   TRY(zero_row_tail(s->dqkv, R, 3 * d, st));
   // A weight gradient with a fused update rewrites the weight's bf16 image: it is enqueued BEHIND the data-gradient GEMM that

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 from typing import Callable, Dict, List, Optional
 
+import os
 import torch
 import torch.distributed as dist
 
@@ -211,10 +212,13 @@ class GradReducer:
         self._launched = [False] * len(self.buckets)
         self._handles: List = []
         self._use_cuda = flat.flat_g.is_cuda
-        self.side_stream = torch.cuda.Stream() if self._use_cuda else None
+        dev_ = flat.flat_g.device
+        if self._use_cuda:
+            rt.aux_stream(dev_)      # exists before the streams below are drawn: they must differ from it (runtime.new_stream)
+        self.side_stream = rt.new_stream(dev_) if self._use_cuda else None
         # with a gradient exchange the per-bucket optimizer gets a stream of its own: on one stream bucket b+1's all-reduce
         # would queue behind bucket b's update and the two (xGMI-bound and HBM-bound) would never overlap each other
-        self.opt_stream = torch.cuda.Stream() if (self._use_cuda and self.comm) else None
+        self.opt_stream = rt.new_stream(dev_, self.side_stream) if (self._use_cuda and self.comm) else None
         self.flat_g16 = (torch.empty(flat.total, dtype=torch.bfloat16, device=flat.flat_g.device)
                          if (comm_dtype == "bf16" and self.comm) else None)
         self.on_bucket: Optional[Callable[[int, int, Tensor, float], None]] = None
@@ -742,7 +746,7 @@ class Trainer(_FusedEpilogue):
         self._graph = None
         # warm up ON the capture stream: the library keeps its split-K workspace per stream and would otherwise
         # allocate it (hipMalloc) inside the capture; also learns the bucket counts and sets the kernel attributes
-        cap = torch.cuda.Stream(device=self.flat.flat_p.device)
+        cap = rt.new_stream(self.flat.flat_p.device, self.reducer.side_stream, self.reducer.opt_stream)
         cap.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cap):
             for _ in range(max(warmup, 2)):

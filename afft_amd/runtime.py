@@ -388,12 +388,31 @@ _AUX_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 _OVERLAP_WGRAD = os.environ.get("AFFT_OVERLAP_WGRAD", "1") != "0"
 
 
+def new_stream(device, *others) -> "torch.cuda.Stream":
+    """A stream from torch's pool (32 per device, handed out round-robin: the 33rd request returns the first stream again) that is
+    none of `others` (streams or None) and not this device's auxiliary stream.  Two roles of one step on one HIP stream are legal
+    for eager work but not inside a capture: a stream that waits for its own alias made hip::Stream::EndCapture recurse until the
+    stack ran out (ROCm 7.0; found in round 5 once the test session had drawn enough streams for the capture stream to come back
+    as the auxiliary one)."""
+    import torch
+    idx = device.index if getattr(device, "index", None) is not None else torch.cuda.current_device()
+    taken = {s.cuda_stream for s in others if s is not None}
+    if idx in _AUX_STREAMS:
+        taken.add(_AUX_STREAMS[idx].cuda_stream)
+    taken.add(torch.cuda.current_stream(idx).cuda_stream)
+    for _ in range(64):
+        st = torch.cuda.Stream(device=idx)
+        if st.cuda_stream not in taken:
+            return st
+    raise RuntimeError("afft_amd.runtime.new_stream: torch's stream pool has no stream left that is distinct from %d others" % len(taken))
+
+
 def aux_stream(device) -> "torch.cuda.Stream":
     """Per-device side stream on which weight-gradient GEMMs run beside the data-gradient chain."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _AUX_STREAMS.get(idx)
     if st is None:
-        st = torch.cuda.Stream(device=idx)
+        st = new_stream(torch.device("cuda", idx))
         _AUX_STREAMS[idx] = st
     return st
 

@@ -341,6 +341,8 @@ int afft_assemble_tokens(const float* const* feats, const int64_t* ldf, int32_t 
  * them up in block order.  NULL: one workgroup per column strip walks all the rows (~1.5x the time on a [5120, 8192] input). */
 int afft_colsum(const void* src, int64_t lds, int32_t dtype, int32_t rows, int32_t cols, float* out,
                 int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+/* p[0 .. bytes) = 0 by a kernel (16-byte aligned, bytes % 16 == 0): usable inside a stream capture where a large hipMemsetAsync is not. */
+int afft_zero(void* p, int64_t bytes, void* stream);
 /* out[clip, t, 0..C) = sum over the (at most 4) sources k with lo[k] <= t < hi[k] of src[k][clip, t + off[k], 0..C), zeros where no
  * source covers t; every output element is written exactly once.  Strides in floats (multiples of 4; C % 4 == 0).  One launch for:
  * torch.cat along the frame axis (models/future_prediction.py:161-170 builds past_futures = [z_1, z_hat_2..] this way) and its backward
