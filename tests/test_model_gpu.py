@@ -1486,7 +1486,7 @@ def test_weight_images_follow_a_state_dict_load():
                 tr.step(feats, tgt, sub)
             torch.cuda.synchronize()
             if precision == "bf16":
-                assert sum(rt.packed_live(p) for _, p, _ in tr.flat.packed) >= 11
+                assert sum(rt.packed_live(p) for _, p, _ in tr.flat.packed) >= 10
             else:
                 assert tr.flat.flat_h16 is not None
             model.load_state_dict(state0)          # weights move under the images
