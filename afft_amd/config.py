@@ -91,10 +91,12 @@ BASELINE_CONFIGS = {
 }
 
 
-def gflop_per_clip(name_or_cfg, fwd_bwd: bool = True, executed: bool = False) -> float:
+def gflop_per_clip(name_or_cfg, fwd_bwd: bool = True, executed: bool = False, token_row_projection: bool = False) -> float:
     """Algorithmic FLOPs per clip (2*MAC), SURVEY.md 8(d) formulas = what the reference executes.
     executed=True: what this implementation executes with runtime.skip_dead_rows() on -- the SA-Fuser's last block runs its MLP
-    half on token 0 of every frame only (16 * T * (S - 1) * d^2 less; the other rows never reach an output)."""
+    half on token 0 of every frame only (16 * T * (S - 1) * d^2 less; the other rows never reach an output) and, with
+    token_row_projection (round 5: batches whose frame count is a multiple of 64 on the composite path, functional.attn_take_ok),
+    its attention output projection too (another 2 * T * (S - 1) * d^2)."""
     c = BASELINE_CONFIGS[name_or_cfg] if isinstance(name_or_cfg, str) else name_or_cfg
     md, d, D, T = c["modal_dims"], c["common_dim"], c.get("fp_inter_dim", 2048), c["T"]
     M = len(md)
@@ -105,6 +107,8 @@ def gflop_per_clip(name_or_cfg, fwd_bwd: bool = True, executed: bool = False) ->
         fl += depth * T * S * 24 * d * d + depth * T * 4 * S * S * d
         if executed and depth >= 1:
             fl -= T * (S - 1) * 16 * d * d
+            if token_row_projection:
+                fl -= T * (S - 1) * 2 * d * d
     elif c["fuser"] == "cm":       # M tokens per frame
         fl += depth * T * M * 24 * d * d + depth * T * 4 * M * M * d
     elif c["fuser"] == "tsa":      # one sequence of M*T tokens per clip

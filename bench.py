@@ -75,6 +75,15 @@ def parse():
     return args
 
 
+def _token_rows(args) -> bool:
+    """does the step project only the token-0 rows in the SA-Fuser's last block (functional.attn_take_ok: composite path, frames % 64 == 0)"""
+    from afft_amd.config import BASELINE_CONFIGS
+    import afft_amd
+    T = BASELINE_CONFIGS[args.config]["T"] if args.config in BASELINE_CONFIGS else 16
+    return (afft_amd.runtime.skip_dead_rows() and afft_amd.runtime.composite() and args.precision in ("bf16", "fp16x2")
+            and (args.batch * T) % 64 == 0 and os.environ.get("AFFT_ATTN_TAKE", "1") != "0")
+
+
 def make_inputs(cfg, B, T, rank, device, ncls=3806):
     g = torch.Generator().manual_seed(1234 + rank)
     feats = {m: torch.randn(B, T, C, 1, 1, 1, generator=g).to(device) for m, C in cfg["modal_dims"].items()}
@@ -446,7 +455,7 @@ def parity_side_measurements(args, device, feats, tgt, sub, c):
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / n
             from afft_amd.config import gflop_per_clip
-            useful = args.batch / dt * gflop_per_clip(args.config, fwd_bwd=True, executed=afft_amd.runtime.skip_dead_rows()) / 1e3   # TFLOP/s executed
+            useful = args.batch / dt * gflop_per_clip(args.config, fwd_bwd=True, executed=afft_amd.runtime.skip_dead_rows(), token_row_projection=_token_rows(args)) / 1e3   # TFLOP/s executed
             if mode == "bf16x3":
                 # three bf16 MFMA passes per product, forward and backward: fp32-grade gradients too (1.4e-5 / 2.8e-5)
                 passes, note = 3.0, "bf16x3: hi*hi + lo*hi + hi*lo on the bf16 MFMAs in every GEMM of the step"
@@ -495,7 +504,7 @@ def ek100_side_measurement(args, device):
         tr.step(feats, tgt, sub)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-    gf = gflop_per_clip("ek100", fwd_bwd=True, executed=afft_amd.runtime.skip_dead_rows())
+    gf = gflop_per_clip("ek100", fwd_bwd=True, executed=afft_amd.runtime.skip_dead_rows(), token_row_projection=_token_rows(args))
     tf = B / dt * gf / 1e3
     del tr, model
     torch.cuda.empty_cache()
@@ -817,7 +826,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     clips_s = world * B * args.steps / elapsed
     gf_ref = gflop_per_clip(args.config, fwd_bwd=True)             # what the reference executes per clip
-    gf = gflop_per_clip(args.config, fwd_bwd=True, executed=afft_amd.runtime.skip_dead_rows())    # what THIS step executes
+    gf = gflop_per_clip(args.config, fwd_bwd=True, executed=afft_amd.runtime.skip_dead_rows(), token_row_projection=_token_rows(args))    # what THIS step executes
 
     result = {
         "metric": "clips/sec (fwd+bwd) EK100 SA-Fuser 4-mod T=16", "value": round(clips_s, 2), "unit": "clips/s",
@@ -919,7 +928,7 @@ def main():
         lat.sort()
         result["fwd_p50_ms"] = round(lat[len(lat) // 2], 3)
         result["fwd_p50_samples"] = len(lat)
-        gff = gflop_per_clip(args.config, fwd_bwd=False, executed=afft_amd.runtime.skip_dead_rows())
+        gff = gflop_per_clip(args.config, fwd_bwd=False, executed=afft_amd.runtime.skip_dead_rows(), token_row_projection=_token_rows(args))
         fwd_tf = B * gff / (result["fwd_p50_ms"] * 1e-3) / 1e3
         passes = {"fp16x2": 2.0, "bf16x3": 3.0}.get(args.precision, 1.0)      # MFMA passes per product of the forward GEMMs
         peak_f = 157.3 if args.precision == "fp32" else PEAK_BF16_TFLOPS
