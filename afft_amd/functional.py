@@ -13,7 +13,6 @@ import ctypes as C
 import threading
 from typing import NamedTuple, List, Optional, Tuple
 
-import os
 import torch
 
 from . import _lib as L_, ops, runtime as rt
@@ -532,7 +531,7 @@ def attn_take_ok(x: Tensor, L: int, H: int, pre_ln: bool = True) -> bool:
     counts whose quotient by L is a multiple of 64 (the weight-gradient GEMM reduces over whole 64-row K-tiles of the strided rows)"""
     R, d = x.shape
     hd = d // H
-    return (L > 1 and R % L == 0 and (R // L) % 64 == 0 and _composite_ok(x, pre_ln, d) and os.environ.get("AFFT_ATTN_TAKE", "1") != "0"
+    return (L > 1 and R % L == 0 and (R // L) % 64 == 0 and _composite_ok(x, pre_ln, d)
             and (rt.precision() != "fp16x2" or (L <= 64 and hd % 64 == 0 and hd <= 1024)))
 
 

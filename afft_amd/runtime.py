@@ -173,14 +173,14 @@ def weight_f16(p: Tensor) -> Tensor:
     return img.h
 
 
-_LO8 = os.environ.get("AFFT_LO8", "1") != "0"
+_LO8 = True
 
 
 def lo8() -> bool:
     """'fp16x2' forward: run the second pass A_lo W of the big nn.Linear GEMMs on the block-scaled fp8 MFMA (afft_gemm_t.split3 = 3:
     A_lo and W as e4m3 bytes with constant block scales, twice the bf16 rate) instead of a second fp16 pass.  The term it computes is
     ~2^-12 of the product, so its 2^-4 operand rounding is ~2^-16 of the result -- below the fp16 rounding of the weight the mode
-    already carries.  AFFT_LO8=0 / set_lo8(False): both passes in fp16."""
+    already carries.  set_lo8(False): both passes in fp16."""
     return _LO8
 
 

@@ -81,7 +81,7 @@ def _token_rows(args) -> bool:
     import afft_amd
     T = BASELINE_CONFIGS[args.config]["T"] if args.config in BASELINE_CONFIGS else 16
     return (afft_amd.runtime.skip_dead_rows() and afft_amd.runtime.composite() and args.precision in ("bf16", "fp16x2")
-            and (args.batch * T) % 64 == 0 and os.environ.get("AFFT_ATTN_TAKE", "1") != "0")
+            and (args.batch * T) % 64 == 0)
 
 
 def make_inputs(cfg, B, T, rank, device, ncls=3806):

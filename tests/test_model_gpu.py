@@ -1554,3 +1554,44 @@ def test_last_block_projection_on_token_rows_equals_all_rows(precision, dim, hea
     assert set(g1) == set(g0) and {"attn.proj.weight", "attn.proj.bias", "attn.qkv.weight", "norm1.weight"} <= set(g1)
     for k in g0:
         assert rel_l2(g1[k], g0[k]) < 5e-3, (k, rel_l2(g1[k], g0[k]))
+
+
+def test_capture_stream_never_comes_back_as_the_auxiliary_stream():
+    """torch hands out 32 pooled streams per device round-robin.  With the pool positioned so that the NEXT draw is the auxiliary
+    stream's own HIP stream (what a long session does by itself), Trainer.capture() must still capture on a different one
+    (runtime.new_stream): a capture whose origin stream was also its auxiliary stream made hip::Stream::EndCapture recurse until the
+    stack ran out (round 5) -- without the guard this test takes the process down."""
+    import afft_amd
+    from afft_amd import dropout as D_, runtime as rt
+    from afft_amd.config import make_model_cfg
+    from afft_amd.models.base_model import BaseModel
+    from afft_amd.parallel import Trainer
+    afft_amd.set_precision("bf16")
+    rt.set_grad_mode("sink")
+    dev = torch.device("cuda:0")
+    aux = rt.aux_stream(dev)
+    others = [rt.new_stream(dev) for _ in range(70)]
+    assert all(s.cuda_stream not in (aux.cuda_stream, torch.cuda.current_stream().cuda_stream) for s in others)
+    mods = {"rgb": 256, "objects": 96, "audio": 256, "flow": 256}
+    B, T = 16, 16
+    g = torch.Generator().manual_seed(13)
+    feats = {m: torch.randn(B, T, C, 1, 1, 1, generator=g).to(dev) for m, C in mods.items()}
+    tgt = {"action": torch.randint(0, 97, (B,), generator=g).to(dev)}
+    sub = {"action": torch.randint(0, 97, (B, T, 1), generator=g).to(dev)}
+    torch.manual_seed(5)
+    model = BaseModel(make_model_cfg(mods, 256, 512, depth=2, fp_layers=2, fp_heads=4, drop=0.0), {"action": 97}, {}).to(dev).eval()
+    tr = Trainer(model, {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}, lr=0.01, bucket_elems=1 << 18)
+    assert tr.reducer.side_stream.cuda_stream != aux.cuda_stream
+    for _ in range(40):      # walk the pool until its next stream is the auxiliary one
+        if torch.cuda.Stream().cuda_stream == aux.cuda_stream:
+            break
+    for _ in range(31):
+        torch.cuda.Stream()
+    try:
+        tr.capture(feats, tgt, sub, warmup=2)
+        for _ in range(2):
+            loss, _ = tr.step(feats, tgt, sub)
+        torch.cuda.synchronize()
+        assert float(loss) == float(loss)
+    finally:
+        D_.disable_device_salt()
