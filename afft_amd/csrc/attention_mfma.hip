@@ -737,6 +737,9 @@ __global__ __launch_bounds__(256) void attn_bwd_sliced_kernel(const AttnArgs a) 
 
 }  // namespace
 
+#ifndef AFFT_ATTN_PL_LDS_KB
+#define AFFT_ATTN_PL_LDS_KB 48
+#endif
 // Returns 0 when launched, -1 when the shape is not handled by the MFMA path (caller falls back), >0 on error.
 int afft_attention_mfma(bool backward, const void* dout, int64_t lddo, const void* q, int64_t ldq, const void* k,
                         int64_t ldk, const void* v, int64_t ldv, float* probs, int nseq, int L, int H, int hd,
@@ -755,10 +758,13 @@ int afft_attention_mfma(bool backward, const void* dout, int64_t lddo, const voi
   int hc = hd;
   const int np = planes ? 2 : 1;       // fp16x2 forward: every operand tile is two planes
   size_t lds = (size_t)(backward ? 4 : 3) * np * 16 * NT * hd * 2;
-  if (lds > 160 * 1024) {
+  // planes (fp16x2 forward): the two-plane tiles of a whole head (96 KiB at hd = 512) leave ONE workgroup per CU, whose load -> barrier ->
+  // compute -> store runs with nothing beside it (2.75 TB/s); chunks that fit 48 KiB keep three workgroups per CU in flight
+  const size_t budget = (planes && !backward) ? (size_t)(AFFT_ATTN_PL_LDS_KB) * 1024 : (size_t)160 * 1024;
+  if (lds > budget) {
     hc = 0;
     for (int cand = hd / 2; cand >= 64; cand /= 2)
-      if (hd % cand == 0 && cand % 64 == 0 && (size_t)(backward ? 3 : 2) * np * 16 * NT * cand * 2 <= 160 * 1024) { hc = cand; break; }
+      if (hd % cand == 0 && cand % 64 == 0 && (size_t)(backward ? 3 : 2) * np * 16 * NT * cand * 2 <= budget) { hc = cand; break; }
     if (!hc) return -1;
     lds = (size_t)(backward ? 3 : 2) * np * 16 * NT * hc * 2;
   }

@@ -1,6 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-( bash tools/cfg_sweep.sh --no-parity-mode --no-reference-loop --no-power --no-ek100
-  for b in 16 128; do echo -n "B=$b "; CFGS=cfg2 bash tools/cfg_sweep.sh --batch $b --no-parity-mode --no-reference-loop --no-power --no-ek100; done
-  echo -n "fp16x2 "; CFGS="cfg2 ek100 cfg5" bash tools/cfg_sweep.sh --precision fp16x2 --no-parity-mode --no-reference-loop --no-power --no-ek100 ) > gpurun_out/r05_configs.txt 2>&1
-cat gpurun_out/r05_configs.txt
+timeout 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "attention" 2>&1 | tail -2
+for i in 1 2; do for v in "" _pl160 _pl32; do
+AFFT_LIB=$GRAFT_REPO_ROOT/afft_amd/lib/libafft_hip$v.so timeout 300 python bench.py --precision fp16x2 --no-ek100 --no-power --no-cpu-baseline --no-parity-mode --no-reference-loop --no-roofline --steps 30 --warmup 5 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('fp16x2 lib$v', d['value'], d['ms_per_step'], d.get('fwd_p50_ms'))"; done; done
