@@ -25,7 +25,7 @@ class Dropout(C.Structure):
 
 class SgdFused(C.Structure):      # afft_sgd_fused_t
     _fields_ = [("p", vp), ("buf", vp), ("p_bf16", vp), ("lr", f32), ("mom", f32), ("wd", f32), ("gscale", f32), ("first_step", i32),
-                ("p_pk16", vp), ("p_f16", vp), ("p_f8", vp)]
+                ("p_pk16", vp), ("p_f16", vp), ("p_f8", vp), ("ok", vp)]
 
 
 SgdP = C.POINTER(SgdFused)
@@ -167,6 +167,7 @@ _SIGS = {
                             vp, i64, vp, i64, vp, i64, vp], C.c_int),
     "afft_softmax_ce": ([vp, i64, i32, i32, vp, vp, i64, vp, f32, vp, vp, vp, i64, i32, vp, vp], C.c_int),
     "afft_loss_reduce": ([C.POINTER(vp), C.POINTER(i64), C.POINTER(f32), i32, vp, vp, vp], C.c_int),
+    "afft_loss_reduce_bwd_ok": ([C.POINTER(vp), C.POINTER(i64), C.POINTER(f32), i32, vp, vp, vp, vp], C.c_int),
     "afft_loss_reduce_bwd": ([C.POINTER(vp), C.POINTER(i64), C.POINTER(f32), i32, vp, vp], C.c_int),
     "afft_layernorm_bwd_take": ([vp, i64, i32, vp, i64, vp, vp, vp, i32, i32, vp, i64, i32, vp, i64, vp, vp, vp, vp, i32, vp, i32, vp, vp], C.c_int),
     "afft_softmax_ce_frames": ([vp, i64, i64, i32, i32, i32, vp, vp, i64, vp, f32, vp, vp, i64, i64, i32, vp, vp], C.c_int),
@@ -182,8 +183,8 @@ _SIGS = {
     "afft_reduce_rows_periodic": ([vp, i64, i32, i32, i32, vp, i64, vp], C.c_int),
     "afft_sgd_nesterov": ([vp, vp, i32, vp, vp, i64, f32, f32, f32, f32, vp, i32, vp], C.c_int),
     "afft_sgd_nesterov_runs": ([vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, i32, vp], C.c_int),
-    "afft_sgd_nesterov2": ([vp, vp, i32, vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, i32, vp], C.c_int),
-    "afft_sgd_nesterov_runs2": ([vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, i32, vp], C.c_int),
+    "afft_sgd_nesterov2": ([vp, vp, i32, vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, i32, vp, vp], C.c_int),
+    "afft_sgd_nesterov_runs2": ([vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, i32, vp, vp], C.c_int),
     "afft_sumsq": ([vp, i32, i64, f32, vp, vp, i64, vp], C.c_int),
     "afft_group_sum": ([vp, i32, i32, i64, f32, vp, vp], C.c_int),
     "afft_set_dropout_salt": ([vp], C.c_int),

@@ -262,7 +262,7 @@ __device__ __forceinline__ void sgd_update(float& p, float& buf, float g, float 
   buf = bb;
   p = __fmaf_rn(-lr, (flags & AFFT_SGD_PLAIN_MOMENTUM) ? bb : __fmaf_rn(mom, bb, gg), p);
 }
-struct SgdEpi { float* p; float* buf; bf16_t* p16; float lr, mom, wd, gscale; int first; bf16_t* p16k; bf16_t* p16h; unsigned char* p8; };   // p16h: fp16 image (row-major, like p16); p8: e4m3(2^8 p) bytes
+struct SgdEpi { float* p; float* buf; bf16_t* p16; float lr, mom, wd, gscale; int first; bf16_t* p16k; bf16_t* p16h; unsigned char* p8; const float* ok; };   // p16h: fp16 image (row-major, like p16); p8: e4m3(2^8 p) bytes
 // element offset of the 8-element fragment that holds W[m][n .. n + 7] (n % 8 == 0) in the fragment-packed image of a [rows, ld] weight
 // (afft_pack_weight, include/afft_hip.h)
 __device__ __forceinline__ int64_t packed_frag(int m, int n, int64_t ld) {
@@ -433,6 +433,7 @@ __device__ __forceinline__ void epilogue4(const EpiParams& e, const DropParams& 
   if (m >= e.M || n >= e.N) return;
   const bool full = e.vec4 && (n + 3 < e.N);
   if (e.sgd.p) {     // fused optimizer: v is the gradient of p[m, n .. n+3]
+    if (e.sgd.ok && *e.sgd.ok == 0.f) return;      // non-finite loss: the step is a no-op (afft_sgd_fused_t.ok)
     const int64_t idx = (int64_t)m * e.ldo + n;
     if (full) {
       float pv[4], bv[4];
@@ -564,6 +565,7 @@ __device__ __forceinline__ void epilogue8(const EpiParams& e, const DropParams& 
     return;
   }
   if (e.sgd.p) {     // fused optimizer, 8 parameters per lane: 16-byte accesses throughout
+    if (e.sgd.ok && *e.sgd.ok == 0.f) return;      // non-finite loss: the step is a no-op (afft_sgd_fused_t.ok)
     const int64_t idx = (int64_t)m * e.ldo + n;
     float pv[8], bv[8];
     load8(e.sgd.p, idx, AFFT_F32, pv);

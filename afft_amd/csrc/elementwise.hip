@@ -356,7 +356,8 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const v
                                                   float* __restrict__ buf, bf16_t* __restrict__ p16, bf16_t* __restrict__ p16h,
                                                   unsigned char* __restrict__ p8, int64_t n, float lr,
                                                   float mom, float wd, float gscale, const float* __restrict__ gscale_dev,
-                                                  int first) {
+                                                  int first, const float* __restrict__ ok) {
+  if (ok && *ok == 0.f) return;            // non-finite loss: the step is a no-op (afft_sgd_fused_t.ok)
   if (gscale_dev) gscale *= *gscale_dev;   // clip coefficient computed on the device (afft_clip_coef)
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
     if (i + 3 < n) {
@@ -393,7 +394,8 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const v
 __global__ __launch_bounds__(256) void sgd_runs_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                                                        bf16_t* __restrict__ p16, bf16_t* __restrict__ p16h, unsigned char* __restrict__ p8,
                                                        const int64_t* __restrict__ runs, float lr, float mom,
-                                                       float wd, float gscale, int first) {
+                                                       float wd, float gscale, int first, const float* __restrict__ ok) {
+  if (ok && *ok == 0.f) return;
   const int64_t s0 = runs[2 * blockIdx.x], len = runs[2 * blockIdx.x + 1];
   for (int64_t j = s0 + threadIdx.x; j < s0 + len; j += 256) {
     float pj = p[j], bj = (first & AFFT_SGD_FIRST_STEP) ? 0.f : buf[j];
@@ -409,18 +411,18 @@ __global__ __launch_bounds__(256) void sgd_runs_kernel(float* __restrict__ p, co
 }  // namespace
 
 extern "C" int afft_sgd_nesterov_runs2(float* p, const float* g, float* buf, void* p_bf16, void* p_f16, void* p_f8, const int64_t* runs, int32_t nruns,
-                                       float lr, float mom, float wd, float gscale, int32_t first_step, void* stream_) {
+                                       float lr, float mom, float wd, float gscale, int32_t first_step, const float* ok, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(p && g && buf && (runs || nruns == 0), "sgd_runs: null pointer");
   if (nruns <= 0) return 0;
   hipLaunchKernelGGL(sgd_runs_kernel, dim3(nruns), dim3(256), 0, stream, p, g, buf, (bf16_t*)p_bf16, (bf16_t*)p_f16, (unsigned char*)p_f8, runs, lr, mom, wd, gscale,
-                     first_step);
+                     first_step, ok);
   AFFT_LAUNCH_CHECK();
   return 0;
 }
 extern "C" int afft_sgd_nesterov_runs(float* p, const float* g, float* buf, void* p_bf16, const int64_t* runs, int32_t nruns,
                                       float lr, float mom, float wd, float gscale, int32_t first_step, void* stream_) {
-  return afft_sgd_nesterov_runs2(p, g, buf, p_bf16, nullptr, nullptr, runs, nruns, lr, mom, wd, gscale, first_step, stream_);
+  return afft_sgd_nesterov_runs2(p, g, buf, p_bf16, nullptr, nullptr, runs, nruns, lr, mom, wd, gscale, first_step, nullptr, stream_);
 }
 
 namespace {
@@ -1089,7 +1091,7 @@ extern "C" int afft_clip_coef(const float* sumsq, float max_norm, float* coef, f
 }
 
 extern "C" int afft_sgd_nesterov2(float* p, const void* g, int32_t g_dtype, float* buf, void* p_bf16, void* p_f16, void* p_f8, int64_t n, float lr,
-                                  float mom, float wd, float gscale, const float* gscale_dev, int32_t first_step, void* stream_) {
+                                  float mom, float wd, float gscale, const float* gscale_dev, int32_t first_step, const float* ok, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(p && g && buf, "sgd: null pointer");
   AFFT_CHECK(((uintptr_t)p & 15) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)buf & 15) == 0, "sgd: buffers must be 16-byte aligned");
@@ -1106,11 +1108,11 @@ extern "C" int afft_sgd_nesterov2(float* p, const void* g, int32_t g_dtype, floa
   }();
   if (blocks > max_blocks) blocks = max_blocks;
   hipLaunchKernelGGL(sgd_kernel, dim3((int)blocks), dim3(256), 0, stream, p, g, g_dtype, buf, (bf16_t*)p_bf16, (bf16_t*)p_f16, (unsigned char*)p_f8, n, lr, mom, wd,
-                     gscale, gscale_dev, first_step);
+                     gscale, gscale_dev, first_step, ok);
   AFFT_LAUNCH_CHECK();
   return 0;
 }
 extern "C" int afft_sgd_nesterov(float* p, const void* g, int32_t g_dtype, float* buf, void* p_bf16, int64_t n, float lr, float mom,
                                  float wd, float gscale, const float* gscale_dev, int32_t first_step, void* stream_) {
-  return afft_sgd_nesterov2(p, g, g_dtype, buf, p_bf16, nullptr, nullptr, n, lr, mom, wd, gscale, gscale_dev, first_step, stream_);
+  return afft_sgd_nesterov2(p, g, g_dtype, buf, p_bf16, nullptr, nullptr, n, lr, mom, wd, gscale, gscale_dev, first_step, nullptr, stream_);
 }

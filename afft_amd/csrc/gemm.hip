@@ -535,7 +535,7 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
   e.out2 = d->out2; e.ldo2 = d->ldo2; e.out2_dtype = d->out2_dtype;
   AFFT_CHECK(d->drop.p >= 0.f && d->drop.p < 1.f && d->drop.path_p >= 0.f && d->drop.path_p < 1.f, "afft_gemm: dropout p outside [0,1)");
   e.drop = make_drop(&d->drop);
-  e.sgd = SgdEpi{nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 1.f, 0, nullptr, nullptr, nullptr};
+  e.sgd = SgdEpi{nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 1.f, 0, nullptr, nullptr, nullptr, nullptr};
   if (d->sgd) {
     AFFT_CHECK(d->sgd->p && d->sgd->buf, "afft_gemm: fused update without parameter / momentum buffers");
     AFFT_CHECK(!d->accumulate && !d->bias && d->act == AFFT_ACT_NONE && !d->residual && !d->rowscale && !d->pre && !d->out2 &&
@@ -543,7 +543,7 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
     AFFT_CHECK(!d->sgd->p_pk16 || (d->ldo % 32 == 0 && d->M % 16 == 0 && ((uintptr_t)d->sgd->p_pk16 & 15) == 0),
                "afft_gemm: a fragment-packed image needs a [16 a, 32 b] weight");
     e.sgd = SgdEpi{d->sgd->p, d->sgd->buf, (bf16_t*)d->sgd->p_bf16, d->sgd->lr, d->sgd->mom, d->sgd->wd, d->sgd->gscale,
-                   d->sgd->first_step, (bf16_t*)d->sgd->p_pk16, (bf16_t*)d->sgd->p_f16, (unsigned char*)d->sgd->p_f8};
+                   d->sgd->first_step, (bf16_t*)d->sgd->p_pk16, (bf16_t*)d->sgd->p_f16, (unsigned char*)d->sgd->p_f8, d->sgd->ok};
   }
   auto ok4 = [](const void* p, int64_t ld, int dtype) {
     if (!p) return true;

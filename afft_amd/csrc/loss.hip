@@ -158,9 +158,12 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const LossTerms t, flo
   if (threadIdx.x == 0) *total = tot;
 }
 // its backward: g[i][:] = g_total * w[i] / n[i]
-__global__ __launch_bounds__(256) void loss_reduce_bwd_kernel(const LossTerms t, const float* __restrict__ g_total) {
+__global__ __launch_bounds__(256) void loss_reduce_bwd_kernel(const LossTerms t, const float* __restrict__ g_total,
+                                                              const float* __restrict__ total, float* __restrict__ ok) {
   const float go = g_total ? g_total[0] : 1.f;
   const int i = blockIdx.y;
+  // the first kernel of a backward pass: "is this step finite" for the optimizer kernels that follow it (afft_sgd_fused_t.ok)
+  if (ok && blockIdx.x == 0 && i == 0 && threadIdx.x == 0) *ok = (!total || isfinite(total[0])) && isfinite(go) ? 1.f : 0.f;
   if (!t.g[i] || t.n[i] <= 0) return;
   const float v = go * t.w[i] / (float)t.n[i];
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < t.n[i]; j += (int64_t)gridDim.x * 256) t.g[i][j] = v;
@@ -183,6 +186,11 @@ extern "C" int afft_loss_reduce(const float* const* x, const int64_t* n, const f
 
 extern "C" int afft_loss_reduce_bwd(float* const* g, const int64_t* n, const float* w, int32_t nterms, const float* g_total,
                                     void* stream_) {
+  return afft_loss_reduce_bwd_ok(g, n, w, nterms, g_total, nullptr, nullptr, stream_);
+}
+
+extern "C" int afft_loss_reduce_bwd_ok(float* const* g, const int64_t* n, const float* w, int32_t nterms, const float* g_total,
+                                       const float* total, float* ok, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   AFFT_CHECK(g && n && w, "loss_reduce_bwd: null pointer");
   AFFT_CHECK(nterms >= 1 && nterms <= 8, "loss_reduce_bwd: 1..8 terms (got %d)", nterms);
@@ -191,7 +199,7 @@ extern "C" int afft_loss_reduce_bwd(float* const* g, const int64_t* n, const flo
   int64_t nmax = 1;
   for (int i = 0; i < nterms; ++i) { t.g[i] = g[i]; t.n[i] = n[i]; t.w[i] = w[i]; nmax = n[i] > nmax ? n[i] : nmax; }
   const int gx = (int)((nmax + 255) / 256 > 64 ? 64 : (nmax + 255) / 256);
-  hipLaunchKernelGGL(loss_reduce_bwd_kernel, dim3(gx, nterms), dim3(256), 0, stream, t, g_total);
+  hipLaunchKernelGGL(loss_reduce_bwd_kernel, dim3(gx, nterms), dim3(256), 0, stream, t, g_total, total, ok);
   AFFT_LAUNCH_CHECK();
   return 0;
 }

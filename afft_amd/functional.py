@@ -1861,6 +1861,7 @@ class ReduceLosses(torch.autograd.Function):
         total = torch.empty((), dtype=torch.float32, device=dev)
         ops.loss_reduce(flat, weights, means, total)
         ctx.weights, ctx.shapes = tuple(weights), [v.shape for v in vals]
+        ctx.total = total.detach()      # backward's kernel tells the optimizer kernels whether the step is finite (runtime.SINK.step_ok)
         ctx.needs = list(ctx.needs_input_grad[1:])
         ctx.mark_non_differentiable(means)
         ctx.set_materialize_grads(False)      # `means` takes no gradient: without this autograd zero-fills one for it every step
@@ -1872,7 +1873,7 @@ class ReduceLosses(torch.autograd.Function):
             return (None,) * (1 + len(ctx.shapes))
         grads = [torch.empty(shp, dtype=torch.float32, device=g_total.device) if need else None
                  for shp, need in zip(ctx.shapes, ctx.needs)]
-        ops.loss_reduce_bwd(grads, ctx.weights, g_total.contiguous())
+        ops.loss_reduce_bwd(grads, ctx.weights, g_total.contiguous(), total=ctx.total, ok=rt.SINK.step_ok)
         return (None, *grads)
 
 

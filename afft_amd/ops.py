@@ -325,13 +325,14 @@ def loss_reduce(vals, weights, means: Optional[Tensor], total: Tensor):
     L.check(L.lib().afft_loss_reduce(ptrs, cnts, ws, n, _p(means), _p(total), _stream()), "loss_reduce")
 
 
-def loss_reduce_bwd(grads, weights, g_total: Optional[Tensor]):
-    """grads[i][:] = g_total * weights[i] / grads[i].numel() (None entries are skipped)"""
+def loss_reduce_bwd(grads, weights, g_total: Optional[Tensor], total: Optional[Tensor] = None, ok: Optional[Tensor] = None):
+    """grads[i][:] = g_total * weights[i] / grads[i].numel() (None entries are skipped); ok (device float, optional) =
+    isfinite(total) and isfinite(g_total): what the optimizer kernels of the step look at (afft_loss_reduce_bwd_ok)"""
     n = len(grads)
     ptrs = (C.c_void_p * n)(*[None if g is None else g.data_ptr() for g in grads])
     cnts = (C.c_int64 * n)(*[0 if g is None else g.numel() for g in grads])
     ws = (C.c_float * n)(*[float(w) for w in weights])
-    L.check(L.lib().afft_loss_reduce_bwd(ptrs, cnts, ws, n, _p(g_total), _stream()), "loss_reduce_bwd")
+    L.check(L.lib().afft_loss_reduce_bwd_ok(ptrs, cnts, ws, n, _p(g_total), _p(total), _p(ok), _stream()), "loss_reduce_bwd")
 
 
 def mse(a: Tensor, b: Tensor, gscale: float, loss_sum: Optional[Tensor], da: Optional[Tensor], db: Optional[Tensor],
@@ -441,8 +442,9 @@ def reduce_rows_periodic(src: Tensor, period: int, out: Tensor):
 
 def sgd_nesterov(p: Tensor, g: Tensor, buf: Tensor, lr: float, mom: float, wd: float, gscale: float, first,
                  p_bf16: Optional[Tensor] = None, gscale_dev: Optional[Tensor] = None, p_f16: Optional[Tensor] = None,
-                 p_f8: Optional[Tensor] = None):
-    """first: bool (first step) or the AFFT_SGD_* flag word (1 = first step, 2 = plain momentum instead of Nesterov);
+                 p_f8: Optional[Tensor] = None, ok: Optional[Tensor] = None):
+    """ok (device float): the update is applied iff ok[0] != 0 (loss_reduce writes isfinite(loss) there).
+    first: bool (first step) or the AFFT_SGD_* flag word (1 = first step, 2 = plain momentum instead of Nesterov);
     p_bf16 / p_f16: the bf16 / fp16 images of the updated weights (same element offsets as p)"""
     assert p.is_contiguous() and g.is_contiguous() and buf.is_contiguous()
     if p_bf16 is not None:
@@ -452,16 +454,17 @@ def sgd_nesterov(p: Tensor, g: Tensor, buf: Tensor, lr: float, mom: float, wd: f
     if p_f8 is not None:
         assert p_f8.dtype == torch.uint8 and p_f8.numel() == p.numel() and p_f8.is_contiguous()
     L.check(L.lib().afft_sgd_nesterov2(_p(p), _p(g), _dt(g), _p(buf), _p(p_bf16), _p(p_f16), _p(p_f8), p.numel(), lr, mom, wd, gscale,
-                                       _p(gscale_dev), int(first), _stream()), "sgd_nesterov")
+                                       _p(gscale_dev), int(first), _p(ok), _stream()), "sgd_nesterov")
 
 
 def sgd_nesterov_runs(p: Tensor, g: Tensor, buf: Tensor, runs: Tensor, lr: float, mom: float, wd: float, gscale: float, first: bool,
-                      p_bf16: Optional[Tensor] = None, p_f16: Optional[Tensor] = None, p_f8: Optional[Tensor] = None):
+                      p_bf16: Optional[Tensor] = None, p_f16: Optional[Tensor] = None, p_f8: Optional[Tensor] = None,
+                      ok: Optional[Tensor] = None):
     """the same update over the runs {start, length} (int64 [nruns, 2] on the device) of whole flat buffers"""
     assert runs.dtype == torch.int64 and runs.dim() == 2 and runs.shape[1] == 2 and runs.is_contiguous()
     assert p.dtype == g.dtype == buf.dtype == torch.float32
     L.check(L.lib().afft_sgd_nesterov_runs2(_p(p), _p(g), _p(buf), _p(p_bf16), _p(p_f16), _p(p_f8), _p(runs), runs.shape[0], lr, mom, wd, gscale,
-                                            int(first), _stream()), "sgd_nesterov_runs")
+                                            int(first), _p(ok), _stream()), "sgd_nesterov_runs")
 
 
 def pack_weight(w: Tensor, dst: Tensor) -> Tensor:

@@ -407,6 +407,13 @@ class FusedSGD:
                  nesterov: bool = True):
         self.flat, self.lr, self.momentum, self.wd, self.nesterov = flat, lr, momentum, weight_decay, nesterov
         self.buf = torch.zeros_like(flat.flat_p)
+        # "the step is finite" (device float; None = no guard): the loss reduction of a step writes isfinite(loss) here when the
+        # owner has put it into runtime.SINK.step_ok, and every update kernel of that step -- bucket kernels and weight-gradient
+        # epilogues alike -- leaves parameters, momentum and images untouched when it reads 0.  The reference raises 'The loss is
+        # NaN!' before backward (common/runner.py:209); with lazy metrics that error surfaces a step later, and this keeps the
+        # state it finds as the reference would have left it.  Single process only: with a gradient exchange the ranks would
+        # have to agree on the flag (not built: the owner leaves SINK.step_ok alone and `ok` stays 1).
+        self.ok: Optional[Tensor] = torch.ones((), dtype=torch.float32, device=flat.flat_p.device)
         self.steps = 0
         self.runs: Optional[Dict[tuple, Tensor]] = None    # per bucket (s, e): the runs NOT updated in a GEMM epilogue
         self.skip: set = set()                             # ids of the parameters updated in a GEMM epilogue (those runs exclude)
@@ -466,12 +473,12 @@ class FusedSGD:
                 if runs is not None:
                     if runs.shape[0]:
                         ops.sgd_nesterov_runs(self.flat.flat_p, self.flat.flat_g, self.buf, runs, self.lr, self.momentum, self.wd,
-                                              gscale, self.flags(), p_bf16=self.flat.flat_p16, p_f16=self.flat.flat_h16, p_f8=self.flat.flat_p8)
+                                              gscale, self.flags(), p_bf16=self.flat.flat_p16, p_f16=self.flat.flat_h16, p_f8=self.flat.flat_p8, ok=self.ok)
                     self.flat.refresh_packed(s, e, skip=self.skip)
                     return
             p16 = self.flat.flat_p16[s:e] if self.flat.flat_p16 is not None else None
             ops.sgd_nesterov(self.flat.flat_p[s:e], grad, self.buf[s:e], self.lr, self.momentum, self.wd, gscale,
-                             self.flags(), p_bf16=p16, gscale_dev=gscale_dev, p_f16=self.flat.h16(s, e), p_f8=self.flat.p8(s, e))
+                             self.flags(), p_bf16=p16, gscale_dev=gscale_dev, p_f16=self.flat.h16(s, e), p_f8=self.flat.p8(s, e), ok=self.ok)
             self.flat.refresh_packed(s, e)
             return
         # per-parameter (lr, wd): the parameters of the range class by class.  [s, e) may cut a parameter at either end (the
@@ -490,7 +497,7 @@ class FusedSGD:
                     g_full = flat.flat_g if grad.data_ptr() == flat.flat_g[s:e].data_ptr() else None
                     if g_full is not None:
                         ops.sgd_nesterov_runs(flat.flat_p, g_full, self.buf, runs, lr, self.momentum, wd, gscale, self.flags(),
-                                              p_bf16=flat.flat_p16, p_f16=flat.flat_h16, p_f8=flat.flat_p8)
+                                              p_bf16=flat.flat_p16, p_f16=flat.flat_h16, p_f8=flat.flat_p8, ok=self.ok)
                         continue
                 elif fused:
                     continue
@@ -501,7 +508,7 @@ class FusedSGD:
                 lo, hi = max(o, s), min(o + _align(p.numel()), e)
                 p16 = flat.flat_p16[lo:hi] if flat.flat_p16 is not None else None
                 ops.sgd_nesterov(flat.flat_p[lo:hi], grad[lo - s:hi - s], self.buf[lo:hi], lr, self.momentum, wd, gscale,
-                                 self.flags(), p_bf16=p16, gscale_dev=gscale_dev, p_f16=flat.h16(lo, hi), p_f8=flat.p8(lo, hi))
+                                 self.flags(), p_bf16=p16, gscale_dev=gscale_dev, p_f16=flat.h16(lo, hi), p_f8=flat.p8(lo, hi), ok=self.ok)
         self.flat.refresh_packed(s, e, skip=(self.skip if fused else ()))
 
     def end_step(self):
@@ -608,7 +615,7 @@ class _FusedEpilogue:
             n = _align(p.numel())
             lr, wd = self.opt.hyper_of(self._index[pid])
             ops.sgd_nesterov(flat.flat_p[o:o + n], flat.flat_g[o:o + n], self.opt.buf[o:o + n], lr, self.opt.momentum,
-                             wd, 1.0, self.opt.flags(), p_bf16=flat.flat_p16[o:o + n], p_f16=flat.h16(o, o + n), p_f8=flat.p8(o, o + n))
+                             wd, 1.0, self.opt.flags(), p_bf16=flat.flat_p16[o:o + n], p_f16=flat.h16(o, o + n), p_f8=flat.p8(o, o + n), ok=self.opt.ok)
             flat.refresh_packed(o, o + 1)
             stale.append(pid)
         if stale:
@@ -637,6 +644,7 @@ class _FusedEpilogue:
             d.p_f16 = (h16.data_ptr() + 2 * self._offset_of(p)) if h16 is not None else None
             d.p_f8 = (self.flat.flat_p8.data_ptr() + self._offset_of(p)) if self.flat.flat_p8 is not None else None
             d.lr, d.mom, d.wd, d.gscale, d.first_step = lr, self.opt.momentum, wd, 1.0, self.opt.flags() & 2
+            d.ok = self.opt.ok.data_ptr() if self.opt.ok is not None else None
         return d
 
 class Trainer(_FusedEpilogue):
@@ -697,6 +705,7 @@ class Trainer(_FusedEpilogue):
         self.reducer.on_bucket = self.opt.step_range if optimize_in_backward else None
         fuse = optimize_in_backward and self._fused is not None and self._can_fuse()
         rt.SINK.fused = self._fused_desc if fuse else None
+        rt.SINK.step_ok = self.opt.ok if not self.reducer.comm else None      # see FusedSGD.ok
         saved_runs, self.opt.runs = self.opt.runs, (self.opt.runs if fuse else None)
         try:
             self.reducer.begin_step()
@@ -720,6 +729,7 @@ class Trainer(_FusedEpilogue):
                 saved_runs = self.opt.runs      # the set shrank: keep the rebuilt runs
         finally:
             rt.SINK.fused = None
+            rt.SINK.step_ok = None
             rt.SINK.fused_applied.clear()      # ids are only meaningful inside the step that recorded them
             self.opt.runs = saved_runs
         if optimize_in_backward:

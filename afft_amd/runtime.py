@@ -341,6 +341,8 @@ class GradSink:
         self.composite_weights: set = set()     # ids of the weights whose gradient GEMM ran inside a composite backward
         self.fused = None          # callable(param) -> _lib.SgdFused or None: the optimizer fused into that weight's gradient GEMM
         self.fused_applied: Dict[int, int] = {}  # weights whose update ran in a GEMM epilogue in the current step (-> count)
+        self.step_ok = None        # device float of the optimizer that owns the running step: the loss reduction writes isfinite(loss)
+                                   # there and the update kernels skip a non-finite step (reference: 'The loss is NaN!' before backward)
 
     def begin_step(self):
         self.touched.clear()

@@ -135,6 +135,9 @@ typedef struct afft_sgd_fused {
   void* p_f16;                                     /* optional: the row-major FP16 image (layout of p_bf16): the B operand of the   */
                                                    /* fp16 two-pass forward GEMMs ("fp16x2" precision)                              */
   void* p_f8;                                      /* optional: the e4m3 byte image e4m3(2^8 p) (afft_gemm_t.b8), same element offsets */
+  const float* ok;                                 /* optional device flag: the update is applied iff ok[0] != 0 (afft_loss_reduce_bwd_ok */
+                                                   /* writes isfinite(total loss) there: a non-finite step leaves p / buf / images    */
+                                                   /* untouched, like the reference's 'The loss is NaN!' raised before backward)      */
 } afft_sgd_fused_t;
 /* `first_step` of every optimizer entry point is a flag word: AFFT_SGD_FIRST_STEP = the momentum buffer does not exist yet (it
  * starts as the gradient: torch.optim.SGD's first step); AFFT_SGD_PLAIN_MOMENTUM = torch.optim.SGD(nesterov=False):
@@ -275,7 +278,13 @@ int afft_softmax_ce_frames(const float* logits, int64_t clip_stride, int64_t ldl
  * afft_loss_reduce_bwd: g[i][0 .. n[i]) = g_total[0] * w[i] / n[i] (g_total NULL = 1; g[i] NULL skips a term): the upstream
  * gradients of the per-row losses, ready for afft_softmax_ce's row_g / afft_mse's g_dev. */
 int afft_loss_reduce(const float* const* x, const int64_t* n, const float* w, int32_t nterms, float* means, float* total, void* stream);
+
 int afft_loss_reduce_bwd(float* const* g, const int64_t* n, const float* w, int32_t nterms, const float* g_total, void* stream);
+/* ... and ok[0] = isfinite(total[0]) && isfinite(g_total[0]) ? 1 : 0 (total: the forward's result, may be NULL): the device-side form
+ * of the reference's 'The loss is NaN!' check (common/runner.py:209), written by the FIRST kernel of the backward pass and read by
+ * the optimizer kernels of the same step (afft_sgd_fused_t.ok): a non-finite loss leaves parameters, momentum and images untouched. */
+int afft_loss_reduce_bwd_ok(float* const* g, const int64_t* n, const float* w, int32_t nterms, const float* g_total, const float* total,
+                            float* ok, void* stream);
 /* Scalar reductions (the MSE loss, the gradient norm) are ORDERED: every workgroup writes one partial sum into the
  * caller-provided per-stream workspace (the same buffer as afft_gemm_t.workspace / afft_colsum: the partials sit behind its
  * AFFT_GEMM_WS_HEADER bytes of counters; at most AFFT_REDUCE_PARTIALS floats) and a second one-workgroup kernel adds them up
@@ -415,14 +424,14 @@ int afft_sgd_nesterov(float* p, const void* g, int32_t g_dtype, float* buf, void
 /* p_f16 (optional, same element offsets as p): the FP16 image of the updated weights ("fp16x2" forward operands), written
  * beside p_bf16 by afft_sgd_nesterov2 / afft_sgd_nesterov_runs2 -- otherwise the functions above. */
 int afft_sgd_nesterov2(float* p, const void* g, int32_t g_dtype, float* buf, void* p_bf16, void* p_f16, void* p_f8, int64_t n, float lr,
-                       float mom, float wd, float gscale, const float* gscale_dev, int32_t first_step, void* stream);      /* p_f8: e4m3(2^8 p) bytes */
+                       float mom, float wd, float gscale, const float* gscale_dev, int32_t first_step, const float* ok, void* stream);      /* p_f8: e4m3(2^8 p) bytes; ok: see afft_sgd_fused_t.ok (NULL = always) */
 /* The same update over `nruns` separate runs of ONE set of flat buffers: runs = device array of nruns x {start, length}
  * (int64 elements, starts multiples of 4).  One launch for all the small parameters of a gradient bucket (LayerNorm
  * weights, biases, tokens) whose big neighbours are updated in their weight-gradient epilogues (afft_sgd_fused_t). */
 int afft_sgd_nesterov_runs(float* p, const float* g, float* buf, void* p_bf16, const int64_t* runs, int32_t nruns, float lr,
                            float mom, float wd, float gscale, int32_t first_step, void* stream);
 int afft_sgd_nesterov_runs2(float* p, const float* g, float* buf, void* p_bf16, void* p_f16, void* p_f8, const int64_t* runs, int32_t nruns,
-                            float lr, float mom, float wd, float gscale, int32_t first_step, void* stream);
+                            float lr, float mom, float wd, float gscale, int32_t first_step, const float* ok, void* stream);
 /* Gradient clipping by global norm (train.py:254-260, torch.nn.utils.clip_grad_norm_), without a host sync:
  *   afft_sumsq: *out += scale * sum x[i]^2 over a flat fp32/bf16 buffer (scale = gscale^2 of the optimizer), ordered
  *   through the stream's workspace (see afft_mse) - the clipping coefficient is bit-reproducible;

@@ -302,7 +302,9 @@ def reduce_rows_periodic(src, period, out):
 
 
 @torch.no_grad()
-def sgd_nesterov(p, g, buf, lr, mom, wd, gscale, first, p_bf16=None, gscale_dev=None, p_f16=None, p_f8=None):
+def sgd_nesterov(p, g, buf, lr, mom, wd, gscale, first, p_bf16=None, gscale_dev=None, p_f16=None, p_f8=None, ok=None):
+    if ok is not None and float(ok) == 0.0:
+        return
     if gscale_dev is not None:
         gscale = gscale * float(gscale_dev)
     flags = int(first)        # AFFT_SGD_* flag word: 1 = first step, 2 = plain momentum (nesterov=False)
@@ -317,7 +319,9 @@ def sgd_nesterov(p, g, buf, lr, mom, wd, gscale, first, p_bf16=None, gscale_dev=
 
 
 @torch.no_grad()
-def sgd_nesterov_runs(p, g, buf, runs, lr, mom, wd, gscale, first, p_bf16=None, p_f16=None, p_f8=None):
+def sgd_nesterov_runs(p, g, buf, runs, lr, mom, wd, gscale, first, p_bf16=None, p_f16=None, p_f8=None, ok=None):
+    if ok is not None and float(ok) == 0.0:
+        return
     for a, n in runs.tolist():
         sgd_nesterov(p[a:a + n], g[a:a + n], buf[a:a + n], lr, mom, wd, gscale, first,
                      p_bf16=None if p_bf16 is None else p_bf16[a:a + n], p_f16=None if p_f16 is None else p_f16[a:a + n])
@@ -336,8 +340,11 @@ def loss_reduce(vals, weights, means, total):
 
 
 @torch.no_grad()
-def loss_reduce_bwd(grads, weights, g_total):
+def loss_reduce_bwd(grads, weights, g_total, total=None, ok=None):
     go = 1.0 if g_total is None else float(g_total)
+    if ok is not None:
+        fin = (total is None or bool(torch.isfinite(total))) and go == go and abs(go) != float("inf")
+        ok.fill_(1.0 if fin else 0.0)
     for g, w in zip(grads, weights):
         if g is not None and g.numel():
             g.fill_(go * w / g.numel())

@@ -1595,3 +1595,50 @@ def test_capture_stream_never_comes_back_as_the_auxiliary_stream():
         assert float(loss) == float(loss)
     finally:
         D_.disable_device_salt()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16x2"])
+def test_a_non_finite_loss_leaves_parameters_momentum_and_images_untouched(precision):
+    """The device-side form of the reference's 'The loss is NaN!' check (common/runner.py:209 raises before backward): the first backward
+    kernel writes isfinite(loss) into FusedSGD.ok and every update of the step -- the weight-gradient EPILOGUES of the fused optimizer and
+    the per-bucket kernels -- skips on 0.  After a poisoned batch parameters, momentum, bf16 / fp16 / e4m3 / packed images are bit-identical
+    to before it; the next clean step trains on."""
+    import afft_amd
+    from afft_amd import runtime as rt
+    from afft_amd.config import make_model_cfg
+    from afft_amd.models.base_model import BaseModel
+    from afft_amd.parallel import Trainer
+    afft_amd.set_precision(precision)
+    rt.set_grad_mode("sink")
+    dev = torch.device("cuda:0")
+    mods = {"rgb": 256, "objects": 96, "audio": 256, "flow": 256}
+    B, T = 16, 16
+    g = torch.Generator().manual_seed(13)
+    feats = {m: torch.randn(B, T, C, 1, 1, 1, generator=g).to(dev) for m, C in mods.items()}
+    bad = {m: f.clone() for m, f in feats.items()}
+    bad["rgb"][3, 5, 7] = float("nan")
+    tgt = {"action": torch.randint(0, 97, (B,), generator=g).to(dev)}
+    sub = {"action": torch.randint(0, 97, (B, T, 1), generator=g).to(dev)}
+    torch.manual_seed(5)
+    model = BaseModel(make_model_cfg(mods, 256, 512, depth=2, fp_layers=2, fp_heads=4, drop=0.0), {"action": 97}, {}).to(dev).train()
+    tr = Trainer(model, {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}, lr=0.01, bucket_elems=1 << 18)
+    try:
+        for _ in range(3):
+            tr.step(feats, tgt, sub)
+        assert tr._fused, "the fused optimizer epilogues are on from step 2"
+        torch.cuda.synchronize()
+        snap = lambda: [t.clone() for t in (tr.flat.flat_p, tr.opt.buf, tr.flat.flat_p16, tr.flat.flat_h16, tr.flat.flat_p8, tr.flat.flat_pk16)
+                        if t is not None]
+        before = snap()
+        loss, _ = tr.step(bad, tgt, sub)
+        torch.cuda.synchronize()
+        assert float(loss) != float(loss) and float(tr.opt.ok) == 0.0
+        for a, b in zip(before, snap()):
+            assert torch.equal(a, b)
+        loss, _ = tr.step(feats, tgt, sub)
+        torch.cuda.synchronize()
+        assert float(loss) == float(loss) and float(tr.opt.ok) == 1.0
+        after = snap()
+        assert not torch.equal(before[0], after[0]) and bool(torch.isfinite(after[0]).all()) and bool(torch.isfinite(after[1]).all())
+    finally:
+        afft_amd.set_precision("bf16")

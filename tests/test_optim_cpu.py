@@ -308,3 +308,41 @@ def test_runner_lazy_metrics_are_the_references_values():
         float(bad)
     arr = LazyHostArray(torch.arange(6.0).reshape(2, 3))
     assert arr.shape == (2, 3) and np.asarray(arr).sum() == 15.0
+
+
+def test_a_non_finite_loss_makes_the_step_a_no_op():
+    """The reference raises 'The loss is NaN!' BEFORE backward (common/runner.py:209), so a batch that produces a NaN loss never touches
+    the parameters.  With lazy metrics that error surfaces later; the update kernels of the step therefore look at a device flag the
+    first backward kernel writes (isfinite(loss): parallel.FusedSGD.ok / afft_sgd_fused_t.ok) and skip: parameters and momentum after a
+    poisoned batch are bit-identical to before it, the optimizer keeps working afterwards, and the loss still reads NaN.  Both loop
+    shapes: Trainer.step and the reference's own loop with afft_amd.optim.SGD (whose zero_grad() comes AFTER the forward pass)."""
+    import cpu_ops
+    from afft_amd.common.runner import Runner
+    from afft_amd.optim import SGD
+    from afft_amd.parallel import Trainer
+    c, state, data, tgt, sub = _afft_case()
+    bad = {m: d.clone() for m, d in data.items()}
+    next(iter(bad.values()))[0, 0, 0] = float("nan")
+    with cpu_ops.installed():
+        m1 = _afft_model(c, state, "fp32")
+        tr = Trainer(m1, WTS, lr=1e-2, momentum=0.9, weight_decay=1e-4, bucket_elems=8192)
+        tr.step(data, {"action": tgt}, {"action": sub})
+        p0, b0 = tr.flat.flat_p.clone(), tr.opt.buf.clone()
+        loss, _ = tr.step(bad, {"action": tgt}, {"action": sub})
+        assert float(loss) != float(loss) and float(tr.opt.ok) == 0.0
+        assert torch.equal(tr.flat.flat_p, p0) and torch.equal(tr.opt.buf, b0)
+        loss, _ = tr.step(data, {"action": tgt}, {"action": sub})
+        assert float(loss) == float(loss) and float(tr.opt.ok) == 1.0 and not torch.equal(tr.flat.flat_p, p0)
+        assert bool(torch.isfinite(tr.flat.flat_p).all())
+        # the reference's loop shape
+        m2 = _afft_model(c, state, "fp32")
+        opt = SGD(_groups(m2), lr=1e-2, momentum=0.9, nesterov=True, bucket_elems=8192)
+        runner = Runner(m2, torch.device("cpu"), WTS, compute_metrics=False)
+        for batch, poisoned in ((data, False), (bad, True), (data, False)):
+            before = opt.flat.flat_p.clone()
+            loss, _ = runner(_batch(batch, tgt, sub), None, True)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            assert torch.equal(opt.flat.flat_p, before) == poisoned
+        assert bool(torch.isfinite(opt.flat.flat_p).all())
