@@ -1305,6 +1305,10 @@ RACE_CASES = [
     ("g128_nt", 1, "nt", 1024, 2048, 2048, False),
     ("g128_nn_splitk", 1, "nn", 1024, 2048, 2048, False),
     ("bd_nt_packed", 0, "nt", 5120, 2048, 8192, True),
+    # the fp16x2 forward instantiations of the ping-pong kernel: "lo8" = fp16 hi segment + block-scaled fp8 lo segment (two K loops over one
+    # ring: X3 = 3), "f16x2" = two fp16 segments (X3 = 2)
+    ("pp_nt_fp16_lo8", 3, "nt", 5120, 2048, 2048, "lo8"),
+    ("pp_nt_fp16x2", 3, "nt", 5120, 2048, 2048, "f16x2"),
 ]
 
 
@@ -1319,7 +1323,10 @@ def test_lds_ring_kernels_are_bitwise_stable_under_lds_pressure(case):
     A = bfr(rnd(K, M, seed=71) if a_t else rnd(M, K, seed=71)).to(torch.bfloat16).to(dev())
     Bm = bfr(rnd(N, K, seed=72) if b_t else rnd(K, N, seed=72)).to(torch.bfloat16).to(dev())
     pk = None
-    if packed:
+    planes = packed if isinstance(packed, str) else None
+    if planes:
+        packed = False
+    elif packed:
         pk = torch.empty(N * K, dtype=torch.bfloat16, device=dev())
         ops.pack_weight(Bm.float(), pk)
     odt = torch.float32 if a_t else torch.bfloat16
@@ -1336,6 +1343,25 @@ def test_lds_ring_kernels_are_bitwise_stable_under_lds_pressure(case):
     try:
         def launch(o):
             ops.gemm(A, Bm, o, a_t=a_t, b_t=b_t, b_packed=pk)
+        if planes:      # operands of the fp16x2 forward: fp16 hi plane (+ e4m3 / fp16 lo plane) of the activation, FP16 (+ e4m3) weight image
+            a32, w32 = A.float(), Bm.float()
+            hi = torch.empty(M, K, dtype=torch.float16, device=dev())
+            a8 = torch.empty(M, K, dtype=torch.uint8, device=dev())
+            ops.quant_e4m3(a32, 2048.0, a8, hi=hi)
+            w16 = w32.half()
+            w8 = torch.empty(N, K, dtype=torch.uint8, device=dev())
+            ops.quant_e4m3(w32, 256.0, w8)
+            sp = ops.Split(a32, f16=True)
+            if planes == "lo8":
+                assert _lib.lib().afft_gemm_lo8_ok(M, N, K) == 1
+
+                def launch(o):
+                    ops.gemm(hi, w16, o, b_t=True, a8=a8, b8=w8)
+            else:
+                def launch(o):
+                    ops.gemm(sp, w16, o, b_t=True)
+            odt = torch.float32
+            outs = [torch.empty(M, N, dtype=odt, device=dev()) for _ in range(4)]
         first = torch.empty(M, N, dtype=odt, device=dev())
         launch(first)
         torch.cuda.synchronize()
