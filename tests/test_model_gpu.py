@@ -1642,3 +1642,66 @@ def test_a_non_finite_loss_leaves_parameters_momentum_and_images_untouched(preci
         assert not torch.equal(before[0], after[0]) and bool(torch.isfinite(after[0]).all()) and bool(torch.isfinite(after[1]).all())
     finally:
         afft_amd.set_precision("bf16")
+
+
+@pytest.mark.parametrize("handover", [False, True])
+def test_token_row_projection_replays_its_dropout_masks_in_backward(handover):
+    """Training mode, output dropout + DropPath on the token-row form of the attention sub-layer (take = S): the masks are functions of
+    (key, compact row, column) forward and backward.  The forward's mask is read off two forwards that differ by +1 in the projection
+    bias (y' - y = mask * scale, exactly, since y = x + drop(proj + b)); the projection-bias gradient of the backward pass must then be
+    the column sums of gy * mask -- and with the MLP half behind it, the same block gives the same gradients with the gradient
+    hand-over across the boundary on and off (the LayerNorm backward replays the mask instead of the cast kernel)."""
+    import afft_amd
+    from afft_amd import dropout as D_, functional as F_, runtime as rt
+    from afft_amd.models.transformerblock import Block
+    afft_amd.set_precision("bf16")
+    dev = torch.device("cuda:0")
+    dim, heads, S, nseq = 256, 4, 5, 128
+    torch.manual_seed(3)
+    blk = Block(dim, heads, mlp_ratio=2.0, qkv_bias=True, drop=0.3, drop_path=0.2).to(dev).train()
+    a = blk.attn
+    x = (torch.randn(nseq * S, dim, generator=torch.Generator().manual_seed(4)) * 0.5).to(dev)
+    gy = torch.randn(nseq, dim, generator=torch.Generator().manual_seed(5)).to(dev)
+    was = rt.handover()
+    rt.set_handover(handover)
+    try:
+        def attn_only(bias):
+            D_.manual_seed(11)
+            cfg = D_.with_path(a.drop_cfg(), 0.2, 1)
+            return F_.AttnSublayer.apply(x, blk.norm1.weight, blk.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, bias,
+                                         S, heads, "none", blk.norm1.eps, False, True, a.scale, cfg, None, S)[0]
+        with torch.no_grad():
+            y0 = attn_only(a.proj.bias)
+            y1 = attn_only(a.proj.bias + 1.0)
+        mask = (y1 - y0)                                   # 0 where dropped, 1 / (keep * keep_path) where kept
+        kept = float((mask != 0).float().mean())
+        assert 0.45 < kept < 0.67, kept                      # (1 - 0.3) * (1 - 0.2) = 0.56
+        for p in blk.parameters():
+            p.grad = None
+        rt.SINK.begin_step()
+        y = attn_only(a.proj.bias)
+        (y * gy).sum().backward()
+        rt.SINK.finish_step(list(blk.parameters()))
+        torch.cuda.synchronize()
+        want = (gy * mask).sum(0)
+        assert rel_l2(a.proj.bias.grad, want) < 1e-2, rel_l2(a.proj.bias.grad, want)
+        # the whole block (attention take + MLP on the token rows): the same masks with the hand-over on and off
+        res = {}
+        for ho in (True, False):
+            rt.set_handover(ho)
+            for p in blk.parameters():
+                p.grad = None
+            rt.SINK.begin_step()
+            D_.manual_seed(21)
+            xi = x.clone().requires_grad_(True)
+            yb, _ = blk.forward_rows_first_token(xi, S, "none")
+            (yb * gy).sum().backward()
+            rt.SINK.finish_step(list(blk.parameters()))
+            torch.cuda.synchronize()
+            res[ho] = (yb.detach().clone(), xi.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters() if p.grad is not None})
+        assert torch.equal(res[True][0], res[False][0])
+        assert rel_l2(res[True][1], res[False][1]) < 2e-3
+        for k in res[False][2]:
+            assert rel_l2(res[True][2][k], res[False][2][k]) < 5e-3, k
+    finally:
+        rt.set_handover(was)
