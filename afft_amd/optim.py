@@ -168,7 +168,7 @@ class SGD(torch.optim.Optimizer, _FusedEpilogue):
         self.reducer.on_bucket = self.opt.step_range if inb else None
         self._fuse_now = inb and self._fused is not None and self._can_fuse()
         rt.SINK.fused = self._fused_desc if self._fuse_now else None
-        rt.SINK.step_ok = self.opt.ok if not self.reducer.comm else None      # parallel.FusedSGD.ok: a non-finite loss makes the step a no-op
+        rt.SINK.step_ok = self.reducer.step_ok = self.opt.ok      # parallel.FusedSGD.ok: a non-finite loss makes the step a no-op (all ranks agree)
         self._saved_runs, self.opt.runs = self.opt.runs, (self.opt.runs if self._fuse_now else None)
         self.reducer.begin_step()
         self._armed = True

@@ -212,6 +212,8 @@ class GradReducer:
         self._launched = [False] * len(self.buckets)
         self._handles: List = []
         self._use_cuda = flat.flat_g.is_cuda
+        self.step_ok: Optional[Tensor] = None     # the optimizer's "step is finite" flag (FusedSGD.ok), set by its owner: see _agree_ok
+        self._ok_agreed = False
         dev_ = flat.flat_g.device
         if self._use_cuda:
             rt.aux_stream(dev_)      # exists before the streams below are drawn: they must differ from it (runtime.new_stream)
@@ -233,6 +235,7 @@ class GradReducer:
         self._count = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._handles = []
+        self._ok_agreed = False
         rt.SINK.begin_step()
         early = self.comm or self.on_bucket is not None
         rt.SINK.on_grad_ready = self._on_ready if early else None
@@ -295,10 +298,19 @@ class GradReducer:
                         dist.all_gather_into_tensor(self.opt_buf[s:e], self.opt_buf[ss:se], group=self.group)
         self.masters_stale = False
 
+    def _agree_ok(self):
+        """N > 1: the ranks agree on "this step is finite" (FusedSGD.ok) before the first update of the step -- a MIN over the
+        flags every rank's first backward kernel wrote; the summed gradient of a step in which ANY rank saw a non-finite loss is
+        non-finite on every rank, so all of them must skip.  One 4-byte collective per step, on the stream the updates follow."""
+        if self.comm and self.step_ok is not None and not self._ok_agreed:
+            dist.all_reduce(self.step_ok, op=dist.ReduceOp.MIN, group=self.group)
+            self._ok_agreed = True
+
     def _launch(self, b: int):
         self._launched[b] = True
         s, e = self.buckets[b]
         if not self._use_cuda:     # CPU tensors (gloo; the build container's tests): same protocol, no streams
+            self._agree_ok()
             if self.sharded_bucket(b):
                 if self.flat_g16 is not None:
                     self.flat_g16[s:e].copy_(self.flat.flat_g[s:e])
@@ -320,6 +332,7 @@ class GradReducer:
         if rt.overlap_wgrad():    # weight gradients of this bucket were enqueued on the auxiliary stream
             self.side_stream.wait_stream(rt.aux_stream(self.flat.flat_g.device))
         with torch.cuda.stream(self.side_stream):
+            self._agree_ok()
             if self.comm and self.flat_g16 is not None:
                 n = e - s
                 ops.cast(self.flat.flat_g[s:e].view(n // 64, 64), self.flat_g16[s:e].view(n // 64, 64))
@@ -411,8 +424,8 @@ class FusedSGD:
         # owner has put it into runtime.SINK.step_ok, and every update kernel of that step -- bucket kernels and weight-gradient
         # epilogues alike -- leaves parameters, momentum and images untouched when it reads 0.  The reference raises 'The loss is
         # NaN!' before backward (common/runner.py:209); with lazy metrics that error surfaces a step later, and this keeps the
-        # state it finds as the reference would have left it.  Single process only: with a gradient exchange the ranks would
-        # have to agree on the flag (not built: the owner leaves SINK.step_ok alone and `ok` stays 1).
+        # state it finds as the reference would have left it.  N > 1: the ranks take the MIN of their flags before the first update
+        # of the step (GradReducer._agree_ok), so a batch that is poisoned on one rank is skipped by all.
         self.ok: Optional[Tensor] = torch.ones((), dtype=torch.float32, device=flat.flat_p.device)
         self.steps = 0
         self.runs: Optional[Dict[tuple, Tensor]] = None    # per bucket (s, e): the runs NOT updated in a GEMM epilogue
@@ -705,7 +718,7 @@ class Trainer(_FusedEpilogue):
         self.reducer.on_bucket = self.opt.step_range if optimize_in_backward else None
         fuse = optimize_in_backward and self._fused is not None and self._can_fuse()
         rt.SINK.fused = self._fused_desc if fuse else None
-        rt.SINK.step_ok = self.opt.ok if not self.reducer.comm else None      # see FusedSGD.ok
+        rt.SINK.step_ok = self.reducer.step_ok = self.opt.ok      # see FusedSGD.ok; N > 1: GradReducer._agree_ok
         saved_runs, self.opt.runs = self.opt.runs, (self.opt.runs if fuse else None)
         try:
             self.reducer.begin_step()

@@ -364,3 +364,55 @@ def test_launcher_reports_a_dead_or_hung_rank(mode, capfd):
     assert len(line) == 1, out
     rep = json.loads(line[0])
     assert rep["rc"] != 0 and rep["n_gpus"] == 2 and "error" in rep
+
+
+# ----------------------------------------------------------------------------- N > 1: a batch that is poisoned on ONE rank is skipped by ALL
+def _poison_worker(rank, world, port, out, comm_algo):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.join(here, "golden"), os.path.dirname(here)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import cpu_ops
+    from afft_amd.parallel import Trainer
+    c, state, data, tgt, sub = _afft_case()
+    with cpu_ops.installed():
+        model = _afft_model(c, state, "fp32")
+        tr = Trainer(model, WTS, lr=1e-2, momentum=0.9, weight_decay=1e-4, bucket_elems=8192, comm_dtype="fp32", comm_algo=comm_algo)
+        h = data[next(iter(data))].shape[0] // world
+        sl = slice(rank * h, (rank + 1) * h)
+        mine = {m: d[sl].clone() for m, d in data.items()}
+        bad = {m: d.clone() for m, d in mine.items()}
+        if rank == 1:                                   # only rank 1's half of the batch carries the NaN
+            next(iter(bad.values()))[0, 0, 0] = float("nan")
+        log = []
+        for feats in (mine, bad, mine):
+            before = tr.flat.flat_p.clone()
+            loss, _ = tr.step(feats, {"action": tgt[sl]}, {"action": sub[sl]})
+            if comm_algo == "sharded":
+                tr.reducer.sync_masters()
+            log.append((bool(torch.equal(tr.flat.flat_p, before)), float(tr.opt.ok), float(loss) == float(loss)))
+        flat = tr.flat.flat_p.clone()
+        others = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(others, flat)
+        assert all(torch.equal(o, others[0]) for o in others), "replicas diverged"
+        assert bool(torch.isfinite(flat).all())
+    torch.save(log, out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("comm_algo", ["allreduce", "sharded"])
+def test_two_ranks_agree_to_skip_a_step_that_is_non_finite_on_one_of_them(tmp_path, comm_algo):
+    """The device-side 'The loss is NaN!' guard (FusedSGD.ok) with a gradient exchange: rank 1's half of the second batch holds a NaN,
+    rank 0's loss is finite -- the summed gradient is non-finite on both, so both must leave parameters and momentum alone
+    (GradReducer._agree_ok: MIN over the ranks' flags before the first update of the step), stay bitwise equal, and train on."""
+    out = str(tmp_path / "poison")
+    mp.spawn(_poison_worker, args=(2, _free_port(), out, comm_algo), nprocs=2, join=True)
+    logs = [torch.load(out + f".{r}") for r in range(2)]
+    for r, log in enumerate(logs):
+        assert [e[0] for e in log] == [False, True, False], (r, log)          # parameters unchanged exactly in the poisoned step
+        assert [e[1] for e in log] == [1.0, 0.0, 1.0], (r, log)               # ... on BOTH ranks
+    assert logs[0][1][2] is True and logs[1][1][2] is False                    # rank 0's own loss was finite, rank 1's was not
