@@ -216,6 +216,7 @@ class TemporalCMFuser(nn.Module):
         self.num_mods = len(modalities) + 1 if frame_level_token else len(modalities)
         self.modality_embedding = nn.Parameter(torch.zeros(self.num_mods, dim)) if modal_encoding else None
         self.position_embeddings = nn.Embedding(max_position_embeddings, dim)
+        self.position_embeddings.weight._afft_fp32_table = True      # fp32 rows for AddRowTable (parallel.FlatParams.owns_image)
         self.embd_drop = nn.Dropout(embd_drop_rate)
         self.frame_level_token = frame_level_token
         self.temporal_sequence_length = temporal_sequence_length
@@ -279,6 +280,7 @@ class TemporalCrossAttentFuser(nn.Module):
         self.norm = norm_layer(dim)
         self.embd_drop = nn.Dropout(embd_drop_rate)
         self.position_embeddings = nn.Embedding(max_position_embeddings, dim)
+        self.position_embeddings.weight._afft_fp32_table = True      # fp32 rows for AddRowTable (parallel.FlatParams.owns_image)
         self.apply(_init_weights)
 
     def forward(self, modal_feats: Dict[str, Tensor], ordered_feature_list: Callable) -> Tuple[Tensor, Tensor]:

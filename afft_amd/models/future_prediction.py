@@ -91,6 +91,7 @@ class GPT2Model(nn.Module):
         super().__init__()
         self.embed_dim = n_embd
         self.wpe = nn.Embedding(n_positions, n_embd)
+        self.wpe.weight._afft_fp32_table = True      # read as fp32 rows (AddRowTable), never a GEMM image: parallel.FlatParams.owns_image
         self.drop = nn.Dropout(embd_pdrop)
         self.h = nn.ModuleList([GPT2Block(n_embd, n_head, attn_pdrop, resid_pdrop, layer_norm_epsilon)
                                 for _ in range(n_layer)])

@@ -125,11 +125,12 @@ class SGD(torch.optim.Optimizer, _FusedEpilogue):
         return [gmap[id(p)] for p in self.flat.params]
 
     def sync_masters(self):
-        """sharded update (comm_algo = 'sharded'): whole fp32 masters and momentum on every rank (a collective); state_dict() calls it"""
+        """sharded update (comm_algo = 'sharded'): whole fp32 masters and momentum on every rank (a collective: EVERY rank calls it;
+        parallel.DistributedDataParallel does at the first evaluation forward after training steps)"""
         self.reducer.sync_masters()
 
     def state_dict(self):
-        self.sync_masters()
+        self.reducer.assert_masters_fresh("afft_amd.optim.SGD.state_dict()")      # never a collective: rank 0 alone saves (train.py:403-411)
         return super().state_dict()
 
     def _name_of(self, p: Tensor) -> str:
@@ -166,6 +167,8 @@ class SGD(torch.optim.Optimizer, _FusedEpilogue):
         self._sync_hyper()
         inb = self.in_backward
         self.reducer.on_bucket = self.opt.step_range if inb else None
+        if not inb and self.reducer.masters_stale:
+            self.reducer.sync_masters()      # a replicated whole-buffer update follows (every rank takes this branch): not from stale masters
         self._fuse_now = inb and self._fused is not None and self._can_fuse()
         rt.SINK.fused = self._fused_desc if self._fuse_now else None
         rt.SINK.step_ok = self.reducer.step_ok = self.opt.ok      # parallel.FusedSGD.ok: a non-finite loss makes the step a no-op (all ranks agree)

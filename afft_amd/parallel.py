@@ -31,6 +31,16 @@ def _align(n: int, a: int = 64) -> int:
     return (n + a - 1) // a * a
 
 
+def mark_fp32_tables(module: torch.nn.Module):
+    """Tag every parameter the kernels read as fp32 rows, never as a GEMM operand image: the weights of nn.Embedding modules
+    (models/future_prediction.py `wpe`, models/fusion.py `position_embeddings`: functional.AddRowTable adds their fp32 rows).  The
+    mirrored modules tag their own tables at construction (so a bare parameter list, afft_amd.optim.SGD, is classified the same
+    way); this walk covers any other nn.Embedding of a foreign module."""
+    for m in module.modules():
+        if isinstance(m, torch.nn.Embedding):
+            m.weight._afft_fp32_table = True
+
+
 class FlatParams:
     """Re-homes every trainable parameter of `model` (and its .grad) in contiguous fp32 buffers."""
 
@@ -41,6 +51,8 @@ class FlatParams:
         the flat buffers come FIRST (module order), everything else -- biases, LayerNorm weights, tokens, odd-shaped matrices:
         what the kernels read as fp32 every step -- behind them, from element `split` on.  The first region is updated in 1 / N
         slices (only its 16-bit images have to be whole on every rank), the second stays replicated."""
+        if isinstance(model, torch.nn.Module):
+            mark_fp32_tables(model)
         src = model.parameters() if isinstance(model, torch.nn.Module) else model
         self.params: List[Tensor] = []
         seen = set()
@@ -105,8 +117,11 @@ class FlatParams:
     @staticmethod
     def owns_image(p: Tensor) -> bool:
         """a GEMM weight whose 16-bit images live in the flat buffers (both dimensions multiples of 64; odd shapes -- the 3806-row
-        classifier, the 352-column objects mapping -- keep a padded cast image that is redone from the fp32 master every step)"""
-        return p.dim() == 2 and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0
+        classifier, the 352-column objects mapping -- keep a padded cast image that is redone from the fp32 master every step).
+        A parameter the forward pass reads as fp32 -- an embedding table (GPT-2 `wpe` is [1024, 2048]), a token -- is never one
+        whatever its shape (mark_fp32_tables): under the sharded update only the 16-bit images of the sharded region are whole on
+        every rank, so everything read in fp32 must stay in the replicated region."""
+        return (p.dim() == 2 and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0 and not getattr(p, "_afft_fp32_table", False))
 
     def ensure_f16(self):
         """the FP16 images exist once the precision is 'fp16x2' (called at construction and when a step begins)"""
@@ -275,7 +290,9 @@ class GradReducer:
         for img in (self.flat.flat_p16, self.flat.flat_h16, self.flat.flat_p8):
             if img is not None:
                 dist.all_gather_into_tensor(img[s:e], img[ss:se], group=self.group)
-        if self.flat.flat_p16 is None:      # CPU tensors (gloo tests): no images -- the fp32 slices themselves are what the next forward reads
+        if self.flat.flat_p16 is None or rt.precision() not in ("bf16", "fp16x2"):
+            # CPU tensors (gloo tests: no images), and the 'fp32' / 'bf16x3' precisions, whose GEMMs read the fp32 master (or its
+            # split) of every weight (functional._lin_fwd): the fp32 slices themselves are what the next forward reads
             dist.all_gather_into_tensor(self.flat.flat_p[s:e], self.flat.flat_p[ss:se], group=self.group)
         self.masters_stale = True           # (the momentum of the other ranks' slices at least)
 
@@ -297,6 +314,19 @@ class GradReducer:
                     if self.opt_buf is not None:
                         dist.all_gather_into_tensor(self.opt_buf[s:e], self.opt_buf[ss:se], group=self.group)
         self.masters_stale = False
+
+    def assert_masters_fresh(self, what: str):
+        """state_dict() of a model / optimizer / DDP wrapper under the sharded update: the reference saves on the main process only
+        (train.py:403-411 inside `if utils.is_main_process()`), so a collective here would be entered by rank 0 alone and hang or
+        pair up with another rank's next reduce-scatter.  The masters are brought up to date where EVERY rank passes -- the first
+        evaluation / no-grad forward after training steps (the reference validates on all ranks before it saves), or an explicit
+        sync_masters() on every rank -- and a state_dict() that still finds them stale says so instead of communicating."""
+        if self.masters_stale and self.world > 1:
+            raise RuntimeError(f"{what}: the fp32 masters / momentum of the other ranks' slices are stale (comm_algo='sharded').  Call "
+                               "sync_masters() on EVERY rank first (a collective), or run an evaluation forward on every rank "
+                               "(model.eval() / torch.no_grad()), which does it; state_dict() itself never communicates")
+        if self.masters_stale:
+            self.sync_masters()
 
     def _agree_ok(self):
         """N > 1: the ranks agree on "this step is finite" (FusedSGD.ok) before the first update of the step -- a MIN over the
@@ -679,8 +709,11 @@ class Trainer(_FusedEpilogue):
                                    force_comm=force_comm, comm_algo=comm_algo)
         self.opt = FusedSGD(self.flat, lr, momentum, weight_decay)
         self.reducer.opt_buf = self.opt.buf
-        if comm_algo == "sharded":      # checkpoints see whole fp32 masters on every rank (a collective: every rank saves or none)
-            model.register_state_dict_pre_hook(lambda *a, **k: self.reducer.sync_masters())
+        if comm_algo == "sharded":
+            # whole fp32 masters before anybody reads them: refreshed at the first evaluation / no-grad forward after training steps
+            # (every rank validates, train.py:399-401), checked -- never communicated -- by state_dict() (rank 0 alone saves)
+            model.register_forward_pre_hook(lambda mod, *a: self._sync_if_evaluating(mod))
+            model.register_state_dict_pre_hook(lambda *a, **k: self.reducer.assert_masters_fresh("state_dict()"))
         if self.reducer.world > 1:
             self.sync_parameters(group)
         self.loss_fn = BasicLossAccuracy(compute_metrics=False)
@@ -689,6 +722,14 @@ class Trainer(_FusedEpilogue):
         self.grad_clip = grad_clip     # opt.grad_clip of the reference's config; needs the whole gradient first
         self.overlap_optimizer = overlap_optimizer and grad_clip is None and (self.flat.flat_p.is_cuda or comm_algo == "sharded")
         self._fused: Optional[Dict[int, object]] = None    # id(weight) -> _lib.SgdFused, once learned (see _enable_fused)
+
+    def sync_masters(self):
+        """sharded update: whole fp32 masters and momentum on every rank (a collective: every rank calls it)"""
+        self.reducer.sync_masters()
+
+    def _sync_if_evaluating(self, mod):
+        if self.reducer.masters_stale and (not mod.training or not torch.is_grad_enabled()):
+            self.reducer.sync_masters()
 
     def sync_parameters(self, group=None, src: int = 0):
         """Every replica starts from rank `src`'s parameters and momentum (what torch DDP does at construction,
@@ -716,6 +757,8 @@ class Trainer(_FusedEpilogue):
         train.use_mixup=true, train.mixup_backbone=true): MixUp inside BaseModel.forward after the backbones, or on the
         features before the model; the losses then take soft targets and the ignore mask MixUp returns."""
         self.reducer.on_bucket = self.opt.step_range if optimize_in_backward else None
+        if not optimize_in_backward and self.reducer.masters_stale:
+            self.reducer.sync_masters()      # a replicated whole-buffer update follows: it must not start from stale masters / momentum
         fuse = optimize_in_backward and self._fused is not None and self._can_fuse()
         rt.SINK.fused = self._fused_desc if fuse else None
         rt.SINK.step_ok = self.reducer.step_ok = self.opt.ok      # see FusedSGD.ok; N > 1: GradReducer._agree_ok
@@ -898,8 +941,8 @@ class DistributedDataParallel(torch.nn.Module):
             self._own = (flat, red)   # flat buffer: gradients are gathered into it when backward is over, then reduced
 
     def state_dict(self, *args, **kwargs):
-        for e in self._engines:      # sharded update: whole fp32 masters on every rank before they are read (a collective)
-            e.sync_masters()
+        for e in self._engines:      # sharded update: whole fp32 masters before they are read -- checked, not communicated (rank 0 alone saves)
+            e.reducer.assert_masters_fresh("DistributedDataParallel.state_dict()")
         return super().state_dict(*args, **kwargs)
 
     # ---- foreign optimizer: the wrapper brackets the backward pass itself
@@ -962,6 +1005,9 @@ class DistributedDataParallel(torch.nn.Module):
 
     def forward(self, *args, **kwargs):
         bracket = self._own is not None and self.training and torch.is_grad_enabled()
+        if not (self.training and torch.is_grad_enabled()):
+            for e in self._engines:      # sharded update: the first evaluation forward after training steps refreshes the masters (every rank validates)
+                e.sync_masters()
         if bracket:
             self._begin()
         out = self.module(*args, **kwargs)

@@ -42,9 +42,17 @@ def parse():
     ap.add_argument("--comm-dtype", default=None, choices=["bf16", "fp32"],
                     help="gradient all-reduce payload; default: bf16 beside --precision bf16 (whose gradients carry bf16 operand rounding anyway), fp32 "
                          "-- what the reference's DDP exchanges, train.py:364-368 -- beside every other precision")
-    ap.add_argument("--comm-algo", default=None, choices=["allreduce", "rs_ag", "sharded"],
-                    help="gradient exchange per bucket: 'sharded' (default for N > 1: reduce-scatter, update of the rank's 1 / N slice, all-gather of the "
-                         "16-bit weight images), one all-reduce + replicated update, or reduce-scatter + all-gather of the gradient + replicated update")
+    ap.add_argument("--comm-algo", default="allreduce", choices=["allreduce", "rs_ag", "sharded"],
+                    help="gradient exchange per bucket of the HEADLINE step: one all-reduce + replicated update (default: what the north star and "
+                         "train.py:364-368 name), reduce-scatter + all-gather of the gradient + replicated update, or 'sharded' (reduce-scatter, "
+                         "update of the rank's 1 / N slice, all-gather of the 16-bit weight images).  With the default, N > 1 also times the "
+                         "sharded step in the same job as `comm.sharded` (--no-sharded-leg skips it)")
+    ap.add_argument("--no-sharded-leg", action="store_true", help="N > 1: do not time the sharded update beside the all-reduce headline")
+    ap.add_argument("--side-leg-budget", type=float, default=None,
+                    help="N > 1: seconds a side measurement (sharded leg, communication report, instrumented step) may take before rank 0 prints "
+                         "the headline line as it stands and every rank exits (default 100: below --collective-timeout, whose watchdog would abort "
+                         "the process; 1500 in a gloo / shared-GPU rehearsal, where buckets travel through the host)")
+    ap.add_argument("--fallback-note", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-comm-report", action="store_true", help="N > 1: skip the RCCL / exposed-communication / payload side measurements")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+loss+bwd(+all-reduce) only")
     ap.add_argument("--eval-drop", action="store_true", help="disable dropout (eval-mode layers) in the timed steps")
@@ -70,8 +78,6 @@ def parse():
     args = ap.parse_args()
     if args.comm_dtype is None:
         args.comm_dtype = "bf16" if args.precision == "bf16" else "fp32"
-    if args.comm_algo is None:      # N > 1: the sharded update (1 / N of the optimizer's HBM traffic per GPU, 16-bit all-gather); N = 1: no exchange
-        args.comm_algo = "sharded" if args.gpus > 1 else "allreduce"
     return args
 
 
@@ -700,33 +706,20 @@ def comm_report(args, trainer, feats, tgt, sub, world, rank, device, ms_with_com
     return rep
 
 
-def launch_ranks(n: int, script: str = None, argv: list = None, timeout: float = None) -> int:
-    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the ranks ourselves, as the reference does
-    (run.py:34-51 calls `torchrun --nproc_per_node=N` through subprocess).  The launcher is a CHILD process (never an exec: this
-    process must not be replaced, and nothing here has touched the GPU yet); its stdout -- rank 0's JSON line -- is ours, and
-    so is its return code.  A run that fails or does not finish within `timeout` seconds (--launch-timeout) cannot hang the
-    caller silently: the child's whole process group is terminated and ONE JSON line {"error": ..., "rc": ...} is printed, and
-    the return code is non-zero (VERDICT r3 #6; the reference's launcher has no such guard, common/utils.py:187-190)."""
+def _run_launcher(cmd, env, timeout, n):
+    """one `python -m torch.distributed.run` child in its own process group; (rc, error text or None, its stdout).  stdout is held back
+    so that the caller decides which child's JSON line becomes THE line of the run (stderr passes through)"""
     import signal
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), script or os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else list(argv))
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL across processes needs it on this pool
-    env.setdefault("OMP_NUM_THREADS", "8")
-    t0 = time.perf_counter()
-    proc = subprocess.Popen(cmd, env=env, start_new_session=True)      # its own process group: the ranks can be ended together
-    err = None
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True, stdout=subprocess.PIPE, text=True)      # own process group: the ranks can be ended together
+    err, out = None, ""
     try:
-        rc = proc.wait(timeout=timeout)
+        out, _ = proc.communicate(timeout=timeout)
+        rc = proc.returncode
         if rc != 0:
             err = f"the launcher exited with code {rc} (a rank failed; its traceback is on stderr above)"
     except subprocess.TimeoutExpired:
-        err = f"no result within --launch-timeout {timeout:.0f} s: ranks terminated (hung collective or rendezvous?)"
+        err = f"no result within {timeout:.0f} s: ranks terminated (hung collective or rendezvous?)"
         rc = 124
     if err is not None:
         for sig in (signal.SIGTERM, signal.SIGKILL):
@@ -735,19 +728,186 @@ def launch_ranks(n: int, script: str = None, argv: list = None, timeout: float =
             except ProcessLookupError:
                 break
             try:
-                proc.wait(timeout=10)
+                more, _ = proc.communicate(timeout=10)
+                out = (out or "") + (more or "")
                 break
             except subprocess.TimeoutExpired:
                 continue
-        print(json.dumps({"error": err, "rc": rc, "n_gpus": n, "elapsed_s": round(time.perf_counter() - t0, 1)}), flush=True)
-        return rc if rc != 0 else 1
-    return 0
+    return rc, err, out or ""
+
+
+def _has_result_line(out: str) -> bool:
+    for ln in out.splitlines():
+        if ln.startswith("{") and '"metric"' in ln and '"value"' in ln:
+            return True
+    return False
+
+
+def launch_ranks(n: int, script: str = None, argv: list = None, timeout: float = None, fallback_argv: list = None) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the ranks ourselves, as the reference does
+    (run.py:34-51 calls `torchrun --nproc_per_node=N` through subprocess).  The launcher is a CHILD process (never an exec: this
+    process must not be replaced, and nothing here has touched the GPU yet); its stdout -- rank 0's JSON line -- is ours, and
+    so is its return code.  A run that fails or does not finish within `timeout` seconds (--launch-timeout) cannot hang the
+    caller silently: the child's whole process group is terminated.  With `fallback_argv` (bench.py's own N > 1 run) a FRESH child
+    then runs the plain all-reduce step alone (no sharded leg, no side reports) and its JSON line carries the first failure's text
+    (`fallback_after`); if that fails too -- or without a fallback -- ONE JSON line {"error": ..., "rc": ...} is printed and the
+    return code is non-zero (VERDICT r3 #6, r5 #3b; the reference's launcher has no such guard, common/utils.py:187-190)."""
+    import socket
+
+    def command(extra):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+                "--master-port", str(port), script or os.path.abspath(__file__)] + list(extra)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "8")
+    t0 = time.perf_counter()
+    first = sys.argv[1:] if argv is None else list(argv)
+    rc, err, out = _run_launcher(command(first), env, timeout, n)
+    if err is None or _has_result_line(out):      # a child that printed its headline line and died afterwards (a side leg) still measured
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        return 0
+    sys.stderr.write(out)
+    if fallback_argv is not None:
+        print(f"bench.py: {err}; starting a fresh child for the all-reduce step alone", file=sys.stderr, flush=True)
+        rc2, err2, out2 = _run_launcher(command(list(fallback_argv) + ["--fallback-note", err]), env, timeout, n)
+        if err2 is None or _has_result_line(out2):
+            sys.stdout.write(out2)
+            sys.stdout.flush()
+            return 0
+        sys.stderr.write(out2)
+        err = f"{err}; the all-reduce-only fallback failed too: {err2}"
+        rc = rc2
+    print(json.dumps({"error": err, "rc": rc, "n_gpus": n, "elapsed_s": round(time.perf_counter() - t0, 1)}), flush=True)
+    return rc if rc != 0 else 1
+
+
+def fallback_args(argv: list) -> list:
+    """the argument list of the all-reduce-only child: the caller's own arguments, minus any --comm-algo, plus the switches that
+    drop every optional leg"""
+    out, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a == "--comm-algo":
+            skip = True
+            continue
+        if a.startswith("--comm-algo=") or a in ("--no-sharded-leg", "--no-comm-report", "--no-roofline"):
+            continue
+        out.append(a)
+    return out + ["--comm-algo", "allreduce", "--no-sharded-leg", "--no-comm-report", "--no-roofline"]
+
+
+class SideLegGuard:
+    """N > 1: everything after the timed region (sharded leg, communication report, instrumented step) is optional, full of
+    collectives and running on hardware this code has never met -- it must not cost the headline line.  arm(name) snapshots the
+    JSON line as it stands; if the leg is still running after `budget` seconds (kept below the process group's collective timeout,
+    whose watchdog would abort the process), or a SIGTERM arrives (torchrun ending the ranks because one of them died), rank 0
+    prints the snapshot -- with the leg's name under `side_leg_cut` -- and the process exits 0.  disarm() when the leg returned."""
+
+    def __init__(self, result: dict, rank: int, budget: float):
+        import signal
+        import threading
+        self.result, self.rank, self.budget = result, rank, budget
+        self._lock = threading.Lock()
+        self._timer = None
+        self._snap = None
+        self._printed = False
+        try:
+            signal.signal(signal.SIGTERM, lambda *_: self._fire("SIGTERM (a rank died?)"))
+        except ValueError:      # not the main thread (tests)
+            pass
+
+    def arm(self, name: str):
+        import threading
+        self.disarm()
+        snap = dict(self.result)
+        snap["side_leg_cut"] = name
+        self._snap = json.dumps(snap, default=str)
+        self._timer = threading.Timer(self.budget, self._fire, args=(f"no return within {self.budget:.0f} s",))
+        self._timer.daemon = True
+        self._timer.start()
+
+    def disarm(self):
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
+        self._snap = None
+
+    def _fire(self, why: str):
+        with self._lock:
+            if self._printed:
+                return
+            self._printed = True
+            if self.rank == 0 and self._snap is not None:
+                d = json.loads(self._snap)
+                d["side_leg_cut"] = f"{d['side_leg_cut']}: {why}"
+                print(json.dumps(d), flush=True)
+        os._exit(0 if self._snap is not None else 1)
+
+    def final(self, line: str):
+        """the one regular exit: print the full line unless the snapshot went out already"""
+        with self._lock:
+            if self._printed:
+                return
+            self._printed = True
+            self.disarm()
+            print(line, flush=True)
+
+
+def timed_steps(trainer, feats, tgt, sub, sync_all, warm: int, n: int, device, world: int) -> float:
+    """ms per step (max over ranks) of `n` steps after `warm` untimed ones"""
+    for _ in range(warm):
+        trainer.step(feats, tgt, sub)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        trainer.step(feats, tgt, sub)
+    sync_all()
+    dt = (time.perf_counter() - t0) / n * 1e3
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    return dt
+
+
+def sharded_leg(args, feats, tgt, sub, world, rank, device, sync_all, n: int = 10):
+    """N > 1, in the same job as the all-reduce headline: the same step with the SHARDED update (reduce-scatter of each weight
+    bucket's gradient, update of this rank's 1 / N slice, all-gather of the 16-bit weight images; parallel.GradReducer) on a
+    fresh replica of the model -- what it is worth against the all-reduce form on this fabric."""
+    from afft_amd import dropout as D_
+    from afft_amd.parallel import Trainer
+    if os.environ.get("AFFT_BENCH_FAIL_LEG") == "sharded":      # test hook: the leg raises on every rank
+        raise RuntimeError("AFFT_BENCH_FAIL_LEG=sharded")
+    if os.environ.get("AFFT_BENCH_FAIL_LEG") == "sharded_hang":  # test hook: the leg never returns
+        time.sleep(3600)
+    D_.manual_seed(42 + rank)
+    model, c = build_model(args.config, device)
+    model.train(not args.eval_drop)
+    tr = Trainer(model, {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}, comm_dtype=args.comm_dtype,
+                 bucket_elems=args.bucket_melems * 1024 * 1024, comm_algo="sharded")
+    ms = timed_steps(tr, feats, tgt, sub, sync_all, 3, n, device, world)
+    nsh = sum(tr.reducer.sharded_bucket(b) for b in range(len(tr.reducer.buckets)))
+    loss, _ = tr.step(feats, tgt, sub)
+    rep = {"ms_per_step": round(ms, 3), "clips_per_s": round(world * args.batch / ms * 1e3, 1), "steps": n,
+           "sharded_buckets": nsh, "buckets": len(tr.reducer.buckets), "replicated_elems": tr.flat.total - tr.flat.split,
+           "optimizer_path": "sharded" if tr.overlap_optimizer else "separate", "loss": round(float(loss), 4)}
+    tr.sync_masters()
+    del tr, model
+    torch.cuda.empty_cache()
+    return rep
 
 
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(args.gpus, timeout=args.launch_timeout))
+        fb = None if (args.fallback_note or os.environ.get("AFFT_BENCH_NO_FALLBACK") == "1") else fallback_args(sys.argv[1:])
+        sys.exit(launch_ranks(args.gpus, timeout=args.launch_timeout, fallback_argv=fb))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -794,6 +954,8 @@ def main():
     B, T = args.batch, c["T"]
     feats, tgt, sub = make_inputs(c, B, T, rank, device)
     wts = {"cls_action": 1.0, "past_cls_action": 1.0, "past_reg": 1.0}
+    if os.environ.get("AFFT_BENCH_FAIL_LEG") == "headline_sharded" and args.comm_algo == "sharded":      # test hook (launcher fallback)
+        raise RuntimeError("AFFT_BENCH_FAIL_LEG=headline_sharded")
     trainer = Trainer(model, wts, comm_dtype=args.comm_dtype, bucket_elems=args.bucket_melems * 1024 * 1024,
                       comm_algo=args.comm_algo)
     model.train(not args.eval_drop)
@@ -857,6 +1019,36 @@ def main():
         "optimizer_path": ("none" if args.no_optimizer else "fused-epilogue" if trainer._fused else
                            "sharded" if (world > 1 and args.comm_algo == "sharded" and trainer.overlap_optimizer) else "separate"),
     }
+    if args.fallback_note:
+        result["fallback_after"] = args.fallback_note      # this line comes from the all-reduce-only child started after that failure
+    # (a rehearsal over gloo moves the buckets through the host: minutes, and gloo raises on a timeout instead of aborting the process)
+    budget = args.side_leg_budget if args.side_leg_budget is not None else (100.0 if (backend == "nccl" and not share) else 1500.0)
+    guard = SideLegGuard(result, rank, budget) if world > 1 else None
+
+    # N = 1: the same step with the SEPARATE per-bucket update kernel -- the kernels every rank of an N > 1 run executes (there the
+    # summed gradient has to exist before the update), so that a scaling curve has an N = 1 anchor on the same code
+    if world == 1 and not captured and not args.no_optimizer and trainer._fused:
+        try:
+            afft_amd.runtime.set_fused_sgd(False)
+            ms_sep = timed_steps(trainer, feats, tgt, sub, sync_all, 3, 10, device, 1)
+            result["separate_update"] = {"ms_per_step": round(ms_sep, 3), "clips_per_s": round(B / ms_sep * 1e3, 1), "steps": 10,
+                                         "note": "optimizer as one kernel per gradient bucket behind the backward pass (gradients go to HBM): "
+                                                 "the N > 1 ranks' code path; the headline N = 1 step updates inside the weight-gradient epilogues"}
+        finally:
+            afft_amd.runtime.set_fused_sgd(True)
+            for _ in range(2):
+                trainer.step(feats, tgt, sub)
+
+    if world > 1:
+        result["comm"] = {}
+    if world > 1 and not args.no_sharded_leg and args.comm_algo != "sharded" and not args.no_optimizer:
+        guard.arm("sharded leg")
+        try:
+            result["comm"]["sharded"] = sharded_leg(args, feats, tgt, sub, world, rank, device, sync_all)
+            result["comm"]["sharded"]["vs_allreduce_step"] = round(result["comm"]["sharded"]["ms_per_step"] / ms_per_step, 4)
+        except Exception as ex:  # noqa: BLE001
+            result["comm"]["sharded"] = {"error": repr(ex)[:400]}
+        guard.disarm()
 
     # the same workload with the reference's full row set (the last SA-Fuser block's MLP on all M + 1 tokens of a frame), in the same
     # process: what the dead-row elimination is worth, on the record beside the headline number
@@ -878,20 +1070,27 @@ def main():
             afft_amd.runtime.set_skip_dead_rows(True)
 
     if world > 1 and not args.no_comm_report:
+        guard.arm("communication report")
         try:     # deterministic on every rank (same code path), so a failure cannot leave a collective half-entered
-            result["comm"] = comm_report(args, trainer, feats, tgt, sub, world, rank, device, ms_per_step, rccl_log, sync_all)
+            result["comm"].update(comm_report(args, trainer, feats, tgt, sub, world, rank, device, ms_per_step, rccl_log, sync_all))
         except Exception as ex:  # noqa: BLE001
-            result["comm"] = {"error": repr(ex)}
+            result["comm"]["error"] = repr(ex)
+        guard.disarm()
 
     # the instrumented step for the roofline object runs on EVERY rank (its gradient all-reduce is a collective);
     # only rank 0 keeps the timings
     summ = summ_alone = None
     ksumm = ksumm_alone = gemm_recs = None
     if not args.no_roofline:
+        if guard is not None:
+            guard.arm("instrumented step")
         with GemmTimer() as gt, KernelTimer() as kt:      # the same kernel sequence as a timed step (fused optimizer epilogues included)
             trainer.step(feats, tgt, sub, optimize=not args.no_optimizer)
         summ = gt.summary()
         ksumm, gemm_recs = kt.summary(), gt.records
+        if guard is not None:
+            sync_all()
+            guard.disarm()
         # the same launches with NOTHING beside them (weight gradients on the main stream for one more instrumented step): what the
         # dominant kernel does alone, to set beside what it does inside the two-stream step (kernel quality vs schedule)
         summ_alone = None
@@ -948,13 +1147,21 @@ def main():
             avg_fl = d["flops"] / d["launches"]
             ach = avg_fl / (avg_ms * 1e-3) / 1e12
             dtype_peak = 157.3 if args.precision == "fp32" else PEAK_BF16_TFLOPS      # bf16 / fp16 dense MFMA peak; exact-fp32 MFMA peak
+            # HBM-side bytes per launch from separate rocprofv3 --pmc passes (tools/profile_round.sh + tools/traffic_summary.py, committed
+            # under profiles/).  A profile belongs to ONE workload: its "_workload" entry (config, per-GPU batch, precision, GPUs) must
+            # match this run, else `traffic` is null -- a kernel symbol alone says nothing about the bytes of another shape set
             traffic, traffic_src = None, None
-            for fn in ("r05_gemm_hbm_traffic_pmc.json", "r04b_gemm_hbm_traffic_pmc.json", "r03c_gemm_hbm_traffic_pmc.json", "r03b_gemm_hbm_traffic_pmc.json", "r03a_gemm_hbm_traffic_pmc.json", "r02i_gemm_hbm_traffic_pmc.json", "r02h_gemm_hbm_traffic_pmc.json", "r02g_gemm_hbm_traffic_pmc.json", "r02_gemm_hbm_traffic_pmc.json", "r01_gemm_hbm_traffic_pmc.json"):
-                try:   # HBM-side bytes per launch from separate rocprofv3 --pmc passes (tools/traffic_summary.py), committed
-                    tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
-                    hit = [v for k, v in tj.items() if isinstance(v, dict) and (k == dom or dom.startswith(k.rstrip(">")))]
+            me = {"config": args.config, "batch": args.batch, "precision": args.precision, "gpus": world}
+            import glob as _glob
+            for fn in sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_hbm_traffic_pmc.json")), reverse=True):
+                try:
+                    tj = json.load(open(fn))
+                    wl = tj.get("_workload", {"config": "cfg2", "batch": 64, "precision": "bf16", "gpus": 1})     # rounds 1-5 profiled the default run only
+                    if any(wl.get(k) != v for k, v in me.items()) or args.no_optimizer or args.full_rows:
+                        continue
+                    hit = [v for k, v in tj.items() if isinstance(v, dict) and k != "_workload" and (k == dom or dom.startswith(k.rstrip(">")))]
                     if hit:
-                        traffic, traffic_src = hit[0].get("hbm_bytes_per_launch"), fn
+                        traffic, traffic_src = hit[0].get("hbm_bytes_per_launch"), os.path.basename(fn)
                         break
                 except Exception:  # noqa: BLE001
                     pass
@@ -964,7 +1171,8 @@ def main():
                 "bound": "mfma", "achieved": round(ach, 1), "peak": dtype_peak, "unit": "TFLOP/s",
                 "frac": round(ach / dtype_peak, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(d["bytes"] / d["launches"]),
-                "traffic_note": f"bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate --pmc passes of this command "
+                "traffic_note": "no committed --pmc profile of this workload (config, batch, precision, GPUs): null" if traffic is None else
+                                f"bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate --pmc passes of this command "
                                 f"(profiles/{traffic_src}); fabric-side: includes Infinity-Cache hits, which the L2's counters cannot tell from HBM "
                                 f"reads (profiles/r03_l2_hit_pmc.txt: 70-79 % L2 hits, ~2 TB/s of fabric reads while the kernel runs: not time-relevant); read from the committed profile of this command, not measured in this run",
                 "fused_optimizer_epilogue": bool(d.get("fused_update_launches")),
@@ -1007,9 +1215,15 @@ def main():
                 result["cpu_baseline"] = {"value": None, "error": repr(ex)}
 
     if rank == 0:
-        print(json.dumps(result))
+        if guard is not None:
+            guard.final(json.dumps(result))
+        else:
+            print(json.dumps(result))
     if world > 1:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 if __name__ == "__main__":

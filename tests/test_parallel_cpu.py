@@ -237,8 +237,20 @@ def _afft_worker(rank, world, port, out, comm_dtype, comm_algo="allreduce"):
             r0, r1 = tr.reducer.shard_of(*tr.reducer.buckets[0])
             mine = tr.opt.buf[r0:r1].clone()
             assert tr.reducer.masters_stale
-            sd = model.state_dict()                      # the pre-hook brings masters and momentum up to date (a collective)
+            try:                                         # state_dict() never communicates (the reference saves on rank 0 alone,
+                model.state_dict()                       # train.py:403-411): stale masters are an error, not a collective
+                raise AssertionError("state_dict() on stale masters must raise")
+            except RuntimeError as ex:
+                assert "sync_masters" in str(ex)
+            with torch.no_grad():                        # the first evaluation forward (every rank validates) brings them up to date
+                model({m: d[sl] for m, d in data.items()}, mixup_fn=None, target={"action": tgt[sl]},
+                      target_subclips={"action": sub[sl]}, target_subclips_ignore_index=None)
             assert not tr.reducer.masters_stale and torch.equal(tr.opt.buf[r0:r1], mine)
+            sd = model.state_dict()
+            # embedding tables are read as fp32 rows: they sit in the replicated region whatever their shape
+            for k, p in model.named_parameters():
+                if k.endswith("wpe.weight") or k.endswith("position_embeddings.weight"):
+                    assert tr.flat.offsets[tr.flat.index_of()[id(p)]] >= tr.flat.split, k
     flat = tr.flat.flat_p.clone()
     buf = tr.opt.buf.clone()
     for t in (flat, buf):
