@@ -1350,7 +1350,6 @@ def test_two_ranks_on_one_gpu_match_single_process_and_each_other(tmp_path, case
             got = torch.cat([r[grp][k].reshape(-1) for k in sorted(one[grp])])
             assert rel_l2(got, ref) < tol, (a, grp, rel_l2(got, ref))
         assert rel_l2(r["logits"], one["logits"]) < 1e-5, (a, rel_l2(r["logits"], one["logits"]))
-        assert abs(sum(r["info"]["losses"]) / len(r["info"]["losses"]) - sum(one["info"]["losses"]) / len(one["info"]["losses"])) < 0.5
     sh = runs["sharded"]["info"]
     assert 0 < sh["split"] < sh["total"] and 2 <= sh["sharded_buckets"] < sh["buckets"], sh
     assert sh["stale_before_sync"] and sh["state_dict_on_stale_masters"] == "raised" and not sh["stale_after_eval_forward"], sh
