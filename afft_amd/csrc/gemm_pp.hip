@@ -66,6 +66,40 @@ unsigned long long* g_pp_stamp = nullptr;
 #define STAMP(var) do { } while (0)
 #endif
 
+// Epilogue of the 256x256 kernels through LDS (the K-loop's ring is free): two passes of 128 rows.  Accumulators are scattered into
+// an fp32 [128][256] image (row stride 1040 B = 1 KiB + 16 B, so the 16 rows a lane group writes fall in 16 different 16-byte
+// slots), then every wave walks 16 whole rows: one conflict-free 16-byte LDS read per lane and fully coalesced global accesses
+// (bias, residual, pre-activation, outputs) in a runtime loop -- no 32-fold unrolled epilogue, no 32-byte store segments.
+__device__ __forceinline__ void pp_epilogue(const GemmFast& g, char* smem, f32x4 (&acc)[2][2][4][2], int m0, int n0, int lane, int wave,
+                                            int gp, int wc) {
+  constexpr int ESTRIDE = 1040;
+  const DropParams dp = with_salt(g.e.drop);
+  if (AFFT_PP_DIAG & 16) return;
+  static_for<0, 2>([&](auto ihc) {
+    constexpr int ih = decltype(ihc)::value;
+    __builtin_amdgcn_s_barrier();   // pass 0: every wave is done with the ring; pass 1: pass 0 has been read back
+    static_for<0, 16>([&](auto idx) {
+      constexpr int v = decltype(idx)::value;
+      constexpr int jh = v >> 3, i = (v >> 1) & 3, j = v & 1;
+      const int row = gp * 64 + i * 16 + (lane & 15);
+      const int col = jh * 128 + wc * 32 + j * 16 + 4 * (lane >> 4);
+      *(f32x4*)(smem + row * ESTRIDE + col * 4) = acc[ih][jh][i][j];
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll AFFT_PP_EPI_UNROLL
+    for (int rr = 0; rr < 8; ++rr) {     // two rows per step: a lane owns 8 consecutive columns (16-byte bf16 stores)
+      const int row = wave * 16 + rr * 2 + (lane >> 5);
+      const int c8 = lane & 31;
+      const f32x4 t0 = *(const f32x4*)(smem + row * ESTRIDE + c8 * 32);
+      const f32x4 t1 = *(const f32x4*)(smem + row * ESTRIDE + c8 * 32 + 16);
+      float o[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+      if (!(AFFT_PP_DIAG & 8)) epilogue8(g.e, dp, m0 + ih * 128 + row, n0 + 8 * c8, o);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  });
+}
+
 // X3: 1 = bf16x3 operand planes, 2 = fp16 planes, two passes (gemm_tiles.h: seg_operands, mfma16).
 template <bool A_KS, bool B_KS, int X3 = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
@@ -316,37 +350,251 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(const GemmFast g
   }
 #endif
 
-  // Epilogue through LDS (the ring is free now): two passes of 128 rows.  Accumulators are scattered into an fp32
-  // [128][256] image (row stride 1040 B = 1 KiB + 16 B, so the 16 rows a lane group writes fall in 16 different
-  // 16-byte slots), then every wave walks 16 whole rows: one conflict-free 16-byte LDS read per lane and fully
-  // coalesced global accesses (bias, residual, pre-activation, outputs) in a runtime loop -- no 32-fold unrolled
-  // epilogue, no 32-byte store segments.
-  constexpr int ESTRIDE = 1040;
-  const DropParams dp = with_salt(g.e.drop);
-  if (AFFT_PP_DIAG & 16) return;
-  static_for<0, 2>([&](auto ihc) {
-    constexpr int ih = decltype(ihc)::value;
-    __builtin_amdgcn_s_barrier();   // pass 0: every wave is done with the ring; pass 1: pass 0 has been read back
-    static_for<0, 16>([&](auto idx) {
-      constexpr int v = decltype(idx)::value;
-      constexpr int jh = v >> 3, i = (v >> 1) & 3, j = v & 1;
-      const int row = gp * 64 + i * 16 + (lane & 15);
-      const int col = jh * 128 + wc * 32 + j * 16 + 4 * (lane >> 4);
-      *(f32x4*)(smem + row * ESTRIDE + col * 4) = acc[ih][jh][i][j];
-    });
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#pragma unroll AFFT_PP_EPI_UNROLL
-    for (int rr = 0; rr < 8; ++rr) {     // two rows per step: a lane owns 8 consecutive columns (16-byte bf16 stores)
-      const int row = wave * 16 + rr * 2 + (lane >> 5);
-      const int c8 = lane & 31;
-      const f32x4 t0 = *(const f32x4*)(smem + row * ESTRIDE + c8 * 32);
-      const f32x4 t1 = *(const f32x4*)(smem + row * ESTRIDE + c8 * 32 + 16);
-      float o[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-      if (!(AFFT_PP_DIAG & 8)) epilogue8(g.e, dp, m0 + ih * 128 + row, n0 + 8 * c8, o);
+  pp_epilogue(g, smem, acc, m0, n0, lane, wave, gp, wc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round 6: the same ping-pong schedule with a steady-state loop that contains nothing but the schedule ("pp2").
+// gemm_bf16_pp_kernel above serves every shape (edge tiles, odd K-tile counts, operand planes); its loop pays for that: a run-time
+// "past the end of K?" test and a dummy transfer beside every LDS-DMA issue (16 branches per two K-tiles), 64-bit source-address
+// arithmetic per piece (scalar multiplies in the k-strided layouts), and fragment registers the allocator renames from phase to
+// phase (a false write-after-write wait in the middle of a phase's LDS reads).  This kernel takes only what the hot shapes are --
+// plain bf16, whole 256x256 tiles (M, N % 256 == 0), an even number >= 4 of K-tiles -- and in exchange:
+//   * the loop over K-tile PAIRS is branch-free: the last pair, whose look-ahead would run past the end of K, is peeled (TAIL
+//     instantiations of the same phase code: fewer issues, the counted waits draining 6 -> 4 -> 2 -> 0);
+//   * every source address is (one of 8 loop-invariant wave-uniform bases, in SGPRs) + (one VGPR per operand: the lane's offset
+//     inside a piece plus the running K offset, advanced by ONE v_add per operand and K-tile) -- no address arithmetic per piece;
+//   * LDS destinations are immediates of the M0 write.
+// Schedule, ring, images, fragment reads, hazards (RAW / WAR derivation) and epilogue are gemm_bf16_pp_kernel's, LEAD = 6.
+// AFFT_PP2_WAIT = 1: the counted wait only in phases 0 and 2 of a K-tile.  Deadlines per half-tile h = 4j + q (wait in L(w), w <= ..):
+// q = 0: 4j - 1, q = 1: 4j - 2, q = 2: 4j, q = 3: 4j + 1 (read phase minus one, see RAW above).  The wait of L(4j - 2) [phase 2 of
+// K-tile j - 1] retires h <= 4j + 1 (q = 0, 1 of K-tile j: in time), the wait of L(4j) [phase 0] retires h <= 4j + 3 (q = 2, 3: in
+// time): each with 3 half-tiles = 6 operations allowed in flight -- the waits of phases 1 and 3 only ever asked for data whose
+// deadline is one phase later, so dropping them relaxes the schedule without touching a deadline.
+#ifndef AFFT_PP2_WAIT
+#define AFFT_PP2_WAIT 1
+#endif
+#ifndef AFFT_PP2_PRIO
+#define AFFT_PP2_PRIO 1       // MFMA segments at raised priority
+#endif
+#ifndef AFFT_PP2_DMA_FIRST
+#define AFFT_PP2_DMA_FIRST 1  // a phase's LDS-DMA before its fragment reads
+#endif
+template <int OFF>
+__device__ __forceinline__ void glds16i(const char* sbase, unsigned voff, unsigned lds_wave) {
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_wave), "n"(OFF) : "memory", "scc");
+}
+
+template <bool A_KS, bool B_KS>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(const GemmFast g) {
+  constexpr int HB = 128 * BK * 2;   // half-tile bytes (16 KiB)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int gp = wave >> 2, wc = wave & 3;
+  int tm, tn;
+  tile_coords(g.tiles_m, g.tiles_n, blockIdx.x, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int npairs = g.K / (2 * BK);      // >= 2 (launch_pp2)
+
+  f32x4 acc[2][2][4][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 aF[4][2], bF[2][2][2];   // A fragments of the live half; B fragments of both halves
+
+  const unsigned lds_wave = lds_addr(smem) + wave * 1024;
+  const unsigned lda2 = (unsigned)(g.lda * 2), ldb2 = (unsigned)(g.ldb * 2);
+  const LaneOffsets lo = lane_offsets(wave, lane);
+  unsigned vA = A_KS ? lo.ks_row * lda2 + lo.ks_c16 : lo.kc_row * lda2 + lo.kc_chunk16;   // lane offset + running K offset
+  unsigned vB = B_KS ? lo.ks_row * ldb2 + lo.ks_c16 : lo.kc_row * ldb2 + lo.kc_chunk16;
+  const unsigned stepA = A_KS ? 64u * lda2 : 128u, stepB = B_KS ? 64u * ldb2 : 128u;     // bytes per K-tile
+  // the 8 source bases of this wave: [operand half][piece]; piece j = wave + 8 jj covers rows 8j.. (k-contiguous) / k-rows 4j.. (k-strided)
+  const char* bA[2][2];
+  const char* bB[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = wave + 8 * jj;
+      bA[h][jj] = A_KS ? (const char*)(g.A + (int64_t)(4 * j) * g.lda + m0 + 128 * h) : (const char*)(g.A + (int64_t)(m0 + 128 * h + 8 * j) * g.lda);
+      bB[h][jj] = B_KS ? (const char*)(g.B + (int64_t)(4 * j) * g.ldb + n0 + 128 * h) : (const char*)(g.B + (int64_t)(n0 + 128 * h + 8 * j) * g.ldb);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  });
+  // half-tile kind q (0 = A rows 0-127, 1 = B 0-127, 2 = B 128-255, 3 = A 128-255) of a K-tile of parity KP -> ring slot KP * 4 + q
+  auto issue = [&](auto qc, auto kpc) {
+    constexpr int q = decltype(qc)::value, KP = decltype(kpc)::value;
+    constexpr int dst = (KP * 4 + q) * HB;
+    if constexpr (q == 0 || q == 3) {
+      glds16i<dst>(bA[q == 3][0], vA, lds_wave);
+      glds16i<dst + 8192>(bA[q == 3][1], vA, lds_wave);
+      if constexpr (q == 3) vA += stepA;       // A's second half closes its K-tile
+    } else {
+      glds16i<dst>(bB[q == 2][0], vB, lds_wave);
+      glds16i<dst + 8192>(bB[q == 2][1], vB, lds_wave);
+      if constexpr (q == 2) vB += stepB;
+    }
+  };
+  // Fragment reads: every lane-dependent part of an LDS address is one of a few VGPRs computed ONCE (made opaque, so that the compiler
+  // neither re-derives them per phase nor hoists one register per (ring slot, fragment) -- 36 address registers and, in the TN
+  // instantiation, 17 spills in the first build); ring slot, k-substep and fragment index are instruction offsets (< 64 KiB: one
+  // register set per half of the ring).  k-contiguous image (gemm_tiles.h frag_kc): address(row, chunk) = row * 128 +
+  // ((chunk ^ ((row >> 1) & 7)) << 4) -- fragment i / j adds 16 rows = 2 KiB, the k-substep flips bit 2 of the chunk (a lane-dependent
+  // +-64 B: one register per substep).  k-strided image (frag_ks): both 4-row blocks and both k-substeps of a fragment are fixed
+  // distances (1 KiB, 8 KiB) from one address that depends on the 32-byte unit = fragment index (one register per fragment).
+  constexpr int NA = A_KS ? 4 : 2, NB = 2;
+  unsigned adA[2][NA], adB[2][NB];      // [ring half][..] LDS byte addresses of ring slot 0 / 4
+  {
+    const unsigned l0 = lds_addr(smem);
+    const int g4 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3, r16 = lane & 15;
+#pragma unroll
+    for (int x = 0; x < NA; ++x) {
+      unsigned a;
+      if constexpr (A_KS) a = (8 * g4 + q4) * 256 + ((((gp * 4 + x) ^ ks_f(8 * g4 + q4))) << 5) + p4 * 8;
+      else { const int row = gp * 64 + r16; a = row * 128 + ((((x * 4 + g4) ^ ((row >> 1) & 7))) << 4); }
+      adA[0][x] = l0 + a; adA[1][x] = l0 + a + 4 * HB;
+      asm volatile("" : "+v"(adA[0][x]), "+v"(adA[1][x]));
+    }
+#pragma unroll
+    for (int x = 0; x < NB; ++x) {
+      unsigned b;
+      if constexpr (B_KS) b = (8 * g4 + q4) * 256 + ((((wc * 2 + x) ^ ks_f(8 * g4 + q4))) << 5) + p4 * 8;
+      else { const int row = wc * 32 + r16; b = row * 128 + ((((x * 4 + g4) ^ ((row >> 1) & 7))) << 4); }
+      adB[0][x] = l0 + b; adB[1][x] = l0 + b + 4 * HB;
+      asm volatile("" : "+v"(adB[0][x]), "+v"(adB[1][x]));
+    }
+  }
+  auto rd128 = [](unsigned addr, auto offc) -> bf16x8 {
+    return *(AFFT_LDS const bf16x8*)(size_t)(addr + decltype(offc)::value);
+  };
+  auto rdtr = [](unsigned addr, auto offc) -> bf16x8 {      // one k-strided fragment: two transposing 8-byte reads 4 k-rows (1 KiB) apart
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AFFT_LDS bf16x4*)(size_t)(addr + decltype(offc)::value));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AFFT_LDS bf16x4*)(size_t)(addr + decltype(offc)::value + 1024));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+  };
+  auto load_a = [&](auto kpc, auto ihc) {
+    constexpr int KP = decltype(kpc)::value, ih = decltype(ihc)::value;
+    constexpr int so = (ih ? 3 : 0) * HB;       // slot offset inside the ring half
+    static_for<0, 2>([&](auto sc) {
+      static_for<0, 4>([&](auto ic) {
+        constexpr int s = decltype(sc)::value, i = decltype(ic)::value;
+        if constexpr (A_KS) aF[i][s] = rdtr(adA[KP][i], std::integral_constant<int, so + s * 8192>{});
+        else aF[i][s] = rd128(adA[KP][s], std::integral_constant<int, so + i * 2048>{});
+      });
+    });
+  };
+  auto load_b = [&](auto kpc, auto jhc, auto slotc) {   // B half jh of a K-tile of parity KP -> fragment slot
+    constexpr int KP = decltype(kpc)::value, jh = decltype(jhc)::value, slot = decltype(slotc)::value;
+    constexpr int so = (1 + jh) * HB;
+    static_for<0, 2>([&](auto sc) {
+      static_for<0, 2>([&](auto jc) {
+        constexpr int s = decltype(sc)::value, j = decltype(jc)::value;
+        if constexpr (B_KS) bF[slot][j][s] = rdtr(adB[KP][j], std::integral_constant<int, so + s * 8192>{});
+        else bF[slot][j][s] = rd128(adB[KP][s], std::integral_constant<int, so + j * 2048>{});
+      });
+    });
+  };
+  auto compute = [&](auto ihc, auto jhc, auto slotc) {
+    constexpr int ih = decltype(ihc)::value, jh = decltype(jhc)::value, slot = decltype(slotc)::value;
+    __builtin_amdgcn_sched_barrier(0);
+    if (AFFT_PP2_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[ih][jh][i][j] = mfma16<0>(bF[slot][j][s], aF[i][s], acc[ih][jh][i][j]);
+    if (AFFT_PP2_PRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+
+  // prologue = "L(-1)": half-tiles 0..5 (K-tile 0 whole, A0 and B0 of K-tile 1)
+  issue(I0{}, I0{}); issue(I1{}, I0{}); issue(I2{}, I0{}); issue(I3{}, I0{}); issue(I0{}, I1{}); issue(I1{}, I1{});
+  wait_vmcnt_only<6>();
+  __builtin_amdgcn_s_barrier();
+  load_b(I0{}, I0{}, I0{});                     // K-tile 0's first B fragments (later ones are read a phase early)
+  if (gp == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one slot behind group 0
+
+  // One K-tile of parity P (ring half P): 4 phases = the 4 quadrants of the wave's 128x64 output, in the order (0,0) (0,1) (1,1) (1,0);
+  // phase p stages half-tile 4 kt + p + 6 = kind (p + 2) & 3 of K-tile kt + 1 (p = 0, 1: ring half 1 - P) / kt + 2 (p = 2, 3: half P).
+  // TAIL: 0 = steady state, 1 = K-tile nk - 2 (only phases 0, 1 still stage), 2 = K-tile nk - 1 (nothing left to stage or to prefetch)
+  auto ktile = [&](auto Pc, auto tailc) {
+    constexpr int P = decltype(Pc)::value, TAIL = decltype(tailc)::value;
+    using KP = std::integral_constant<int, P>;
+    using KQ = std::integral_constant<int, 1 - P>;
+    using SP = KP;      // fragment slot of B half 0 (the two slots swap roles every K-tile)
+    using SQ = KQ;
+    constexpr bool W = AFFT_PP2_WAIT != 0;
+    // phase 0
+    if constexpr (TAIL < 2 && AFFT_PP2_DMA_FIRST) issue(I2{}, KQ{});
+    load_a(KP{}, I0{});
+    if constexpr (TAIL < 2 && !AFFT_PP2_DMA_FIRST) issue(I2{}, KQ{});
+    if constexpr (TAIL == 0 || TAIL == 1) wait_vmcnt_only<6>(); else wait_vmcnt_only<0>();
+    __builtin_amdgcn_s_barrier();
+    compute(I0{}, I0{}, SP{});
+    // phase 1
+    if constexpr (TAIL < 2 && AFFT_PP2_DMA_FIRST) issue(I3{}, KQ{});
+    load_b(KP{}, I1{}, SQ{});
+    if constexpr (TAIL < 2 && !AFFT_PP2_DMA_FIRST) issue(I3{}, KQ{});
+    if constexpr (TAIL == 0) { if constexpr (!W) wait_vmcnt_only<6>(); } else if constexpr (TAIL == 1) wait_vmcnt_only<6>();
+    __builtin_amdgcn_s_barrier();
+    compute(I0{}, I1{}, SQ{});
+    // phase 2
+    if constexpr (TAIL == 0 && AFFT_PP2_DMA_FIRST) issue(I0{}, KP{});
+    load_a(KP{}, I1{});
+    if constexpr (TAIL == 0 && !AFFT_PP2_DMA_FIRST) issue(I0{}, KP{});
+    if constexpr (TAIL == 0) wait_vmcnt_only<6>(); else if constexpr (TAIL == 1) wait_vmcnt_only<4>();
+    __builtin_amdgcn_s_barrier();
+    compute(I1{}, I1{}, SQ{});
+    // phase 3
+    if constexpr (TAIL == 0 && AFFT_PP2_DMA_FIRST) issue(I1{}, KP{});
+    if constexpr (TAIL < 2) load_b(KQ{}, I0{}, SQ{});
+    if constexpr (TAIL == 0 && !AFFT_PP2_DMA_FIRST) issue(I1{}, KP{});
+    if constexpr (TAIL == 0) { if constexpr (!W) wait_vmcnt_only<6>(); } else if constexpr (TAIL == 1) wait_vmcnt_only<2>();
+    __builtin_amdgcn_s_barrier();
+    compute(I1{}, I0{}, SP{});
+  };
+  for (int pr = 0; pr < npairs - 1; ++pr) {
+    ktile(I0{}, I0{});
+    ktile(I1{}, I0{});
+  }
+  ktile(I0{}, I1{});
+  ktile(I1{}, I2{});
+  if (gp == 0) __builtin_amdgcn_s_barrier();
+  pp_epilogue(g, smem, acc, m0, n0, lane, wave, gp, wc);
+}
+
+#ifndef AFFT_PP2
+#define AFFT_PP2 1      // 0: every shape on gemm_bf16_pp_kernel (A/B builds)
+#endif
+template <bool A_KS, bool B_KS>
+bool pp2_takes(const GemmFast& g) {
+  return AFFT_PP2 && g.e.M % 256 == 0 && g.e.N % 256 == 0 && g.K % (2 * BK) == 0 && g.K >= 4 * BK;
+}
+
+template <bool A_KS, bool B_KS>
+int launch_pp2(GemmFast& g, hipStream_t stream) {
+  constexpr size_t lds = 128 * 1040;
+  g.tiles_m = g.e.M / 256;
+  g.tiles_n = g.e.N / 256;
+  auto kern = gemm_bf16_pp2_kernel<A_KS, B_KS>;
+  static std::atomic<uint64_t> attr_done{0};
+  if (int rc = afft_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, &attr_done)) return rc;
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), lds, stream, g);
+  AFFT_LAUNCH_CHECK();
+  return 0;
 }
 
 template <bool A_KS, bool B_KS, int X3 = 0>
@@ -393,10 +641,10 @@ int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipSt
     if (a_ks && b_ks) return launch_pp<true, true, 1>(g, stream);
   }
 #endif
-  if (!a_ks && !b_ks) return launch_pp<false, false>(g, stream);
+  if (!a_ks && !b_ks) return pp2_takes<false, false>(g) ? launch_pp2<false, false>(g, stream) : launch_pp<false, false>(g, stream);
 #ifndef AFFT_PP_NT_ONLY
-  if (!a_ks && b_ks) return launch_pp<false, true>(g, stream);
-  if (a_ks && b_ks) return launch_pp<true, true>(g, stream);
+  if (!a_ks && b_ks) return pp2_takes<false, true>(g) ? launch_pp2<false, true>(g, stream) : launch_pp<false, true>(g, stream);
+  if (a_ks && b_ks) return pp2_takes<true, true>(g) ? launch_pp2<true, true>(g, stream) : launch_pp<true, true>(g, stream);
 #endif
   afft_set_error("afft_gemm: layout (A k-strided, B k-contiguous) is not built");
   return 1;

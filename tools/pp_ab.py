@@ -1,0 +1,137 @@
+"""Interleaved A/B of several builds of the library's 256x256 bf16 GEMM in ONE process (guide rule 24): every library is loaded with
+its own ctypes handle, every round times every (library, shape) pair back to back, the table shows median and best per pair.
+Operands are uniform random in [-1, 1) (rule 25).  Before timing, every library's result is checked against an fp32 torch product
+(relative L2) on every layout, and each timed shape is run `RACE` times and compared BITWISE with its first result (a race in the
+LDS ring shows up as a run-to-run difference).
+
+    python tools/pp_ab.py afft_amd/lib/libafft_hip.so afft_amd/lib/libafft_hip_x.so ...
+env: ROUNDS (5), ITERS (20), RACE (10), SHAPES=path|big|all, VARIANT (3 = force the 256x256 kernels; 0 = the library's dispatch)"""
+import ctypes as C
+import os
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from afft_amd import _lib as L  # noqa: E402
+
+dev = "cuda:0"
+ROUNDS, ITERS, RACE = int(os.environ.get("ROUNDS", 5)), int(os.environ.get("ITERS", 20)), int(os.environ.get("RACE", 10))
+VARIANT = int(os.environ.get("VARIANT", 3))
+PATH = [("nt", 5120, 6144, 2048), ("nt", 5120, 8192, 2048), ("nt", 5120, 2048, 8192), ("nn", 5120, 2048, 6144), ("nn", 5120, 8192, 2048),
+        ("nn", 5120, 2048, 8192), ("tn", 6144, 2048, 5120), ("tn", 8192, 2048, 5120), ("tn", 2048, 8192, 5120), ("tn", 8192, 2048, 1024)]
+BIG = [("nt", 4096, 4096, 4096), ("nt", 8192, 8192, 8192)]
+SHAPES = {"path": PATH, "big": BIG, "all": PATH + BIG}[os.environ.get("SHAPES", "all")]
+
+
+def load(path):
+    lib = C.CDLL(os.path.abspath(path))
+    lib.afft_last_error.restype = C.c_char_p
+    for name in ("afft_gemm", "afft_set_gemm_variant", "afft_set_gemm_splitk"):
+        fn = getattr(lib, name)
+        fn.argtypes, fn.restype = L._SIGS[name]
+    assert lib.afft_set_gemm_variant(VARIANT) == 0
+    return lib
+
+
+def operands(layout, M, N, K, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    u = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(torch.bfloat16).to(dev)      # noqa: E731
+    if layout == "nt":
+        return u(M, K), u(N, K)
+    if layout == "nn":
+        return u(M, K), u(K, N)
+    return u(K, M), u(K, N)
+
+
+def desc(layout, a, b, out):
+    d = L.GemmDesc()
+    a_t, b_t = layout == "tn", layout == "nt"
+    M, K = (a.shape[1], a.shape[0]) if a_t else a.shape
+    N = b.shape[0] if b_t else b.shape[1]
+    d.M, d.N, d.K, d.dtype = M, N, K, L.BF16
+    d.A, d.B = a.data_ptr(), b.data_ptr()
+    d.a_rs, d.a_cs = (a.stride(1), a.stride(0)) if a_t else (a.stride(0), a.stride(1))
+    d.b_rs, d.b_cs = (b.stride(1), b.stride(0)) if b_t else (b.stride(0), b.stride(1))
+    d.alpha = 1.0
+    d.out, d.ldo, d.out_dtype = out.data_ptr(), out.stride(0), (L.F32 if out.dtype == torch.float32 else L.BF16)
+    return d
+
+
+def run(lib, d, n=1):
+    s = torch.cuda.current_stream().cuda_stream
+    for _ in range(n):
+        rc = lib.afft_gemm(C.byref(d), s)
+        if rc:
+            raise RuntimeError(lib.afft_last_error().decode())
+
+
+def reference(layout, a, b):
+    a32, b32 = a.float(), b.float()
+    return (a32.t() if layout == "tn" else a32) @ (b32.t() if layout == "nt" else b32)
+
+
+def main():
+    paths = sys.argv[1:] or [L.LIB_PATH]
+    libs = [(os.path.basename(p).replace("libafft_hip", "").replace(".so", "") or "product", load(p)) for p in paths]
+    print("libraries:", ", ".join(n for n, _ in libs), f"| variant {VARIANT} rounds {ROUNDS} iters {ITERS} race repeats {RACE}")
+    # correctness: every layout, a shape with several tiles and K-tile pairs, plus one edge shape that must take the general kernel
+    for layout, M, N, K in (("nt", 512, 768, 1024), ("nn", 512, 768, 1024), ("tn", 768, 512, 1024), ("nt", 1088, 3840, 2048), ("tn", 512, 512, 320),
+                            ("nt", 256, 256, 256), ("tn", 2048, 2048, 1024)):
+        a, b = operands(layout, M, N, K, seed=1)
+        ref = reference(layout, a, b)
+        for name, lib in libs:
+            out = torch.zeros(M, N, dtype=torch.float32 if layout == "tn" else torch.bfloat16, device=dev)
+            run(lib, desc(layout, a, b, out))
+            torch.cuda.synchronize()
+            err = float((out.float() - ref).norm() / ref.norm())
+            flag = "" if err < (1e-5 if layout == "tn" else 4e-3) else "   <-- WRONG"
+            print(f"check {layout} {M}x{N}x{K} {name:>10}: rel err {err:.2e}{flag}")
+    times = {(n, s): [] for n, _ in libs for s in SHAPES}
+    races = {}
+    data = {}
+    for s in SHAPES:
+        layout, M, N, K = s
+        a, b = operands(layout, M, N, K)
+        data[s] = (a, b, {n: torch.zeros(M, N, dtype=torch.float32 if layout == "tn" else torch.bfloat16, device=dev) for n, _ in libs})
+    for (layout, M, N, K) in SHAPES:      # race screen
+        a, b, outs = data[(layout, M, N, K)]
+        for name, lib in libs:
+            d = desc(layout, a, b, outs[name])
+            run(lib, d)
+            first = outs[name].clone()
+            bad = 0
+            for _ in range(RACE):
+                run(lib, d)
+                bad += int(not torch.equal(outs[name], first))
+            races[(name, (layout, M, N, K))] = bad
+    ev = lambda: torch.cuda.Event(enable_timing=True)      # noqa: E731
+    for _ in range(ROUNDS):
+        for s in SHAPES:
+            a, b, outs = data[s]
+            for name, lib in libs:
+                d = desc(s[0], a, b, outs[name])
+                run(lib, d, 3)
+                e0, e1 = ev(), ev()
+                e0.record()
+                run(lib, d, ITERS)
+                e1.record()
+                torch.cuda.synchronize()
+                times[(name, s)].append(e0.elapsed_time(e1) / ITERS)
+    print(f"{'layout':6} {'M':>5} {'N':>5} {'K':>5} | " + " | ".join(f"{n:>10} med us / TF (best TF)" for n, _ in libs) + " | ratio of medians to the first")
+    for s in SHAPES:
+        layout, M, N, K = s
+        fl = 2.0 * M * N * K
+        cells, meds = [], []
+        for name, _ in libs:
+            t = times[(name, s)]
+            med, best = statistics.median(t), min(t)
+            meds.append(med)
+            r = races[(name, s)]
+            cells.append(f"{med * 1e3:8.1f} {fl / med / 1e9:7.1f} ({fl / best / 1e9:7.1f}){' RACE ' + str(r) if r else ''}")
+        print(f"{layout:6} {M:5d} {N:5d} {K:5d} | " + " | ".join(cells) + " | " + " ".join(f"{meds[0] / m:5.3f}" for m in meds))
+
+
+if __name__ == "__main__":
+    main()
