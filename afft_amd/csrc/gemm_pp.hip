@@ -579,10 +579,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(const GemmFast g)
 #ifndef AFFT_PP2
 #define AFFT_PP2 1      // 0: every shape on gemm_bf16_pp_kernel (A/B builds)
 #endif
+bool pp2_shape(int M, int N, int K) { return AFFT_PP2 && M % 256 == 0 && N % 256 == 0 && K % (2 * BK) == 0 && K >= 4 * BK; }
 template <bool A_KS, bool B_KS>
-bool pp2_takes(const GemmFast& g) {
-  return AFFT_PP2 && g.e.M % 256 == 0 && g.e.N % 256 == 0 && g.K % (2 * BK) == 0 && g.K >= 4 * BK;
-}
+bool pp2_takes(const GemmFast& g) { return pp2_shape(g.e.M, g.e.N, g.K); }
 
 template <bool A_KS, bool B_KS>
 int launch_pp2(GemmFast& g, hipStream_t stream) {
@@ -621,6 +620,8 @@ int launch_pp(GemmFast& g, hipStream_t stream) {
 #ifdef AFFT_PP_STAMP
 extern "C" void afft_debug_pp_stamp(void* p) { g_pp_stamp = (unsigned long long*)p; }
 #endif
+
+bool afft_gemm_pp2_takes(int M, int N, int K, int x3) { return x3 == 0 && pp2_shape(M, N, K); }
 
 int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream, int x3) {
 #ifndef AFFT_PP_NT_ONLY   // development switch: build only the plain NT instantiation (compile time)

@@ -139,6 +139,8 @@ class GemmTimer:
         b = lambda x: "true" if x else "false"    # noqa: E731
         if r.variant == 3:
             return f"gemm_bf16_pp_kernel<{b(r.a_kstrided)}, {b(r.b_kstrided)}, {int(r.split3)}>"
+        if r.variant == 13:      # round 6: the steady-state 256x256 kernel (whole tiles, even K-tile count, plain bf16)
+            return f"gemm_bf16_pp2_kernel<{b(r.a_kstrided)}, {b(r.b_kstrided)}>"
         if r.variant in (7, 8, 9, 10):       # B-direct kernels (csrc/gemm_bd.hip): <16-row blocks per tile, A look-ahead, B look-ahead, packed B>
             return f"gemm_bf16_bd_kernel<{10 if r.variant in (8, 10) else 16}, 3, {2 if r.variant in (8, 10) else 1}, {b(r.variant >= 9)}>"
         return f"gemm_bf16_kernel<2, 2, 2, {b(r.a_kstrided)}, {b(r.b_kstrided)}, {b(r.splitk > 1)}, {int(r.split3)}>"
@@ -1166,8 +1168,8 @@ def main():
                 except Exception:  # noqa: BLE001
                     pass
             result["roofline"] = {
-                "kernel": dom + " (bf16 MFMA GEMM, v_mfma_f32_16x16x32_bf16; template <A k-strided, B k-strided, operand planes (0 = plain bf16, 1 = bf16x3, 2 = fp16x2)>: "
-                          "A,B = false,false NT forward / false,true NN data gradient / true,true TN weight gradient)",
+                "kernel": dom + " (bf16 MFMA GEMM, v_mfma_f32_16x16x32_bf16; template <A k-strided, B k-strided[, operand planes (0 = plain bf16, 1 = bf16x3, 2 = fp16x2)]>: "
+                          "A,B = false,false NT forward / false,true NN data gradient / true,true TN weight gradient; pp2 = the round-6 steady-state loop)",
                 "bound": "mfma", "achieved": round(ach, 1), "peak": dtype_peak, "unit": "TFLOP/s",
                 "frac": round(ach / dtype_peak, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(d["bytes"] / d["launches"]),

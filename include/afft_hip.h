@@ -169,7 +169,8 @@ int afft_gemm_splitk_for(int M, int N, int K, int a_kstrided, int b_kstrided);
 /* Measurement hook (bench.py's roofline object): while a trace is open, every afft_gemm launch of the bf16 fast path --
  * from any entry point, the composite ones included -- is bracketed by a HIP event pair ON THE STREAM IT IS LAUNCHED ON.
  * afft_gemm_trace_end synchronises those events and returns the records (at most `capacity`; return value = count, < 0 on
- * error).  One trace at a time, process-wide.  variant: 1 = 128x128 tile, 3 = 256x256 ping-pong, 10 = B-direct 160x256 (4, 7-9: tests). */
+ * error).  One trace at a time, process-wide.  variant: 1 = 128x128 tile, 3 = 256x256 ping-pong (general kernel), 13 = 256x256 ping-pong,
+ * steady-state kernel (whole tiles, even K-tile count, plain bf16: gemm_bf16_pp2_kernel), 10 = B-direct 160x256 (4, 7-9: tests). */
 typedef struct {
   int32_t M, N, K, a_kstrided, b_kstrided, variant, splitk, split3, fused_update;
   float ms;

@@ -1302,6 +1302,12 @@ RACE_CASES = [
     ("pp_nn_full_round", 3, "nn", 8192, 2048, 2048, False),      # 256 tiles: every small-register kernel of the mix lands BESIDE a GEMM workgroup
     ("pp_nt_fwd", 3, "nt", 8192, 2048, 2048, False),
     ("pp_tn_wgrad", 3, "tn", 2048, 8192, 1024, False),
+    # whole-tile shapes with an even number of K-tiles run the round-6 steady-state kernel (gemm_bf16_pp2_kernel: the four cases above and
+    # the two below); edge tiles / odd K-tile counts stay on the general kernel (gemm_bf16_pp_kernel): both are screened
+    ("pp2_tn_wgrad_long_k", 3, "tn", 2048, 6144, 5120, False),
+    ("pp2_nt_fwd_qkv", 3, "nt", 5120, 6144, 2048, False),
+    ("pp_nt_edge_tiles_general", 3, "nt", 5056, 2048, 2048, False),
+    ("pp_nn_odd_ktiles_general", 3, "nn", 5120, 2048, 1984, False),
     ("g128_nt", 1, "nt", 1024, 2048, 2048, False),
     ("g128_nn_splitk", 1, "nn", 1024, 2048, 2048, False),
     ("bd_nt_packed", 0, "nt", 5120, 2048, 8192, True),

@@ -1,6 +1,7 @@
 #!/bin/bash
-# The race net's self-check: the same stress test against (a) the product library and (b) a library whose 256x256
-# kernel is built with the round-3 schedule, LEAD = 7 (a write-after-read race on a ring slot, profiles/r04_pp_war_race.txt).
+# The race net's self-check: the same stress test against (a) the product library and (b) a control library (built HERE,
+# never shipped with the product: afft_amd/lib/libafft_hip_lead7.so is git- and gpurun-ignored until `build` makes it) whose 256x256
+# kernel is the general one on every shape (-DAFFT_PP2=0) built with the round-3 schedule, LEAD = 7 (a write-after-read race on a ring slot, profiles/r04_pp_war_race.txt).
 #   build here (no GPU needed):  bash tools/race_net.sh build
 #   run on the GPU box:          bash tools/race_net.sh run [repeats]      -> gpurun_out/race_net.txt
 set -e
@@ -8,7 +9,7 @@ cd "$(dirname "$0")/.."
 if [ "$1" = "build" ]; then
   cd afft_amd/csrc
   mkdir -p build_var
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DAFFT_PP_LEAD=7 -DAFFT_PP_ALLOW_RACY_LEAD -c gemm_pp.hip -o build_var/gemm_pp_lead7.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DAFFT_PP_LEAD=7 -DAFFT_PP_ALLOW_RACY_LEAD -DAFFT_PP2=0 -c gemm_pp.hip -o build_var/gemm_pp_lead7.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libafft_hip_lead7.so build_var/gemm_pp_lead7.o build/gemm.o build/gemm_bd.o build/norm.o build/attention.o build/attention_mfma.o build/loss.o build/elementwise.o build/sublayer.o
   ls -la ../lib/
   exit 0
