@@ -166,6 +166,161 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf1
 }
 
 // ---------------------------------------------------------------------------------------------
+// Round 6: gemm_bf16_kernel<2, 2, 2, ..> with a loop that holds nothing but the schedule ("g2"), for what the small-grid launches of
+// the step are -- plain bf16, whole 128x128 tiles, an even number of K-tiles per slice: the predictor's M = B*T rows, the EK100 widths,
+// the reference's batch of 16.  Same tile, ring (2 stages), images, split-K seam and epilogue; what changes is what gemm_pp.hip's pp2
+// kernel changed: the K loop runs over K-tile PAIRS without a branch (the last pair, which has no successor to stage, is peeled), the 8
+// LDS-DMA sources of a wave are 8 loop-invariant SGPR bases + one running VGPR per operand (the general kernel recomputes row clamps and
+// 64-bit products per piece and K-tile), ring stage and fragment index are instruction offsets of a handful of precomputed LDS addresses.
+template <int OFF>
+__device__ __forceinline__ void glds16c(const char* sbase, unsigned voff, unsigned lds_wave) {
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_wave), "n"(OFF) : "memory", "scc");
+}
+
+template <bool A_KS, bool B_KS, bool SPLITK>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_g2_kernel(const GemmFast g) {
+  constexpr int A_BYTES = 128 * BK * 2, STAGE_BYTES = 2 * A_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A image | B image]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  int tm, tn;
+  tile_coords(g.tiles_m, g.tiles_n, blockIdx.x, tm, tn);
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int nk = g.K / BK / g.splitk;          // K-tiles of this slice: even, >= 2 (g2_takes)
+  const int ktbase = blockIdx.y * nk;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const unsigned lds_wave = lds_addr(smem) + wave * 1024;
+  const unsigned lda2 = (unsigned)(g.lda * 2), ldb2 = (unsigned)(g.ldb * 2);
+  const LaneOffsets lo = lane_offsets(wave, lane);
+  const unsigned stepA = A_KS ? 64u * lda2 : 128u, stepB = B_KS ? 64u * ldb2 : 128u;     // bytes per K-tile
+  unsigned vA = (A_KS ? lo.ks_row * lda2 + lo.ks_c16 : lo.kc_row * lda2 + lo.kc_chunk16) + (unsigned)ktbase * stepA;
+  unsigned vB = (B_KS ? lo.ks_row * ldb2 + lo.ks_c16 : lo.kc_row * ldb2 + lo.kc_chunk16) + (unsigned)ktbase * stepB;
+  const char* bA[4];
+  const char* bB[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {      // piece j = wave + 4 jj: rows 8j.. (k-contiguous) / k-rows 4j.. (k-strided) of the 128-wide tile
+    const int j = wave + 4 * jj;
+    bA[jj] = A_KS ? (const char*)(g.A + (int64_t)(4 * j) * g.lda + m0) : (const char*)(g.A + (int64_t)(m0 + 8 * j) * g.lda);
+    bB[jj] = B_KS ? (const char*)(g.B + (int64_t)(4 * j) * g.ldb + n0) : (const char*)(g.B + (int64_t)(n0 + 8 * j) * g.ldb);
+  }
+  auto stage = [&](auto pc) {      // the next K-tile into ring stage P
+    constexpr int P = decltype(pc)::value;
+    static_for<0, 4>([&](auto jc) { glds16c<P * STAGE_BYTES + decltype(jc)::value * 4096>(bA[decltype(jc)::value], vA, lds_wave); });
+    static_for<0, 4>([&](auto jc) { glds16c<P * STAGE_BYTES + A_BYTES + decltype(jc)::value * 4096>(bB[decltype(jc)::value], vB, lds_wave); });
+    vA += stepA;
+    vB += stepB;
+  };
+  // fragment addresses (see gemm_pp.hip pp2): k-contiguous image -> one register per k-substep, fragment index = +2 KiB; k-strided
+  // image -> one register per fragment, k-substep = +8 KiB, second 4-row block = +1 KiB
+  constexpr int NA = A_KS ? 4 : 2, NB = B_KS ? 4 : 2;
+  unsigned adA[NA], adB[NB];
+  {
+    const unsigned l0 = lds_addr(smem);
+    const int g4 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3, r16 = lane & 15;
+#pragma unroll
+    for (int x = 0; x < NA; ++x) {
+      unsigned a;
+      if constexpr (A_KS) a = (8 * g4 + q4) * 256 + ((((wr * 4 + x) ^ ks_f(8 * g4 + q4))) << 5) + p4 * 8;
+      else { const int row = wr * 64 + r16; a = row * 128 + ((((x * 4 + g4) ^ ((row >> 1) & 7))) << 4); }
+      adA[x] = l0 + a;
+      asm volatile("" : "+v"(adA[x]));
+    }
+#pragma unroll
+    for (int x = 0; x < NB; ++x) {
+      unsigned b;
+      if constexpr (B_KS) b = (8 * g4 + q4) * 256 + ((((wc * 4 + x) ^ ks_f(8 * g4 + q4))) << 5) + p4 * 8;
+      else { const int row = wc * 64 + r16; b = row * 128 + ((((x * 4 + g4) ^ ((row >> 1) & 7))) << 4); }
+      adB[x] = l0 + A_BYTES + b;
+      asm volatile("" : "+v"(adB[x]));
+    }
+  }
+  auto rd128 = [](unsigned addr, auto offc) -> bf16x8 { return *(AFFT_LDS const bf16x8*)(size_t)(addr + decltype(offc)::value); };
+  auto rdtr = [](unsigned addr, auto offc) -> bf16x8 {
+    const bf16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AFFT_LDS bf16x4*)(size_t)(addr + decltype(offc)::value));
+    const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AFFT_LDS bf16x4*)(size_t)(addr + decltype(offc)::value + 1024));
+    bf16x8 f;
+    f[0] = lo4[0]; f[1] = lo4[1]; f[2] = lo4[2]; f[3] = lo4[3];
+    f[4] = hi4[0]; f[5] = hi4[1]; f[6] = hi4[2]; f[7] = hi4[3];
+    return f;
+  };
+  auto ktile = [&](auto pc, auto lastc) {
+    constexpr int P = decltype(pc)::value;
+    constexpr bool LAST = decltype(lastc)::value;
+    if constexpr (!LAST) stage(std::integral_constant<int, 1 - P>{});      // refills the stage read one K-tile ago (every wave passed its barrier)
+    static_for<0, 2>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      bf16x8 af[4], bfr[4];
+      static_for<0, 4>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (A_KS) af[i] = rdtr(adA[i], std::integral_constant<int, P * STAGE_BYTES + s * 8192>{});
+        else af[i] = rd128(adA[s], std::integral_constant<int, P * STAGE_BYTES + i * 2048>{});
+        if constexpr (B_KS) bfr[i] = rdtr(adB[i], std::integral_constant<int, P * STAGE_BYTES + s * 8192>{});
+        else bfr[i] = rd128(adB[s], std::integral_constant<int, P * STAGE_BYTES + i * 2048>{});
+      });
+      // operands swapped on purpose: D[row = n][col = m] -> each lane owns 4 consecutive n of one row m
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<0>(bfr[j], af[i], acc[i][j]);
+    });
+    if constexpr (!LAST) {
+      wait_vmcnt<0>();      // the next K-tile has landed (this wave's pieces) and this wave's reads of the current one have returned
+      __builtin_amdgcn_s_barrier();
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  stage(I0{});
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  for (int pr = 0; pr < nk / 2 - 1; ++pr) {
+    ktile(I0{}, std::false_type{});
+    ktile(I1{}, std::false_type{});
+  }
+  ktile(I0{}, std::false_type{});
+  ktile(I1{}, std::true_type{});
+
+  if constexpr (SPLITK) {
+    __syncthreads();   // every wave is done reading the ring -> smem is free
+    if (!splitk_combine<16, 256>(reinterpret_cast<f32x4(&)[16]>(acc), g.ws, g.counters, blockIdx.x, g.splitk, blockIdx.y, tid, smem)) return;
+  }
+  constexpr int ESTRIDE = 128 * 4 + 16;
+  __builtin_amdgcn_s_barrier();   // every wave is done reading the ring
+  static_for<0, 16>([&](auto idx) {
+    constexpr int i = decltype(idx)::value >> 2, j = decltype(idx)::value & 3;
+    const int row = wr * 64 + i * 16 + (lane & 15);
+    const int col = wc * 64 + j * 16 + 4 * (lane >> 4);
+    *(f32x4*)(smem + row * ESTRIDE + col * 4) = acc[i][j];
+  });
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const DropParams dp = with_salt(g.e.drop);
+#pragma unroll AFFT_G128_EPI_UNROLL
+  for (int it = 0; it < 8; ++it) {       // 4 rows per wave-iteration, 16 lanes (8 columns each) per row
+    const int row = wave * 32 + it * 4 + lane / 16;
+    const int c8 = lane % 16;
+    const f32x4 t0 = *(const f32x4*)(smem + row * ESTRIDE + c8 * 32);
+    const f32x4 t1 = *(const f32x4*)(smem + row * ESTRIDE + c8 * 32 + 16);
+    float o[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+    epilogue8(g.e, dp, m0 + row, n0 + 8 * c8, o);
+  }
+}
+
+#ifndef AFFT_G2
+#define AFFT_G2 1      // 0: every 128x128 launch on gemm_bf16_kernel (A/B builds)
+#endif
+bool g2_shape(int M, int N, int K, int splitk) {
+  return AFFT_G2 && M % 128 == 0 && N % 128 == 0 && K % (BK * splitk) == 0 && (K / BK / splitk) % 2 == 0 && K / BK / splitk >= 2;
+}
+
+// ---------------------------------------------------------------------------------------------
 // exact-fp32 path: 64x64x16 tiles, 4 waves (2x2), each wave one 32x32 tile on v_mfma_f32_32x32x2_f32.
 struct GemmF32 {
   const void* A; int64_t a_rs, a_cs;
@@ -259,6 +414,16 @@ int launch_fast(GemmFast& g, hipStream_t stream) {
   constexpr size_t lds = ring > epi ? ring : epi;
   g.tiles_m = (g.e.M + BM - 1) / BM;
   g.tiles_n = (g.e.N + BN - 1) / BN;
+  if constexpr (WM == 2 && WN == 2 && STAGES == 2 && X3 == 0) {
+    if (g2_shape(g.e.M, g.e.N, g.K, g.splitk)) {      // whole tiles, even K-tile count per slice: the steady-state kernel
+      auto k2 = gemm_bf16_g2_kernel<A_KS, B_KS, SPLITK>;
+      static std::atomic<uint64_t> attr2_done{0};
+      if (int rc = afft_ensure_dynamic_lds(reinterpret_cast<const void*>(k2), lds, &attr2_done)) return rc;
+      hipLaunchKernelGGL(k2, dim3(g.tiles_m * g.tiles_n, g.splitk), dim3(256), lds, stream, g);
+      AFFT_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   auto kern = gemm_bf16_kernel<WM, WN, STAGES, A_KS, B_KS, SPLITK, X3>;
   static std::atomic<uint64_t> attr_done{0};
   if (int rc = afft_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, &attr_done)) return rc;

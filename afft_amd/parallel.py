@@ -601,7 +601,7 @@ class _FusedEpilogue:
         for p, o in zip(flat.params, flat.offsets):
             img = getattr(p, "_afft_img", None)
             if (p.dim() == 2 and id(p) in rt.SINK.composite_weights and rt.SINK.touch_count.get(id(p), 0) == 1
-                    and img is not None and img.external):
+                    and img is not None and img.external and p.numel() >= rt.fuse_min_elems()):
                 d = L_.SgdFused()
                 d.p, d.buf, d.p_bf16 = flat.flat_p.data_ptr() + 4 * o, self.opt.buf.data_ptr() + 4 * o, flat.flat_p16.data_ptr() + 2 * o
                 fused[id(p)] = d

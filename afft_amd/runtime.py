@@ -474,6 +474,21 @@ def set_fused_sgd(on: bool):
     _FUSED_SGD = bool(on)
 
 
+_FUSE_MIN_ELEMS = int(os.environ.get("AFFT_FUSE_MIN_ELEMS", "0"))
+
+
+def fuse_min_elems() -> int:
+    """Smallest weight (elements) whose update runs inside its own weight-gradient GEMM epilogue; smaller weights are left to the per-bucket
+    update kernel.  The epilogue's optimizer traffic (18 B per parameter) is carried by the GEMM's own workgroups: a weight with fewer
+    tiles than the chip has CUs streams it from a fraction of the chip, while the bucket kernel spreads the same bytes over all of it."""
+    return _FUSE_MIN_ELEMS
+
+
+def set_fuse_min_elems(n: int):
+    global _FUSE_MIN_ELEMS
+    _FUSE_MIN_ELEMS = int(n)
+
+
 CAPTURING = False          # a hipGraph capture of the step is under way (afft_amd.parallel.Trainer.capture)
 KEEPALIVE: list = []       # tensors read on the auxiliary stream during a capture: kept until the capture ends, because
                            # inside a capture the allocator would hand their memory to a later main-stream allocation

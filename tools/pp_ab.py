@@ -22,7 +22,11 @@ VARIANT = int(os.environ.get("VARIANT", 3))
 PATH = [("nt", 5120, 6144, 2048), ("nt", 5120, 8192, 2048), ("nt", 5120, 2048, 8192), ("nn", 5120, 2048, 6144), ("nn", 5120, 8192, 2048),
         ("nn", 5120, 2048, 8192), ("tn", 6144, 2048, 5120), ("tn", 8192, 2048, 5120), ("tn", 2048, 8192, 5120), ("tn", 8192, 2048, 1024)]
 BIG = [("nt", 4096, 4096, 4096), ("nt", 8192, 8192, 8192)]
-SHAPES = {"path": PATH, "big": BIG, "all": PATH + BIG}[os.environ.get("SHAPES", "all")]
+# the small-grid launches of the step (128x128 tiles, VARIANT=0 or 1): predictor M = B*T = 1024 rows, EK100 widths, weight gradients over 1024 rows
+SMALL = [("nn", 1024, 6144, 2048), ("nn", 1024, 2048, 2048), ("nn", 1024, 8192, 2048), ("nn", 1024, 2048, 8192), ("nt", 1024, 6144, 2048),
+         ("nt", 1024, 2048, 2048), ("nt", 1024, 8192, 2048), ("nt", 1024, 2048, 8192), ("tn", 2048, 2048, 1024), ("tn", 2048, 2048, 5120),
+         ("nt", 5120, 1024, 1024), ("nn", 5120, 1024, 4096), ("tn", 1024, 3072, 5120), ("nt", 1280, 6144, 2048), ("tn", 2048, 6144, 1280)]
+SHAPES = {"path": PATH, "big": BIG, "all": PATH + BIG, "small": SMALL}[os.environ.get("SHAPES", "all")]
 
 
 def load(path):
@@ -56,7 +60,11 @@ def desc(layout, a, b, out):
     d.b_rs, d.b_cs = (b.stride(1), b.stride(0)) if b_t else (b.stride(0), b.stride(1))
     d.alpha = 1.0
     d.out, d.ldo, d.out_dtype = out.data_ptr(), out.stride(0), (L.F32 if out.dtype == torch.float32 else L.BF16)
+    d.workspace, d.workspace_bytes = WS.data_ptr(), WS.numel()      # split-K scratch (counters zero between launches)
     return d
+
+
+WS = torch.zeros(192 << 20, dtype=torch.uint8, device=dev)
 
 
 def run(lib, d, n=1):
@@ -78,7 +86,8 @@ def main():
     print("libraries:", ", ".join(n for n, _ in libs), f"| variant {VARIANT} rounds {ROUNDS} iters {ITERS} race repeats {RACE}")
     # correctness: every layout, a shape with several tiles and K-tile pairs, plus one edge shape that must take the general kernel
     for layout, M, N, K in (("nt", 512, 768, 1024), ("nn", 512, 768, 1024), ("tn", 768, 512, 1024), ("nt", 1088, 3840, 2048), ("tn", 512, 512, 320),
-                            ("nt", 256, 256, 256), ("tn", 2048, 2048, 1024)):
+                            ("nt", 256, 256, 256), ("tn", 2048, 2048, 1024), ("nn", 1024, 2048, 8192), ("nt", 1024, 2048, 8192), ("tn", 1024, 1024, 1280),
+                            ("nn", 384, 640, 896)):
         a, b = operands(layout, M, N, K, seed=1)
         ref = reference(layout, a, b)
         for name, lib in libs:
