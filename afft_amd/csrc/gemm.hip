@@ -142,6 +142,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void gemm_bf1
   // Epilogue through LDS (same scheme as gemm_pp.hip): accumulators -> fp32 [BM][BN] image with a 16-byte row pad
   // (conflict-free scatter), then whole rows per wave with 16-byte LDS reads and fully coalesced global accesses.
   constexpr int ESTRIDE = BN * 4 + 16;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and its reads have returned (see gemm_bf16_g2_kernel: s_barrier alone does not say so)
   __builtin_amdgcn_s_barrier();   // every wave is done reading the ring
   static_for<0, 16>([&](auto idx) {
     constexpr int i = decltype(idx)::value >> 2, j = decltype(idx)::value & 3;
@@ -292,7 +293,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_g2_kernel(const GemmFast g) 
     if (!splitk_combine<16, 256>(reinterpret_cast<f32x4(&)[16]>(acc), g.ws, g.counters, blockIdx.x, g.splitk, blockIdx.y, tid, smem)) return;
   }
   constexpr int ESTRIDE = 128 * 4 + 16;
-  __builtin_amdgcn_s_barrier();   // every wave is done reading the ring
+  // Every wave is done READING the ring -- its LDS reads have RETURNED, not merely been issued: s_barrier does not wait for lgkmcnt, and
+  // the compiler is free to sink the last K-tile's MFMAs (register-only) below the barrier together with the waits it puts in front of
+  // them.  Without this wait a wave could pass the barrier with fragment reads of the last K-tile in flight while another wave already
+  // scattered its accumulators into the same LDS bytes: the first build of this kernel did exactly that -- rare per launch, but a
+  // training step has hundreds, and ~half of the bench processes ended with a NaN loss (profiles/r06_g2_epilogue_race.txt).
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
   static_for<0, 16>([&](auto idx) {
     constexpr int i = decltype(idx)::value >> 2, j = decltype(idx)::value & 3;
     const int row = wr * 64 + i * 16 + (lane & 15);

@@ -243,6 +243,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_bd_kernel(const GemmFast g) {
   static_for<0, 2>([&](auto pc) {
     constexpr int p = decltype(pc)::value;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS reads of the ring have RETURNED (s_barrier alone does not say so: gemm.hip, g2 kernel)
     __builtin_amdgcn_s_barrier();   // pass 0: every wave is done with the ring; pass 1: pass 0 has been read back
     static_for<0, HI * 4>([&](auto idx) {
       constexpr int v = decltype(idx)::value;

@@ -77,6 +77,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmFast& g, char* smem, f32x4
   if (AFFT_PP_DIAG & 16) return;
   static_for<0, 2>([&](auto ihc) {
     constexpr int ih = decltype(ihc)::value;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS reads of the ring have RETURNED (s_barrier alone does not say so: gemm.hip, g2 kernel)
     __builtin_amdgcn_s_barrier();   // pass 0: every wave is done with the ring; pass 1: pass 0 has been read back
     static_for<0, 16>([&](auto idx) {
       constexpr int v = decltype(idx)::value;

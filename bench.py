@@ -985,6 +985,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     loss_val = float(loss)
+    if loss_val != loss_val or abs(loss_val) == float("inf"):
+        # A non-finite loss voids the timing: every update kernel of such a step leaves parameters and momentum untouched (FusedSGD.ok), i.e.
+        # the step does less work (round 6: a race in a new GEMM kernel produced NaN losses in half of the processes -- and "faster" steps)
+        if rank == 0:
+            print(json.dumps({"error": "the loss of the timed region is not finite: measurement void", "final_loss": repr(loss_val), "n_gpus": world,
+                              "ms_per_step_void": round(elapsed / args.steps * 1e3, 3)}), flush=True)
+        raise SystemExit(3)
     if captured:
         trainer.release_graph()
     ms_per_step = elapsed / args.steps * 1e3

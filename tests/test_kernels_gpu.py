@@ -1309,6 +1309,12 @@ RACE_CASES = [
     ("pp_nt_edge_tiles_general", 3, "nt", 5056, 2048, 2048, False),
     ("pp_nn_odd_ktiles_general", 3, "nn", 5120, 2048, 1984, False),
     ("g128_nt", 1, "nt", 1024, 2048, 2048, False),
+    # whole 128x128 tiles with an even K-tile count per slice run the round-6 steady-state kernel (gemm_bf16_g2_kernel); its first build let a
+    # wave pass the epilogue barrier with fragment reads in flight (NaN losses in half of the bench processes): unsplit layouts, long and short K
+    ("g2_nt_unsplit", 1, "nt", 1024, 8192, 2048, False),
+    ("g2_nn_unsplit", 1, "nn", 1024, 6144, 2048, False),
+    ("g2_tn_short_k", 1, "tn", 2048, 2048, 256, False),
+    ("g128_nt_edge_general", 1, "nt", 1088, 3840, 2048, False),
     ("g128_nn_splitk", 1, "nn", 1024, 2048, 2048, False),
     ("bd_nt_packed", 0, "nt", 5120, 2048, 8192, True),
     # the fp16x2 forward instantiations of the ping-pong kernel: "lo8" = fp16 hi segment + block-scaled fp8 lo segment (two K loops over one
