@@ -161,6 +161,7 @@ _SIGS = {
                             vp, i32, vp, vp], C.c_int),
     "afft_attention_fwd": ([vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, i32, i32, f32, C.c_uint32,
                             vp, i64, vp, vp], C.c_int),
+    "afft_attention_fwd_table": ([vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, vp, f32, C.c_uint32, vp, i64, vp, vp], C.c_int),
     "afft_attention_fwd_split": ([vp, i64, vp, i64, vp, i64, i64, i32, i32, i32, i32, f32, i32, i32, f32, C.c_uint32,
                                   vp, i64, i64, vp, i64, vp, vp, vp], C.c_int),
     "afft_attention_bwd": ([vp, i64, vp, i64, vp, i64, vp, i64, i32, vp, i32, i32, i32, i32, f32, f32, C.c_uint32,

@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, 
                                                        int64_t ldk, const T* __restrict__ v, int64_t ldv, int L, int H,
                                                        int hd, float scale, int mask, int period, unsigned dthresh,
                                                        unsigned dkey, float dinv, const unsigned* __restrict__ salt,
-                                                       T* __restrict__ out, int64_t ldo, float* __restrict__ probs) {
+                                                       T* __restrict__ out, int64_t ldo, float* __restrict__ probs,
+                                                       const float* __restrict__ addm) {      // addm: additive fp32 [L][L] table or null
   if (salt) dkey ^= *salt;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float (*sc)[LM + 1] = reinterpret_cast<float (*)[LM + 1]>(smem_raw);
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, 
       for (int u = 0; u < 4; ++u) {
         const int j = j0 + u;
         if (j < L) {
-          const float sv = masked(mask, period, i, j) ? -INFINITY : wave_sum(acc4[u]) * scale;
+          float sv = masked(mask, period, i, j) ? -INFINITY : wave_sum(acc4[u]) * scale;
+          if (addm) sv += addm[i * L + j];      // models/transformerblock.py:27-28: attn = attn + attn_mask (any values, -inf included)
           if (lane == 0) sc[i][j] = sv;
         }
       }
@@ -199,14 +201,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ dou
 template <typename T, int LM>
 int launch_fwd(dim3 grid, hipStream_t stream, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                int L, int H, int hd, float scale, int mask, int period, const DropParams& dp, void* out, int64_t ldo,
-               float* probs) {
+               float* probs, const float* addm = nullptr) {
   constexpr size_t lds = sizeof(float) * LM * (LM + 1);
   auto kern = attn_fwd_kernel<T, LM>;
   static std::atomic<uint64_t> attr_done{0};
   if (lds > 48 * 1024)
     if (int rc = afft_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, &attr_done)) return rc;
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv, L, H, hd, scale,
-                     mask, period, dp.thresh, dp.key, dp.inv_keep, dp.salt, (T*)out, ldo, probs);
+                     mask, period, dp.thresh, dp.key, dp.inv_keep, dp.salt, (T*)out, ldo, probs, addm);
   return 0;
 }
 template <typename T, int LM>
@@ -265,6 +267,32 @@ extern "C" int afft_attention_fwd(const void* q, int64_t ldq, const void* k, int
   AFFT_CHECK(dtype == AFFT_F32 || dtype == AFFT_BF16, "attention_fwd: bad dtype %d", dtype);
   int rc;
 #define FWD(T, LM) launch_fwd<T, LM>(grid, stream, q, ldq, k, ldk, v, ldv, L, H, hd, scale, mask, mask_period, dp, out, ldo, probs)
+  if (dtype == AFFT_F32) rc = L <= 32 ? FWD(float, 32) : L <= 64 ? FWD(float, 64) : FWD(float, 128);
+  else rc = L <= 32 ? FWD(bf16_t, 32) : L <= 64 ? FWD(bf16_t, 64) : FWD(bf16_t, 128);
+#undef FWD
+  if (rc) return rc;
+  AFFT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int afft_attention_fwd_table(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                                        int32_t dtype, int32_t nseq, int32_t L, int32_t H, int32_t hd, float scale,
+                                        const float* mask_table, float drop_p, uint32_t drop_key, void* out, int64_t ldo,
+                                        float* probs, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AFFT_CHECK(q && k && v && out && mask_table, "attention_fwd_table: null pointer");
+  AFFT_CHECK(L >= 1 && L <= LMAX, "attention_fwd_table: sequence length %d outside 1..%d", L, LMAX);
+  AFFT_CHECK(drop_p >= 0.f && drop_p < 1.f, "attention_fwd_table: dropout p outside [0,1)");
+  AFFT_CHECK(hd >= 1 && hd <= 1024, "attention_fwd_table: head dimension %d outside 1..1024", hd);
+  AFFT_CHECK(dtype == AFFT_F32 || dtype == AFFT_BF16, "attention_fwd_table: bad dtype %d", dtype);
+  if (nseq == 0) return 0;
+  const int64_t es_ = dtype == AFFT_F32 ? 4 : 2, rw_ = (int64_t)nseq * L * H * hd, pb_ = probs ? (int64_t)nseq * H * L * L * 4 : 0;
+  AfftKernelScope ktrace(AFFT_K_ATTN_FWD, nseq * L, H * hd, 4 * es_ * rw_ + pb_, 4 * (int64_t)nseq * H * L * L * hd, stream);
+  afft_dropout_t dd = {drop_p, drop_key, 0.f, 0u, 1};
+  const DropParams dp = make_drop(&dd);
+  const dim3 grid(nseq * H);
+  int rc;
+#define FWD(T, LM) launch_fwd<T, LM>(grid, stream, q, ldq, k, ldk, v, ldv, L, H, hd, scale, AFFT_MASK_NONE, 0, dp, out, ldo, probs, mask_table)
   if (dtype == AFFT_F32) rc = L <= 32 ? FWD(float, 32) : L <= 64 ? FWD(float, 64) : FWD(float, 128);
   else rc = L <= 32 ? FWD(bf16_t, 32) : L <= 64 ? FWD(bf16_t, 64) : FWD(bf16_t, 128);
 #undef FWD

@@ -516,6 +516,20 @@ def _mask_args(mask):
     return _MASK[mask[0]], int(mask[1])
 
 
+def mask_table(mask) -> Optional[Tensor]:
+    """('table', fp32 [L, L] device tensor): an arbitrary additive mask (models/transformerblock.py:26-28) -- the attention core then runs on
+    the generic kernel with the table added to the scores (afft_attention_fwd_table), call by call (no composite entry point takes a table)"""
+    return mask[1] if isinstance(mask, tuple) and mask[0] == "table" else None
+
+
+def _attention_fwd(q, k, v, nseq, L, H, hd, scale, mask, out, probs, drop):
+    tab = mask_table(mask)
+    if tab is not None:
+        return ops.attention_fwd_table(q, k, v, nseq, L, H, hd, scale, tab, out, probs, *(_attn_drop(drop)))
+    mk, per = _mask_args(mask)
+    return ops.attention_fwd(q, k, v, nseq, L, H, hd, scale, mk, out, probs, *(_attn_drop(drop)), mask_period=per)
+
+
 # --------------------------------------------------------------------------- composite path: one C-ABI call per sub-layer
 # afft_{attn,mlp,cross_attn}_sublayer_{fwd,bwd} (include/afft_hip.h, csrc/sublayer.hip) enqueue exactly the kernel sequences
 # written out call by call in the three Functions below.  What stays here is bookkeeping: buffers (one allocation for the
@@ -1026,7 +1040,7 @@ def _cross_bwd_c(ctx, dy):
     join_side(dev)
     ctx.acts = None
     flush_ready()
-    return dx, dmem, g_qw, g_qb, g_kw, g_kb, g_q, g_k, g_v, g_wp, g_bp, None, None, None, None, None, None, None
+    return dx, dmem, g_qw, g_qb, g_kw, g_kb, g_q, g_k, g_v, g_wp, g_bp, None, None, None, None, None, None, None, None, None, None
 
 
 
@@ -1053,7 +1067,7 @@ class AttnSublayer(torch.autograd.Function):
         # freshly ZERO-FILLED tensor of its shape for it on every call (a fill kernel per attention sub-layer and step)
         ctx.set_materialize_grads(False)
         # fp16x2: the attention core on hi + lo planes exists on the MFMA path only (L <= 64, head dimension a multiple of 64)
-        if _composite_ok(x, pre_ln, d) and (rt.precision() != "fp16x2" or (L <= 64 and hd % 64 == 0 and hd <= 1024)):
+        if mask_table(mask) is None and _composite_ok(x, pre_ln, d) and (rt.precision() != "fp16x2" or (L <= 64 and hd % 64 == 0 and hd <= 1024)):
             return _attn_fwd_c(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, eps, conv1d, scale, drop, probs_out, take)
         ctx.up = _upstream_of(x) if pre_ln else None
         mean, rstd = _stats(R if pre_ln else 0, dev)
@@ -1067,9 +1081,7 @@ class AttnSublayer(torch.autograd.Function):
         ao = Act(R, d, dev)
         probs = probs_out if probs_out is not None else torch.empty(nseq, H, L, L, dtype=torch.float32, device=dev)
         scale = float(scale) if scale else float(hd) ** -0.5
-        mk, per = _mask_args(mask)
-        ops.attention_fwd(qkv.cols(0, d), qkv.cols(d, 2 * d), qkv.cols(2 * d, 3 * d), nseq, L, H, hd, scale,
-                          mk, ao.live, probs, *(_attn_drop(drop)), mask_period=per)
+        _attention_fwd(qkv.cols(0, d), qkv.cols(d, 2 * d), qkv.cols(2 * d, 3 * d), nseq, L, H, hd, scale, mask, ao.live, probs, drop)
         y = torch.empty(R, d, dtype=torch.float32, device=dev)
         _lin_fwd(ao, w_proj, conv1d, y, bias=b_proj, residual=x if pre_ln else None, drop=_out_drop(drop))
         ctx.save_for_backward(x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, mean, rstd, probs)
@@ -1196,38 +1208,42 @@ class CrossAttnSublayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mem, nq_w, nq_b, nkv_w, nkv_b, w_q, w_k, w_v, w_proj, b_proj, L, H, mask, eps, pre_ln=True,
-                scale=None, drop=None):
+                scale=None, drop=None, b_q=None, b_k=None, b_v=None):
+        """b_q / b_k / b_v: CrossAttention(qkv_bias=True); mem may be narrower or wider than x (mem_dim != dim: w_k, w_v are [d, mem_dim]) --
+        both off the AFFT configurations (models/transformerblock.py:41-50) and served call by call."""
         R, d = x.shape
+        dm = mem.shape[1]
         nseq, hd = R // L, d // H
         dev = x.device
         ctx.composite = False
-        if _composite_ok(x, pre_ln, d, f16x2=False) and mem.stride(0) == d:
+        ctx.qkv_bias = b_q is not None or b_k is not None or b_v is not None
+        if (mask_table(mask) is None and not ctx.qkv_bias and dm == d and _composite_ok(x, pre_ln, d, f16x2=False)
+                and mem.stride(0) == d):
             return _cross_fwd_c(ctx, x, mem, nq_w, nq_b, nkv_w, nkv_b, w_q, w_k, w_v, w_proj, b_proj, L, H, mask, eps, scale,
                                 drop)
         ctx.up = _upstream_of(x) if pre_ln else None
         mq, rq = _stats(R if pre_ln else 0, dev)
         mk, rk = _stats(R if pre_ln else 0, dev)
         if pre_ln:
-            xq, mkv = Act(R, d, dev), Act(R, d, dev)
+            xq, mkv = Act(R, d, dev), Act(R, dm, dev)
             ops.layernorm_fwd(x, nq_w, nq_b, eps, xq.live, mq, rq)
             ops.layernorm_fwd(mem, nkv_w, nkv_b, eps, mkv.live, mk, rk)
         else:  # bare CrossAttention module (models/transformerblock.py:56-76)
             xq, mkv = to_act(x), to_act(mem)
         q, k, v = Act(R, d, dev), Act(R, d, dev), Act(R, d, dev)
-        _lin_fwd(xq, w_q, False, q.live)
-        _lin_fwd(mkv, w_k, False, k.live)
-        _lin_fwd(mkv, w_v, False, v.live)
+        _lin_fwd(xq, w_q, False, q.live, bias=b_q)
+        _lin_fwd(mkv, w_k, False, k.live, bias=b_k)
+        _lin_fwd(mkv, w_v, False, v.live, bias=b_v)
         ao = Act(R, d, dev)
         probs = torch.empty(nseq, H, L, L, dtype=torch.float32, device=dev)
         scale = float(scale) if scale else float(hd) ** -0.5
-        mask_id, per = _mask_args(mask)
-        ops.attention_fwd(q.live, k.live, v.live, nseq, L, H, hd, scale, mask_id, ao.live, probs,
-                          *(_attn_drop(drop)), mask_period=per)
+        _attention_fwd(q.live, k.live, v.live, nseq, L, H, hd, scale, mask, ao.live, probs, drop)
         y = torch.empty(R, d, dtype=torch.float32, device=dev)
         _lin_fwd(ao, w_proj, False, y, bias=b_proj, residual=x if pre_ln else None, drop=_out_drop(drop))
         ctx.save_for_backward(x, mem, nq_w, nq_b, nkv_w, nkv_b, w_q, w_k, w_v, w_proj, b_proj, mq, rq, mk, rk, probs)
         ctx.acts = (xq, mkv, q, k, v, ao)
         ctx.cfg = (L, H, scale, pre_ln, drop)
+        ctx.qkv_b = (b_q, b_k, b_v)
         _note_output(y, _out_drop(drop), b_proj)
         return y
 
@@ -1254,11 +1270,15 @@ class CrossAttnSublayer(torch.autograd.Function):
         dq, dk, dv = Act(R, d, dev), Act(R, d, dev), Act(R, d, dev)
         ops.attention_bwd(dao.live, q.live, k.live, v.live, probs, nseq, L, H, hd, scale, dq.live, dk.live, dv.live,
                           *(_attn_drop(drop)))
+        b_q, b_k, b_v = ctx.qkv_b
         with _Side(dev):
             g_q = _wgrad(dq, xq, w_q, False)
             g_k = _wgrad(dk, mkv, w_k, False)
             g_v = _wgrad(dv, mkv, w_v, False)
-        dmkv = torch.empty(R, d, dtype=torch.float32, device=dev)
+            g_bq = _bgrad(dq.live, b_q) if b_q is not None else None
+            g_bk = _bgrad(dk.live, b_k) if b_k is not None else None
+            g_bv = _bgrad(dv.live, b_v) if b_v is not None else None
+        dmkv = torch.empty(R, mem.shape[1], dtype=torch.float32, device=dev)
         _lin_dgrad(dk, w_k, False, dmkv)
         _lin_dgrad(dv, w_v, False, dmkv, accumulate=True)
         if pre_ln:
@@ -1273,7 +1293,7 @@ class CrossAttnSublayer(torch.autograd.Function):
         join_side(dev)
         ctx.acts = None
         flush_ready()
-        return dx, dmem, g_qw, g_qb, g_kw, g_kb, g_q, g_k, g_v, g_wp, g_bp, None, None, None, None, None, None, None
+        return dx, dmem, g_qw, g_qb, g_kw, g_kb, g_q, g_k, g_v, g_wp, g_bp, None, None, None, None, None, None, None, g_bq, g_bk, g_bv
 
 
 # --------------------------------------------------------------------------- plain linear (mapping, enc/dec, classifier)

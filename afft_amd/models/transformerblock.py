@@ -25,10 +25,13 @@ MaskArg = Union[None, str, Tensor]
 def mask_kind(attn_mask: MaskArg, n: int):
     """The HIP attention kernels apply their mask in-register from a kind: 'none' | 'diag' | 'causal' |
     ('blockcausal', T).  The reference passes additive -inf tensors (models/fusion.py:30-32,170-171,313-317);
-    recognise those."""
+    recognise those.  Any other (N, N) tensor -- the reference adds whatever it is given -- becomes ('table', fp32 tensor);
+    masks that broadcast over batch or heads ((B, 1, N, N), ...) are not supported."""
     if attn_mask is None:
         return "none"
     if isinstance(attn_mask, tuple):
+        if len(attn_mask) == 2 and attn_mask[0] == "table":
+            return attn_mask
         if len(attn_mask) != 2 or attn_mask[0] != "blockcausal" or n % int(attn_mask[1]) != 0:
             raise ValueError(f"unknown mask kind {attn_mask!r}")
         return ("blockcausal", int(attn_mask[1]))
@@ -51,8 +54,9 @@ def mask_kind(attn_mask: MaskArg, n: int):
     for t in range(1, n):            # T-SA-Fuser: the causal T x T mask tiled over the modalities
         if n % t == 0 and torch.equal(m, causal(t).repeat(n // t, n // t)):
             return ("blockcausal", t)
-    raise NotImplementedError("afft_amd: only the reference's masks (none / -inf diagonal / causal / causal tiled "
-                              "over the modalities) are supported")
+    # anything else: `attn = attn + attn_mask` for an arbitrary (N, N) tensor (models/transformerblock.py:26-28, :66-68) -- the table goes to
+    # the generic attention kernel (afft_attention_fwd_table) instead of an in-register mask of the MFMA kernels
+    return ("table", attn_mask.detach().to(torch.float32).contiguous())
 
 
 def _flat(x: Tensor):
@@ -93,11 +97,7 @@ class CrossAttention(nn.Module):
         self.num_heads = num_heads
         head_dim = dim // num_heads
         self.scale = qk_scale or head_dim ** -0.5
-        mem_dim = mem_dim or dim
-        if mem_dim != dim:
-            raise NotImplementedError("afft_amd: CrossAttention with mem_dim != dim is not on the AFFT path")
-        if qkv_bias:
-            raise NotImplementedError("afft_amd: CrossAttention with qkv_bias=True is not on the AFFT path")
+        mem_dim = mem_dim or dim      # mem_dim != dim and qkv_bias=True are off the AFFT configurations: served call by call (functional.CrossAttnSublayer)
         self.w_q = nn.Linear(dim, dim, bias=qkv_bias)
         self.w_k = nn.Linear(mem_dim, dim, bias=qkv_bias)
         self.w_v = nn.Linear(mem_dim, dim, bias=qkv_bias)
@@ -113,7 +113,8 @@ class CrossAttention(nn.Module):
         m2, _, _, _ = _flat(mem)
         y = F_.CrossAttnSublayer.apply(x2, m2, None, None, None, None, self.w_q.weight, self.w_k.weight,
                                        self.w_v.weight, self.proj.weight, self.proj.bias, N, self.num_heads,
-                                       mask_kind(attn_mask, N), 0.0, False, self.scale, self.drop_cfg())
+                                       mask_kind(attn_mask, N), 0.0, False, self.scale, self.drop_cfg(),
+                                       self.w_q.bias, self.w_k.bias, self.w_v.bias)
         return y.view(B, N, C)
 
 
@@ -122,7 +123,7 @@ class MLP(nn.Module):
         super().__init__()
         out_features = out_features or in_features
         hidden_features = hidden_features or in_features
-        if act_layer is not nn.GELU:
+        if act_layer is not nn.GELU:      # every call site of the reference passes nn.GELU (exact erf: the GEMM epilogue's activation)
             raise NotImplementedError("afft_amd: only nn.GELU (exact erf) is on the AFFT path")
         self.mlp = nn.Sequential(
             nn.Linear(in_features, hidden_features),
@@ -249,7 +250,7 @@ class DecoderBlock(nn.Module):
         x2 = F_.CrossAttnSublayer.apply(x2, m2, self.norm_q.weight, self.norm_q.bias, self.norm_kv.weight,
                                         self.norm_kv.bias, c.w_q.weight, c.w_k.weight, c.w_v.weight, c.proj.weight,
                                         c.proj.bias, L, c.num_heads, mask, self.norm_q.eps, True, c.scale,
-                                        D_.with_path(c.drop_cfg(), dp, L))
+                                        D_.with_path(c.drop_cfg(), dp, L), c.w_q.bias, c.w_k.bias, c.w_v.bias)
         m = self.mlp.mlp
         x2 = F_.MLPSublayer.apply(x2, self.norm_mlp.weight, self.norm_mlp.bias, m[0].weight, m[0].bias, m[2].weight,
                                   m[2].bias, self.norm_mlp.eps, "erf", False, True,

@@ -249,6 +249,17 @@ def attention_fwd(q: Tensor, k: Tensor, v: Tensor, nseq: int, L_: int, H: int, h
     return out
 
 
+def attention_fwd_table(q: Tensor, k: Tensor, v: Tensor, nseq: int, L_: int, H: int, hd: int, scale: float, table: Tensor,
+                        out: Tensor, probs: Optional[Tensor], drop_p: float = 0.0, drop_key: int = 0) -> Tensor:
+    """attention with an arbitrary additive fp32 [L, L] mask (afft_attention_fwd_table)"""
+    assert q.dtype == k.dtype == v.dtype == out.dtype
+    assert table.dtype == torch.float32 and table.shape == (L_, L_) and table.is_contiguous() and table.device == q.device
+    L.check(L.lib().afft_attention_fwd_table(_p(q), _rowmajor(q, "q"), _p(k), _rowmajor(k, "k"), _p(v), _rowmajor(v, "v"),
+                                             _dt(q), nseq, L_, H, hd, scale, _p(table), drop_p, drop_key, _p(out),
+                                             _rowmajor(out, "out"), _p(probs), _stream()), "attention_fwd_table")
+    return out
+
+
 def attention_fwd_split(q: Tensor, k: Tensor, v: Tensor, in_lo: int, nseq: int, L_: int, H: int, hd: int, scale: float, mask: int,
                         out_hi: Tensor, out_lo: int, out_bf16: Optional[Tensor], probs: Optional[Tensor], drop_p: float = 0.0,
                         drop_key: int = 0, mask_period: int = 0, out_lo8: Optional[Tensor] = None) -> Tensor:

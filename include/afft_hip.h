@@ -235,6 +235,14 @@ int afft_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, c
                        int32_t dtype, int32_t nseq, int32_t L, int32_t H, int32_t hd, float scale, int32_t mask,
                        int32_t mask_period, float drop_p, uint32_t drop_key, void* out, int64_t ldo, float* probs,
                        void* stream);
+/* The same with an ARBITRARY additive mask: mask_table fp32 [L, L] (device), added to the scaled scores before the softmax -- what
+ * `attn = attn + attn_mask` does for any (N, N) tensor the caller passes (models/transformerblock.py:26-28 Attention, :66-68
+ * CrossAttention); entries may be -inf.  Generic kernel (the in-register masks above stay on the MFMA kernels).  The backward pass
+ * needs no table: afft_attention_bwd works from the saved probabilities. */
+int afft_attention_fwd_table(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                             int32_t dtype, int32_t nseq, int32_t L, int32_t H, int32_t hd, float scale,
+                             const float* mask_table, float drop_p, uint32_t drop_key, void* out, int64_t ldo, float* probs,
+                             void* stream);
 /* "fp16x2" forward: q / k / v are the HI planes of two-plane fp16 splits (lo planes in_lo ELEMENTS behind, same strides); scores and
  * P V are accumulated from three fp16 MFMA products each (hi*hi + lo*hi + hi*lo: fp32-grade, ~2^-21) so that the attention core
  * adds no 2^-11 operand rounding to the forward pass; the result is written as planes again (out_hi, lo out_lo elements behind)

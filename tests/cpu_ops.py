@@ -173,6 +173,17 @@ def attention_fwd(q, k, v, nseq, L_, H, hd, scale, mask, out, probs, drop_p=0.0,
 
 
 @torch.no_grad()
+def attention_fwd_table(q, k, v, nseq, L_, H, hd, scale, table, out, probs, drop_p=0.0, drop_key=0):
+    assert drop_p == 0.0
+    qh, kh, vh = (_heads(t, nseq, L_, H, hd) for t in (q, k, v))
+    p = torch.softmax(qh @ kh.transpose(-1, -2) * scale + table, -1)
+    if probs is not None:
+        probs.copy_(p)
+    out.copy_((p @ vh).permute(0, 2, 1, 3).reshape(nseq * L_, H * hd))
+    return out
+
+
+@torch.no_grad()
 def attention_bwd(dout, q, k, v, probs, nseq, L_, H, hd, scale, dq, dk, dv, drop_p=0.0, drop_key=0):
     assert drop_p == 0.0
     qh, kh, vh, doh = (_heads(t, nseq, L_, H, hd) for t in (q, k, v, dout))
@@ -428,7 +439,7 @@ def softmax_rows(x, y):
     return y
 
 
-_NAMES = ["Split", "gemm", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "softmax_ce", "softmax_ce_frames", "mse", "mse_loss", "mse_frames_bwd", "cast",
+_NAMES = ["Split", "gemm", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_fwd_table", "attention_bwd", "softmax_ce", "softmax_ce_frames", "mse", "mse_loss", "mse_frames_bwd", "cast",
           "assemble_tokens", "colsum", "gather_frames", "add_rows_periodic", "reduce_rows_periodic", "sgd_nesterov", "sgd_nesterov_runs", "loss_reduce", "loss_reduce_bwd", "sumsq", "clip_coef",
           "group_sum", "group_bcast", "act_bwd", "softmax_small_fwd", "softmax_small_bwd", "weighted_sum_fwd",
           "weighted_sum_bwd", "softmax_rows"]

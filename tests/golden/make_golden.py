@@ -424,6 +424,69 @@ def run_reader_case():
     print("[r0_reader]", {k: v.shape for k, v in out.items()})
 
 
+def run_edge_case():
+    """e0_edges: the reference's transformerblock.Block with an ARBITRARY additive attention mask (models/transformerblock.py:26-28 adds
+    whatever tensor it is given) and DecoderBlock(dim, mem_dim != dim, qkv_bias=True) (:41-50, :66-68) -- interface edges the AFFT
+    configurations never use.  Closed-form weights and inputs; outputs, attention maps and every gradient of loss = mean(y^2) stored."""
+    import closed_form as cf
+    from models.transformerblock import Block, DecoderBlock
+    from oracle import afft_oracle as O
+    N, L, d, dm, H = 3, 6, 64, 128, 4
+    out = {}
+
+    def mask(tag):
+        m = cf.tensor_for(f"e0.{tag}.mask", (L, L), "input")           # values in [-2, 2)
+        kill = cf.tensor_for(f"e0.{tag}.kill", (L, L), "input") > 1.2  # ~ 20 % of the entries: -inf (no row is masked whole: checked)
+        kill.fill_diagonal_(False)
+        m = m.masked_fill(kill, float("-inf"))
+        assert bool(torch.isfinite(m).any(dim=1).all())
+        return m
+
+    def fill(mod, tag):
+        sd = mod.state_dict()
+        state = {k: cf.tensor_for(f"e0.{tag}.{k}", tuple(v.shape)) for k, v in sd.items()}
+        mod.load_state_dict(state)
+        return state
+
+    # --- Block + arbitrary mask
+    blk = Block(d, H).eval()
+    st = fill(blk, "block")
+    x = cf.tensor_for("e0.block.x", (N, L, d), "input").requires_grad_(True)
+    m1 = mask("block")
+    y, attn = blk(x, m1)
+    (y.pow(2).mean()).backward()
+    P = {("b." + k): v.detach().clone().requires_grad_(True) for k, v in st.items()}
+    xo = x.detach().clone().requires_grad_(True)
+    yo, ao = O.block(P, "b.", xo, H, m1)
+    yo.pow(2).mean().backward()
+    err = max(float((yo - y).abs().max()), float((ao - attn).abs().max()), float((xo.grad - x.grad).abs().max()))
+    assert err < 2e-5, err
+    out.update({"block.y": y, "block.attn": attn, "block.dx": x.grad, "block.mask": m1})
+    out.update({f"block.grad.{k}": p.grad for k, p in blk.named_parameters()})
+    # --- DecoderBlock, mem_dim != dim, qkv_bias, arbitrary mask
+    dec = DecoderBlock(d, mem_dim=dm, num_heads=H, qkv_bias=True).eval()
+    st2 = fill(dec, "dec")
+    x2 = cf.tensor_for("e0.dec.x", (N, L, d), "input").requires_grad_(True)
+    mem = cf.tensor_for("e0.dec.mem", (N, L, dm), "input").requires_grad_(True)
+    m2 = mask("dec")
+    y2 = dec(x2, mem, m2)
+    y2.pow(2).mean().backward()
+    P2 = {("d." + k): v.detach().clone().requires_grad_(True) for k, v in st2.items()}
+    x2o, memo = x2.detach().clone().requires_grad_(True), mem.detach().clone().requires_grad_(True)
+    y2o = O.decoder_block(P2, "d.", x2o, memo, H, m2)
+    y2o.pow(2).mean().backward()
+    err2 = max(float((y2o - y2).abs().max()), float((x2o.grad - x2.grad).abs().max()), float((memo.grad - mem.grad).abs().max()))
+    assert err2 < 2e-5, err2
+    out.update({"dec.y": y2, "dec.dx": x2.grad, "dec.dmem": mem.grad, "dec.mask": m2})
+    out.update({f"dec.grad.{k}": p.grad for k, p in dec.named_parameters()})
+    shapes = {"block": {k: list(v.shape) for k, v in st.items()}, "dec": {k: list(v.shape) for k, v in st2.items()}}
+    np.savez_compressed(os.path.join(HERE, "e0_edges.npz"), **{k: v.detach().float().numpy() for k, v in out.items()},
+                        shapes=np.asarray(json.dumps(shapes)),
+                        meta=np.asarray(json.dumps(dict(case="e0_edges", N=N, L=L, d=d, mem_dim=dm, heads=H, torch=torch.__version__,
+                                                        reference="zeyun-zhong/AFFT @ /root/reference (v1)"))))
+    print("[e0_edges] oracle == reference:", err, err2, "tensors", len(out))
+
+
 def main():
     install_stubs()
     sys.path.insert(0, os.path.dirname(HERE))       # tests/helpers.py
@@ -441,6 +504,8 @@ def main():
         run_eval_case()
     if not only or "r0_reader" in only:
         run_reader_case()
+    if not only or "e0_edges" in only:
+        run_edge_case()
 
 
 if __name__ == "__main__":

@@ -113,3 +113,57 @@ def full_gradient_errors(named_grads: dict, z) -> dict:
         out[nm] = max(abs(float(g.norm()) - float(norms[i])) / scale,
                       float((smp - ref).norm()) / max(float(ref.norm()), scale * (smp.numel() / g.numel()) ** 0.5))
     return out
+
+
+# ---- interface edges (tests/golden/e0_edges.npz: the reference's Block with an arbitrary additive mask, DecoderBlock(mem_dim != dim, qkv_bias))
+def edge_fixture():
+    """(npz, meta dict, {'block': state, 'dec': state}, inputs dict) -- weights and inputs regenerated from closed form"""
+    z = np.load(os.path.join(GOLDEN, "e0_edges.npz"), allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    shapes = json.loads(str(z["shapes"]))
+    states = {tag: {k: cf.tensor_for(f"e0.{tag}.{k}", tuple(shp)) for k, shp in shapes[tag].items()} for tag in ("block", "dec")}
+    N, L, d, dm = meta["N"], meta["L"], meta["d"], meta["mem_dim"]
+    inputs = {"block.x": cf.tensor_for("e0.block.x", (N, L, d), "input"), "dec.x": cf.tensor_for("e0.dec.x", (N, L, d), "input"),
+              "dec.mem": cf.tensor_for("e0.dec.mem", (N, L, dm), "input"),
+              "block.mask": torch.from_numpy(z["block.mask"]), "dec.mask": torch.from_numpy(z["dec.mask"])}
+    return z, meta, states, inputs
+
+
+def run_edge_modules(device, states, inputs, meta):
+    """the mirrored Block / DecoderBlock on `device` -> {name: tensor} with the fixture's keys (outputs, attention, every gradient)"""
+    from afft_amd.models.transformerblock import Block, DecoderBlock
+    from afft_amd import runtime as rt
+    d, dm, H = meta["d"], meta["mem_dim"], meta["heads"]
+    out = {}
+    rt.SINK.begin_step()
+    blk = Block(d, H).eval()
+    blk.load_state_dict(states["block"])
+    blk = blk.to(device)
+    x = inputs["block.x"].to(device).requires_grad_(True)
+    y, attn = blk(x, inputs["block.mask"].to(device))
+    y.pow(2).mean().backward()
+    rt.SINK.finish_step(list(blk.parameters()))
+    out.update({"block.y": y, "block.attn": attn, "block.dx": x.grad})
+    out.update({f"block.grad.{k}": p.grad for k, p in blk.named_parameters()})
+    rt.SINK.begin_step()
+    dec = DecoderBlock(d, mem_dim=dm, num_heads=H, qkv_bias=True).eval()
+    dec.load_state_dict(states["dec"])
+    dec = dec.to(device)
+    x2 = inputs["dec.x"].to(device).requires_grad_(True)
+    mem = inputs["dec.mem"].to(device).requires_grad_(True)
+    y2 = dec(x2, mem, inputs["dec.mask"].to(device))
+    y2.pow(2).mean().backward()
+    rt.SINK.finish_step(list(dec.parameters()))
+    out.update({"dec.y": y2, "dec.dx": x2.grad, "dec.dmem": mem.grad})
+    out.update({f"dec.grad.{k}": p.grad for k, p in dec.named_parameters()})
+    return out
+
+
+def edge_error(got: torch.Tensor, ref: torch.Tensor) -> float:
+    """relative L2 -- except for a gradient that is analytically ZERO (the k-projection bias of an attention layer: a constant added to
+    every key moves no softmax weight), which the fixture holds as 1e-9 rounding noise: there, the absolute size of what we computed"""
+    ref = ref.detach().double().cpu()
+    got = got.detach().double().cpu()
+    if float(ref.abs().max()) < 1e-7:
+        return float(got.abs().max())
+    return float((got - ref).norm() / ref.norm())

@@ -318,3 +318,23 @@ def test_zero_weighted_loss_terms_leave_the_total_and_the_graph():
         assert torch.equal(a.grad, torch.tensor([1.0, 1.0])) and b.grad is None
         with pytest.raises(RuntimeError, match="every loss weight"):
             Runner._reduce_loss({"cls_action": a.detach()}, {"cls_action": 0.0}, sync=False)
+
+
+def test_interface_edges_arbitrary_mask_mem_dim_qkv_bias_reproduce_the_reference():
+    """What the AFFT configurations never use but the reference's classes accept (missing #4): Block with an ARBITRARY additive
+    (N, N) mask (models/transformerblock.py:26-28) and DecoderBlock(mem_dim != dim, qkv_bias=True) (:41-50) -- the mirrored modules
+    route them call by call (attention core with an additive table, biased q / k / v projections, a memory of another width); outputs,
+    attention maps and every gradient against the reference's own (tests/golden/e0_edges.npz), host wiring on the torch test double."""
+    import afft_amd
+    from afft_amd import runtime as rt
+    from helpers import edge_error, edge_fixture, run_edge_modules
+    z, meta, states, inputs = edge_fixture()
+    afft_amd.set_precision("fp32")
+    rt.set_grad_mode("sink")
+    with cpu_ops.installed():
+        got = run_edge_modules(torch.device("cpu"), states, inputs, meta)
+    afft_amd.set_precision("bf16")
+    assert set(got) == {k for k in z.files if k not in ("shapes", "meta", "block.mask", "dec.mask")}
+    for k, t in got.items():
+        assert t is not None, k
+        assert edge_error(t, torch.from_numpy(z[k])) < 2e-5, (k, edge_error(t, torch.from_numpy(z[k])))

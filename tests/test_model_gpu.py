@@ -1822,3 +1822,26 @@ def test_token_row_projection_replays_its_dropout_masks_in_backward(handover):
             assert rel_l2(res[True][2][k], res[False][2][k]) < 5e-3, k
     finally:
         rt.set_handover(was)
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16x3", 1e-3), ("bf16", 3e-2)])
+def test_interface_edges_arbitrary_mask_mem_dim_qkv_bias_on_the_hip_path(precision, tol):
+    """Block with an arbitrary additive (N, N) mask (afft_attention_fwd_table: models/transformerblock.py:26-28) and
+    DecoderBlock(mem_dim != dim, qkv_bias=True) (:41-50, :66-68) through the C-ABI against the reference's own outputs, attention maps
+    and gradients (tests/golden/e0_edges.npz)."""
+    import afft_amd
+    from afft_amd import runtime as rt
+    from helpers import edge_error, edge_fixture, run_edge_modules
+    z, meta, states, inputs = edge_fixture()
+    afft_amd.set_precision(precision)
+    rt.set_grad_mode("sink")
+    try:
+        got = run_edge_modules(torch.device("cuda:0"), states, inputs, meta)
+    finally:
+        afft_amd.set_precision("bf16")
+    worst = {}
+    for k, t in got.items():
+        assert t is not None, k
+        worst[k] = edge_error(t, torch.from_numpy(z[k]))
+    bad = {k: v for k, v in worst.items() if not v < tol}
+    assert not bad, bad

@@ -131,3 +131,29 @@ def test_eval_path_oracle_and_host_metrics_match_reference_golden():
     assert set(got) == set(want)
     for k, v in want.items():
         assert (np.isnan(v) and np.isnan(got[k])) or abs(got[k] - v) < 1e-9, (k, got[k], v)
+
+
+def test_oracle_reproduces_the_reference_on_the_interface_edges():
+    """tests/golden/e0_edges.npz (the reference's Block with an arbitrary additive mask; DecoderBlock(mem_dim != dim, qkv_bias=True)):
+    the oracle's block / decoder_block from closed-form weights and inputs, outputs + input gradients."""
+    import torch
+    from helpers import edge_error as rel_l2, edge_fixture
+    from oracle import afft_oracle as O
+    z, meta, states, inputs = edge_fixture()
+    H = meta["heads"]
+    P = {("b." + k): v.clone().requires_grad_(True) for k, v in states["block"].items()}
+    x = inputs["block.x"].clone().requires_grad_(True)
+    y, attn = O.block(P, "b.", x, H, inputs["block.mask"])
+    y.pow(2).mean().backward()
+    for k, t in (("block.y", y), ("block.attn", attn), ("block.dx", x.grad)):
+        assert rel_l2(t, torch.from_numpy(z[k])) < 2e-5, k
+    for k, p in P.items():
+        assert rel_l2(p.grad, torch.from_numpy(z["block.grad." + k[2:]])) < 2e-5, k
+    P2 = {("d." + k): v.clone().requires_grad_(True) for k, v in states["dec"].items()}
+    x2, mem = inputs["dec.x"].clone().requires_grad_(True), inputs["dec.mem"].clone().requires_grad_(True)
+    y2 = O.decoder_block(P2, "d.", x2, mem, H, inputs["dec.mask"])
+    y2.pow(2).mean().backward()
+    for k, t in (("dec.y", y2), ("dec.dx", x2.grad), ("dec.dmem", mem.grad)):
+        assert rel_l2(t, torch.from_numpy(z[k])) < 2e-5, k
+    for k, p in P2.items():
+        assert rel_l2(p.grad, torch.from_numpy(z["dec.grad." + k[2:]])) < 2e-5, k
