@@ -1012,6 +1012,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Python's cyclic collector: ~20 steps into a process it runs its first full (generation-2) collection over the ~200 k objects that
+    # importing torch / building the model left behind -- 50-65 ms on the enqueueing thread (tools/gc_probe.py, profiles/r06_gc_stall.txt).
+    # A training loop absorbs that in the host's lead over the GPU (~150 ms of queued launches); a 20-step timed region that starts right
+    # after a synchronisation does not (+2.7 ms/step).  Set-up objects are moved out of the collector's sight; the collector stays on.
+    import gc
+    gc.collect()
+    gc.freeze()
+
     captured = False
     if world == 1 and not args.no_optimizer and args.graph != "off":
         if args.graph in ("on", "single") or args.config in GRAPH_AUTO:
