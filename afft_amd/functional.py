@@ -1757,10 +1757,17 @@ class GradLanding:
 
     def __init__(self, shape, n):
         self.shape, self.n, self.dx = tuple(shape), n, None
+        self.written = [False, False]      # per half: a loss kernel has stored its gradient there in THIS backward pass
 
-    def half(self, which: int, device, dtype=torch.float32) -> Tensor:
+    def half(self, which: int, device, dtype=torch.float32) -> Optional[Tensor]:
+        """the half's slice of the shared buffer for ONE writer per backward pass; None for a second one (two losses on the same
+        half: each must return its own tensor, autograd adds them -- a second in-place write would replace the first and the sum of
+        the two aliasing views would come out as twice the last gradient)"""
+        if self.written[which]:
+            return None
         if self.dx is None:
             self.dx = torch.empty(self.shape, dtype=dtype, device=device)
+        self.written[which] = True
         return self.dx[:, :self.n] if which == 0 else self.dx[:, self.n:]
 
     def holds(self, which: int, g: Tensor) -> bool:
@@ -1797,10 +1804,11 @@ class SoftmaxCE(torch.autograd.Function):
         lg, labels, soft, keep = ctx.saved_tensors
         if lg.dim() == 3:
             C = lg.shape[2]
+            d = None
             if ctx.landing is not None and ctx.landing[0].shape[2] == C:
                 d = ctx.landing[0].half(ctx.landing[1], lg.device)
-                assert d.shape == lg.shape
-            else:
+                assert d is None or d.shape == lg.shape
+            if d is None:
                 d = torch.empty(lg.shape, dtype=torch.float32, device=lg.device)
             ops.softmax_ce_frames(lg, C, labels=labels, soft=soft, keep=keep, dlogits3=d, row_g=g_rows.contiguous())
             flush_ready()
@@ -1921,6 +1929,8 @@ class SplitRows(torch.autograd.Function):
                 view.zero_()
             elif rec is None or not rec.holds(which, g):
                 view.copy_(g)
+        if ctx.landing is not None:
+            ctx.landing.written = [False, False]      # the next backward pass through this record starts clean
         return dx, None, None
 
 

@@ -338,3 +338,35 @@ def test_interface_edges_arbitrary_mask_mem_dim_qkv_bias_reproduce_the_reference
     for k, t in got.items():
         assert t is not None, k
         assert edge_error(t, torch.from_numpy(z[k])) < 2e-5, (k, edge_error(t, torch.from_numpy(z[k])))
+
+
+def test_two_losses_on_one_half_of_the_merged_logits_add_up():
+    """SplitRows hands each half of the merged classifier output ONE landing slice for its loss gradient.  Two cross-entropy
+    terms on the SAME half (two targets on one tensor) must not both write it in place -- autograd would add two aliasing views and
+    return twice the last gradient.  The second writer of a backward pass gets its own tensor; the sum equals autograd's."""
+    import afft_amd
+    from afft_amd import functional as F_, runtime as rt
+    from afft_amd.common.runner import MultiDimCrossEntropy
+    afft_amd.set_precision("fp32")
+    rt.set_grad_mode("sink")
+    torch.manual_seed(5)
+    B, T, C = 3, 4, 7
+    x0 = torch.randn(B, T + 1, C)
+    t1 = torch.randint(0, C, (B, T))
+    t2 = torch.randint(0, C, (B, T))
+    t3 = torch.randint(0, C, (B, 1))
+    ce = MultiDimCrossEntropy()
+    with cpu_ops.installed():
+        for rep in range(2):      # twice through one graph shape: the per-pass 'written' flags are reset by SplitRows.backward
+            x = x0.clone().requires_grad_(True)
+            past, fut = F_.split_rows(x * 1.0, T)
+            loss = ce(past, t1).mean() + 0.5 * ce(past, t2).mean() + ce(fut, t3).mean()
+            loss.backward()
+            xr = x0.clone().requires_grad_(True)
+            lr = (torch.nn.functional.cross_entropy(xr[:, :T].reshape(-1, C), t1.reshape(-1))
+                  + 0.5 * torch.nn.functional.cross_entropy(xr[:, :T].reshape(-1, C), t2.reshape(-1))
+                  + torch.nn.functional.cross_entropy(xr[:, T:].reshape(-1, C), t3.reshape(-1)))
+            lr.backward()
+            assert abs(float(loss) - float(lr)) < 1e-5
+            assert rel_l2(x.grad, xr.grad) < 1e-5, rel_l2(x.grad, xr.grad)
+    afft_amd.set_precision("bf16")
