@@ -27,6 +27,10 @@ using namespace afft_gemm_detail;
                           // 8 = no global accesses in the epilogue, 16 = no epilogue at all
 #endif
 
+#if !defined(AFFT_DIAG_BUILD) && (AFFT_PP_DIAG || defined(AFFT_PP_SAMETILE) || defined(AFFT_PP_STAMP) || AFFT_HANDOFF_DIAG)
+#error "AFFT_PP_DIAG / AFFT_PP_SAMETILE / AFFT_PP_STAMP / AFFT_HANDOFF_DIAG give wrong results or change the kernel's signature: diagnostic builds only (make DIAG=1 DIAGFLAGS=-D...)"
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------

@@ -316,20 +316,20 @@ extern "C" int afft_layernorm_bwd_take(const void* dy, int64_t lddy, int32_t dy_
   AFFT_CHECK(in_take >= 1 && lddx_in % 4 == 0, "layernorm_bwd: bad in_take / lddx_in");
   AFFT_CHECK(dy && x && mean && rstd && dx_out && partial, "layernorm_bwd: null pointer");
   AFFT_CHECK(d > 0 && d % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "layernorm_bwd: d/ld must be multiples of 4");
-  AFFT_CHECK(d <= 4096, "layernorm_bwd: d=%d exceeds 4096", d);
+  AFFT_CHECK(d <= 2048, "layernorm_bwd: d=%d exceeds 2048 (the widest stream of the path; the 4096-wide instantiation spilled 101-125 registers and was removed in round 6)", d);
   if (rows == 0) return 0;
   AfftKernelScope ktrace(AFFT_K_LN_BWD, rows, d,
                          (int64_t)rows * d * ((dy_dtype == AFFT_F32 ? 4 : 2) + 4 + (dx_in ? 4 : 0) + 4 + (dx_bf16 ? 2 : 0)) + (int64_t)rows * 8, 0, stream);
   const int qs = (d / 4 + LNB_CS - 1) / LNB_CS;
-  const int nv = qs <= 64 ? 1 : qs <= 128 ? 2 : 4;
+  const int nv = qs <= 64 ? 1 : 2;
   const int grid = afft_layernorm_bwd_nparts(rows);
   const int nslab = dcol ? 3 : 2;
   const DropParams drop = make_drop(copy_drop);
   const size_t lds = (size_t)nslab * d * sizeof(float) + 2 * LNB_RG * LNB_CS * 2 * sizeof(float);
   AFFT_CHECK(dy_dtype == AFFT_F32 || dy_dtype == AFFT_BF16, "layernorm_bwd: dy is fp32 or bf16");
 #define LN_BWD(NV, F) hipLaunchKernelGGL((ln_bwd_kernel<NV, F>), dim3(grid), dim3(1024), lds, stream, dy, lddy, x, ldx, w, mean, rstd, rows, d, dx_in, dx_out, lddx, (bf16_t*)dx_bf16, drop, nslab, partial, lddx_in, in_take)
-  if (dy_dtype == AFFT_F32) { switch (nv) { case 1: LN_BWD(1, true); break; case 2: LN_BWD(2, true); break; default: LN_BWD(4, true); } }
-  else { switch (nv) { case 1: LN_BWD(1, false); break; case 2: LN_BWD(2, false); break; default: LN_BWD(4, false); } }
+  if (dy_dtype == AFFT_F32) { if (nv == 1) LN_BWD(1, true); else LN_BWD(2, true); }
+  else { if (nv == 1) LN_BWD(1, false); else LN_BWD(2, false); }
 #undef LN_BWD
   AFFT_LAUNCH_CHECK();
   if (dw || db || dcol) {

@@ -1,4 +1,4 @@
-"""Diagnostic: per-segment cycle shares of the ping-pong GEMM (needs a -DAFFT_PP_STAMP build of gemm_pp.hip linked
+"""Diagnostic: per-segment cycle shares of the ping-pong GEMM (needs `tools/lib_variant_one.sh stamp gemm_pp -DAFFT_DIAG_BUILD -DAFFT_PP_STAMP -DAFFT_PP2=0`:
 into afft_amd/lib/libafft_hip_stamp.so). Prints, for each wave of workgroup 0, average cycles per phase spent in
 L (LDS reads + DMA issue), W (vmcnt wait), B1 (barrier after L), C (16 MFMAs), B2 (barrier after C)."""
 import ctypes, os, sys
