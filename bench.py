@@ -75,6 +75,7 @@ def parse():
                     help="skip the side measurement of the reference's own loop (Runner + MixUp + optimizer over 151 groups + lr scheduler)")
     ap.add_argument("--no-power", action="store_true", help="skip the package power / clock poll")
     ap.add_argument("--no-ek100", action="store_true", help="skip the side measurement at the EK100 widths of expts/01 (d = 1024)")
+    ap.add_argument("--no-separate-update", action="store_true", help="N = 1: skip the leg with the per-bucket update kernel (profiling runs: one kernel mix)")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the side measurement at the reference's per-GPU batch of 16 clips")
     args = ap.parse_args()
     if args.comm_dtype is None:
@@ -1089,7 +1090,7 @@ def main():
 
     # N = 1: the same step with the SEPARATE per-bucket update kernel -- the kernels every rank of an N > 1 run executes (there the
     # summed gradient has to exist before the update), so that a scaling curve has an N = 1 anchor on the same code
-    if world == 1 and not captured and not args.no_optimizer and trainer._fused:
+    if world == 1 and not captured and not args.no_optimizer and trainer._fused and not args.no_separate_update:
         try:
             afft_amd.runtime.set_fused_sgd(False)
             ms_sep = timed_steps(trainer, feats, tgt, sub, sync_all, 3, 10, device, 1)
