@@ -409,12 +409,30 @@ def new_stream(device, *others) -> "torch.cuda.Stream":
     raise RuntimeError("afft_amd.runtime.new_stream: torch's stream pool has no stream left that is distinct from %d others" % len(taken))
 
 
+_AUX_PRIORITY = os.environ.get("AFFT_AUX_PRIORITY", "normal")      # "low" | "normal" | "high": HIP priority of the auxiliary stream
+
+
+def priority_stream(idx: int, which: str) -> "torch.cuda.Stream":
+    """A HIP stream of the lowest ('low') or highest ('high') priority the device offers, as a torch stream (torch's own pool only
+    has normal- and high-priority streams).  Created once per call with hipStreamCreateWithPriority and never destroyed."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    least, greatest = ctypes.c_int(0), ctypes.c_int(0)
+    if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0:
+        raise RuntimeError("hipDeviceGetStreamPriorityRange failed")
+    h = ctypes.c_void_p()
+    with torch.cuda.device(idx):
+        if hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, least.value if which == "low" else greatest.value) != 0:      # 1 = hipStreamNonBlocking
+            raise RuntimeError("hipStreamCreateWithPriority failed")
+    return torch.cuda.ExternalStream(h.value, device=idx)
+
+
 def aux_stream(device) -> "torch.cuda.Stream":
     """Per-device side stream on which weight-gradient GEMMs run beside the data-gradient chain."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _AUX_STREAMS.get(idx)
     if st is None:
-        st = new_stream(torch.device("cuda", idx))
+        st = priority_stream(idx, _AUX_PRIORITY) if _AUX_PRIORITY in ("low", "high") else new_stream(torch.device("cuda", idx))
         _AUX_STREAMS[idx] = st
     return st
 
