@@ -422,7 +422,9 @@ int launch_fast(GemmFast& g, hipStream_t stream) {
   g.tiles_m = (g.e.M + BM - 1) / BM;
   g.tiles_n = (g.e.N + BN - 1) / BN;
   if constexpr (WM == 2 && WN == 2 && STAGES == 2 && X3 == 0) {
-    if (g2_shape(g.e.M, g.e.N, g.K, g.splitk)) {      // whole tiles, even K-tile count per slice: the steady-state kernel
+    const bool fits32 = (A_KS ? (int64_t)(g.K + 8) * g.lda * 2 : (8 * g.lda + g.K) * 2) < (1LL << 32) &&
+                        (B_KS ? (int64_t)(g.K + 8) * g.ldb * 2 : (8 * g.ldb + g.K) * 2) < (1LL << 32);      // the running K offset is a 32-bit VGPR
+    if (fits32 && g2_shape(g.e.M, g.e.N, g.K, g.splitk)) {      // whole tiles, even K-tile count per slice: the steady-state kernel
       auto k2 = gemm_bf16_g2_kernel<A_KS, B_KS, SPLITK>;
       static std::atomic<uint64_t> attr2_done{0};
       if (int rc = afft_ensure_dynamic_lds(reinterpret_cast<const void*>(k2), lds, &attr2_done)) return rc;

@@ -585,8 +585,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(const GemmFast g)
 #define AFFT_PP2 1      // 0: every shape on gemm_bf16_pp_kernel (A/B builds)
 #endif
 bool pp2_shape(int M, int N, int K) { return AFFT_PP2 && M % 256 == 0 && N % 256 == 0 && K % (2 * BK) == 0 && K >= 4 * BK; }
+// the running K offset lives in a 32-bit VGPR (k-strided operands: K rows of `ld` elements): the whole walk must stay below 4 GiB
+inline bool walk_fits32(bool ks, int K, int64_t ld) { return ks ? (int64_t)(K + 8) * ld * 2 < (1LL << 32) : (8 * ld + K) * 2 < (1LL << 32); }
 template <bool A_KS, bool B_KS>
-bool pp2_takes(const GemmFast& g) { return pp2_shape(g.e.M, g.e.N, g.K); }
+bool pp2_takes(const GemmFast& g) { return pp2_shape(g.e.M, g.e.N, g.K) && walk_fits32(A_KS, g.K, g.lda) && walk_fits32(B_KS, g.K, g.ldb); }
 
 template <bool A_KS, bool B_KS>
 int launch_pp2(GemmFast& g, hipStream_t stream) {
