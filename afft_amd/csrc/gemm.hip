@@ -34,7 +34,7 @@
 using namespace afft_gemm_detail;
 
 int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream, int x3);
-bool afft_gemm_pp2_takes(int M, int N, int K, int x3);      // gemm_pp.hip: the launch runs gemm_bf16_pp2_kernel (whole tiles, even K-tile count, plain bf16)
+bool afft_gemm_pp2_takes(int M, int N, int K, int x3);      // gemm_pp.hip: the launch runs gemm_bf16_pp2_kernel (whole tiles, even K-tile count; plain bf16 or the NT fp16 + fp8 forward; K = the caller's K)
 int afft_gemm_launch_bd(int rows160, int packed, afft_gemm_detail::GemmFast& g, hipStream_t stream);
 #ifdef AFFT_EXPERIMENT_Q4      // tools/experiments/gemm_q4.hip (tools/experiments/build_q4.sh): the four-quadrant kernel, variant 11
 int afft_gemm_launch_q4(afft_gemm_detail::GemmFast& g, hipStream_t stream);
@@ -494,7 +494,7 @@ int launch_layout(GemmFast& g, hipStream_t stream, const afft_gemm_t* d) {
   (void)hipEventRecord(t.b, stream);
   int variant = choose_variant(g.e.M, g.e.N, g.K, A_KS, B_KS);
   if (!A_KS && !B_KS && d->b_packed && !d->split3 && g_variant == 0 && g.ldb == d->K && bd_packed_wins(g.e.M, g.e.N, g.K)) variant = 10;
-  if (variant == 3 && afft_gemm_pp2_takes(g.e.M, g.e.N, g.K, d->split3)) variant = 13;      // the steady-state 256x256 kernel (gemm_bf16_pp2_kernel)
+  if (variant == 3 && afft_gemm_pp2_takes(g.e.M, g.e.N, d->K, d->split3)) variant = 13;      // the steady-state 256x256 kernel (gemm_bf16_pp2_kernel)
   t.r = afft_gemm_trace_rec_t{g.e.M, g.e.N, d->K, A_KS, B_KS, variant, g.splitk, d->split3, d->sgd != nullptr, 0.f};
   std::lock_guard<std::mutex> lk(g_trace_mu);
   if (g_trace) g_trace->push_back(t);

@@ -390,8 +390,15 @@ __device__ __forceinline__ void glds16i(const char* sbase, unsigned voff, unsign
   asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_wave), "n"(OFF) : "memory", "scc");
 }
 
-template <bool A_KS, bool B_KS>
+// X3 = 3 (NT only): the "fp16x2" forward GEMM -- nk_seg K-tiles of (A hi fp16, B fp16 image) on v_mfma_f32_16x16x32_f16, then nk_seg / 2 K-tiles
+// of 128 k each of the e4m3 byte planes (A8, B8: their own bases and row pitches) on the block-scaled fp8 MFMA (gemm_tiles.h: mfma_lo8).  The
+// LDS-DMA stream runs 1.5 K-tiles ahead of the MFMAs, so it changes planes inside the fp16 segment's LAST PAIR of K-tiles: in K-tile nk_seg - 2
+// (TAIL code 3, "TRANS") phase 0 stages the last fp16 B half and then switches B's bases and lane offset, phase 1 does the same for A, phases
+// 2 and 3 already stage the first fp8 K-tile -- all at compile-time positions.  Fragments are kept as PAIRS (k-substeps 0 | 1 in one
+// 8-register tuple): the fp8 MFMA takes the tuple whole, the fp16 MFMA its halves (sub-registers, no copies).
+template <bool A_KS, bool B_KS, int X3 = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(const GemmFast g) {
+  static_assert(X3 == 0 || (X3 == 3 && !A_KS && !B_KS), "the steady-state kernel is built for plain bf16 and for the NT fp16 + fp8 forward");
   constexpr int HB = 128 * BK * 2;   // half-tile bytes (16 KiB)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(const GemmFast g)
   int tm, tn;
   tile_coords(g.tiles_m, g.tiles_n, blockIdx.x, tm, tn);
   const int m0 = tm * 256, n0 = tn * 256;
-  const int npairs = g.K / (2 * BK);      // >= 2 (launch_pp2)
+  const int npairs = (X3 == 3 ? g.nk_seg * BK : g.K) / (2 * BK);      // K-tile pairs of the (first) segment: >= 2 (X3 = 0) / >= 1 (X3 = 3)
 
   f32x4 acc[2][2][4][2];
 #pragma unroll
@@ -412,6 +419,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(const GemmFast g)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 aF[4][2], bF[2][2][2];   // A fragments of the live half; B fragments of both halves
+  bf16x16 aP[4], bP[2][2];        // X3 = 3: the same as pairs
+  (void)aF; (void)bF; (void)aP; (void)bP;
 
   const unsigned lds_wave = lds_addr(smem) + wave * 1024;
   const unsigned lda2 = (unsigned)(g.lda * 2), ldb2 = (unsigned)(g.ldb * 2);
@@ -430,18 +439,37 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(const GemmFast g)
       bA[h][jj] = A_KS ? (const char*)(g.A + (int64_t)(4 * j) * g.lda + m0 + 128 * h) : (const char*)(g.A + (int64_t)(m0 + 128 * h + 8 * j) * g.lda);
       bB[h][jj] = B_KS ? (const char*)(g.B + (int64_t)(4 * j) * g.ldb + n0 + 128 * h) : (const char*)(g.B + (int64_t)(n0 + 128 * h + 8 * j) * g.ldb);
     }
+  // X3 = 3: the LDS-DMA stream moves on to the e4m3 byte planes (K offset back to 0, their own row pitch)
+  bool sw_now = false;      // wave-uniform: this pair of K-tiles is the fp16 segment's last (set by the pair loop)
+  unsigned incA = stepA, incB = stepB;      // K advance per staged K-tile; X3 = 3: 0 in the last pair of the fp8 segment (below)
+  auto switch_a = [&] {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) bA[h][jj] = (const char*)(g.A8 + (int64_t)(m0 + 128 * h + 8 * (wave + 8 * jj)) * g.lda8);
+    vA = lo.kc_row * (unsigned)(g.lda8 * 2) + lo.kc_chunk16;
+  };
+  auto switch_b = [&] {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) bB[h][jj] = (const char*)(g.B8 + (int64_t)(n0 + 128 * h + 8 * (wave + 8 * jj)) * g.ldb8);
+    vB = lo.kc_row * (unsigned)(g.ldb8 * 2) + lo.kc_chunk16;
+  };
   // half-tile kind q (0 = A rows 0-127, 1 = B 0-127, 2 = B 128-255, 3 = A 128-255) of a K-tile of parity KP -> ring slot KP * 4 + q
-  auto issue = [&](auto qc, auto kpc) {
+  // SW: this is the first segment's last half-tile of the operand: switch planes instead of stepping on
+  auto issue = [&](auto qc, auto kpc, auto swc) {
     constexpr int q = decltype(qc)::value, KP = decltype(kpc)::value;
+    constexpr bool SW = decltype(swc)::value;
     constexpr int dst = (KP * 4 + q) * HB;
     if constexpr (q == 0 || q == 3) {
       glds16i<dst>(bA[q == 3][0], vA, lds_wave);
       glds16i<dst + 8192>(bA[q == 3][1], vA, lds_wave);
-      if constexpr (q == 3) vA += stepA;       // A's second half closes its K-tile
+      if constexpr (q == 3) { if constexpr (SW) { if (sw_now) switch_a(); else vA += incA; } else vA += incA; }      // A's second half closes its K-tile
     } else {
       glds16i<dst>(bB[q == 2][0], vB, lds_wave);
       glds16i<dst + 8192>(bB[q == 2][1], vB, lds_wave);
-      if constexpr (q == 2) vB += stepB;
+      if constexpr (q == 2) { if constexpr (SW) { if (sw_now) switch_b(); else vB += incB; } else vB += incB; }
     }
   };
   // Fragment reads: every lane-dependent part of an LDS address is one of a few VGPRs computed ONCE (made opaque, so that the compiler
@@ -484,38 +512,61 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(const GemmFast g)
     f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
     return f;
   };
-  auto load_a = [&](auto kpc, auto ihc) {
+  // PAIR (X3 = 3, fp8 K-tiles): both k-substeps of a fragment side by side in one 8-register tuple, as the block-scaled MFMA takes them; the fp16
+  // K-tiles keep the two substeps as separate 4-register fragments (pairs everywhere spilled 80 registers: 8-register tuples fragment the file)
+  auto load_a = [&](auto kpc, auto ihc, auto pairc) {
     constexpr int KP = decltype(kpc)::value, ih = decltype(ihc)::value;
+    constexpr bool PAIR = decltype(pairc)::value;
     constexpr int so = (ih ? 3 : 0) * HB;       // slot offset inside the ring half
     static_for<0, 2>([&](auto sc) {
       static_for<0, 4>([&](auto ic) {
         constexpr int s = decltype(sc)::value, i = decltype(ic)::value;
-        if constexpr (A_KS) aF[i][s] = rdtr(adA[KP][i], std::integral_constant<int, so + s * 8192>{});
+        if constexpr (PAIR) { if constexpr (s == 0) aP[i] = frag_pair(rd128(adA[KP][0], std::integral_constant<int, so + i * 2048>{}),
+                                                                         rd128(adA[KP][1], std::integral_constant<int, so + i * 2048>{})); }
+        else if constexpr (A_KS) aF[i][s] = rdtr(adA[KP][i], std::integral_constant<int, so + s * 8192>{});
         else aF[i][s] = rd128(adA[KP][s], std::integral_constant<int, so + i * 2048>{});
       });
     });
   };
-  auto load_b = [&](auto kpc, auto jhc, auto slotc) {   // B half jh of a K-tile of parity KP -> fragment slot
+  auto load_b = [&](auto kpc, auto jhc, auto slotc, auto pairc) {   // B half jh of a K-tile of parity KP -> fragment slot
     constexpr int KP = decltype(kpc)::value, jh = decltype(jhc)::value, slot = decltype(slotc)::value;
+    constexpr bool PAIR = decltype(pairc)::value;
     constexpr int so = (1 + jh) * HB;
     static_for<0, 2>([&](auto sc) {
       static_for<0, 2>([&](auto jc) {
         constexpr int s = decltype(sc)::value, j = decltype(jc)::value;
-        if constexpr (B_KS) bF[slot][j][s] = rdtr(adB[KP][j], std::integral_constant<int, so + s * 8192>{});
+        if constexpr (PAIR) { if constexpr (s == 0) bP[slot][j] = frag_pair(rd128(adB[KP][0], std::integral_constant<int, so + j * 2048>{}),
+                                                                               rd128(adB[KP][1], std::integral_constant<int, so + j * 2048>{})); }
+        else if constexpr (B_KS) bF[slot][j][s] = rdtr(adB[KP][j], std::integral_constant<int, so + s * 8192>{});
         else bF[slot][j][s] = rd128(adB[KP][s], std::integral_constant<int, so + j * 2048>{});
       });
     });
   };
-  auto compute = [&](auto ihc, auto jhc, auto slotc) {
+  auto compute = [&](auto ihc, auto jhc, auto slotc, auto lo8c) {
     constexpr int ih = decltype(ihc)::value, jh = decltype(jhc)::value, slot = decltype(slotc)::value;
+    constexpr bool LO8 = decltype(lo8c)::value;      // compile-time: one MFMA form per K-tile instantiation (a run-time choice spilled 241 registers in round 5)
     __builtin_amdgcn_sched_barrier(0);
     if (AFFT_PP2_PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
+    if constexpr (X3 == 3 && LO8) {       // 8 block-scaled fp8 MFMAs of 128 k
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[ih][jh][i][j] = mfma16<0>(bF[slot][j][s], aF[i][s], acc[ih][jh][i][j]);
+        for (int j = 0; j < 2; ++j) acc[ih][jh][i][j] = mfma_lo8(bP[slot][j], aP[i], acc[ih][jh][i][j]);
+    } else if constexpr (X3 == 3) {      // fp16 segment: A in 4-register fragments, B the halves of its pairs (sub-registers)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[ih][jh][i][j] = mfma16<3>(frag_half(bP[slot][j], s), aF[i][s], acc[ih][jh][i][j]);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[ih][jh][i][j] = mfma16<0>(bF[slot][j][s], aF[i][s], acc[ih][jh][i][j]);
+    }
     if (AFFT_PP2_PRIO) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -526,57 +577,93 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(const GemmFast g)
   using I3 = std::integral_constant<int, 3>;
 
   // prologue = "L(-1)": half-tiles 0..5 (K-tile 0 whole, A0 and B0 of K-tile 1)
-  issue(I0{}, I0{}); issue(I1{}, I0{}); issue(I2{}, I0{}); issue(I3{}, I0{}); issue(I0{}, I1{}); issue(I1{}, I1{});
+  using NoSw = std::false_type;
+  issue(I0{}, I0{}, NoSw{}); issue(I1{}, I0{}, NoSw{}); issue(I2{}, I0{}, NoSw{}); issue(I3{}, I0{}, NoSw{}); issue(I0{}, I1{}, NoSw{}); issue(I1{}, I1{}, NoSw{});
   wait_vmcnt_only<6>();
   __builtin_amdgcn_s_barrier();
-  load_b(I0{}, I0{}, I0{});                     // K-tile 0's first B fragments (later ones are read a phase early)
+  load_b(I0{}, I0{}, I0{}, std::integral_constant<bool, X3 == 3>{});  // K-tile 0's first B fragments (later ones are read a phase early)
   if (gp == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one slot behind group 0
 
   // One K-tile of parity P (ring half P): 4 phases = the 4 quadrants of the wave's 128x64 output, in the order (0,0) (0,1) (1,1) (1,0);
   // phase p stages half-tile 4 kt + p + 6 = kind (p + 2) & 3 of K-tile kt + 1 (p = 0, 1: ring half 1 - P) / kt + 2 (p = 2, 3: half P).
   // TAIL: 0 = steady state, 1 = K-tile nk - 2 (only phases 0, 1 still stage), 2 = K-tile nk - 1 (nothing left to stage or to prefetch)
-  auto ktile = [&](auto Pc, auto tailc) {
-    constexpr int P = decltype(Pc)::value, TAIL = decltype(tailc)::value;
+  // TAIL code 3 ("TRANS", X3 = 3): the steady state's schedule, but phases 0 and 1 stage the first segment's LAST B / A half and switch planes
+  auto ktile = [&](auto Pc, auto tailc, auto lo8c) {
+    constexpr int P = decltype(Pc)::value, TC = decltype(tailc)::value;
+    constexpr int TAIL = TC >= 3 ? 0 : TC;      // 3 = steady state whose phases 0 / 1 may switch planes (sw_now)
+    using SW = std::integral_constant<bool, TC == 3>;
+    using LO8 = decltype(lo8c);
+    using PR = std::integral_constant<bool, X3 == 3 && LO8::value>;      // this K-tile's A fragments are pairs (fp8 K-tiles)
+    using PRB = std::integral_constant<bool, X3 == 3>;                   // B fragments: pairs in every K-tile (they are read a K-tile early, across the segment boundary)
     using KP = std::integral_constant<int, P>;
     using KQ = std::integral_constant<int, 1 - P>;
     using SP = KP;      // fragment slot of B half 0 (the two slots swap roles every K-tile)
     using SQ = KQ;
     constexpr bool W = AFFT_PP2_WAIT != 0;
     // phase 0
-    if constexpr (TAIL < 2 && AFFT_PP2_DMA_FIRST) issue(I2{}, KQ{});
-    load_a(KP{}, I0{});
-    if constexpr (TAIL < 2 && !AFFT_PP2_DMA_FIRST) issue(I2{}, KQ{});
+    if constexpr (TAIL < 2 && AFFT_PP2_DMA_FIRST) issue(I2{}, KQ{}, SW{});
+    load_a(KP{}, I0{}, PR{});
+    if constexpr (TAIL < 2 && !AFFT_PP2_DMA_FIRST) issue(I2{}, KQ{}, SW{});
     if constexpr (TAIL == 0 || TAIL == 1) wait_vmcnt_only<6>(); else wait_vmcnt_only<0>();
     __builtin_amdgcn_s_barrier();
-    compute(I0{}, I0{}, SP{});
+    compute(I0{}, I0{}, SP{}, LO8{});
     // phase 1
-    if constexpr (TAIL < 2 && AFFT_PP2_DMA_FIRST) issue(I3{}, KQ{});
-    load_b(KP{}, I1{}, SQ{});
-    if constexpr (TAIL < 2 && !AFFT_PP2_DMA_FIRST) issue(I3{}, KQ{});
+    if constexpr (TAIL < 2 && AFFT_PP2_DMA_FIRST) issue(I3{}, KQ{}, SW{});
+    load_b(KP{}, I1{}, SQ{}, PRB{});
+    if constexpr (TAIL < 2 && !AFFT_PP2_DMA_FIRST) issue(I3{}, KQ{}, SW{});
     if constexpr (TAIL == 0) { if constexpr (!W) wait_vmcnt_only<6>(); } else if constexpr (TAIL == 1) wait_vmcnt_only<6>();
     __builtin_amdgcn_s_barrier();
-    compute(I0{}, I1{}, SQ{});
+    compute(I0{}, I1{}, SQ{}, LO8{});
     // phase 2
-    if constexpr (TAIL == 0 && AFFT_PP2_DMA_FIRST) issue(I0{}, KP{});
-    load_a(KP{}, I1{});
-    if constexpr (TAIL == 0 && !AFFT_PP2_DMA_FIRST) issue(I0{}, KP{});
+    if constexpr (TAIL == 0 && AFFT_PP2_DMA_FIRST) issue(I0{}, KP{}, NoSw{});
+    load_a(KP{}, I1{}, PR{});
+    if constexpr (TAIL == 0 && !AFFT_PP2_DMA_FIRST) issue(I0{}, KP{}, NoSw{});
     if constexpr (TAIL == 0) wait_vmcnt_only<6>(); else if constexpr (TAIL == 1) wait_vmcnt_only<4>();
     __builtin_amdgcn_s_barrier();
-    compute(I1{}, I1{}, SQ{});
+    compute(I1{}, I1{}, SQ{}, LO8{});
     // phase 3
-    if constexpr (TAIL == 0 && AFFT_PP2_DMA_FIRST) issue(I1{}, KP{});
-    if constexpr (TAIL < 2) load_b(KQ{}, I0{}, SQ{});
-    if constexpr (TAIL == 0 && !AFFT_PP2_DMA_FIRST) issue(I1{}, KP{});
+    if constexpr (TAIL == 0 && AFFT_PP2_DMA_FIRST) issue(I1{}, KP{}, NoSw{});
+    if constexpr (TAIL < 2) load_b(KQ{}, I0{}, SQ{}, PRB{});
+    if constexpr (TAIL == 0 && !AFFT_PP2_DMA_FIRST) issue(I1{}, KP{}, NoSw{});
     if constexpr (TAIL == 0) { if constexpr (!W) wait_vmcnt_only<6>(); } else if constexpr (TAIL == 1) wait_vmcnt_only<2>();
     __builtin_amdgcn_s_barrier();
-    compute(I1{}, I0{}, SP{});
+    compute(I1{}, I0{}, SP{}, LO8{});
   };
-  for (int pr = 0; pr < npairs - 1; ++pr) {
-    ktile(I0{}, I0{});
-    ktile(I1{}, I0{});
+  using F16 = std::false_type;
+  using F8 = std::true_type;
+  if constexpr (X3 == 3) {
+    // every pair of the fp16 segment in ONE loop body (a separate body for the last pair made the allocator permute the accumulators
+    // through scratch at its boundaries): the first K-tile of a pair carries the plane switch under a wave-uniform flag
+    int sw_pair = npairs - 1;
+    asm volatile("" : "+s"(sw_pair));      // opaque: the compiler would peel the last iteration into a body of its own (and permute the accumulators around it)
+    for (int pr = 0; pr < npairs; ++pr) {
+      sw_now = pr == sw_pair;
+      ktile(I0{}, I3{}, F16{});
+      ktile(I1{}, I0{}, F16{});
+    }
+    // fp8 segment: nk_seg / 2 K-tiles of 128 k (even: launch_pp2), EVERY pair in the steady-state body -- a peeled tail made the allocator
+    // permute the accumulators through scratch (the instantiation sits at 256 registers).  The look-ahead of the last pair stays inside K: the
+    // running offsets stop advancing, so its six surplus half-tiles re-read the last K-tile (L2 hits, 96 KiB per tile) into ring slots that
+    // nobody reads any more -- the same slots at the same phases as in every other pair, so the WAR analysis is unchanged -- and the counted
+    // wait stays vmcnt(6) throughout; the surplus is drained before the epilogue reuses the ring.
+    const int npairs8 = g.nk_seg / 4;
+    int last8 = npairs8 - 1;
+    asm volatile("" : "+s"(last8));
+    for (int pr = 0; pr < npairs8; ++pr) {
+      incA = pr == last8 ? 0u : stepA;
+      incB = pr == last8 ? 0u : stepB;
+      ktile(I0{}, I0{}, F8{});
+      ktile(I1{}, I0{}, F8{});
+    }
+    wait_vmcnt_only<0>();
+  } else {
+    for (int pr = 0; pr < npairs - 1; ++pr) {
+      ktile(I0{}, I0{}, F16{});
+      ktile(I1{}, I0{}, F16{});
+    }
+    ktile(I0{}, I1{}, F16{});
+    ktile(I1{}, I2{}, F16{});
   }
-  ktile(I0{}, I1{});
-  ktile(I1{}, I2{});
   if (gp == 0) __builtin_amdgcn_s_barrier();
   pp_epilogue(g, smem, acc, m0, n0, lane, wave, gp, wc);
 }
@@ -590,12 +677,23 @@ inline bool walk_fits32(bool ks, int K, int64_t ld) { return ks ? (int64_t)(K + 
 template <bool A_KS, bool B_KS>
 bool pp2_takes(const GemmFast& g) { return pp2_shape(g.e.M, g.e.N, g.K) && walk_fits32(A_KS, g.K, g.lda) && walk_fits32(B_KS, g.K, g.ldb); }
 
-template <bool A_KS, bool B_KS>
+// fp16 + fp8 forward (X3 = 3): g.K counts both segments in 64-wide K-tiles (nk_seg + nk_seg / 2); pairs in both: nk_seg % 4 == 0, nk_seg >= 4
+bool pp2x3_takes(const GemmFast& g) {
+#ifdef AFFT_PP2_X3_OFF
+  return false;
+#else
+  return AFFT_PP2 && g.e.M % 256 == 0 && g.e.N % 256 == 0 && g.nk_seg % 4 == 0 && g.nk_seg >= 4 && g.K == g.nk_seg * BK + g.nk_seg * BK / 2 &&
+         walk_fits32(false, g.nk_seg * BK, g.lda) && walk_fits32(false, g.nk_seg * BK, g.ldb) && walk_fits32(false, g.nk_seg * BK, g.lda8) &&
+         walk_fits32(false, g.nk_seg * BK, g.ldb8);
+#endif
+}
+
+template <bool A_KS, bool B_KS, int X3 = 0>
 int launch_pp2(GemmFast& g, hipStream_t stream) {
   constexpr size_t lds = 128 * 1040;
   g.tiles_m = g.e.M / 256;
   g.tiles_n = g.e.N / 256;
-  auto kern = gemm_bf16_pp2_kernel<A_KS, B_KS>;
+  auto kern = gemm_bf16_pp2_kernel<A_KS, B_KS, X3>;
   static std::atomic<uint64_t> attr_done{0};
   if (int rc = afft_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, &attr_done)) return rc;
   hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), lds, stream, g);
@@ -628,12 +726,15 @@ int launch_pp(GemmFast& g, hipStream_t stream) {
 extern "C" void afft_debug_pp_stamp(void* p) { g_pp_stamp = (unsigned long long*)p; }
 #endif
 
-bool afft_gemm_pp2_takes(int M, int N, int K, int x3) { return x3 == 0 && pp2_shape(M, N, K); }
+bool afft_gemm_pp2_takes(int M, int N, int K, int x3) {      // K: the caller's K (one segment)
+  if (x3 == 3) { const int ns = K / BK; return AFFT_PP2 && M % 256 == 0 && N % 256 == 0 && ns % 4 == 0 && ns >= 4; }
+  return x3 == 0 && pp2_shape(M, N, K);
+}
 
 int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipStream_t stream, int x3) {
 #ifndef AFFT_PP_NT_ONLY   // development switch: build only the plain NT instantiation (compile time)
   if (x3 == 3) {   // fp16 + fp8 lo pass: nn.Linear forward GEMMs (NT) only
-    if (!a_ks && !b_ks) return launch_pp<false, false, 3>(g, stream);
+    if (!a_ks && !b_ks) return pp2x3_takes(g) ? launch_pp2<false, false, 3>(g, stream) : launch_pp<false, false, 3>(g, stream);
     afft_set_error("afft_gemm: the fp16 + fp8 mode (split3 = 3) is built for the NT layout only");
     return 1;
   }

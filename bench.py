@@ -142,7 +142,7 @@ class GemmTimer:
         if r.variant == 3:
             return f"gemm_bf16_pp_kernel<{b(r.a_kstrided)}, {b(r.b_kstrided)}, {int(r.split3)}>"
         if r.variant == 13:      # round 6: the steady-state 256x256 kernel (whole tiles, even K-tile count, plain bf16)
-            return f"gemm_bf16_pp2_kernel<{b(r.a_kstrided)}, {b(r.b_kstrided)}>"
+            return f"gemm_bf16_pp2_kernel<{b(r.a_kstrided)}, {b(r.b_kstrided)}, {int(r.split3)}>"
         if r.variant in (7, 8, 9, 10):       # B-direct kernels (csrc/gemm_bd.hip): <16-row blocks per tile, A look-ahead, B look-ahead, packed B>
             return f"gemm_bf16_bd_kernel<{10 if r.variant in (8, 10) else 16}, 3, {2 if r.variant in (8, 10) else 1}, {b(r.variant >= 9)}>"
         return f"gemm_bf16_kernel<2, 2, 2, {b(r.a_kstrided)}, {b(r.b_kstrided)}, {b(r.splitk > 1)}, {int(r.split3)}>"

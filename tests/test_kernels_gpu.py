@@ -1319,7 +1319,9 @@ RACE_CASES = [
     ("bd_nt_packed", 0, "nt", 5120, 2048, 8192, True),
     # the fp16x2 forward instantiations of the ping-pong kernel: "lo8" = fp16 hi segment + block-scaled fp8 lo segment (two K loops over one
     # ring: X3 = 3), "f16x2" = two fp16 segments (X3 = 2)
-    ("pp_nt_fp16_lo8", 3, "nt", 5120, 2048, 2048, "lo8"),
+    ("pp_nt_fp16_lo8", 3, "nt", 5120, 2048, 2048, "lo8"),                 # whole tiles, K-tile count % 4 == 0: the steady-state kernel (pp2, X3 = 3)
+    ("pp2_nt_fp16_lo8_long_k", 3, "nt", 5120, 2048, 8192, "lo8"),
+    ("pp_nt_fp16_lo8_edge_general", 3, "nt", 5056, 2048, 2048, "lo8"),  # edge tiles: the general kernel's two loops
     ("pp_nt_fp16x2", 3, "nt", 5120, 2048, 2048, "f16x2"),
 ]
 

@@ -26,7 +26,9 @@ BIG = [("nt", 4096, 4096, 4096), ("nt", 8192, 8192, 8192)]
 SMALL = [("nn", 1024, 6144, 2048), ("nn", 1024, 2048, 2048), ("nn", 1024, 8192, 2048), ("nn", 1024, 2048, 8192), ("nt", 1024, 6144, 2048),
          ("nt", 1024, 2048, 2048), ("nt", 1024, 8192, 2048), ("nt", 1024, 2048, 8192), ("tn", 2048, 2048, 1024), ("tn", 2048, 2048, 5120),
          ("nt", 5120, 1024, 1024), ("nn", 5120, 1024, 4096), ("tn", 1024, 3072, 5120), ("nt", 1280, 6144, 2048), ("tn", 2048, 6144, 1280)]
-SHAPES = {"path": PATH, "big": BIG, "all": PATH + BIG, "small": SMALL}[os.environ.get("SHAPES", "all")]
+# the fuser's forward GEMMs in the fp16x2 precision: fp16 hi segment + block-scaled fp8 lo segment (afft_gemm_t.split3 = 3), NT
+LO8 = [("lo8", 5120, 6144, 2048), ("lo8", 5120, 2048, 2048), ("lo8", 5120, 8192, 2048), ("lo8", 5120, 2048, 8192), ("lo8", 1024, 2048, 2048)]
+SHAPES = {"path": PATH, "big": BIG, "all": PATH + BIG, "small": SMALL, "lo8": LO8}[os.environ.get("SHAPES", "all")]
 
 
 def load(path):
@@ -41,6 +43,16 @@ def load(path):
 
 def operands(layout, M, N, K, seed=0):
     g = torch.Generator(device="cpu").manual_seed(seed)
+    if layout == "lo8":      # (hi fp16 plane, e4m3(2^11 (a - hi))) of the activation, (fp16 image, e4m3(2^8 w)) of the weight: what the producers write
+        from afft_amd import ops
+        a32 = (torch.rand(M, K, generator=g) * 2 - 1).to(dev)
+        w32 = ((torch.rand(N, K, generator=g) * 2 - 1) * 0.05).to(dev)
+        hi = torch.empty(M, K, dtype=torch.float16, device=dev)
+        a8 = torch.empty(M, K, dtype=torch.uint8, device=dev)
+        ops.quant_e4m3(a32, 2048.0, a8, hi=hi)
+        w8 = torch.empty(N, K, dtype=torch.uint8, device=dev)
+        ops.quant_e4m3(w32, 256.0, w8)
+        return (hi, a8, a32), (w32.half(), w8, w32)
     u = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(torch.bfloat16).to(dev)      # noqa: E731
     if layout == "nt":
         return u(M, K), u(N, K)
@@ -51,6 +63,19 @@ def operands(layout, M, N, K, seed=0):
 
 def desc(layout, a, b, out):
     d = L.GemmDesc()
+    if layout == "lo8":
+        (hi, a8, _), (w16, w8, _) = a, b
+        M, K = hi.shape
+        N = w16.shape[0]
+        d.M, d.N, d.K, d.dtype = M, N, K, L.BF16
+        d.A, d.a_rs, d.a_cs = hi.data_ptr(), hi.stride(0), 1
+        d.B, d.b_rs, d.b_cs = w16.data_ptr(), 1, w16.stride(0)
+        d.split3 = 3
+        d.a8, d.a8_ld, d.b8, d.b8_ld = a8.data_ptr(), a8.stride(0), w8.data_ptr(), w8.stride(0)
+        d.alpha = 1.0
+        d.out, d.ldo, d.out_dtype = out.data_ptr(), out.stride(0), L.F32
+        d.workspace, d.workspace_bytes = WS.data_ptr(), WS.numel()
+        return d
     a_t, b_t = layout == "tn", layout == "nt"
     M, K = (a.shape[1], a.shape[0]) if a_t else a.shape
     N = b.shape[0] if b_t else b.shape[1]
@@ -76,6 +101,8 @@ def run(lib, d, n=1):
 
 
 def reference(layout, a, b):
+    if layout == "lo8":
+        return a[2].double() @ b[1 - 1].double().t() if False else (a[2].double() @ b[0].double().t()).float()      # exact activation x fp16-rounded weight
     a32, b32 = a.float(), b.float()
     return (a32.t() if layout == "tn" else a32) @ (b32.t() if layout == "nt" else b32)
 
@@ -85,17 +112,20 @@ def main():
     libs = [(os.path.basename(p).replace("libafft_hip", "").replace(".so", "") or "product", load(p)) for p in paths]
     print("libraries:", ", ".join(n for n, _ in libs), f"| variant {VARIANT} rounds {ROUNDS} iters {ITERS} race repeats {RACE}")
     # correctness: every layout, a shape with several tiles and K-tile pairs, plus one edge shape that must take the general kernel
-    for layout, M, N, K in (("nt", 512, 768, 1024), ("nn", 512, 768, 1024), ("tn", 768, 512, 1024), ("nt", 1088, 3840, 2048), ("tn", 512, 512, 320),
-                            ("nt", 256, 256, 256), ("tn", 2048, 2048, 1024), ("nn", 1024, 2048, 8192), ("nt", 1024, 2048, 8192), ("tn", 1024, 1024, 1280),
-                            ("nn", 384, 640, 896)):
+    checks = (("nt", 512, 768, 1024), ("nn", 512, 768, 1024), ("tn", 768, 512, 1024), ("nt", 1088, 3840, 2048), ("tn", 512, 512, 320),
+              ("nt", 256, 256, 256), ("tn", 2048, 2048, 1024), ("nn", 1024, 2048, 8192), ("nt", 1024, 2048, 8192), ("tn", 1024, 1024, 1280),
+              ("nn", 384, 640, 896))
+    if os.environ.get("SHAPES") == "lo8":      # whole tiles (steady-state kernel), edge tiles and a K-tile count that is not a multiple of 4 (general kernel)
+        checks = (("lo8", 512, 768, 1024), ("lo8", 2560, 2048, 256), ("lo8", 2560, 2304, 2048), ("lo8", 2500, 2048, 1024), ("lo8", 2560, 2048, 384))
+    for layout, M, N, K in checks:
         a, b = operands(layout, M, N, K, seed=1)
         ref = reference(layout, a, b)
         for name, lib in libs:
-            out = torch.zeros(M, N, dtype=torch.float32 if layout == "tn" else torch.bfloat16, device=dev)
+            out = torch.zeros(M, N, dtype=torch.float32 if layout in ("tn", "lo8") else torch.bfloat16, device=dev)
             run(lib, desc(layout, a, b, out))
             torch.cuda.synchronize()
             err = float((out.float() - ref).norm() / ref.norm())
-            flag = "" if err < (1e-5 if layout == "tn" else 4e-3) else "   <-- WRONG"
+            flag = "" if err < (1e-5 if layout == "tn" else 2e-4 if layout == "lo8" else 4e-3) else "   <-- WRONG"
             print(f"check {layout} {M}x{N}x{K} {name:>10}: rel err {err:.2e}{flag}")
     times = {(n, s): [] for n, _ in libs for s in SHAPES}
     races = {}
@@ -103,7 +133,7 @@ def main():
     for s in SHAPES:
         layout, M, N, K = s
         a, b = operands(layout, M, N, K)
-        data[s] = (a, b, {n: torch.zeros(M, N, dtype=torch.float32 if layout == "tn" else torch.bfloat16, device=dev) for n, _ in libs})
+        data[s] = (a, b, {n: torch.zeros(M, N, dtype=torch.float32 if layout in ("tn", "lo8") else torch.bfloat16, device=dev) for n, _ in libs})
     for (layout, M, N, K) in SHAPES:      # race screen
         a, b, outs = data[(layout, M, N, K)]
         for name, lib in libs:
