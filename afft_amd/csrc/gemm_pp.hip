@@ -398,7 +398,7 @@ __device__ __forceinline__ void glds16i(const char* sbase, unsigned voff, unsign
 // 8-register tuple): the fp8 MFMA takes the tuple whole, the fp16 MFMA its halves (sub-registers, no copies).
 template <bool A_KS, bool B_KS, int X3 = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(const GemmFast g) {
-  static_assert(X3 == 0 || (X3 == 3 && !A_KS && !B_KS), "the steady-state kernel is built for plain bf16 and for the NT fp16 + fp8 forward");
+  static_assert(X3 != 3 || (!A_KS && !B_KS), "the fp16 + fp8 forward is NT only");
   constexpr int HB = 128 * BK * 2;   // half-tile bytes (16 KiB)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(const GemmFast g)
   int tm, tn;
   tile_coords(g.tiles_m, g.tiles_n, blockIdx.x, tm, tn);
   const int m0 = tm * 256, n0 = tn * 256;
-  const int npairs = (X3 == 3 ? g.nk_seg * BK : g.K) / (2 * BK);      // K-tile pairs of the (first) segment: >= 2 (X3 = 0) / >= 1 (X3 = 3)
+  const int npairs = (X3 == 3 ? g.nk_seg * BK : g.K) / (2 * BK);      // K-tile pairs: of all segments (X3 = 0, 1, 2: >= 2) / of the fp16 segment (X3 = 3: >= 1)
 
   f32x4 acc[2][2][4][2];
 #pragma unroll
@@ -441,7 +441,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(const GemmFast g)
     }
   // X3 = 3: the LDS-DMA stream moves on to the e4m3 byte planes (K offset back to 0, their own row pitch)
   bool sw_now = false;      // wave-uniform: this pair of K-tiles is the fp16 segment's last (set by the pair loop)
-  unsigned incA = stepA, incB = stepB;      // K advance per staged K-tile; X3 = 3: 0 in the last pair of the fp8 segment (below)
+  // K advance after a staged K-tile's closing half-tile, by the parity of the K-tile that ISSUES it (first / second of a pair).  Plain steps, except:
+  // X3 = 1 / 2 -- at a segment's end the first K-tile of a pair jumps to the next pair of operand planes (a_lo / b_lo elements away, K offset back
+  // to 0): a different addend, no branch; X3 = 3 -- 0 in the last pair of the fp8 segment (below)
+  unsigned incA[2] = {stepA, stepA}, incB[2] = {stepB, stepB};
   auto switch_a = [&] {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -465,11 +468,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(const GemmFast g)
     if constexpr (q == 0 || q == 3) {
       glds16i<dst>(bA[q == 3][0], vA, lds_wave);
       glds16i<dst + 8192>(bA[q == 3][1], vA, lds_wave);
-      if constexpr (q == 3) { if constexpr (SW) { if (sw_now) switch_a(); else vA += incA; } else vA += incA; }      // A's second half closes its K-tile
+      if constexpr (q == 3) { if constexpr (SW) { if (sw_now) switch_a(); else vA += incA[1 - KP]; } else vA += incA[1 - KP]; }      // A's second half closes its K-tile
     } else {
       glds16i<dst>(bB[q == 2][0], vB, lds_wave);
       glds16i<dst + 8192>(bB[q == 2][1], vB, lds_wave);
-      if constexpr (q == 2) { if constexpr (SW) { if (sw_now) switch_b(); else vB += incB; } else vB += incB; }
+      if constexpr (q == 2) { if constexpr (SW) { if (sw_now) switch_b(); else vB += incB[1 - KP]; } else vB += incB[1 - KP]; }
     }
   };
   // Fragment reads: every lane-dependent part of an LDS address is one of a few VGPRs computed ONCE (made opaque, so that the compiler
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(const GemmFast g)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[ih][jh][i][j] = mfma16<0>(bF[slot][j][s], aF[i][s], acc[ih][jh][i][j]);
+          for (int j = 0; j < 2; ++j) acc[ih][jh][i][j] = mfma16<X3>(bF[slot][j][s], aF[i][s], acc[ih][jh][i][j]);
     }
     if (AFFT_PP2_PRIO) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -650,14 +653,27 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(const GemmFast g)
     int last8 = npairs8 - 1;
     asm volatile("" : "+s"(last8));
     for (int pr = 0; pr < npairs8; ++pr) {
-      incA = pr == last8 ? 0u : stepA;
-      incB = pr == last8 ? 0u : stepB;
+      incA[0] = incA[1] = pr == last8 ? 0u : stepA;
+      incB[0] = incB[1] = pr == last8 ? 0u : stepB;
       ktile(I0{}, I0{}, F8{});
       ktile(I1{}, I0{}, F8{});
     }
     wait_vmcnt_only<0>();
   } else {
+    // X3 = 1 (bf16x3) / 2 (fp16 two-pass): segments of nk_seg K-tiles -- (A, B), (A + a_lo, B), X3 = 1 also (A, B + b_lo) -- walked as ONE stream: in the
+    // pair that holds a segment's last two K-tiles the first K-tile's closing half-tiles add a jump instead of a step (gemm_tiles.h seg_operands)
+    const int sp = g.nk_seg / 2;      // pairs per segment
+    unsigned jA1 = stepA, jB1 = stepB, jA2 = stepA, jB2 = stepB;
+    if constexpr (X3 == 1 || X3 == 2) {
+      const unsigned backA = (unsigned)(g.nk_seg - 1) * stepA, backB = (unsigned)(g.nk_seg - 1) * stepB;
+      jA1 = (unsigned)(g.a_lo * 2) - backA;  jB1 = 0u - backB;                              // segment 0 -> 1: A's lo planes, B rewinds
+      jA2 = 0u - (unsigned)(g.a_lo * 2) - backA;  jB2 = (unsigned)(g.b_lo * 2) - backB;      // segment 1 -> 2: A back to hi, B's lo planes
+    }
     for (int pr = 0; pr < npairs - 1; ++pr) {
+      if constexpr (X3 == 1 || X3 == 2) {
+        incA[0] = pr == sp - 1 ? jA1 : pr == 2 * sp - 1 ? jA2 : stepA;
+        incB[0] = pr == sp - 1 ? jB1 : pr == 2 * sp - 1 ? jB2 : stepB;
+      }
       ktile(I0{}, I0{}, F16{});
       ktile(I1{}, I0{}, F16{});
     }
@@ -685,6 +701,21 @@ bool pp2x3_takes(const GemmFast& g) {
   return AFFT_PP2 && g.e.M % 256 == 0 && g.e.N % 256 == 0 && g.nk_seg % 4 == 0 && g.nk_seg >= 4 && g.K == g.nk_seg * BK + g.nk_seg * BK / 2 &&
          walk_fits32(false, g.nk_seg * BK, g.lda) && walk_fits32(false, g.nk_seg * BK, g.ldb) && walk_fits32(false, g.nk_seg * BK, g.lda8) &&
          walk_fits32(false, g.nk_seg * BK, g.ldb8);
+#endif
+}
+
+// bf16x3 / fp16 two-pass (X3 = 1 / 2): g.K counts all segments; whole tiles, an even number of K-tiles per segment (pairs never straddle a
+// segment), every plane inside the 32-bit walk
+template <bool A_KS, bool B_KS, int X3>
+bool pp2planes_takes(const GemmFast& g) {
+#ifdef AFFT_PP2_PLANES_OFF
+  return false;
+#else
+  const int64_t span = ((int64_t)(g.a_lo > g.b_lo ? g.a_lo : g.b_lo)) * 2;
+  return AFFT_PP2 && g.e.M % 256 == 0 && g.e.N % 256 == 0 && g.nk_seg % 2 == 0 && g.nk_seg >= 2 && g.K == (X3 == 1 ? 3 : 2) * g.nk_seg * BK &&
+         span < (1LL << 30) && walk_fits32(A_KS, g.nk_seg * BK, g.lda) && walk_fits32(B_KS, g.nk_seg * BK, g.ldb) &&
+         (A_KS ? (int64_t)g.nk_seg * BK * g.lda * 2 : (int64_t)8 * g.lda * 2) + span < (1LL << 31) &&
+         (B_KS ? (int64_t)g.nk_seg * BK * g.ldb * 2 : (int64_t)8 * g.ldb * 2) + span < (1LL << 31);
 #endif
 }
 
@@ -728,6 +759,7 @@ extern "C" void afft_debug_pp_stamp(void* p) { g_pp_stamp = (unsigned long long*
 
 bool afft_gemm_pp2_takes(int M, int N, int K, int x3) {      // K: the caller's K (one segment)
   if (x3 == 3) { const int ns = K / BK; return AFFT_PP2 && M % 256 == 0 && N % 256 == 0 && ns % 4 == 0 && ns >= 4; }
+  if (x3 == 1 || x3 == 2) { const int ns = K / BK; return AFFT_PP2 && M % 256 == 0 && N % 256 == 0 && ns % 2 == 0 && ns >= 2; }
   return x3 == 0 && pp2_shape(M, N, K);
 }
 
@@ -739,15 +771,15 @@ int afft_gemm_launch_pp(int a_ks, int b_ks, afft_gemm_detail::GemmFast& g, hipSt
     return 1;
   }
   if (x3 == 2) {   // fp16x2: forward GEMMs only (NT, and NN for [in, out] weights)
-    if (!a_ks && !b_ks) return launch_pp<false, false, 2>(g, stream);
-    if (!a_ks && b_ks) return launch_pp<false, true, 2>(g, stream);
+    if (!a_ks && !b_ks) return pp2planes_takes<false, false, 2>(g) ? launch_pp2<false, false, 2>(g, stream) : launch_pp<false, false, 2>(g, stream);
+    if (!a_ks && b_ks) return pp2planes_takes<false, true, 2>(g) ? launch_pp2<false, true, 2>(g, stream) : launch_pp<false, true, 2>(g, stream);
     afft_set_error("afft_gemm: the fp16 two-pass mode is built for the forward layouts only");
     return 1;
   }
   if (x3) {        // bf16x3 operand planes
-    if (!a_ks && !b_ks) return launch_pp<false, false, 1>(g, stream);
-    if (!a_ks && b_ks) return launch_pp<false, true, 1>(g, stream);
-    if (a_ks && b_ks) return launch_pp<true, true, 1>(g, stream);
+    if (!a_ks && !b_ks) return pp2planes_takes<false, false, 1>(g) ? launch_pp2<false, false, 1>(g, stream) : launch_pp<false, false, 1>(g, stream);
+    if (!a_ks && b_ks) return pp2planes_takes<false, true, 1>(g) ? launch_pp2<false, true, 1>(g, stream) : launch_pp<false, true, 1>(g, stream);
+    if (a_ks && b_ks) return pp2planes_takes<true, true, 1>(g) ? launch_pp2<true, true, 1>(g, stream) : launch_pp<true, true, 1>(g, stream);
   }
 #endif
   if (!a_ks && !b_ks) return pp2_takes<false, false>(g) ? launch_pp2<false, false>(g, stream) : launch_pp<false, false>(g, stream);
