@@ -22,7 +22,7 @@ for lib in product lead7; do
   red=0
   for i in $(seq $n); do
     if [ $lib = lead7 ]; then export AFFT_LIB=$PWD/afft_amd/lib/libafft_hip_lead7.so; else unset AFFT_LIB; fi
-    if timeout 900 python -m pytest tests/test_kernels_gpu.py -q -k "lds_ring and pp_" > /tmp/race_${lib}_$i.log 2>&1; then r=green; else r=RED; red=$((red+1)); fi
+    if timeout 900 python -m pytest tests/test_kernels_gpu.py -q -k "lds_ring" > /tmp/race_${lib}_$i.log 2>&1; then r=green; else r=RED; red=$((red+1)); fi
     echo "$lib run $i: $r $(grep -E 'passed|failed' /tmp/race_${lib}_$i.log | tail -1)" | tee -a $out
     grep -E "elements differed" /tmp/race_${lib}_$i.log | head -4 | cut -c1-200 >> $out || true
   done
