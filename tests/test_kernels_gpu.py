@@ -179,6 +179,12 @@ X3_CASES = [
     ("nn_x3_pp", 512, 300, 320, "nn", 3, dict(residual=True)),
     ("tn_x3_pp", 512, 264, 704, "tn", 3, dict(accumulate=True)),
     ("nt_x3_big", 1100, 3806, 2048, "nt", 0, dict(bias=True)),      # auto-selected ping-pong kernel, classifier-shaped tails
+    # whole 256x256 tiles with an even K-tile count per segment: the steady-state kernel (gemm_bf16_pp2_kernel<*, *, 1>), whose LDS-DMA stream
+    # JUMPS from one pair of operand planes to the next where a segment ends -- a wrong jump reads a hi plane for a lo one: 1e-3, not 1e-5
+    ("nt_x3_pp2", 512, 768, 256, "nt", 3, dict(bias=True, act=1, pre=True)),
+    ("nn_x3_pp2", 512, 512, 384, "nn", 3, dict(residual=True)),
+    ("tn_x3_pp2", 512, 256, 640, "tn", 3, dict(accumulate=True)),
+    ("nt_x3_pp2_two_ktiles", 256, 256, 128, "nt", 3, dict()),       # one pair per segment: the jump sits in the first loop iteration
 ]
 
 
@@ -226,6 +232,8 @@ F16X2_CASES = [
     ("nt_f16x2_pp", 300, 520, 200, "nt", 3, dict(bias=True, act=2)),
     ("nn_f16x2_pp", 512, 300, 320, "nn", 3, dict(residual=True)),
     ("nt_f16x2_big", 1100, 3806, 2048, "nt", 0, dict(bias=True)),
+    ("nt_f16x2_pp2", 512, 768, 256, "nt", 3, dict(bias=True, act=2)),      # whole tiles: gemm_bf16_pp2_kernel<false, *, 2>
+    ("nn_f16x2_pp2", 256, 512, 384, "nn", 3, dict(residual=True)),
 ]
 
 
@@ -334,7 +342,7 @@ def _e4m3_decode(b):
     return torch.where(s == 1, -v, v)
 
 
-@pytest.mark.parametrize("M,N,K", [(5120, 2048, 2048), (3000, 4096, 1024), (4096, 4096, 128)])
+@pytest.mark.parametrize("M,N,K", [(5120, 2048, 2048), (3000, 4096, 1024), (4096, 4096, 128), (5120, 2048, 256)])      # the last: the steady-state kernel at its shortest (two fp16 pairs, ONE fp8 pair = the frozen-offset pair)
 def test_gemm_fp16_hi_pass_plus_fp8_lo_pass(M, N, K):
     """afft_gemm_t.split3 = 3: first pass A_hi W on the fp16 MFMA, second pass A_lo W on the block-scaled fp8 MFMA over e4m3 byte planes
     (a8 = e4m3(2^11 (a - hi)), b8 = e4m3(2^8 w), constant scales).  Against float64 on the SAME quantised operands the result is
