@@ -64,10 +64,34 @@ def compute_accuracy(predictions: np.ndarray, labels: np.ndarray, classes=None):
     return top1 * 100, top5 * 100, topk_recall(predictions, labels, k=5, classes=classes) * 100
 
 
+def _read_id_column(path: str) -> np.ndarray:
+    """the RULSTM id tables are header-less one-column CSV files (one narration id per line)"""
+    with open(path, "r", encoding="utf-8") as fh:
+        return np.asarray([line.strip() for line in fh if line.strip()])
+
+
+def epic100_unseen_tail_eval(probs, dataset) -> Dict[str, float]:
+    """challenge.py:109-158: mean top-5 recall on the validation segments of unseen participants and on the segments whose
+    verb / noun / action is a tail class.  The four id tables are read from dataset.rulstm_annotation_dir
+    (validation_unseen_participants_ids.csv, validation_tail_{verbs,nouns,actions}_ids.csv) and matched against
+    dataset.df.narration_id; the verb table selects rows for the verb scores, and so on; the unseen table for all three."""
+    import os.path as osp  # noqa: PLC0415
+    narration = np.asarray(dataset.df.narration_id.values).astype(str)
+    res = {}
+    tables = {"tail": {k: f"validation_tail_{k}s_ids.csv" for k in ("verb", "noun", "action")},
+              "unseen": dict.fromkeys(("verb", "noun", "action"), "validation_unseen_participants_ids.csv")}
+    for split, files in tables.items():
+        for i, key in enumerate(("verb", "noun", "action")):
+            rows = np.isin(narration, _read_id_column(osp.join(dataset.rulstm_annotation_dir, files[key])))
+            labels = getattr(dataset.df, f"{key}_class").values[rows]
+            res[f"{key[0]}mt5r_{split}"] = compute_accuracy(np.asarray(probs[i])[rows], labels)[2]
+    return res
+
+
 def compute_accuracies_epic(probs, dataset, compute_manyshot_unseen_tail: bool = False) -> Dict[str, float]:
     """challenge.py:161-193: probs = [verb, noun, action] score matrices; dataset.df carries verb_class / noun_class /
-    action_class, dataset.classes_manyshot the many-shot subsets.  (The EPIC-100 unseen / tail split of :109-158 needs the
-    dataset's participant tables and is not mirrored.)"""
+    action_class, dataset.classes_manyshot the many-shot subsets; with compute_manyshot_unseen_tail on an EPIC-100 dataset
+    the unseen / tail recalls of :109-158 are added."""
     assert len(probs) == 3, 'Probs should contain probs for verb, noun and action'
     many = dataset.classes_manyshot
     res = {}
@@ -79,9 +103,7 @@ def compute_accuracies_epic(probs, dataset, compute_manyshot_unseen_tail: bool =
         if key in many and compute_manyshot_unseen_tail:
             res[f"{short}mt5r_ms"] = compute_accuracy(p, labels, classes=many[key])[2]
     if compute_manyshot_unseen_tail and getattr(dataset, "version", None) == EPIC100_VERSION:
-        # challenge.py:190-191 adds {v,n,a}mt5r_{tail,unseen} from the dataset's participant / tail-class tables here
-        raise NotImplementedError("EPIC-100 unseen / tail metrics (challenge.py:109-158) need the RULSTM annotation tables and are not "
-                                  "mirrored: call with compute_manyshot_unseen_tail=False")
+        res.update(epic100_unseen_tail_eval(probs, dataset))
     return res
 
 

@@ -100,6 +100,20 @@ def eval_inputs(N=48, A=30, V=7, Nn=11, seed=0):
 
 
 
+def unseen_tail_tables(N=48, A=30):
+    """closed-form EPIC-100 bookkeeping of the unseen / tail fixture: one narration id per clip, the four RULSTM id tables
+    (unseen participants; tail verbs / nouns / actions: each also holds ids that are not in the split) and many-shot subsets"""
+    ids = np.asarray([f"P{1 + i % 9:02d}_{100 + i % 4}_{i}" for i in range(N)])
+    i = np.arange(N)
+    tables = {"validation_unseen_participants_ids.csv": list(ids[i % 5 == 0]) + ["P35_105_7"],
+              "validation_tail_verbs_ids.csv": list(ids[i % 3 != 0]),
+              "validation_tail_nouns_ids.csv": list(ids[(i % 4 == 1) | (i > 40)]) + ["P01_101_999"],
+              "validation_tail_actions_ids.csv": list(ids[i % 2 == 1])}
+    manyshot = {"verb": {f"v{c}": c for c in (0, 2, 3)}, "noun": {f"n{c}": c for c in (1, 4, 5, 9)},
+                "action": {f"a{c}": c for c in range(0, A, 3)}}
+    return ids, tables, manyshot
+
+
 def reader_stores(C_rgb=12, C_audio=6):
     """closed-form RULSTM-style feature stores for the reader fixture: key "<video>_frame_{:010d}.jpg" -> float32 bytes.
     'rgb' store (30 fps ids): frames 3.. of P01_101 stored except every 7th and a hole of 12 (beyond the 9-frame search);

@@ -380,6 +380,49 @@ def run_eval_case():
                                                         reference="zeyun-zhong/AFFT @ /root/reference (v1)"))))
 
 
+def run_unseen_tail_case():
+    """m1_unseen_tail: the reference's compute_accuracies_epic(..., compute_manyshot_unseen_tail=True) on an EPIC-100 stub
+    (challenge.py:109-193): many-shot, unseen-participant and tail-class recalls.  The reference calls
+    pd.read_csv(..., squeeze=True), a keyword pandas 2 removed; for this run pd.read_csv is wrapped to give the keyword its
+    pandas-1 meaning (a one-column frame comes back as its Series) -- nothing of the reference itself is changed."""
+    import tempfile
+    import pandas as pd
+    _mod("h5py")
+    _mod("numpyencoder", NumpyEncoder=object)
+    import challenge as RC
+    from closed_form import eval_inputs, unseen_tail_tables
+    logits, mv, mn, a_lab, v_lab, n_lab = eval_inputs()
+    ids, tables, manyshot = unseen_tail_tables(len(a_lab), logits.shape[1])
+    z = np.load(os.path.join(HERE, "m0_marginalize.npz"))
+    scores = [z["verb"], z["noun"], z["action"]]
+    plain_read_csv = pd.read_csv
+
+    def read_csv(*a, squeeze=False, **kw):
+        out = plain_read_csv(*a, **kw)
+        return out.squeeze("columns") if squeeze else out
+    with tempfile.TemporaryDirectory() as d:
+        for fn, rows in tables.items():
+            with open(os.path.join(d, fn), "w") as fh:
+                fh.write("\n".join(rows) + "\n")
+
+        class _DS:
+            df = pd.DataFrame(dict(verb_class=v_lab, noun_class=n_lab, action_class=a_lab, narration_id=ids))
+            classes_manyshot = manyshot
+            version = RC.EPIC100_VERSION
+            rulstm_annotation_dir = d
+        RC.pd.read_csv = read_csv
+        try:
+            acc = RC.compute_accuracies_epic(scores, _DS, compute_manyshot_unseen_tail=True)
+        finally:
+            RC.pd.read_csv = plain_read_csv
+    print("[m1_unseen_tail]", {k: round(float(v), 3) for k, v in acc.items()})
+    assert len(acc) == 18 and not any(np.isnan(float(v)) for v in acc.values())
+    np.savez_compressed(os.path.join(HERE, "m1_unseen_tail.npz"), acc_names=np.asarray(sorted(acc)),
+                        acc_values=np.asarray([float(acc[k]) for k in sorted(acc)], np.float64),
+                        meta=np.asarray(json.dumps(dict(case="m1_unseen_tail", scores="m0_marginalize.npz", pandas=pd.__version__,
+                                                        reference="zeyun-zhong/AFFT @ /root/reference (v1)"))))
+
+
 def run_reader_case():
     """r0_reader: the reference's EpicRULSTMFeatsReader (datasets/reader_fns.py:41-157) over dict-backed fake LMDB
     environments (the `lmdb` / torchvision packages are stubbed; the reader only calls env.begin().get(key))."""
@@ -502,6 +545,8 @@ def main():
         run_full_case(name, c)
     if not only or "m0_marginalize" in only:
         run_eval_case()
+    if not only or "m1_unseen_tail" in only:
+        run_unseen_tail_case()
     if not only or "r0_reader" in only:
         run_reader_case()
     if not only or "e0_edges" in only:

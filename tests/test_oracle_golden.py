@@ -133,6 +133,35 @@ def test_eval_path_oracle_and_host_metrics_match_reference_golden():
         assert (np.isnan(v) and np.isnan(got[k])) or abs(got[k] - v) < 1e-9, (k, got[k], v)
 
 
+def test_unseen_tail_and_manyshot_recalls_match_reference_golden(tmp_path):
+    """m1_unseen_tail.npz = the reference's compute_accuracies_epic(..., compute_manyshot_unseen_tail=True) on an EPIC-100 stub
+    (challenge.py:109-193) with closed-form narration ids, RULSTM id tables and many-shot subsets: afft_amd.challenge reproduces all
+    18 numbers (top-1 / top-5 / recall, many-shot, tail, unseen participants) from the same tables on disk."""
+    import os
+    import numpy as np
+    import pandas as pd
+    from afft_amd import challenge as CH
+    from closed_form import unseen_tail_tables
+    z, (logits, mv, mn, a_lab, v_lab, n_lab) = _eval_fixture()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "m1_unseen_tail.npz"))
+    want = dict(zip([str(k) for k in g["acc_names"]], g["acc_values"]))
+    ids, tables, manyshot = unseen_tail_tables(len(a_lab), logits.shape[1])
+    for fn, rows in tables.items():
+        (tmp_path / fn).write_text("\n".join(rows) + "\n")
+
+    class _DS:
+        df = pd.DataFrame(dict(verb_class=v_lab, noun_class=n_lab, action_class=a_lab, narration_id=ids))
+        classes_manyshot = manyshot
+        version = CH.EPIC100_VERSION
+        rulstm_annotation_dir = str(tmp_path)
+    got = CH.compute_accuracies_epic([z["verb"], z["noun"], z["action"]], _DS, compute_manyshot_unseen_tail=True)
+    assert set(got) == set(want) and len(want) == 18
+    for k, v in want.items():
+        assert abs(got[k] - v) < 1e-9, (k, got[k], v)
+    _DS.version = 0.1                       # EPIC-55: many-shot only, no unseen / tail keys (challenge.py:190)
+    assert not any("tail" in k or "unseen" in k for k in CH.compute_accuracies_epic([z["verb"], z["noun"], z["action"]], _DS, True))
+
+
 def test_oracle_reproduces_the_reference_on_the_interface_edges():
     """tests/golden/e0_edges.npz (the reference's Block with an arbitrary additive mask; DecoderBlock(mem_dim != dim, qkv_bias=True)):
     the oracle's block / decoder_block from closed-form weights and inputs, outputs + input gradients."""
