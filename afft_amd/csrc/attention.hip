@@ -313,11 +313,11 @@ extern "C" int afft_attention_fwd_split(const void* q, int64_t ldq, const void* 
              "attention_fwd_split: block-causal mask needs a period that divides L (L=%d, period=%d)", L, mask_period);
   AFFT_CHECK(!(mask == AFFT_MASK_DIAG && L == 1), "attention_fwd_split: diagonal mask with L=1 masks every key");
   AFFT_CHECK(drop_p >= 0.f && drop_p < 1.f, "attention_fwd_split: dropout p outside [0,1)");
-  AFFT_CHECK(in_lo > 0, "attention_fwd_split: the inputs are two-plane splits (in_lo > 0)");
+  AFFT_CHECK(in_lo >= 0, "attention_fwd_split: in_lo is the distance to the inputs' lo planes (0: one fp16 plane each)");
   AFFT_CHECK(!out_lo8 || (out_lo == 0 && (((uintptr_t)out_lo8) & 3) == 0), "attention_fwd_split: out_lo8 excludes out_lo and must be 4-byte aligned");
   if (nseq == 0) return 0;
   const int64_t rw_ = (int64_t)nseq * L * H * hd, pb_ = probs ? (int64_t)nseq * H * L * L * 4 : 0;
-  AfftKernelScope ktrace(AFFT_K_ATTN_FWD, nseq * L, H * hd, (3 * 4 + (out_lo ? 4 : 2) + (out_bf16 ? 2 : 0)) * rw_ + pb_,
+  AfftKernelScope ktrace(AFFT_K_ATTN_FWD, nseq * L, H * hd, (3 * (in_lo ? 4 : 2) + (out_lo ? 4 : out_lo8 ? 3 : 2) + (out_bf16 ? 2 : 0)) * rw_ + pb_,
                          3 * 4 * (int64_t)nseq * H * L * L * hd, stream);
   const int rc = afft_attention_mfma(false, nullptr, 0, q, ldq, k, ldk, v, ldv, probs, nseq, L, H, hd, scale,
                                      mask | (mask == AFFT_MASK_BLOCKCAUSAL ? mask_period << 8 : 0), drop_p, drop_key, out_hi, ldo,

@@ -109,13 +109,14 @@ __device__ __forceinline__ f32x4 mfma16_h(bf16x4 a, h4 b, f32x4 c) {
 // PL ("planes", the fp16x2 forward): q, k, v arrive as two-plane fp16 splits x = hi + lo and every product is accumulated from
 // hi*hi + lo*hi + hi*lo on the fp16 MFMAs (exact to ~2^-21: the attention core adds no operand rounding of its own to a forward
 // pass whose GEMMs carry their activations as hi + lo); the probabilities are split the same way in registers, and the output is
-// written as planes again (+ the bf16 copy the backward pass reads).
-template <int NT, bool PL>
+// written as planes again (+ the bf16 copy the backward pass reads).  PL = 2: q, k, v are ONE fp16 plane each (a.in_lo = 0: the sub-layer's
+// AFFT_F16X2_ONE_PASS_ATTN site -- the operands carry one fp16 rounding like a weight does); the probabilities stay hi + lo, the output planes too.
+template <int NT, int PL>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned dkey = a.dkey ^ (a.salt ? *a.salt : 0u);
   constexpr int R = 16 * NT;
-  constexpr int NP = PL ? 2 : 1;       // planes per operand tile
+  constexpr int NP = PL == 1 ? 2 : 1;  // planes per operand tile
   const int hd = a.hd, hc = a.hc, L = a.L, H = a.H;
   const int rb = hc * 2;               // bytes per LDS row: one head-dimension chunk
   const int nch = hd / hc;
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
       for (int t = 0; t < NT; ++t) {
         kf[t] = row_frag(Ks, t * 16 + (lane & 15), ch, rb);
         qf[t] = row_frag(Qs, t * 16 + (lane & 15), ch, rb);
-        if constexpr (PL) {
+        if constexpr (PL == 1) {
           kl[t] = row_frag(Ks + tb, t * 16 + (lane & 15), ch, rb);
           ql[t] = row_frag(Qs + tb, t * 16 + (lane & 15), ch, rb);
         }
@@ -161,9 +162,11 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
       for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
         for (int qt = 0; qt < NT; ++qt) {
-          if constexpr (PL) {
+          if constexpr (PL == 1) {
             s[kt][qt] = mfma32_h(kl[kt], qf[qt], s[kt][qt]);       // small terms first
             s[kt][qt] = mfma32_h(kf[kt], ql[qt], s[kt][qt]);
+            s[kt][qt] = mfma32_h(kf[kt], qf[qt], s[kt][qt]);
+          } else if constexpr (PL == 2) {
             s[kt][qt] = mfma32_h(kf[kt], qf[qt], s[kt][qt]);
           } else {
             s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], s[kt][qt], 0, 0, 0);
@@ -254,11 +257,17 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
         const bf16x4 vt = tr_frag(Vs, kt * 16, cb, lane, rb);
-        if constexpr (PL) {
+        if constexpr (PL == 1) {
           const bf16x4 vl = tr_frag(Vs + tb, kt * 16, cb, lane, rb);
 #pragma unroll
           for (int qt = 0; qt < NT; ++qt) {
             o[qt] = mfma16_h(vl, ph[kt][qt], o[qt]);
+            o[qt] = mfma16_h(vt, pq[kt][qt], o[qt]);
+            o[qt] = mfma16_h(vt, ph[kt][qt], o[qt]);
+          }
+        } else if constexpr (PL == 2) {
+#pragma unroll
+          for (int qt = 0; qt < NT; ++qt) {
             o[qt] = mfma16_h(vt, pq[kt][qt], o[qt]);
             o[qt] = mfma16_h(vt, ph[kt][qt], o[qt]);
           }
@@ -747,7 +756,7 @@ int afft_attention_mfma(bool backward, const void* dout, int64_t lddo, const voi
                         int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, hipStream_t stream,
                         int planes, int64_t in_lo, int64_t out_lo, void* out_b, int64_t ldob, void* out_lo8) {
   if (L > 64 || hd % 64 != 0 || hd > 1024) return -1;
-  if (planes && (backward || in_lo % 8 || out_lo % 4 || ldob % 4 || (((uintptr_t)out_b) & 7))) return -1;
+  if (planes && (backward || in_lo % 8 || in_lo < 0 || out_lo % 4 || ldob % 4 || (((uintptr_t)out_b) & 7))) return -1;
   if (ldq % 8 || ldk % 8 || ldv % 8 || !al16(q) || !al16(k) || !al16(v)) return -1;
   if (!backward && (ldo % 4 || (((uintptr_t)out) & 7))) return -1;
   if (backward && (lddo % 8 || !al16(dout) || lddq % 4 || lddk % 4 || lddv % 4 || (((uintptr_t)dq) & 7) ||
@@ -756,7 +765,7 @@ int afft_attention_mfma(bool backward, const void* dout, int64_t lddo, const voi
   // the whole head dimension in LDS when it fits (3 tiles forward, 4 backward); else chunks of the head dimension,
   // the scores / dP accumulate over the chunks and the operand tiles are re-staged (2 tiles forward, 3 backward)
   int hc = hd;
-  const int np = planes ? 2 : 1;       // fp16x2 forward: every operand tile is two planes
+  const int np = (planes && in_lo) ? 2 : 1;       // fp16x2 forward: every operand tile is two planes (in_lo = 0: the hi plane alone)
   size_t lds = (size_t)(backward ? 4 : 3) * np * 16 * NT * hd * 2;
   // planes (fp16x2 forward): the two-plane tiles of a whole head (96 KiB at hd = 512) leave ONE workgroup per CU, whose load -> barrier ->
   // compute -> store runs with nothing beside it (2.75 TB/s); chunks that fit 48 KiB keep three workgroups per CU in flight
@@ -788,14 +797,18 @@ int afft_attention_mfma(bool backward, const void* dout, int64_t lddo, const voi
     if (afft_ensure_dynamic_lds(reinterpret_cast<const void*>(KERN), 160 * 1024, &attr_done)) return -1;    \
     hipLaunchKernelGGL(KERN, grid, block, lds, stream, a);                                                  \
   } while (0)
-  if (!backward && planes) {
-    if (NT == 1) AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<1, true>));
-    else if (NT == 2) AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<2, true>));
-    else AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<4, true>));
+  if (!backward && planes && in_lo) {
+    if (NT == 1) AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<1, 1>));
+    else if (NT == 2) AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<2, 1>));
+    else AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<4, 1>));
+  } else if (!backward && planes) {
+    if (NT == 1) AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<1, 2>));
+    else if (NT == 2) AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<2, 2>));
+    else AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<4, 2>));
   } else if (!backward) {
-    if (NT == 1) AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<1, false>));
-    else if (NT == 2) AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<2, false>));
-    else AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<4, false>));
+    if (NT == 1) AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<1, 0>));
+    else if (NT == 2) AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<2, 0>));
+    else AFFT_ATTN_LAUNCH((attn_fwd_mfma_kernel<4, 0>));
   } else {
     if (NT <= 2 && hd % 128 == 0 && hd <= 512 && lddq % 8 == 0 && lddk % 8 == 0 && lddv % 8 == 0 && al16(dq) && al16(dk) && al16(dv)) {
       // column-sliced backward (attn_bwd_sliced_kernel): 2 wave-private buffers of [16 NT][hd / 4] bf16 per wave + the partial dP tiles

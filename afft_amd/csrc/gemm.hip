@@ -546,7 +546,7 @@ int launch_layout_impl(GemmFast& g, hipStream_t stream, const afft_gemm_t* d) {
     afft_set_error("afft_gemm: split3 = 3 needs the NT layout and a problem the 256x256 kernel takes (afft_gemm_lo8_ok)");
     return 1;
   }
-  if (d->split3 == 2) {     // fp16 two-pass (forward layouts only): same tile choice as bf16x3
+  if (d->split3 == 2 || d->split3 == 4) {     // fp16 two-pass / one pass (g.K = one segment) (forward layouts only): same tile choice as bf16x3
     if constexpr (!A_KS) {
       if (variant == 3) return afft_gemm_launch_pp(A_KS, B_KS, g, stream, 2);
       // small grids (the predictor's M = B*T rows): split-K over the 2K-long loop -- with two slices one workgroup runs the hi
@@ -743,7 +743,7 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
   fast = fast && (a_kc || a_ks) && (b_kc || b_ks) && lda % 8 == 0 && ldb % 8 == 0 && lda >= 8 && ldb >= 8;
   fast = fast && !(a_ks && !a_kc && b_kc && !b_ks);   // (A k-strided, B k-contiguous) does not occur on the path
 
-  AFFT_CHECK(d->split3 >= 0 && d->split3 <= 3, "afft_gemm: split3 is 0, 1 (bf16x3), 2 (fp16 two-pass) or 3 (fp16 + fp8 lo pass)");
+  AFFT_CHECK(d->split3 >= 0 && d->split3 <= 4, "afft_gemm: split3 is 0, 1 (bf16x3), 2 (fp16 two-pass), 3 (fp16 + fp8 lo pass) or 4 (one fp16 pass)");
   AFFT_CHECK(d->split3 != 3 || (d->a8 && d->b8 && d->K % 128 == 0 && d->a8_ld % 16 == 0 && d->b8_ld % 16 == 0 && d->a8_ld >= d->K && d->b8_ld >= d->K &&
                                 aligned16(d->a8) && aligned16(d->b8)),
              "afft_gemm: split3 = 3 needs the two e4m3 byte planes (16-byte aligned rows) and K %% 128 == 0");
@@ -752,7 +752,7 @@ extern "C" int afft_gemm(const afft_gemm_t* d, void* stream_) {
     GemmFast g;
     g.A = (const bf16_t*)d->A; g.B = (const bf16_t*)d->B;
     g.lda = lda; g.ldb = ldb;
-    g.K = d->split3 == 3 ? d->K + d->K / 2 : d->split3 == 2 ? 2 * d->K : d->split3 ? 3 * d->K : d->K;      // in 64-wide K-tiles of 128 B per row
+    g.K = d->split3 == 3 ? d->K + d->K / 2 : d->split3 == 2 ? 2 * d->K : d->split3 == 1 ? 3 * d->K : d->K;      // in 64-wide K-tiles of 128 B per row
     g.nk_seg = d->K / BK;
     g.a_lo = d->a_lo; g.b_lo = d->b_lo;
     g.A8 = (const bf16_t*)d->a8; g.B8 = (const bf16_t*)d->b8; g.lda8 = d->a8_ld / 2; g.ldb8 = d->b8_ld / 2;

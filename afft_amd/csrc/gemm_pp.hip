@@ -712,7 +712,8 @@ bool pp2planes_takes(const GemmFast& g) {
   return false;
 #else
   const int64_t span = ((int64_t)(g.a_lo > g.b_lo ? g.a_lo : g.b_lo)) * 2;
-  return AFFT_PP2 && g.e.M % 256 == 0 && g.e.N % 256 == 0 && g.nk_seg % 2 == 0 && g.nk_seg >= 2 && g.K == (X3 == 1 ? 3 : 2) * g.nk_seg * BK &&
+  const bool one_pass = X3 == 2 && g.K == g.nk_seg * BK && g.nk_seg >= 4;      // afft_gemm_t.split3 = 4: the first segment alone (no jump is ever taken)
+  return AFFT_PP2 && g.e.M % 256 == 0 && g.e.N % 256 == 0 && g.nk_seg % 2 == 0 && g.nk_seg >= 2 && (g.K == (X3 == 1 ? 3 : 2) * g.nk_seg * BK || one_pass) &&
          span < (1LL << 30) && walk_fits32(A_KS, g.nk_seg * BK, g.lda) && walk_fits32(B_KS, g.nk_seg * BK, g.ldb) &&
          (A_KS ? (int64_t)g.nk_seg * BK * g.lda * 2 : (int64_t)8 * g.lda * 2) + span < (1LL << 31) &&
          (B_KS ? (int64_t)g.nk_seg * BK * g.ldb * 2 : (int64_t)8 * g.ldb * 2) + span < (1LL << 31);
@@ -760,6 +761,7 @@ extern "C" void afft_debug_pp_stamp(void* p) { g_pp_stamp = (unsigned long long*
 bool afft_gemm_pp2_takes(int M, int N, int K, int x3) {      // K: the caller's K (one segment)
   if (x3 == 3) { const int ns = K / BK; return AFFT_PP2 && M % 256 == 0 && N % 256 == 0 && ns % 4 == 0 && ns >= 4; }
   if (x3 == 1 || x3 == 2) { const int ns = K / BK; return AFFT_PP2 && M % 256 == 0 && N % 256 == 0 && ns % 2 == 0 && ns >= 2; }
+  if (x3 == 4) { const int ns = K / BK; return AFFT_PP2 && M % 256 == 0 && N % 256 == 0 && ns % 2 == 0 && ns >= 4; }
   return x3 == 0 && pp2_shape(M, N, K);
 }
 

@@ -68,6 +68,8 @@ bool has_drop(const afft_dropout_t& d) { return d.p > 0.f || d.path_p > 0.f; }
 
 // "fp16x2" forward: A is a two-plane fp16 split (lo plane a_lo elements behind the hi plane), the weight an FP16 image
 void as_f16x2(afft_gemm_t& g, int64_t a_lo) { g.split3 = 2; g.a_lo = a_lo; g.b_lo = 0; g.b_packed = nullptr; }
+// ... or ONE fp16 pass on A's hi plane (AFFT_F16X2_ONE_PASS_* sites)
+void as_f16_one(afft_gemm_t& g) { g.split3 = 4; g.a_lo = 0; g.b_lo = 0; g.b_packed = nullptr; }
 // ... with the lo pass on the block-scaled fp8 MFMA: a8 = the activation's e4m3 lo byte plane (row pitch = its element pitch in bytes),
 // w8 = the weight's e4m3 byte image
 void as_f16_lo8(afft_gemm_t& g, const void* a8, int64_t a8_ld, const void* w8, int64_t w8_ld) {
@@ -92,26 +94,29 @@ extern "C" int afft_attn_sublayer_fwd(const afft_attn_sublayer_t* s, void* strea
     // the qkv epilogue, the attention kernel); the bf16 copies (xn_b / qkv_b / ao_b) are what the bf16 backward reads
     const int pr = pad64(R);
     const int64_t lo1 = (int64_t)pr * d, lo3 = (int64_t)pr * 3 * d;
-    const bool lo8 = s->f16x2 == 2;      // lo planes of xn / ao as e4m3 bytes directly behind their hi planes, lo pass on the fp8 MFMA
-    AFFT_CHECK(!lo8 || (!s->conv1d && s->w_qkv8 && s->w_proj8), "attn_sublayer_fwd: f16x2 = 2 needs nn.Linear weights with e4m3 images");
+    const bool lo8 = (s->f16x2 & 3) == 2;      // lo planes of xn / ao as e4m3 bytes directly behind their hi planes, lo pass on the fp8 MFMA
+    const bool one1 = s->f16x2 & AFFT_F16X2_ONE_PASS_1, one2 = s->f16x2 & AFFT_F16X2_ONE_PASS_2;      // qkv / proj: one fp16 pass, no lo plane of xn / ao
+    const bool one_attn = s->f16x2 & AFFT_F16X2_ONE_PASS_ATTN;      // the attention core on the hi planes of q, k, v: no lo plane of qkv
+    AFFT_CHECK(!lo8 || (!s->conv1d && (one1 || s->w_qkv8) && (one2 || s->w_proj8)), "attn_sublayer_fwd: f16x2 = 2 needs nn.Linear weights with e4m3 images");
     unsigned char* xn8 = (unsigned char*)s->xn + lo1 * 2;
     unsigned char* ao8 = (unsigned char*)s->ao + lo1 * 2;
     if (s->xn_b) TRY(zero_row_tail(s->xn_b, R, d, st));
     if (s->qkv_b) TRY(zero_row_tail(s->qkv_b, R, 3 * d, st));
     if (s->ao_b) TRY(zero_row_tail(s->ao_b, R, d, st));
-    TRY(afft_layernorm_fwd_split(s->x, d, s->ln_w, s->ln_b, s->eps, R, d, s->xn, d, lo8 ? 0 : lo1, s->xn_b, d, s->mean, s->rstd,
-                                 lo8 ? xn8 : nullptr, st));
+    TRY(afft_layernorm_fwd_split(s->x, d, s->ln_w, s->ln_b, s->eps, R, d, s->xn, d, (lo8 || one1) ? 0 : lo1, s->xn_b, d, s->mean, s->rstd,
+                                 (lo8 && !one1) ? xn8 : nullptr, st));
     afft_gemm_t g = lin_fwd(s->xn, d, R, d, s->w_qkv, s->ldw_qkv, 3 * d, s->conv1d, ws);
-    if (lo8) as_f16_lo8(g, xn8, d, s->w_qkv8, s->ldw_qkv); else as_f16x2(g, lo1);
+    if (one1) as_f16_one(g); else if (lo8) as_f16_lo8(g, xn8, d, s->w_qkv8, s->ldw_qkv); else as_f16x2(g, lo1);
     g.bias = s->b_qkv;
-    g.out = s->qkv; g.ldo = 3 * d; g.out_dtype = AFFT_F16; g.out_lo = lo3;
+    g.out = s->qkv; g.ldo = 3 * d; g.out_dtype = AFFT_F16; g.out_lo = one_attn ? 0 : lo3;
     g.out2 = s->qkv_b; g.ldo2 = 3 * d; g.out2_dtype = AFFT_BF16;
     TRY(afft_gemm(&g, st));
     const char* q = (const char*)s->qkv;
-    TRY(afft_attention_fwd_split(q, 3 * d, q + 2 * d, 3 * d, q + 4 * d, 3 * d, lo3, R / s->L, s->L, s->H, d / s->H, s->scale, s->mask,
-                                 s->mask_period, s->p_attn, s->k_attn, s->ao, d, lo8 ? 0 : lo1, s->ao_b, d, s->probs, lo8 ? ao8 : nullptr, st));
+    TRY(afft_attention_fwd_split(q, 3 * d, q + 2 * d, 3 * d, q + 4 * d, 3 * d, one_attn ? 0 : lo3, R / s->L, s->L, s->H, d / s->H, s->scale, s->mask,
+                                 s->mask_period, s->p_attn, s->k_attn, s->ao, d, (lo8 || one2) ? 0 : lo1, s->ao_b, d, s->probs,
+                                 (lo8 && !one2) ? ao8 : nullptr, st));
     g = lin_fwd(s->ao, (int64_t)d * take, Ry, d, s->w_proj, s->ldw_proj, d, s->conv1d, ws);
-    if (lo8) as_f16_lo8(g, ao8, (int64_t)d * take, s->w_proj8, s->ldw_proj); else as_f16x2(g, lo1);
+    if (one2) as_f16_one(g); else if (lo8) as_f16_lo8(g, ao8, (int64_t)d * take, s->w_proj8, s->ldw_proj); else as_f16x2(g, lo1);
     g.bias = s->b_proj;
     g.residual = s->x; g.ldres = (int64_t)d * take;
     g.drop = s->out_drop;
@@ -202,26 +207,27 @@ extern "C" int afft_mlp_sublayer_fwd(const afft_mlp_sublayer_t* s, void* stream_
   if (s->f16x2) {      // see afft_attn_sublayer_fwd
     const int pr = pad64(R);
     const int64_t lo1 = (int64_t)pr * d, loh = (int64_t)pr * hd;
-    const bool lo8 = s->f16x2 == 2;      // see afft_attn_sublayer_fwd
-    AFFT_CHECK(!lo8 || (!s->conv1d && s->w1_8 && s->w2_8), "mlp_sublayer_fwd: f16x2 = 2 needs nn.Linear weights with e4m3 images");
+    const bool lo8 = (s->f16x2 & 3) == 2;      // see afft_attn_sublayer_fwd
+    const bool one1 = s->f16x2 & AFFT_F16X2_ONE_PASS_1, one2 = s->f16x2 & AFFT_F16X2_ONE_PASS_2;      // fc1 / fc2: one fp16 pass, no lo plane of xn / h
+    AFFT_CHECK(!lo8 || (!s->conv1d && (one1 || s->w1_8) && (one2 || s->w2_8)), "mlp_sublayer_fwd: f16x2 = 2 needs nn.Linear weights with e4m3 images");
     unsigned char* xn8 = (unsigned char*)s->xn + lo1 * 2;
     unsigned char* h8 = (unsigned char*)s->h + loh * 2;
     if (s->xn_b) TRY(zero_row_tail(s->xn_b, R, d, st));
     if (s->h_b) TRY(zero_row_tail(s->h_b, R, hd, st));
     if (s->u) TRY(zero_row_tail(s->u, R, hd, st));
-    TRY(afft_layernorm_fwd_split(s->x, d, s->ln_w, s->ln_b, s->eps, R, d, s->xn, d, lo8 ? 0 : lo1, s->xn_b, d, s->mean, s->rstd,
-                                 lo8 ? xn8 : nullptr, st));
+    TRY(afft_layernorm_fwd_split(s->x, d, s->ln_w, s->ln_b, s->eps, R, d, s->xn, d, (lo8 || one1) ? 0 : lo1, s->xn_b, d, s->mean, s->rstd,
+                                 (lo8 && !one1) ? xn8 : nullptr, st));
     afft_gemm_t g = lin_fwd(s->xn, d, R, d, s->w1, s->ldw1, hd, s->conv1d, ws);
-    if (lo8) as_f16_lo8(g, xn8, d, s->w1_8, s->ldw1); else as_f16x2(g, lo1);
+    if (one1) as_f16_one(g); else if (lo8) as_f16_lo8(g, xn8, d, s->w1_8, s->ldw1); else as_f16x2(g, lo1);
     g.bias = s->b1;
     g.act = s->gelu;
     g.pre = s->u; g.ldpre = hd; g.pre_dtype = AFFT_BF16;
     g.out = s->h; g.ldo = hd; g.out_dtype = AFFT_F16;
-    if (lo8) g.out_lo8 = h8; else g.out_lo = loh;
+    if (one2) {} else if (lo8) g.out_lo8 = h8; else g.out_lo = loh;
     g.out2 = s->h_b; g.ldo2 = hd; g.out2_dtype = AFFT_BF16;
     TRY(afft_gemm(&g, st));
     g = lin_fwd(s->h, hd, R, hd, s->w2, s->ldw2, d, s->conv1d, ws);
-    if (lo8) as_f16_lo8(g, h8, hd, s->w2_8, s->ldw2); else as_f16x2(g, loh);
+    if (one2) as_f16_one(g); else if (lo8) as_f16_lo8(g, h8, hd, s->w2_8, s->ldw2); else as_f16x2(g, loh);
     g.bias = s->b2;
     g.residual = s->x; g.ldres = d;
     g.drop = s->out_drop;

@@ -714,6 +714,7 @@ def _attn_fwd_c(ctx, x, ln_w, ln_b, w_qkv, b_qkv, w_proj, b_proj, L, H, mask, ep
         if _lo8_ok(conv1d, R, (3 * d, d)) and _lo8_ok(conv1d, Ry, (d, d)):      # second pass on the block-scaled fp8 MFMA: e4m3 lo planes of xn / ao, e4m3 weight images
             s.f16x2 = 2
             s.w_qkv8, s.w_proj8 = rt.weight_f8(w_qkv).data_ptr(), rt.weight_f8(w_proj).data_ptr()
+        s.f16x2 |= rt.one_pass_flags(conv1d, d, "qkv", "proj", "attn")
         base = planes.data_ptr()
         s.xn, s.qkv, s.ao = base, base + 2 * (2 * pr * d), base + 2 * (2 * pr * 4 * d)      # [hi | lo] of xn, then of qkv, then of ao
         if saved is not None:
@@ -840,6 +841,7 @@ def _mlp_fwd_c(ctx, x, ln_w, ln_b, w1, b1, w2, b2, eps, gelu, conv1d, hidden, dr
         if _lo8_ok(conv1d, R, (hidden, d), (d, hidden)):
             s.f16x2 = 2
             s.w1_8, s.w2_8 = rt.weight_f8(w1).data_ptr(), rt.weight_f8(w2).data_ptr()
+        s.f16x2 |= rt.one_pass_flags(conv1d, d, "fc1", "fc2")
         base = planes.data_ptr()
         s.xn, s.h = base, base + 2 * (2 * pr * d)
         if saved is not None:

@@ -98,7 +98,8 @@ def gemm(a, b, out: Tensor, *, a_t: bool = False, b_t: bool = False, bias: Optio
          out_lo: int = 0, a8: Optional[Tensor] = None, b8: Optional[Tensor] = None, out_lo8: Optional[Tensor] = None) -> Tensor:
     """out = epilogue(alpha * A @ B).  A = a (or a.T if a_t), B = b (or b.T if b_t); a, b 2-D views -- or both `Split`
     (two-plane bf16 splits of fp32 matrices): the bf16x3 GEMM, fp32-accurate products on the bf16 MFMA path; or a an fp16 `Split`
-    and b a plain fp16 matrix (a weight's FP16 image): the fp16 two-pass forward GEMM (afft_gemm_t.split3 = 2).
+    and b a plain fp16 matrix (a weight's FP16 image): the fp16 two-pass forward GEMM (afft_gemm_t.split3 = 2); a and b both plain fp16
+    matrices: one fp16 pass (split3 = 4: the activation's hi plane alone, runtime.one_pass_sites).
     b_packed: the fragment-packed copy of a weight `b` [N, K] used as b.T (pack_weight; afft_gemm_t.b_packed).
     out_lo: `out` (fp16) is the hi plane of a two-plane split of the result, the lo plane sits out_lo elements behind it.
     a8 / b8 (uint8, the shapes of a / b): the lo pass on the block-scaled fp8 MFMA (afft_gemm_t.split3 = 3): a = the fp16 HI plane of the
@@ -132,6 +133,8 @@ def gemm(a, b, out: Tensor, *, a_t: bool = False, b_t: bool = False, bias: Optio
     else:
         M, K = (a.shape[1], a.shape[0]) if a_t else (a.shape[0], a.shape[1])
         Kb, N = (b.shape[1], b.shape[0]) if b_t else (b.shape[0], b.shape[1])
+        if a.dtype == torch.float16 and b.dtype == torch.float16:      # ONE fp16 pass (afft_gemm_t.split3 = 4): forward layouts, like the two-pass GEMM
+            d.split3 = 4
     if K != Kb:
         raise ValueError(f"afft_amd.gemm: inner sizes differ ({K} vs {Kb})")
     if a.dtype != b.dtype:

@@ -189,6 +189,54 @@ def set_lo8(on: bool):
     _LO8 = bool(on)
 
 
+ONE_PASS_SITES = ("linear.qkv", "linear.attn", "linear.proj", "linear.fc1", "linear.fc2", "conv1d.qkv", "conv1d.attn", "conv1d.proj", "conv1d.fc1", "conv1d.fc2")
+
+
+def _parse_sites(text: str) -> frozenset:
+    names = [t.strip() for t in text.split(",") if t.strip()]
+    out = set()
+    for n in names:
+        hit = [s for s in ONE_PASS_SITES if s == n or s.startswith(n + ".") or s.endswith("." + n)]
+        if not hit:
+            raise ValueError(f"afft_amd: unknown one-pass site {n!r}; sites: {', '.join(ONE_PASS_SITES)} (or 'linear', 'conv1d', 'qkv', ...)")
+        out.update(hit)
+    return frozenset(out)
+
+
+# default: the predictor's sub-layers (M = B*T rows: their second pass is a full fp16 pass on the 128x128 kernel, +55 % per GEMM, and their
+# operand rounding barely reaches the logits) and the fusers' fc2 (K = 4d: the most expensive lo pass and lo plane).  cfg2: logits 6.6e-4 ->
+# 7.5e-4 of the 1e-3 tolerance, step 17.70 -> 16.54 ms on one box; EK100 widths 7.1e-4 -> 8.1e-4 (profiles/r06_lo_pass_sweep.txt).
+# AFFT_ONE_PASS_SITES= (empty): every site two passes.
+_ONE_PASS = _parse_sites(os.environ.get("AFFT_ONE_PASS_SITES", "conv1d.qkv,conv1d.proj,conv1d.fc1,conv1d.fc2,linear.fc2"))
+
+
+def one_pass_sites() -> frozenset:
+    """'fp16x2' forward: the GEMM sites of the composite sub-layers that read their activation as ONE fp16 plane (afft_gemm_t.split3 = 4,
+    AFFT_F16X2_ONE_PASS_*) instead of hi + lo -- '<linear|conv1d>.<qkv|attn|proj|fc1|fc2>': nn.Linear sub-layers (the fusers) or GPT-2 Conv1D
+    ones (the predictor); 'attn' = the attention core's q, k, v.  Each such site adds one fp16 operand rounding (what its weight already carries) to the forward; how many the 1e-3
+    logits tolerance affords is measured by tools/lo_pass_sweep.py."""
+    return _ONE_PASS
+
+
+def set_one_pass_sites(sites):
+    global _ONE_PASS
+    _ONE_PASS = _parse_sites(sites) if isinstance(sites, str) else _parse_sites(",".join(sites))
+
+
+_ONE_PASS_MIN_DIM = int(os.environ.get("AFFT_ONE_PASS_MIN_DIM", "1024"))
+
+
+def one_pass_flags(conv1d: bool, width: int, first: str, second: str, core: str = "") -> int:
+    """the AFFT_F16X2_ONE_PASS_* flags of a composite sub-layer of model width `width`: its sites in one_pass_sites(), taken only where the
+    second pass costs time -- width >= AFFT_ONE_PASS_MIN_DIM (1024); below (the small test models, whose fp16 weight rounding alone sits at
+    ~9e-4 of the 1e-3 tolerance) a lo pass is microseconds and every site keeps it"""
+    if width < _ONE_PASS_MIN_DIM:
+        return 0
+    kind = "conv1d." if conv1d else "linear."
+    return ((4 if kind + first in _ONE_PASS else 0) | (8 if kind + second in _ONE_PASS else 0)      # AFFT_F16X2_ONE_PASS_1 | _2 | _ATTN
+            | (16 if core and kind + core in _ONE_PASS else 0))
+
+
 def weight_f8(p: Tensor) -> Tensor:
     """e4m3 byte image e4m3(2^8 p) [pad64(rows), pad64(cols)] of a 2-D parameter (afft_gemm_t.b8): in the flat buffers when the parameter
     is homed there (written by the optimizer kernels), else a quantised copy redone when the parameter changes"""

@@ -139,13 +139,14 @@ class GemmTimer:
     @staticmethod
     def symbol(r) -> str:
         b = lambda x: "true" if x else "false"    # noqa: E731
+        x3 = 2 if int(r.split3) == 4 else int(r.split3)      # one fp16 pass (split3 = 4) runs the two-pass instantiation over one segment
         if r.variant == 3:
-            return f"gemm_bf16_pp_kernel<{b(r.a_kstrided)}, {b(r.b_kstrided)}, {int(r.split3)}>"
+            return f"gemm_bf16_pp_kernel<{b(r.a_kstrided)}, {b(r.b_kstrided)}, {x3}>"
         if r.variant == 13:      # round 6: the steady-state 256x256 kernel (whole tiles, even K-tile count, plain bf16)
-            return f"gemm_bf16_pp2_kernel<{b(r.a_kstrided)}, {b(r.b_kstrided)}, {int(r.split3)}>"
+            return f"gemm_bf16_pp2_kernel<{b(r.a_kstrided)}, {b(r.b_kstrided)}, {x3}>"
         if r.variant in (7, 8, 9, 10):       # B-direct kernels (csrc/gemm_bd.hip): <16-row blocks per tile, A look-ahead, B look-ahead, packed B>
             return f"gemm_bf16_bd_kernel<{10 if r.variant in (8, 10) else 16}, 3, {2 if r.variant in (8, 10) else 1}, {b(r.variant >= 9)}>"
-        return f"gemm_bf16_kernel<2, 2, 2, {b(r.a_kstrided)}, {b(r.b_kstrided)}, {b(r.splitk > 1)}, {int(r.split3)}>"
+        return f"gemm_bf16_kernel<2, 2, 2, {b(r.a_kstrided)}, {b(r.b_kstrided)}, {b(r.splitk > 1)}, {x3}>"
 
     def summary(self):
         out = {}
@@ -465,6 +466,10 @@ def parity_side_measurements(args, device, feats, tgt, sub, c):
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / n
             last_loss = float(tr.step(feats, tgt, sub)[0])
+            with GemmTimer() as gt:       # the MFMA passes this step really runs, from the library's own launch records
+                tr.step(feats, tgt, sub)
+            w = {0: 1.0, 1: 3.0, 2: 2.0, 3: 1.5, 4: 1.0}      # split3: bf16 | bf16x3 | two fp16 passes | fp16 + fp8 (twice the rate) | one fp16 pass
+            traced_passes = sum(2.0 * r.M * r.N * r.K * w[int(r.split3)] for r in gt.records) / max(1.0, sum(2.0 * r.M * r.N * r.K for r in gt.records))
             from afft_amd.config import gflop_per_clip
             useful = args.batch / dt * gflop_per_clip(args.config, fwd_bwd=True, executed=afft_amd.runtime.skip_dead_rows(), token_row_projection=_token_rows(args)) / 1e3   # TFLOP/s executed
             if mode == "bf16x3":
@@ -473,15 +478,21 @@ def parity_side_measurements(args, device, feats, tgt, sub, c):
             else:
                 # forward two fp16 MFMA passes (activation hi + lo, weight rounded once), backward one bf16 pass: the step's GEMM work
                 # is (2 + 2) / 3 of the algorithmic FLOPs (backward = 2 x forward)
-                passes, note = 4.0 / 3.0, ("fp16x2: forward A_hi W + A_lo W on v_mfma_f32_16x16x32_f16 with the operand planes written by the "
-                                          "producing kernels, backward = the bf16 mode's on bf16 copies (gradients inside the bf16 bound)")
+                sites = sorted(afft_amd.runtime.one_pass_sites())
+                passes, note = traced_passes, ("fp16x2: forward A_hi W + A_lo W (fp16 MFMA; the lo pass on the block-scaled fp8 MFMA at twice the rate where the "
+                                               "256x256 kernel runs) with the operand planes written by the producing kernels; ONE fp16 pass at the sites "
+                                               f"{', '.join(sites) or '(none)'} (runtime.one_pass_sites, tools/lo_pass_sweep.py); backward = the bf16 mode's on "
+                                               "bf16 copies (gradients inside the bf16 bound).  passes = bf16-rate MFMA passes per algorithmic FLOP, from "
+                                               "the GEMM launch records of one step")
             rec = {"precision": mode, "clips_per_s": round(args.batch / dt, 1), "ms_per_step": round(dt * 1e3, 2), "steps": n,
                    "final_loss": round(last_loss, 4) if last_loss == last_loss else "nan: MEASUREMENT VOID (updates skipped)",
                    "roofline": {"bound": "mfma", "achieved": round(useful, 1), "peak": round(PEAK_BF16_TFLOPS / passes, 1),
                                 "unit": "TFLOP/s (algorithmic, whole step)", "frac": round(useful * passes / PEAK_BF16_TFLOPS, 4),
-                                "executed_tflops": round(passes * useful, 1)},
+                                "executed_tflops": round(passes * useful, 1), "passes": round(passes, 3)},
                    "note": note}
             # the mode whose LOGITS meet the north-star 1e-3 at the highest training rate is the parity mode of the line
+            if mode == "fp16x2":
+                rec["one_pass_sites"] = sorted(afft_amd.runtime.one_pass_sites())
             out["parity_mode" if mode == "fp16x2" else "parity_mode_bf16x3"] = rec
             del tr
         del model

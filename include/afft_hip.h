@@ -92,7 +92,9 @@ typedef struct {
    * split3 = 2, "fp16x2" (forward layouts only: A k-contiguous): the planes are FP16 (afft_split_f16) and only the first two
    * segments run, A_hi*B_hi + A_lo*B_hi on v_mfma_f32_16x16x32_f16 -- A exact to ~2^-22, B rounded once to fp16 (2^-11): the
    * evaluation forward at 2/3 of the bf16x3 MFMA work (operands must stay inside fp16's range: weights and activations do,
-   * gradients do not, hence no backward). */
+   * gradients do not, hence no backward).
+   * split3 = 4: ONE fp16 pass, A_hi*B_hi alone (same operands and layouts as split3 = 2; a_lo is not read): a GEMM whose activation
+   * operand is rounded once to fp16 like its weight -- the sub-layers' AFFT_F16X2_ONE_PASS_* sites. */
   int32_t split3; int64_t a_lo, b_lo;
   /* Optional: apply the optimizer IN the epilogue instead of storing the result (see afft_sgd_fused_t below): the GEMM is a
    * weight gradient whose value is consumed once, by the update of that weight.  Needs accumulate = 0, no bias / act. */
@@ -465,6 +467,9 @@ int afft_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_
  * events; NOTHING on `stream` waits for them -- the caller joins the streams when its backward pass is over.
  * Saved by forward for backward (caller-owned, see each struct): the bf16 activations, mean / rstd, probs.            */
 
+#define AFFT_F16X2_ONE_PASS_1 4      /* flags of afft_attn_sublayer_t.f16x2 / afft_mlp_sublayer_t.f16x2 (below) */
+#define AFFT_F16X2_ONE_PASS_2 8
+#define AFFT_F16X2_ONE_PASS_ATTN 16   /* afft_attn_sublayer_t only: the attention core reads q, k, v as one fp16 plane each */
 typedef struct {       /* y = x + drop(proj(attention(split(qkv(LN(x))))))                                          */
   /* Block / DecoderBlock self-attention half: models/transformerblock.py:19-36,131-133,158-159 ; HF GPT2Block attn half  */
   int32_t rows, d, L, H;                 /* rows = nseq * L tokens; H heads of d / H                                   */
@@ -508,6 +513,11 @@ typedef struct {       /* y = x + drop(proj(attention(split(qkv(LN(x))))))      
    * afft_gemm_lo8_ok says yes): w_qkv8 / w_proj8 = the weights' e4m3 byte images (row pitch ldw_* bytes); the lo planes of xn and ao are
    * e4m3 BYTE planes (rows_pad * d bytes, directly behind their hi planes); qkv keeps its fp16 lo plane (the attention kernel reads it). */
   const void* w_qkv8; const void* w_proj8;
+  /* f16x2 may carry AFFT_F16X2_ONE_PASS_1 / _2 on top of 1 or 2: the sub-layer's first (qkv; fc1) / second (proj; fc2) GEMM runs ONE
+   * fp16 pass on its operand's hi plane (afft_gemm_t.split3 = 4) and the producer of that operand writes no lo plane for it (xn: the
+   * LayerNorm; ao: the attention kernel; h: the fc1 epilogue); AFFT_F16X2_ONE_PASS_ATTN: the qkv epilogue writes no lo plane and the attention
+   * core multiplies the hi planes of q, k, v alone (its probabilities stay hi + lo in registers).  Which sites afford this inside the 1e-3 logits tolerance is the caller's
+   * measurement (afft_amd.runtime.one_pass_sites, tools/lo_pass_sweep.py). */
   /* take > 1: only the first token of every `take` = L rows leaves the sub-layer (the SA-Fuser's last block, models/fusion.py:362-365
    * returns token 0 of every frame): attention runs over all rows, the output projection (+ residual, bias, dropout) on rows
    * 0, take, 2 take, .. only; y, dy and dya are [rows / take, d].  Backward: the projection's data gradient lands on those rows of

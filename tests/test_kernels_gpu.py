@@ -286,6 +286,54 @@ def test_gemm_fp16x2(case):
     assert torch.equal(out_b, out)
 
 
+ONE_PASS_CASES = [
+    ("nt_pp2", 512, 768, 256, "nt", 3, dict(bias=True, act=2)),        # whole tiles, 4 K-tiles: gemm_bf16_pp2_kernel<false, false, 2>, one segment
+    ("nt_pp2_fc2", 5120, 2048, 8192, "nt", 0, dict(bias=True, residual=True)),      # the fusers' fc2 at cfg2 (runtime.one_pass_sites default)
+    ("nn_pp2", 256, 512, 384, "nn", 3, dict(residual=True)),
+    ("nt_pp_tail", 300, 520, 192, "nt", 3, dict(bias=True)),            # ragged: the general 256x256 kernel
+    ("nt_pp_2tiles", 512, 512, 128, "nt", 3, dict()),                   # 2 K-tiles: below the steady-state kernel's minimum
+    ("nn_128_predictor", 1024, 2048, 2048, "nn", 0, dict(bias=True)),   # the predictor's Conv1D shapes (128x128 kernel, split-K by the cost model)
+    ("nn_128_fc2", 1024, 2048, 8192, "nn", 0, dict(bias=True, residual=True)),
+    ("nn_128_tail", 130, 256, 320, "nn", 1, dict(bias=True, act=1, pre=True)),
+]
+
+
+@pytest.mark.parametrize("case", ONE_PASS_CASES, ids=[c[0] for c in ONE_PASS_CASES])
+def test_gemm_fp16_one_pass(case):
+    """ONE fp16 pass (afft_gemm_t.split3 = 4, the AFFT_F16X2_ONE_PASS_* sites of the sub-layers): the activation's hi plane against the
+    weight's FP16 image on the fp16 MFMA, one segment of the two-pass kernels.  Against float64 on the fp16-rounded operands the result
+    is fp32-grade; against the exact product it carries both roundings (~2.4e-4 relative)."""
+    from afft_amd import _lib, ops
+    name, M, N, K, layout, variant, ep = case
+    A, Bm = rnd(M, K, seed=41), rnd(K, N, seed=42)
+    b_t = layout[1] == "t"
+    a16 = A.half().to(dev())
+    b16 = (Bm.t().contiguous() if b_t else Bm).half().to(dev())
+    bias = rnd(N, seed=3) if ep.get("bias") else None
+    act = ep.get("act", 0)
+    res = rnd(M, N, seed=5) if ep.get("residual") else None
+    out = torch.zeros(M, N, device=dev())
+    pre = torch.zeros(M, N, device=dev()) if ep.get("pre") else None
+    _lib.check(_lib.lib().afft_set_gemm_variant(variant))
+    ops.gemm(a16, b16, out, b_t=b_t, bias=None if bias is None else bias.to(dev()), act=act, pre=pre,
+             residual=None if res is None else res.to(dev()))
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().afft_set_gemm_variant(0))
+
+    def finish(prod):
+        r = prod.float()
+        if bias is not None:
+            r = r + bias
+        r = _act(act, r, None)
+        return r + res if res is not None else r
+    rounded, exact = finish(A.half().double() @ Bm.half().double()), finish(A.double() @ Bm.double())
+    assert rel_l2(out.cpu(), rounded) < 1e-5, (name, rel_l2(out.cpu(), rounded))
+    if not ep.get("residual"):
+        assert 5e-5 < rel_l2(out.cpu(), exact) < 6e-4, (name, rel_l2(out.cpu(), exact))
+    with pytest.raises(RuntimeError, match="forward layouts only|fast-path layout"):
+        ops.gemm(a16.t().contiguous(), b16, torch.zeros(M, N, device=dev()), a_t=True, b_t=b_t)
+
+
 @pytest.mark.parametrize("case", [("nt_pp", 512, 768, 256, "nt", 3), ("nn_128", 130, 256, 320, "nn", 1), ("nt_tail", 300, 520, 200, "nt", 0)],
                          ids=lambda c: c[0])
 def test_gemm_fp16x2_plane_output_feeds_the_next_gemm(case):
