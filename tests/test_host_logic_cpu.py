@@ -370,3 +370,26 @@ def test_two_losses_on_one_half_of_the_merged_logits_add_up():
             assert abs(float(loss) - float(lr)) < 1e-5
             assert rel_l2(x.grad, xr.grad) < 1e-5, rel_l2(x.grad, xr.grad)
     afft_amd.set_precision("bf16")
+
+
+def test_one_pass_sites_parse_default_and_width_gate():
+    """runtime.one_pass_sites: the default set (the predictor's four GEMM sites and the fusers' fc2), group names, the flags a composite sub-layer
+    receives (AFFT_F16X2_ONE_PASS_1 = 4, _2 = 8, _ATTN = 16) and the width gate below which every site keeps its second pass."""
+    from afft_amd import runtime as rt
+    saved = rt.one_pass_sites()
+    try:
+        rt.set_one_pass_sites("conv1d.qkv,conv1d.proj,conv1d.fc1,conv1d.fc2,linear.fc2")
+        assert rt.one_pass_flags(True, 2048, "qkv", "proj", "attn") == 12 and rt.one_pass_flags(True, 2048, "fc1", "fc2") == 12
+        assert rt.one_pass_flags(False, 2048, "qkv", "proj", "attn") == 0 and rt.one_pass_flags(False, 2048, "fc1", "fc2") == 8
+        assert rt.one_pass_flags(False, 128, "fc1", "fc2") == 0 and rt.one_pass_flags(True, 512, "qkv", "proj", "attn") == 0
+        rt.set_one_pass_sites("linear")
+        assert rt.one_pass_sites() == {"linear.qkv", "linear.attn", "linear.proj", "linear.fc1", "linear.fc2"}
+        assert rt.one_pass_flags(False, 1024, "qkv", "proj", "attn") == 28
+        rt.set_one_pass_sites(["attn", "conv1d.fc2"])
+        assert rt.one_pass_sites() == {"linear.attn", "conv1d.attn", "conv1d.fc2"}
+        rt.set_one_pass_sites("")
+        assert rt.one_pass_sites() == frozenset() and rt.one_pass_flags(True, 4096, "qkv", "proj", "attn") == 0
+        with pytest.raises(ValueError, match="unknown one-pass site"):
+            rt.set_one_pass_sites("linear.fc3")
+    finally:
+        rt.set_one_pass_sites(saved)
