@@ -178,7 +178,8 @@ __device__ __forceinline__ void glds16c(const char* sbase, unsigned voff, unsign
   asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_wave), "n"(OFF) : "memory", "scc");
 }
 
-template <bool A_KS, bool B_KS, bool SPLITK>
+// F16: the operands are fp16 (one fp16 pass of the "fp16x2" forward, afft_gemm_t.split3 = 4: the predictor's GEMMs) -- the MFMA form is all that changes.
+template <bool A_KS, bool B_KS, bool SPLITK, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_g2_kernel(const GemmFast g) {
   constexpr int A_BYTES = 128 * BK * 2, STAGE_BYTES = 2 * A_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A image | B image]
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_g2_kernel(const GemmFast g) 
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<0>(bfr[j], af[i], acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<F16 ? 2 : 0>(bfr[j], af[i], acc[i][j]);
     });
     if constexpr (!LAST) {
       wait_vmcnt<0>();      // the next K-tile has landed (this wave's pieces) and this wave's reads of the current one have returned
@@ -421,11 +422,12 @@ int launch_fast(GemmFast& g, hipStream_t stream) {
   constexpr size_t lds = ring > epi ? ring : epi;
   g.tiles_m = (g.e.M + BM - 1) / BM;
   g.tiles_n = (g.e.N + BN - 1) / BN;
-  if constexpr (WM == 2 && WN == 2 && STAGES == 2 && X3 == 0) {
+  if constexpr (WM == 2 && WN == 2 && STAGES == 2 && (X3 == 0 || X3 == 2)) {
     const bool fits32 = (A_KS ? (int64_t)(g.K + 8) * g.lda * 2 : (8 * g.lda + g.K) * 2) < (1LL << 32) &&
                         (B_KS ? (int64_t)(g.K + 8) * g.ldb * 2 : (8 * g.ldb + g.K) * 2) < (1LL << 32);      // the running K offset is a 32-bit VGPR
-    if (fits32 && g2_shape(g.e.M, g.e.N, g.K, g.splitk)) {      // whole tiles, even K-tile count per slice: the steady-state kernel
-      auto k2 = gemm_bf16_g2_kernel<A_KS, B_KS, SPLITK>;
+    const bool one_segment = X3 == 0 || g.K == g.nk_seg * BK;      // X3 = 2: only the one-pass form (split3 = 4) -- the kernel has no operand planes
+    if (fits32 && one_segment && g2_shape(g.e.M, g.e.N, g.K, g.splitk)) {      // whole tiles, even K-tile count per slice: the steady-state kernel
+      auto k2 = gemm_bf16_g2_kernel<A_KS, B_KS, SPLITK, X3 == 2>;
       static std::atomic<uint64_t> attr2_done{0};
       if (int rc = afft_ensure_dynamic_lds(reinterpret_cast<const void*>(k2), lds, &attr2_done)) return rc;
       hipLaunchKernelGGL(k2, dim3(g.tiles_m * g.tiles_n, g.splitk), dim3(256), lds, stream, g);

@@ -28,7 +28,11 @@ SMALL = [("nn", 1024, 6144, 2048), ("nn", 1024, 2048, 2048), ("nn", 1024, 8192, 
          ("nt", 5120, 1024, 1024), ("nn", 5120, 1024, 4096), ("tn", 1024, 3072, 5120), ("nt", 1280, 6144, 2048), ("tn", 2048, 6144, 1280)]
 # the fuser's forward GEMMs in the fp16x2 precision: fp16 hi segment + block-scaled fp8 lo segment (afft_gemm_t.split3 = 3), NT
 LO8 = [("lo8", 5120, 6144, 2048), ("lo8", 5120, 2048, 2048), ("lo8", 5120, 8192, 2048), ("lo8", 5120, 2048, 8192), ("lo8", 1024, 2048, 2048)]
-SHAPES = {"path": PATH, "big": BIG, "all": PATH + BIG, "small": SMALL, "lo8": LO8}[os.environ.get("SHAPES", "all")]
+# one fp16 pass (afft_gemm_t.split3 = 4, F16=1 is implied): the predictor's GEMMs of the fp16x2 forward (NN, M = B*T rows) and the fusers' fc2
+H1 = [("nn", 1024, 6144, 2048), ("nn", 1024, 2048, 2048), ("nn", 1024, 8192, 2048), ("nn", 1024, 2048, 8192), ("nt", 5120, 2048, 8192),
+      ("nn", 1024, 3072, 1024), ("nn", 1024, 1024, 1024), ("nn", 1024, 2048, 1024), ("nt", 5120, 1024, 4096)]
+SHAPES = {"path": PATH, "big": BIG, "all": PATH + BIG, "small": SMALL, "lo8": LO8, "h1": H1}[os.environ.get("SHAPES", "all")]
+F16 = os.environ.get("F16", "0") == "1" or os.environ.get("SHAPES") == "h1"      # fp16 operands, one pass
 
 
 def load(path):
@@ -53,7 +57,7 @@ def operands(layout, M, N, K, seed=0):
         w8 = torch.empty(N, K, dtype=torch.uint8, device=dev)
         ops.quant_e4m3(w32, 256.0, w8)
         return (hi, a8, a32), (w32.half(), w8, w32)
-    u = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(torch.bfloat16).to(dev)      # noqa: E731
+    u = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(torch.float16 if F16 else torch.bfloat16).to(dev)      # noqa: E731
     if layout == "nt":
         return u(M, K), u(N, K)
     if layout == "nn":
@@ -84,6 +88,8 @@ def desc(layout, a, b, out):
     d.a_rs, d.a_cs = (a.stride(1), a.stride(0)) if a_t else (a.stride(0), a.stride(1))
     d.b_rs, d.b_cs = (b.stride(1), b.stride(0)) if b_t else (b.stride(0), b.stride(1))
     d.alpha = 1.0
+    if F16:
+        d.split3 = 4
     d.out, d.ldo, d.out_dtype = out.data_ptr(), out.stride(0), (L.F32 if out.dtype == torch.float32 else L.BF16)
     d.workspace, d.workspace_bytes = WS.data_ptr(), WS.numel()      # split-K scratch (counters zero between launches)
     return d
@@ -115,6 +121,8 @@ def main():
     checks = (("nt", 512, 768, 1024), ("nn", 512, 768, 1024), ("tn", 768, 512, 1024), ("nt", 1088, 3840, 2048), ("tn", 512, 512, 320),
               ("nt", 256, 256, 256), ("tn", 2048, 2048, 1024), ("nn", 1024, 2048, 8192), ("nt", 1024, 2048, 8192), ("tn", 1024, 1024, 1280),
               ("nn", 384, 640, 896))
+    if F16:
+        checks = tuple(c for c in checks if c[0] != "tn")      # forward layouts only
     if os.environ.get("SHAPES") == "lo8":      # whole tiles (steady-state kernel), edge tiles and a K-tile count that is not a multiple of 4 (general kernel)
         checks = (("lo8", 512, 768, 1024), ("lo8", 2560, 2048, 256), ("lo8", 2560, 2304, 2048), ("lo8", 2500, 2048, 1024), ("lo8", 2560, 2048, 384))
     for layout, M, N, K in checks:
