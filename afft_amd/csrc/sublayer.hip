@@ -223,7 +223,7 @@ extern "C" int afft_mlp_sublayer_fwd(const afft_mlp_sublayer_t* s, void* stream_
     g.act = s->gelu;
     g.pre = s->u; g.ldpre = hd; g.pre_dtype = AFFT_BF16;
     g.out = s->h; g.ldo = hd; g.out_dtype = AFFT_F16;
-    if (one2) {} else if (lo8) g.out_lo8 = h8; else g.out_lo = loh;
+    if (!one2) { if (lo8) g.out_lo8 = h8; else g.out_lo = loh; }      // fc2 on one pass: h goes out as its hi plane alone
     g.out2 = s->h_b; g.ldo2 = hd; g.out2_dtype = AFFT_BF16;
     TRY(afft_gemm(&g, st));
     g = lin_fwd(s->h, hd, R, hd, s->w2, s->ldw2, d, s->conv1d, ws);
