@@ -226,6 +226,13 @@ def set_one_pass_sites(sites):
 _ONE_PASS_MIN_DIM = int(os.environ.get("AFFT_ONE_PASS_MIN_DIM", "1024"))
 
 
+def set_one_pass_min_dim(width: int) -> int:
+    """the model width from which one_pass_sites() apply (tests run the sites on the small goldens with 0); returns the previous value"""
+    global _ONE_PASS_MIN_DIM
+    prev, _ONE_PASS_MIN_DIM = _ONE_PASS_MIN_DIM, int(width)
+    return prev
+
+
 def one_pass_flags(conv1d: bool, width: int, first: str, second: str, core: str = "") -> int:
     """the AFFT_F16X2_ONE_PASS_* flags of a composite sub-layer of model width `width`: its sites in one_pass_sites(), taken only where the
     second pass costs time -- width >= AFFT_ONE_PASS_MIN_DIM (1024); below (the small test models, whose fp16 weight rounding alone sits at

@@ -74,6 +74,50 @@ def test_fp16x2_forward_matches_reference_golden(name):
         afft_amd.set_precision("bf16")
 
 
+@pytest.mark.parametrize("name", list(CASES))
+def test_fp16x2_one_pass_sites_on_the_small_goldens(name):
+    """The one-pass sites (runtime.one_pass_sites: every site here, attention core included) forced on at the small goldens' widths
+    (set_one_pass_min_dim(0)): every fuser / predictor variant of the goldens runs its composite sub-layers with the AFFT_F16X2_ONE_PASS_*
+    flags -- the GEMM launch records show split3 = 4 -- and stays within 2e-3 of the reference's outputs (a wiring error -- a lo plane read
+    that was never written, a wrong operand -- would be orders of magnitude; single-pass fp16 sits at ~1e-3, which is why the default keeps
+    the second pass at these widths)."""
+    from afft_amd import runtime as rt, _lib
+    import afft_amd
+    z, shapes = load_golden(name)
+    c, state, data, tgt, sub = case_tensors(name)
+    if c.get("soft"):
+        pytest.skip("the MixUp golden is a training-mode case")
+    saved_sites, saved_dim = rt.one_pass_sites(), rt.set_one_pass_min_dim(0)
+    rt.set_one_pass_sites("linear,conv1d")
+    model = build(c, "fp16x2")
+    model.load_state_dict(state, strict=True)
+    model = model.cuda().eval()
+    dev = torch.device("cuda:0")
+    try:
+        rt.SINK.begin_step()
+        _lib.check(_lib.lib().afft_gemm_trace_begin(2048))
+        with torch.no_grad():
+            out, _ = model({m: d.to(dev) for m, d in data.items()}, mixup_fn=None, target={"action": tgt.to(dev)},
+                           target_subclips={"action": sub.to(dev)}, target_subclips_ignore_index=None)
+        torch.cuda.synchronize()
+        buf = (_lib.GemmTraceRec * 2048)()
+        nrec = _lib.lib().afft_gemm_trace_end(buf, 2048)
+        one_pass = sum(1 for i in range(nrec) if buf[i].split3 == 4)
+        flat = flatten_outputs(out)
+        worst = 0.0
+        for k in z.files:
+            if not k.startswith("out:") or (k[4:] == "attentions/modality_attns" and c["fuser"] == "ca"):
+                continue
+            worst = max(worst, rel_l2(flat[k[4:]].detach().float().cpu(), torch.from_numpy(z[k])))
+        print(f"[{name}/fp16x2/every site one pass] worst output error {worst:.2e}, {one_pass} of {nrec} traced GEMM launches one fp16 pass")
+        assert worst < 2e-3, worst
+        assert one_pass >= 4, (one_pass, nrec)      # the composite sub-layers of this golden ran with the flags
+    finally:
+        afft_amd.set_precision("bf16")
+        rt.set_one_pass_sites(saved_sites)
+        rt.set_one_pass_min_dim(saved_dim)
+
+
 @pytest.mark.parametrize("sites", ["two_pass_everywhere", "default"])
 @pytest.mark.parametrize("name", ["f_cfg2", "f_ek100"])
 def test_fp16x2_forward_full_size(name, sites):
