@@ -13,7 +13,7 @@ from afft_amd.parallel import Trainer  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-afft_amd.set_precision("bf16")
+afft_amd.set_precision(os.environ.get("PRECISION", "bf16"))      # PRECISION=fp16x2: the parity-grade step
 afft_amd.set_grad_mode("sink")
 dev = torch.device("cuda:0")
 model, c = B.build_model(name, dev)
@@ -36,15 +36,15 @@ for _ in range(5):
             tr.step(feats, tgt, sub)
     for r in gt.records:
         lay = ("t" if r.a_kstrided else "n") + ("n" if r.b_kstrided else "t")
-        k = (lay, r.M, r.N, r.K, r.variant, r.splitk, r.fused_update)
+        k = (lay, r.M, r.N, r.K, r.variant, r.splitk, r.fused_update, int(r.split3))
         agg[k][0] += 1
         agg[k][1] += r.ms
 print(f"{name} B={batch}: {'eval-mode forward' if EVAL else 'in-step'} GEMM launches, 5 instrumented {'forwards' if EVAL else 'steps'} (layout: nt forward of nn.Linear / dgrad of Conv1D, nn dgrad of nn.Linear / forward of Conv1D, tn weight gradient)")
-print(f"{'layout':6} {'M':>6} {'N':>6} {'K':>6} {'tile':>5} {'splitK':>6} {'fusedSGD':>8} {'n/step':>6} {'avg us':>8} {'TFLOP/s':>8}")
+print(f"{'layout':6} {'M':>6} {'N':>6} {'K':>6} {'tile':>5} {'splitK':>6} {'fusedSGD':>8} {'split3':>6} {'n/step':>6} {'avg us':>8} {'TFLOP/s':>8}")
 tot = 0.0
 for k, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    lay, M, N, K, var, sk, fu = k
+    lay, M, N, K, var, sk, fu, x3 = k
     avg = ms / n
     tot += ms / 5
-    print(f"{lay:6} {M:6d} {N:6d} {K:6d} {({3: '256', 10: 'bd160', 9: 'bd256', 8: 'bd160', 7: 'bd256'}.get(var, '128')):>5} {sk:6d} {fu:8d} {n / 5:6.1f} {avg * 1e3:8.1f} {2.0 * M * N * K / avg / 1e9:8.1f}")
+    print(f"{lay:6} {M:6d} {N:6d} {K:6d} {({3: '256', 13: '256s', 10: 'bd160', 9: 'bd256', 8: 'bd160', 7: 'bd256'}.get(var, '128')):>5} {sk:6d} {fu:8d} {x3:6d} {n / 5:6.1f} {avg * 1e3:8.1f} {2.0 * M * N * K / avg / 1e9:8.1f}")
 print(f"sum of GEMM launch durations per step: {tot:.2f} ms")
